@@ -1,0 +1,206 @@
+"""CPU oracle for the rollout + PPO-update hot path — TEST INFRASTRUCTURE ONLY.
+
+`oracle/cusrl_oracle.c` restates the reference's algorithm (chengruiz/cusrl, file:line cited
+per function in the C source); this module is its numpy/ctypes face.  It is imported only by
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg — never by
+``cusrl_amd``.  Parity status: PINNED — checked against golden vectors produced by running
+the reference itself (``tests/golden/make_golden.py``) and against the reference's own
+known-answer tests (``tests/test_oracle_golden.py``).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "libcusrl_oracle.so"
+_lib = None
+
+c_f = ctypes.POINTER(ctypes.c_float)
+c_u8 = ctypes.POINTER(ctypes.c_uint8)
+c_i64 = ctypes.POINTER(ctypes.c_int64)
+c_u32 = ctypes.POINTER(ctypes.c_uint32)
+
+
+def build(force: bool = False) -> Path:
+    """Compile the C restatement with gcc (seconds)."""
+    src = _HERE / "cusrl_oracle.c"
+    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "-B", "libcusrl_oracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(str(_LIB_PATH))
+        _lib.oracle_next_value.restype = ctypes.c_int64
+    return _lib
+
+
+def _f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def _u8(x):
+    return np.ascontiguousarray(np.asarray(x).astype(np.uint8))
+
+
+def _p(arr, typ):
+    return None if arr is None else arr.ctypes.data_as(typ)
+
+
+# ------------------------------------------------------------------------------------------ a1
+def buffer_push(step: np.ndarray, storage: np.ndarray, cursor: int) -> None:
+    step = np.ascontiguousarray(step)
+    assert storage.flags.c_contiguous and storage.dtype == step.dtype and storage.shape[1:] == step.shape
+    lib().oracle_buffer_push(
+        step.ctypes.data_as(ctypes.c_void_p), storage.ctypes.data_as(ctypes.c_void_p),
+        ctypes.c_int64(cursor), ctypes.c_int64(step.nbytes),
+    )
+
+
+# ------------------------------------------------------------------------------------------ a3
+def next_value(value, terminated, truncated, last_value, trunc_values=None, bootstrap=True, termination_value=0.0):
+    value = _f32(value)
+    T, N, D = value.shape
+    out = np.empty_like(value)
+    tv = None if trunc_values is None else _f32(trunc_values)
+    term, trunc, last = _u8(terminated), _u8(truncated), _f32(last_value)
+    k = lib().oracle_next_value(
+        _p(value, c_f), _p(term, c_u8), _p(trunc, c_u8), _p(last, c_f), _p(tv, c_f),
+        ctypes.c_int(int(bootstrap)), ctypes.c_float(termination_value), _p(out, c_f),
+        ctypes.c_int64(T), ctypes.c_int64(N), ctypes.c_int64(D),
+    )
+    return out, int(k)
+
+
+# ------------------------------------------------------------------------------------------ a4
+def gae(reward, done, value, next_value_, gamma, lamda, lamda_value=None):
+    reward, value, next_value_ = _f32(reward), _f32(value), _f32(next_value_)
+    T, N, D = reward.shape
+    done = _u8(done)
+    assert done.size == T * N
+    adv, ret = np.empty_like(reward), np.empty_like(reward)
+    lib().oracle_gae(
+        _p(reward, c_f), _p(done, c_u8), _p(value, c_f), _p(next_value_, c_f),
+        ctypes.c_double(gamma), ctypes.c_double(lamda), ctypes.c_double(-1.0 if lamda_value is None else lamda_value),
+        _p(adv, c_f), _p(ret, c_f), ctypes.c_int64(T), ctypes.c_int64(N), ctypes.c_int64(D),
+    )
+    return adv, ret
+
+
+# ------------------------------------------------------------------------------------------ a5
+def var_mean(x):
+    x = _f32(x)
+    D = x.shape[-1]
+    rows = x.size // D
+    mean, var = np.empty(D, np.float32), np.empty(D, np.float32)
+    lib().oracle_var_mean(_p(x, c_f), ctypes.c_int64(rows), ctypes.c_int64(D), _p(mean, c_f), _p(var, c_f))
+    return var, mean
+
+
+def normalize(x, mean, var):
+    out = _f32(x).copy()
+    D = out.shape[-1]
+    mean, var = _f32(mean), _f32(var)
+    lib().oracle_normalize(_p(out, c_f), ctypes.c_int64(out.size // D), ctypes.c_int64(D), _p(mean, c_f), _p(var, c_f))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ a6
+def merge_mean_var(means, vars_):
+    means, vars_ = _f32(means), _f32(vars_)
+    W, D = means.shape
+    mean, var = np.empty(D, np.float32), np.empty(D, np.float32)
+    lib().oracle_merge_mean_var(_p(means, c_f), _p(vars_, c_f), ctypes.c_int64(W), ctypes.c_int64(D), _p(mean, c_f), _p(var, c_f))
+    return mean, var
+
+
+# ------------------------------------------------------------------------------------------ a7/a8
+def gather_rows(storage: np.ndarray, indices, temporal: bool = False) -> np.ndarray:
+    storage = np.ascontiguousarray(storage)
+    T, N = storage.shape[:2]
+    indices = np.ascontiguousarray(indices, dtype=np.int64)
+    B = indices.size
+    row_bytes = storage[0, 0].nbytes
+    shape = ((T, B) if temporal else (B,)) + storage.shape[2:]
+    out = np.empty(shape, storage.dtype)
+    lib().oracle_gather_rows(
+        storage.ctypes.data_as(ctypes.c_void_p), _p(indices, c_i64), out.ctypes.data_as(ctypes.c_void_p),
+        ctypes.c_int64(B), ctypes.c_int64(T), ctypes.c_int64(N), ctypes.c_int64(row_bytes), ctypes.c_int(int(temporal)),
+    )
+    return out
+
+
+class Mt19937:
+    """torch's CPU generator stream as consumed by ``torch.randperm`` (see the C source)."""
+
+    def __init__(self, seed: int):
+        self.state = np.zeros(625, np.uint32)
+        lib().oracle_mt19937_seed(_p(self.state, c_u32), ctypes.c_uint64(seed))
+
+    def randperm(self, n: int) -> np.ndarray:
+        out = np.empty(n, np.int64)
+        lib().oracle_randperm(_p(self.state, c_u32), ctypes.c_int64(n), _p(out, c_i64))
+        return out
+
+
+def mini_batch_indices(seed_or_gen, num_samples, num_epochs, num_mini_batches, shuffle=True):
+    """cusrl/sampler/mini_batch_sampler.py:52-78 — the index vector of every minibatch, in order."""
+    gen = seed_or_gen if isinstance(seed_or_gen, Mt19937) else Mt19937(seed_or_gen)
+    epoch_indices = gen.randperm(num_samples)
+    result = []
+    for epoch in range(num_epochs):
+        mbs = num_mini_batches if isinstance(num_mini_batches, int) else num_mini_batches[epoch]
+        size = num_samples // mbs
+        if shuffle and epoch > 0:
+            epoch_indices = gen.randperm(num_samples)
+        result.append([epoch_indices[j * size:(j + 1) * size].copy() for j in range(mbs)])
+    return result
+
+
+# ------------------------------------------------------------------------------------------ a9-a13
+def normal_logp_entropy(action, mean, std):
+    action, mean, std = _f32(action), _f32(mean), _f32(std)
+    B, A = mean.shape
+    logp, ent = np.empty((B, 1), np.float32), np.empty((B, 1), np.float32)
+    lib().oracle_normal_logp_entropy(_p(action, c_f), _p(mean, c_f), _p(std, c_f), _p(logp, c_f), _p(ent, c_f), ctypes.c_int64(B), ctypes.c_int64(A))
+    return logp, ent
+
+
+def normal_kl(mean_p, std_p, mean_q, std_q):
+    mean_p, std_p, mean_q, std_q = _f32(mean_p), _f32(std_p), _f32(mean_q), _f32(std_q)
+    B, A = mean_p.shape
+    kl = np.empty((B, 1), np.float32)
+    lib().oracle_normal_kl(_p(mean_p, c_f), _p(std_p, c_f), _p(mean_q, c_f), _p(std_q, c_f), _p(kl, c_f), ctypes.c_int64(B), ctypes.c_int64(A))
+    return kl
+
+
+def ppo_loss(advantage, old_logp, action, mean, std, ret, curr_value, old_value=None, *, clip=0.2,
+             value_clip=None, w_sur=1.0, w_val=0.5, w_ent=0.01):
+    """Returns dict(losses[3]=(value, surrogate, entropy), logp, entropy, ratio, d_mean, d_std, d_value)."""
+    advantage, old_logp, action = _f32(advantage), _f32(old_logp), _f32(action)
+    mean, std, ret, curr_value = _f32(mean), _f32(std), _f32(ret), _f32(curr_value)
+    old_value = None if old_value is None else _f32(old_value)
+    B, A = mean.shape
+    D = ret.shape[-1]
+    out = dict(
+        losses=np.empty(3, np.float32), logp=np.empty((B, 1), np.float32), entropy=np.empty((B, 1), np.float32),
+        ratio=np.empty((B, 1), np.float32), d_mean=np.empty((B, A), np.float32), d_std=np.empty((B, A), np.float32),
+        d_value=np.empty((B, D), np.float32),
+    )
+    lib().oracle_ppo_loss(
+        _p(advantage, c_f), _p(old_logp, c_f), _p(action, c_f), _p(mean, c_f), _p(std, c_f), _p(ret, c_f),
+        _p(curr_value, c_f), _p(old_value, c_f), ctypes.c_int64(B), ctypes.c_int64(A), ctypes.c_int64(D),
+        ctypes.c_double(clip), ctypes.c_double(-1.0 if value_clip is None else value_clip),
+        ctypes.c_double(w_sur), ctypes.c_double(w_val), ctypes.c_double(w_ent),
+        _p(out["losses"], c_f), _p(out["logp"], c_f), _p(out["entropy"], c_f), _p(out["ratio"], c_f),
+        _p(out["d_mean"], c_f), _p(out["d_std"], c_f), _p(out["d_value"], c_f),
+    )
+    return out

@@ -1,0 +1,410 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING the reference (chengruiz/cusrl) on CPU.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU
+box); the resulting ``*.npz`` files are data — inputs and expected outputs —
+and are committed under ``tests/golden/``.  Nothing of the reference (source or
+bytecode) is copied: the reference package is imported from where it lies, with
+four non-arithmetic third-party modules stubbed: ``gymnasium``,
+``git``, ``tyro`` and ``objprint``.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Every fixture records ``torch_version`` because the permutation stream and the
+reduction order are properties of the installed torch build.
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import types
+from pathlib import Path
+from unittest.mock import MagicMock
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REFERENCE = Path(os.environ.get("CUSRL_REFERENCE", "/root/reference"))
+
+
+def import_reference():
+    for name in (
+        "gymnasium",
+        "gymnasium.envs",
+        "gymnasium.envs.registration",
+        "gymnasium.spaces",
+        "gymnasium.vector",
+        "gymnasium.wrappers",
+        "git",
+        "tyro",
+        "tyro.constructors",
+        "tyro.conf",
+        "tyro.extras",
+    ):
+        sys.modules.setdefault(name, MagicMock())
+    objprint = types.ModuleType("objprint")
+    objprint.add_objprint = lambda *a, **k: (lambda cls: cls)
+    objprint.objstr = repr
+    objprint.op = print
+    sys.modules.setdefault("objprint", objprint)
+    sys.path.insert(0, str(REFERENCE))
+    import cusrl  # noqa: PLC0415
+
+    return cusrl
+
+
+def np_(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().numpy().copy()
+
+
+META = {"torch_version": np.array(torch.__version__)}
+
+
+# --------------------------------------------------------------------------- GAE
+def make_gae(cusrl):
+    """Rows a4/a5: GAE scan, return, advantage normalisation (gae.py:8-110, advantage.py:108-115)."""
+    from cusrl.hook.on_policy.gae import _generalized_advantage_estimation  # noqa: PLC0415
+
+    out = dict(META)
+    cases = []
+    gen = torch.Generator().manual_seed(1234)
+    idx = 0
+    for T, N, D in [(24, 64, 1), (24, 64, 2), (7, 33, 3), (1, 5, 1), (2, 1, 1)]:
+        for gamma, lamda, lamda_value in [(0.99, 0.95, None), (0.99, 0.95, 0.995), (0.5, 1.0, 0.0)]:
+            reward = torch.randn(T, N, D, generator=gen)
+            value = torch.randn(T, N, D, generator=gen)
+            next_value = torch.randn(T, N, D, generator=gen)
+            done = torch.rand(T, N, 1, generator=gen) < 0.05
+            hook = cusrl.hook.GeneralizedAdvantageEstimation(gamma=gamma, lamda=lamda, lamda_value=lamda_value)
+            data = {"reward": reward, "done": done, "value": value, "next_value": next_value}
+            hook.pre_update(data)
+            advantage = data["advantage"].clone()
+            ret = data["return"].clone()
+            norm = cusrl.hook.AdvantageNormalization(synchronize=False)
+            normalized = advantage.clone()
+            var, mean = torch.var_mean(advantage, dim=(0, 1))
+            if T * N > 1:
+                norm.normalize_(normalized)
+            # sanity: functional form agrees with the hook
+            assert torch.equal(
+                advantage, _generalized_advantage_estimation(reward, done, value, next_value, gamma, lamda)
+            )
+            p = f"c{idx}_"
+            out[p + "reward"] = np_(reward)
+            out[p + "value"] = np_(value)
+            out[p + "next_value"] = np_(next_value)
+            out[p + "done"] = np_(done)
+            out[p + "advantage"] = np_(advantage)
+            out[p + "return"] = np_(ret)
+            out[p + "mean"] = np_(mean)
+            out[p + "var"] = np_(var)
+            out[p + "normalized"] = np_(normalized)
+            out[p + "params"] = np.array([gamma, lamda, -1.0 if lamda_value is None else lamda_value], dtype=np.float64)
+            cases.append(idx)
+            idx += 1
+    out["num_cases"] = np.array(idx)
+    np.savez_compressed(HERE / "gae.npz", **out)
+    print("gae.npz:", idx, "cases")
+
+
+# ------------------------------------------------------------------- next_value
+def make_next_value(cusrl):
+    """Row a3: ValueComputation.pre_update (value.py:56-82) with a closed-form critic."""
+    from types import SimpleNamespace  # noqa: PLC0415
+    from contextlib import nullcontext  # noqa: PLC0415
+
+    out = dict(META)
+    gen = torch.Generator().manual_seed(77)
+    idx = 0
+
+    class Critic:
+        # value(state) = 0.25 * sum(state) + 0.5 * state[0], per value channel d scaled by (d+1)
+        def __init__(self, D):
+            self.D = D
+
+        def evaluate(self, state, memory=None):
+            base = 0.25 * state.sum(-1, keepdim=True) + 0.5 * state[..., :1]
+            return torch.cat([base * (d + 1) for d in range(self.D)], dim=-1)
+
+    for T, N, D, O in [(24, 64, 1, 5), (8, 16, 2, 3), (1, 4, 1, 2), (5, 7, 1, 4)]:
+        for term_p, trunc_p, bootstrap, term_value in [
+            (0.05, 0.05, True, 0.0),
+            (0.1, 0.0, True, 0.0),
+            (0.05, 0.1, False, 0.0),
+            (0.2, 0.2, True, -1.5),
+        ]:
+            value = torch.randn(T, N, D, generator=gen)
+            next_obs = torch.randn(T, N, O, generator=gen)
+            terminated = torch.rand(T, N, 1, generator=gen) < term_p
+            truncated = torch.rand(T, N, 1, generator=gen) < trunc_p
+            buffer = cusrl.Buffer(capacity=T, parallelism=N, device="cpu")
+            buffer["value"] = value.clone()
+            buffer["next_observation"] = next_obs.clone()
+            buffer["terminated"] = terminated.clone()
+            buffer["truncated"] = truncated.clone()
+            hook = cusrl.hook.ValueComputation(termination_value=term_value, bootstrap_truncated_states=bootstrap)
+            hook.agent = SimpleNamespace(critic=Critic(D), autocast=nullcontext)
+            hook._critic_memory = None
+            hook.pre_update(buffer)
+            p = f"c{idx}_"
+            out[p + "value"] = np_(value)
+            out[p + "next_observation"] = np_(next_obs)
+            out[p + "terminated"] = np_(terminated)
+            out[p + "truncated"] = np_(truncated)
+            out[p + "next_value"] = np_(buffer["next_value"])
+            out[p + "params"] = np.array([term_value, float(bootstrap)], dtype=np.float64)
+            idx += 1
+    out["num_cases"] = np.array(idx)
+    np.savez_compressed(HERE / "next_value.npz", **out)
+    print("next_value.npz:", idx, "cases")
+
+
+# --------------------------------------------------------------------- randperm
+def make_randperm(cusrl):
+    """Row a7: the permutation stream of MiniBatchSampler (mini_batch_sampler.py:56,68).
+
+    Recorded through the reference sampler itself: a buffer holding its own flat
+    sample index is sampled for 3 epochs, so the gathered values ARE the indices.
+    """
+    out = dict(META)
+    idx = 0
+    for seed, T, N, mbs in [(0, 4, 4, 2), (0, 24, 4096, 4), (42, 1, 4096, 1), (7, 3, 5, 4)]:
+        buffer = cusrl.Buffer(capacity=T, parallelism=N, device="cpu")
+        flat = torch.arange(T * N, dtype=torch.int64).reshape(T, N, 1)
+        for t in range(T):
+            buffer.push({"flat_index": flat[t]})
+        torch.manual_seed(seed)
+        sampler = cusrl.MiniBatchSampler(num_epochs=3, num_mini_batches=mbs)
+        epochs = [[] for _ in range(3)]
+        for metadata, batch in sampler(buffer):
+            epochs[metadata["epoch_index"]].append(batch["flat_index"].squeeze(-1))
+        p = f"c{idx}_"
+        out[p + "params"] = np.array([seed, T, N, mbs], dtype=np.int64)
+        out[p + "indices"] = np.stack([np_(torch.cat(e)) for e in epochs])  # [3, mbs * (S // mbs)]
+        # the raw stream, for the C restatement of torch's CPU randperm
+        torch.manual_seed(seed)
+        first = torch.randperm(T * N)
+        second = torch.randperm(T * N, out=first.clone())
+        out[p + "raw0"] = np_(first)
+        out[p + "raw1"] = np_(second)
+        idx += 1
+    # temporal sampler: permutes env ids (mini_batch_sampler.py:110-114)
+    T, N = 3, 10
+    buffer = cusrl.Buffer(capacity=T, parallelism=N, device="cpu")
+    for t in range(T):
+        env = torch.arange(N, dtype=torch.float32).reshape(N, 1)
+        buffer.push({"observation": env * 100 + t, "actor_memory": env * 100 + t + 0.5})
+    torch.manual_seed(3)
+    got = []
+    for metadata, batch in cusrl.AutoMiniBatchSampler(num_epochs=2, num_mini_batches=3)(buffer):
+        assert metadata["temporal"] is True
+        got.append(np_(batch["observation"]))
+    out["temporal_obs"] = np.stack(got)  # [6, T, 3, 1]
+    out["num_cases"] = np.array(idx)
+    np.savez_compressed(HERE / "randperm.npz", **out)
+    print("randperm.npz:", idx, "cases")
+
+
+# ----------------------------------------------------------------------- losses
+def make_losses(cusrl):
+    """Rows a9-a12: surrogate / value / entropy losses and Normal log-prob with their gradients."""
+    from cusrl.hook.on_policy.ppo import _ppo_surrogate_loss  # noqa: PLC0415
+    from cusrl.hook.on_policy.value import _clipped_value_loss  # noqa: PLC0415
+
+    out = dict(META)
+    gen = torch.Generator().manual_seed(2024)
+    idx = 0
+    dist = cusrl.NormalDist(4, 3)  # only its stateless compute_* methods are used
+    for B, A, D, clip, vclip, w in [
+        (257, 12, 1, 0.2, None, (1.0, 0.5, 0.01)),
+        (64, 3, 1, 0.1, 0.2, (2.0, 1.0, 0.0)),
+        (1000, 12, 2, 0.3, 0.5, (1.0, 0.25, 0.05)),
+        (1, 1, 1, 0.2, None, (1.0, 0.5, 0.01)),
+    ]:
+        w_sur, w_val, w_ent = w
+        mean = torch.randn(B, A, generator=gen).requires_grad_()
+        std = (torch.rand(B, A, generator=gen) * 0.9 + 0.1).requires_grad_()
+        old_mean = mean.detach() + 0.1 * torch.randn(B, A, generator=gen)
+        old_std = std.detach() * (1 + 0.05 * torch.randn(B, A, generator=gen)).abs()
+        action = old_mean + old_std * torch.randn(B, A, generator=gen)
+        old_logp = dist.compute_logp({"mean": old_mean, "std": old_std}, action)
+        advantage = torch.randn(B, 1, generator=gen)
+        ret = torch.randn(B, D, generator=gen)
+        old_value = ret + 0.3 * torch.randn(B, D, generator=gen)
+        curr_value = (old_value + 0.3 * torch.randn(B, D, generator=gen)).requires_grad_()
+
+        params = {"mean": mean, "std": std}
+        logp = dist.compute_logp(params, action)
+        entropy = dist.compute_entropy(params)
+        kl = dist.compute_kl_div({"mean": old_mean, "std": old_std}, params)
+        logp_ratio = logp - old_logp
+        ratio = logp_ratio.exp()
+        surrogate = _ppo_surrogate_loss(advantage, ratio, clip) * w_sur
+        if vclip is None:
+            value_loss = torch.nn.functional.mse_loss(ret, curr_value) * w_val
+        else:
+            value_loss = _clipped_value_loss(old_value, curr_value, ret, vclip) * w_val
+        entropy_loss = -entropy.mean() * w_ent
+        # the reference sums objectives as a Python left fold in hook order (actor_critic.py:309)
+        loss = sum({"value_loss": value_loss, "surrogate_loss": surrogate, "entropy_loss": entropy_loss}.values())
+        loss.backward()
+        p = f"c{idx}_"
+        for k, v in dict(
+            mean=mean, std=std, old_mean=old_mean, old_std=old_std, action=action, old_logp=old_logp,
+            advantage=advantage, ret=ret, old_value=old_value, curr_value=curr_value, logp=logp,
+            entropy=entropy, kl=kl, logp_ratio=logp_ratio, ratio=ratio, surrogate=surrogate,
+            value_loss=value_loss, entropy_loss=entropy_loss, loss=loss, d_mean=mean.grad,
+            d_std=std.grad, d_value=curr_value.grad,
+        ).items():
+            out[p + k] = np_(v)
+        out[p + "params"] = np.array([clip, -1.0 if vclip is None else vclip, w_sur, w_val, w_ent], dtype=np.float64)
+        idx += 1
+    out["num_cases"] = np.array(idx)
+    np.savez_compressed(HERE / "losses.npz", **out)
+    print("losses.npz:", idx, "cases")
+
+
+# -------------------------------------------------------------- merge mean/var
+def make_merge(cusrl):
+    """Row a6: distributed.reduce_mean_var_ (distributed.py:175-183) with gather_stack replaced by given stacks."""
+    from cusrl.utils import distributed  # noqa: PLC0415
+
+    out = dict(META)
+    gen = torch.Generator().manual_seed(5)
+    idx = 0
+    orig_conf, orig_gather = distributed.configure_distributed, distributed.gather_stack
+    try:
+        for W, D in [(2, 1), (8, 1), (8, 3), (4, 2)]:
+            means = torch.randn(W, D, generator=gen)
+            vars_ = torch.rand(W, D, generator=gen) + 0.1
+            stack = torch.cat((means, vars_), dim=-1)
+            distributed.configure_distributed = lambda *a, **k: True
+            distributed.gather_stack = lambda tensor, _s=stack: _s
+            mean, var = means[0].clone(), vars_[0].clone()
+            distributed.reduce_mean_var_(mean, var)
+            p = f"c{idx}_"
+            out[p + "means"] = np_(means)
+            out[p + "vars"] = np_(vars_)
+            out[p + "mean"] = np_(mean)
+            out[p + "var"] = np_(var)
+            idx += 1
+    finally:
+        distributed.configure_distributed, distributed.gather_stack = orig_conf, orig_gather
+    out["num_cases"] = np.array(idx)
+    np.savez_compressed(HERE / "merge_mean_var.npz", **out)
+    print("merge_mean_var.npz:", idx, "cases")
+
+
+# ----------------------------------------------------------------- update trace
+def make_update_trace(cusrl):
+    """Golden (4): one rollout + one full ``agent.update()`` of the `ppo` preset on an 8-env x 16-obs x 8-act
+    dummy task — buffer-in, per-minibatch indices, losses, flat gradient, post-step parameters."""
+    from cusrl.testing.environment import DummyTorchEnvironment  # noqa: PLC0415
+    from cusrl.template.environment import get_done_indices  # noqa: PLC0415
+
+    cusrl.config.set_device("cpu")
+    out = dict(META)
+    for tag, factory_kwargs in [
+        ("a", dict(num_steps_per_update=6, sampler_epochs=2, sampler_mini_batches=3)),
+        ("b", dict(num_steps_per_update=5, sampler_epochs=2, sampler_mini_batches=2, gae_lamda_value=0.98,
+                   value_loss_clip=0.2)),
+    ]:
+        torch.manual_seed(11)
+        env = DummyTorchEnvironment(num_instances=8, observation_dim=16, action_dim=8, reward_dim=1)
+        factory = cusrl.preset.PpoAgentFactory(actor_hidden_dims=(32, 16), critic_hidden_dims=(32, 16), **factory_kwargs)
+        underlying = factory.to_underlying()
+
+        trace = {"objectives": [], "indices": [], "grads_unclipped": [], "grads": [], "params_after": []}
+
+        class Capture(cusrl.Hook):
+            def __init__(self, where):
+                super().__init__()
+                self.where = where
+                self.name_(f"capture_{where}")
+
+            def pre_optim(self, optimizer):
+                flat = torch.cat([p.grad.reshape(-1) for g in optimizer.param_groups for p in g["params"]])
+                trace["grads_unclipped" if self.where == "pre" else "grads"].append(np_(flat))
+
+            def post_optim(self):
+                if self.where == "post":
+                    flat = torch.cat([p.detach().reshape(-1) for _, p in self.agent.named_parameters()])
+                    trace["params_after"].append(np_(flat))
+
+            def objective(self, metadata, batch):
+                if self.where == "post":
+                    trace["indices"].append(np_(batch["flat_index"].squeeze(-1)))
+
+        underlying.register_hook(Capture("pre"), before="gradient_clipping")
+        underlying.register_hook(Capture("post"), after="gradient_clipping")
+        agent = underlying(env.spec)
+
+        state0 = {n: np_(p) for n, p in agent.named_parameters()}
+        orig_objective = agent.hook.objective
+
+        def wrapped(metadata, batch, _o=orig_objective):
+            res = _o(metadata, batch)
+            trace["objectives"].append(np.array([res["value_loss"].item(), res["surrogate_loss"].item(),
+                                                 res["entropy_loss"].item()], dtype=np.float32))
+            return res
+
+        agent.hook.objective = wrapped
+
+        observation, state, _ = env.reset()
+        T = factory.num_steps_per_update
+        step = 0
+        while True:
+            action = agent.act(observation, state)
+            observation, state, reward, terminated, truncated, _ = env.step(action)
+            flat_index = (torch.arange(8) + step * 8).reshape(8, 1)
+            ready = agent.step(observation, reward, terminated, truncated, state, flat_index=flat_index)
+            step += 1
+            if ready:
+                break
+        buffer_in = {k: np_(v) for k, v in agent.buffer.storage.items()}
+        torch.manual_seed(99)  # generator state at the update boundary
+        metrics = agent.update()
+        buffer_out = {k: np_(agent.buffer.storage[k]) for k in ("next_value", "advantage", "return")}
+
+        p = tag + "_"
+        out[p + "factory_keys"] = np.array(list(factory_kwargs.keys()))
+        out[p + "factory_vals"] = np.array([-1.0 if v is None else float(v) for v in factory_kwargs.values()])
+        for k, v in state0.items():
+            out[p + "param0/" + k] = v
+        out[p + "param_names"] = np.array(list(state0.keys()))
+        for k, v in buffer_in.items():
+            out[p + "buffer_in/" + k] = v
+        out[p + "buffer_keys"] = np.array(list(buffer_in.keys()))
+        for k, v in buffer_out.items():
+            out[p + "buffer_out/" + k] = v
+        out[p + "objectives"] = np.stack(trace["objectives"])
+        out[p + "indices"] = np.stack(trace["indices"])
+        out[p + "grads_unclipped"] = np.stack(trace["grads_unclipped"])
+        out[p + "grads"] = np.stack(trace["grads"])
+        out[p + "params_after"] = np.stack(trace["params_after"])
+        out[p + "metric_keys"] = np.array(list(metrics.keys()))
+        out[p + "metric_vals"] = np.array(list(metrics.values()), dtype=np.float64)
+        print(f"update trace {tag}: {len(trace['objectives'])} train steps, buffer leaves {list(buffer_in)}")
+    np.savez_compressed(HERE / "update_trace.npz", **out)
+
+
+def main():
+    cusrl = import_reference()
+    cusrl.config.set_device("cpu")
+    make_gae(cusrl)
+    make_next_value(cusrl)
+    make_randperm(cusrl)
+    make_losses(cusrl)
+    make_merge(cusrl)
+    make_update_trace(cusrl)
+    leaked = list(REFERENCE.rglob("__pycache__"))
+    assert not leaked, f"bytecode leaked into the reference tree: {leaked[:3]}"
+
+
+if __name__ == "__main__":
+    main()

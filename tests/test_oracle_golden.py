@@ -1,0 +1,181 @@
+"""Pin the CPU oracle: every function of oracle/cusrl_oracle.c against (i) golden vectors produced by
+running the reference (tests/golden/make_golden.py) and (ii) the reference's own known-answer tests
+(values quoted from cusrl_test/hook/on_policy/test_gae.py:8-31, test_ppo.py:8-32)."""
+
+import numpy as np
+import pytest
+
+import oracle
+
+
+def cases(npz):
+    return range(int(npz["num_cases"]))
+
+
+def test_gae_bit_exact_vs_reference(golden):
+    g = golden("gae")
+    for i in cases(g):
+        p = f"c{i}_"
+        gamma, lamda, lv = g[p + "params"]
+        adv, ret = oracle.gae(g[p + "reward"], g[p + "done"], g[p + "value"], g[p + "next_value"], gamma, lamda,
+                              None if lv < 0 else lv)
+        assert np.array_equal(adv, g[p + "advantage"]), f"case {i}: advantage not bit-exact"
+        assert np.array_equal(ret, g[p + "return"]), f"case {i}: return not bit-exact"
+
+
+def test_gae_known_answers_from_reference_tests():
+    # test_gae.py:8-16
+    reward = np.ones((3, 1, 1), np.float32)
+    done = np.array([False, True, False]).reshape(3, 1, 1)
+    zeros = np.zeros_like(reward)
+    adv, _ = oracle.gae(reward, done, zeros, zeros, 0.5, 1.0)
+    assert np.allclose(adv.ravel(), [1.5, 1.0, 1.0])
+    # test_gae.py:19-31
+    adv, ret = oracle.gae(np.array([1.0, 2.0]).reshape(2, 1, 1), np.zeros((2, 1, 1), bool),
+                          np.array([0.5, 1.0]).reshape(2, 1, 1), np.array([1.0, 0.0]).reshape(2, 1, 1), 0.5, 1.0, 0.0)
+    assert np.allclose(adv.ravel(), [1.5, 1.0])
+    assert np.allclose(ret.ravel(), [1.5, 2.0])
+
+
+def test_advantage_normalisation_vs_reference(golden):
+    g = golden("gae")
+    for i in cases(g):
+        p = f"c{i}_"
+        adv = g[p + "advantage"]
+        if adv.shape[0] * adv.shape[1] < 2:
+            continue
+        var, mean = oracle.var_mean(adv)
+        np.testing.assert_allclose(mean, g[p + "mean"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(var, g[p + "var"], rtol=1e-5)
+        # torch's var_mean is alignment dependent at the last ulp (the reference recomputes the statistics on
+        # its own copy), so even with the recorded statistics the apply step is compared by tolerance
+        np.testing.assert_allclose(oracle.normalize(adv, g[p + "mean"], g[p + "var"]), g[p + "normalized"],
+                                   rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(oracle.normalize(adv, mean, var), g[p + "normalized"], rtol=1e-5, atol=1e-6)
+
+
+def test_next_value_vs_reference(golden):
+    g = golden("next_value")
+
+    def critic(state, D):
+        base = np.float32(0.25) * state.sum(-1, keepdims=True, dtype=np.float32) + np.float32(0.5) * state[..., :1]
+        return np.concatenate([base * np.float32(d + 1) for d in range(D)], -1).astype(np.float32)
+
+    for i in cases(g):
+        p = f"c{i}_"
+        value, nobs = g[p + "value"], g[p + "next_observation"]
+        term, trunc = g[p + "terminated"], g[p + "truncated"]
+        term_value, bootstrap = g[p + "params"]
+        D = value.shape[-1]
+        tv = critic(nobs[trunc.squeeze(-1)], D)
+        out, k = oracle.next_value(value, term, trunc, critic(nobs[-1], D), tv, bool(bootstrap), term_value)
+        assert k == int(trunc.sum())
+        np.testing.assert_allclose(out, g[p + "next_value"], rtol=1e-6, atol=1e-6)
+        # everything that is not a critic output is a pure copy -> bit-exact
+        copied = np.ones(value.shape[:2], bool)
+        copied[-1] = False
+        if bootstrap:
+            copied &= ~trunc.squeeze(-1)
+        assert np.array_equal(out[copied], g[p + "next_value"][copied])
+
+
+def test_randperm_stream_bit_exact(golden):
+    g = golden("randperm")
+    for i in cases(g):
+        p = f"c{i}_"
+        seed, T, N, mbs = (int(v) for v in g[p + "params"])
+        gen = oracle.Mt19937(seed)
+        assert np.array_equal(gen.randperm(T * N), g[p + "raw0"])
+        assert np.array_equal(gen.randperm(T * N), g[p + "raw1"])
+        batches = oracle.mini_batch_indices(seed, T * N, 3, mbs)
+        for e in range(3):
+            assert np.array_equal(np.concatenate(batches[e]), g[p + "indices"][e])
+    # first values observed in SURVEY.md §8c (torch 2.10.0 CPU)
+    assert oracle.Mt19937(0).randperm(16)[:8].tolist() == [12, 10, 9, 6, 11, 8, 13, 5]
+    assert oracle.Mt19937(0).randperm(98304)[:4].tolist() == [2732, 3934, 72341, 64776]
+    assert oracle.Mt19937(42).randperm(4096)[:4].tolist() == [3174, 3363, 876, 1219]
+
+
+def test_randperm_matches_installed_torch():
+    torch = pytest.importorskip("torch")
+    for seed, n in [(0, 1), (1, 2), (5, 1000), (123456789, 4097)]:
+        torch.manual_seed(seed)
+        a = torch.randperm(n)
+        b = torch.randperm(n)
+        gen = oracle.Mt19937(seed)
+        assert np.array_equal(gen.randperm(n), a.numpy())
+        assert np.array_equal(gen.randperm(n), b.numpy())
+
+
+def test_temporal_gather_vs_reference(golden):
+    g = golden("randperm")
+    T, N = 3, 10
+    env = np.arange(N, dtype=np.float32).reshape(N, 1)
+    storage = np.stack([env * 100 + t for t in range(T)])
+    batches = oracle.mini_batch_indices(3, N, 2, 3)
+    got = [oracle.gather_rows(storage, idx, temporal=True) for epoch in batches for idx in epoch]
+    assert np.array_equal(np.stack(got), g["temporal_obs"])
+
+
+def test_gather_rows_is_flat_indexing():
+    rng = np.random.default_rng(0)
+    storage = rng.standard_normal((5, 7, 3)).astype(np.float32)
+    idx = rng.permutation(35)[:20]
+    assert np.array_equal(oracle.gather_rows(storage, idx), storage.reshape(35, 3)[idx])
+    flags = rng.random((5, 7, 1)) < 0.5
+    assert np.array_equal(oracle.gather_rows(flags, idx), flags.reshape(35, 1)[idx])
+    assert oracle.gather_rows(storage, np.zeros(0, np.int64)).shape == (0, 3)
+
+
+def test_buffer_push_copies_one_step():
+    storage = np.zeros((3, 2, 4), np.float32)
+    step = np.arange(8, dtype=np.float32).reshape(2, 4)
+    oracle.buffer_push(step, storage, 1)
+    assert np.array_equal(storage[1], step) and not storage[0].any() and not storage[2].any()
+
+
+def test_merge_mean_var_vs_reference(golden):
+    g = golden("merge_mean_var")
+    for i in cases(g):
+        p = f"c{i}_"
+        mean, var = oracle.merge_mean_var(g[p + "means"], g[p + "vars"])
+        np.testing.assert_allclose(mean, g[p + "mean"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(var, g[p + "var"], rtol=1e-6)
+
+
+def test_losses_and_gradients_vs_reference(golden):
+    g = golden("losses")
+    for i in cases(g):
+        p = f"c{i}_"
+        clip, vclip, w_sur, w_val, w_ent = g[p + "params"]
+        out = oracle.ppo_loss(g[p + "advantage"], g[p + "old_logp"], g[p + "action"], g[p + "mean"], g[p + "std"],
+                              g[p + "ret"], g[p + "curr_value"], g[p + "old_value"], clip=clip,
+                              value_clip=None if vclip < 0 else vclip, w_sur=w_sur, w_val=w_val, w_ent=w_ent)
+        np.testing.assert_allclose(out["logp"], g[p + "logp"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out["entropy"], g[p + "entropy"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out["ratio"], g[p + "ratio"], rtol=2e-5)
+        np.testing.assert_allclose(out["losses"][0], g[p + "value_loss"], rtol=1e-5)
+        np.testing.assert_allclose(out["losses"][1], g[p + "surrogate"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(out["losses"][2], g[p + "entropy_loss"], rtol=1e-5, atol=1e-8)
+        scale = 1.0 / g[p + "mean"].shape[0]
+        np.testing.assert_allclose(out["d_mean"], g[p + "d_mean"], rtol=1e-4, atol=1e-6 * scale)
+        np.testing.assert_allclose(out["d_std"], g[p + "d_std"], rtol=1e-4, atol=1e-5 * scale)
+        np.testing.assert_allclose(out["d_value"], g[p + "d_value"], rtol=1e-5, atol=1e-7 * scale)
+        lp, en = oracle.normal_logp_entropy(g[p + "action"], g[p + "mean"], g[p + "std"])
+        np.testing.assert_allclose(lp, g[p + "logp"], rtol=1e-5, atol=1e-5)
+        kl = oracle.normal_kl(g[p + "old_mean"], g[p + "old_std"], g[p + "mean"], g[p + "std"])
+        np.testing.assert_allclose(kl, g[p + "kl"], rtol=1e-4, atol=1e-5)
+
+
+def test_loss_known_answers_from_reference_tests():
+    # test_ppo.py:8-14 — A=[1,-2], ratio=[1.5,0.5], eps=0.2 -> 0.2.  Build ratio through logp: one action dim,
+    # std=1, action=mean -> logp = -log(sqrt(2pi)); old_logp = logp - log(ratio).
+    mean = np.zeros((2, 1), np.float32)
+    std = np.ones((2, 1), np.float32)
+    logp = np.float32(-np.log(np.sqrt(2 * np.pi)))
+    old_logp = (logp - np.log(np.array([[1.5], [0.5]]))).astype(np.float32)
+    out = oracle.ppo_loss(np.array([[1.0], [-2.0]]), old_logp, mean, mean, std, np.zeros((2, 1)), np.zeros((2, 1)),
+                          clip=0.2, w_sur=1.0, w_val=0.5, w_ent=0.5)
+    assert out["losses"][1] == pytest.approx(0.2, rel=1e-5)
+    # test_ppo.py:28-32 form: entropy loss = -mean(entropy) * w
+    assert out["losses"][2] == pytest.approx(-0.5 * (0.5 + 0.5 * np.log(2 * np.pi)), rel=1e-6)
