@@ -1,0 +1,81 @@
+"""ctypes binding of ``libcusrl_hip.so`` (C ABI declared in ``include/cusrl_hip.h``).
+
+The library is the product: there is no CPU or eager fallback.  If it has not been built
+(``python __graft_entry__.py`` / ``__graft_entry__.build()``) every hot-path call raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libcusrl_hip.so"
+ABI_VERSION = 1
+MAX_FIELDS = 24
+
+
+class Field(Structure):
+    """``cusrl_field_t`` — one buffer leaf of a multi-leaf launch."""
+
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("row_bytes", c_int64)]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_P = c_void_p
+_SIGNATURES = {
+    "cusrl_abi_version": (c_int, []),
+    "cusrl_error_string": (c_char_p, [c_int]),
+    "cusrl_buffer_push": (c_int, [POINTER(Field), c_int, c_int64, c_int64, _P]),
+    "cusrl_next_value": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, c_int64, c_int64, c_int64, _P]),
+    "cusrl_flag_blocks": (c_int64, [c_int64]),
+    "cusrl_compact_flags": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P]),
+    "cusrl_scatter_rows": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
+    "cusrl_gae": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_double, c_double, c_double, _P]),
+    "cusrl_gae_num_partials": (c_int64, [c_int64, c_int64, c_int64]),
+    "cusrl_col_stats": (c_int, [_P, c_int64, c_int64, _P, _P]),
+    "cusrl_col_stats_num_partials": (c_int64, [c_int64, c_int64]),
+    "cusrl_stats_finalize": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P]),
+    "cusrl_normalize": (c_int, [_P, _P, _P, c_float, c_int64, c_int64, _P]),
+    "cusrl_merge_mean_var": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
+    "cusrl_gather_rows": (c_int, [POINTER(Field), c_int, _P, c_int64, c_int64, c_int64, c_int, _P]),
+    "cusrl_ppo_loss_fwd_bwd": (
+        c_int,
+        [_P] * 8 + [c_int64] * 3 + [c_double] * 5 + [_P] * 8 + [_P, _P],
+    ),
+    "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library once; fail loudly when it is missing or stale."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise NativeError(
+                f"{LIB_PATH} is missing: the gfx950 HIP extension has not been built. "
+                "Run `python __graft_entry__.py` (or `__graft_entry__.build()`) first; "
+                "cusrl_amd has no CPU / eager fallback for the rollout + PPO-update hot path."
+            )
+        handle = ctypes.CDLL(str(LIB_PATH))
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = stale library
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.cusrl_abi_version() != ABI_VERSION:
+            raise NativeError(f"ABI mismatch: library {handle.cusrl_abi_version()}, binding {ABI_VERSION}; rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        text = lib().cusrl_error_string(code).decode()
+        raise NativeError(f"{what} failed with code {code}: {text}")

@@ -1,0 +1,350 @@
+// Rollout-buffer data movement for gfx950: step append (a1), minibatch gather (a7/a8), ordered flag
+// compaction and row scatter (a3 support).  All kernels are HBM-bound byte movers: 16 B per lane where
+// alignment allows, every leaf of a transition handled by ONE launch through a by-value leaf table
+// (no device-side table upload, no per-leaf launches).
+#include "common.hpp"
+
+namespace cusrl {
+
+// --------------------------------------------------------------------------------------------- push
+constexpr int kPushUnroll = 2;                                 // independent 16 B transactions per lane
+constexpr int64_t kPushBlockBytes = int64_t(kBlock) * 16 * kPushUnroll;
+
+struct PushTable {
+    const char *src[CUSRL_MAX_FIELDS];
+    char *dst[CUSRL_MAX_FIELDS];
+    int64_t bytes[CUSRL_MAX_FIELDS];
+    int32_t block_start[CUSRL_MAX_FIELDS + 1];
+    int32_t vec[CUSRL_MAX_FIELDS];  // 16 / 4 / 1 bytes per lane access
+    int32_t n;
+};
+
+__global__ __launch_bounds__(kBlock) void push_kernel(const PushTable tab) {
+    const int blk = blockIdx.x;
+    int f = 0;
+    while (f + 1 < tab.n && blk >= tab.block_start[f + 1]) ++f;  // wave-uniform scan of <= 24 entries
+    const char *__restrict__ src = tab.src[f];
+    char *__restrict__ dst = tab.dst[f];
+    const int64_t total = tab.bytes[f];
+    const int64_t begin = int64_t(blk - tab.block_start[f]) * kPushBlockBytes;
+    const int64_t end = min(begin + kPushBlockBytes, total);
+    const int vec = tab.vec[f];
+    if (vec == 16) {
+        uint4 regs[kPushUnroll];
+        int64_t offs[kPushUnroll];
+#pragma unroll
+        for (int u = 0; u < kPushUnroll; ++u) {
+            offs[u] = begin + (int64_t(u) * kBlock + threadIdx.x) * 16;
+            if (offs[u] < end) regs[u] = *reinterpret_cast<const uint4 *>(src + offs[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kPushUnroll; ++u)
+            if (offs[u] < end) *reinterpret_cast<uint4 *>(dst + offs[u]) = regs[u];
+    } else if (vec == 4) {
+        for (int64_t o = begin + int64_t(threadIdx.x) * 4; o < end; o += int64_t(kBlock) * 4)
+            *reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(src + o);
+    } else {
+        for (int64_t o = begin + threadIdx.x; o < end; o += kBlock) dst[o] = src[o];
+    }
+}
+
+// --------------------------------------------------------------------------------------------- gather
+constexpr int kGatherItems = 4;                       // lane-ops per thread, all loads issued before any store
+constexpr int kGatherOpsPerBlock = kBlock * kGatherItems;
+
+struct GatherTable {
+    const char *src[CUSRL_MAX_FIELDS];
+    char *dst[CUSRL_MAX_FIELDS];
+    int32_t row_bytes[CUSRL_MAX_FIELDS];
+    int32_t unit[CUSRL_MAX_FIELDS];           // bytes per lane-op: 16 / 8 / 4 / 2 / 1;  0 = "four 1-byte rows packed"
+    int32_t lanes_per_row[CUSRL_MAX_FIELDS];  // row_bytes / unit
+    int32_t block_start[CUSRL_MAX_FIELDS + 1];
+    int32_t n;
+};
+
+template <typename V>
+__device__ __forceinline__ void gather_unit(const char *__restrict__ src, char *__restrict__ dst,
+                                            const int64_t *__restrict__ idx, int64_t ops, int64_t op0, int lpr,
+                                            int64_t row_bytes, int64_t B, int64_t N, bool temporal) {
+    V regs[kGatherItems];
+    int64_t dst_off[kGatherItems];
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it) {
+        const int64_t op = op0 + int64_t(it) * kBlock;
+        dst_off[it] = -1;
+        if (op < ops) {
+            int64_t r, c;
+            if (lpr == 1) {
+                r = op;
+                c = 0;
+            } else {
+                r = op / lpr;
+                c = op - r * lpr;
+            }
+            int64_t src_row;
+            if (temporal) {
+                const int64_t t = r / B, b = r - t * B;
+                src_row = t * N + idx[b];
+            } else {
+                src_row = idx[r];
+            }
+            regs[it] = *reinterpret_cast<const V *>(src + src_row * row_bytes + c * int64_t(sizeof(V)));
+            dst_off[it] = r * row_bytes + c * int64_t(sizeof(V));
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it)
+        if (dst_off[it] >= 0) *reinterpret_cast<V *>(dst + dst_off[it]) = regs[it];
+}
+
+__global__ __launch_bounds__(kBlock) void gather_kernel(const GatherTable tab, const int64_t *__restrict__ idx,
+                                                        int64_t B, int64_t T, int64_t N, int temporal) {
+    const int blk = blockIdx.x;
+    int f = 0;
+    while (f + 1 < tab.n && blk >= tab.block_start[f + 1]) ++f;
+    const char *__restrict__ src = tab.src[f];
+    char *__restrict__ dst = tab.dst[f];
+    const int unit = tab.unit[f];
+    const int lpr = tab.lanes_per_row[f];
+    const int64_t row_bytes = tab.row_bytes[f];
+    const int64_t rows = temporal ? T * B : B;
+    const int64_t op0 = int64_t(blk - tab.block_start[f]) * kGatherOpsPerBlock + threadIdx.x;
+    const bool temp = temporal != 0;
+    if (unit == 0) {
+        // 1-byte leaves (terminated / truncated / done): one lane gathers 4 consecutive output rows and
+        // issues a single 4-byte store instead of four byte stores.
+        const int64_t ops = (rows + 3) / 4;
+#pragma unroll
+        for (int it = 0; it < kGatherItems; ++it) {
+            const int64_t op = op0 + int64_t(it) * kBlock;
+            if (op >= ops) break;
+            const int64_t r0 = op * 4;
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r = r0 + j;
+                if (r < rows) {
+                    int64_t src_row;
+                    if (temp) {
+                        const int64_t t = r / B, b = r - t * B;
+                        src_row = t * N + idx[b];
+                    } else {
+                        src_row = idx[r];
+                    }
+                    packed |= uint32_t(uint8_t(src[src_row])) << (8 * j);
+                }
+            }
+            if (r0 + 4 <= rows) {
+                *reinterpret_cast<uint32_t *>(dst + r0) = packed;
+            } else {
+                for (int j = 0; r0 + j < rows; ++j) dst[r0 + j] = char(packed >> (8 * j));
+            }
+        }
+        return;
+    }
+    const int64_t ops = rows * lpr;
+    switch (unit) {
+        case 16: gather_unit<uint4>(src, dst, idx, ops, op0, lpr, row_bytes, B, N, temp); break;
+        case 8: gather_unit<uint2>(src, dst, idx, ops, op0, lpr, row_bytes, B, N, temp); break;
+        case 4: gather_unit<uint32_t>(src, dst, idx, ops, op0, lpr, row_bytes, B, N, temp); break;
+        case 2: gather_unit<uint16_t>(src, dst, idx, ops, op0, lpr, row_bytes, B, N, temp); break;
+        default: gather_unit<uint8_t>(src, dst, idx, ops, op0, lpr, row_bytes, B, N, temp); break;
+    }
+}
+
+// --------------------------------------------------------------------------------------------- compaction
+constexpr int kFlagChunk = kBlock * 16;  // flags per block: one 16 B load per lane
+
+__device__ __forceinline__ int load_flags16(const uint8_t *__restrict__ flags, int64_t base, int64_t n,
+                                            uint32_t (&w)[4]) {
+    // returns the number of set flags among the 16 bytes starting at `base` (bounds-checked)
+    int count = 0;
+    if (base + 16 <= n && (reinterpret_cast<uintptr_t>(flags + base) & 15) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(flags + base);
+        w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+    } else {
+        w[0] = w[1] = w[2] = w[3] = 0;
+        for (int j = 0; j < 16; ++j)
+            if (base + j < n && flags[base + j]) w[j >> 2] |= 1u << (8 * (j & 3));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // bools are 0/1 bytes in torch, but treat any non-zero byte as set
+        uint32_t x = w[k];
+        x |= x >> 4;
+        x |= x >> 2;
+        x |= x >> 1;
+        x &= 0x01010101u;
+        w[k] = x;
+        count += __popc(x);
+    }
+    return count;
+}
+
+__global__ __launch_bounds__(kBlock) void count_flags_kernel(const uint8_t *__restrict__ flags, int64_t n,
+                                                             int32_t *__restrict__ block_counts) {
+    __shared__ int scratch[kWavesPerBlock];
+    uint32_t w[4];
+    const int64_t base = int64_t(blockIdx.x) * kFlagChunk + int64_t(threadIdx.x) * 16;
+    const int c = base < n ? load_flags16(flags, base, n, w) : 0;
+    const int total = block_sum(c, scratch);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void compact_flags_kernel(const uint8_t *__restrict__ flags, int64_t n,
+                                                               const int32_t *__restrict__ block_counts,
+                                                               int64_t *__restrict__ indices_out,
+                                                               int32_t *__restrict__ count_out) {
+    __shared__ int scratch[kWavesPerBlock];
+    // offset of this block = sum of the counts of all earlier blocks (fixed order -> deterministic output)
+    int before = 0;
+    for (int i = threadIdx.x; i < int(blockIdx.x); i += kBlock) before += block_counts[i];
+    __shared__ int block_offset;
+    const int prefix = block_sum(before, scratch);
+    if (threadIdx.x == 0) block_offset = prefix;
+    __syncthreads();
+
+    uint32_t w[4];
+    const int64_t base = int64_t(blockIdx.x) * kFlagChunk + int64_t(threadIdx.x) * 16;
+    const int c = base < n ? load_flags16(flags, base, n, w) : 0;
+    int total;
+    int pos = block_offset + block_exclusive_scan(c, scratch, total);
+    if (c) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if ((w[j >> 2] >> (8 * (j & 3))) & 1u) indices_out[pos++] = base + j;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count_out = block_offset + total;
+}
+
+// --------------------------------------------------------------------------------------------- scatter
+template <typename V>
+__global__ __launch_bounds__(kBlock) void scatter_rows_kernel(const char *__restrict__ src,
+                                                              const int64_t *__restrict__ indices,
+                                                              char *__restrict__ dst, int64_t K, int lpr,
+                                                              int64_t row_bytes, const int32_t *__restrict__ count_dev) {
+    const int64_t limit = count_dev ? min(K, int64_t(*count_dev)) : K;
+    const int64_t op = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (op >= limit * lpr) return;
+    const int64_t k = op / lpr, c = op - k * lpr;
+    *reinterpret_cast<V *>(dst + indices[k] * row_bytes + c * int64_t(sizeof(V))) =
+        *reinterpret_cast<const V *>(src + k * row_bytes + c * int64_t(sizeof(V)));
+}
+
+static int pick_unit(const void *a, const void *b, int64_t row_bytes) {
+    for (int unit : {16, 8, 4, 2})
+        if (row_bytes % unit == 0 && aligned(a, unit) && aligned(b, unit)) return unit;
+    return 1;
+}
+
+}  // namespace cusrl
+
+using namespace cusrl;
+
+extern "C" int cusrl_buffer_push(const cusrl_field_t *fields, int n_fields, int64_t cursor, int64_t N, void *stream) {
+    if (n_fields == 0) return 0;
+    if (!fields || n_fields < 0 || cursor < 0 || N < 0) return CUSRL_E_INVALID;
+    if (n_fields > CUSRL_MAX_FIELDS) return CUSRL_E_TOO_MANY;
+    PushTable tab;
+    int32_t blocks = 0;
+    int n = 0;
+    for (int i = 0; i < n_fields; ++i) {
+        const int64_t bytes = N * fields[i].row_bytes;
+        if (fields[i].row_bytes < 0 || (bytes > 0 && (!fields[i].src || !fields[i].dst))) return CUSRL_E_INVALID;
+        if (bytes == 0) continue;
+        tab.src[n] = static_cast<const char *>(fields[i].src);
+        tab.dst[n] = static_cast<char *>(fields[i].dst) + cursor * bytes;
+        tab.bytes[n] = bytes;
+        tab.vec[n] = (bytes % 16 == 0 && aligned(tab.src[n], 16) && aligned(tab.dst[n], 16))  ? 16
+                     : (bytes % 4 == 0 && aligned(tab.src[n], 4) && aligned(tab.dst[n], 4)) ? 4
+                                                                                             : 1;
+        tab.block_start[n] = blocks;
+        const int64_t nb = ceil_div(bytes, kPushBlockBytes);
+        if (nb + blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+        blocks += int32_t(nb);
+        ++n;
+    }
+    if (n == 0) return 0;
+    tab.block_start[n] = blocks;
+    tab.n = n;
+    hipLaunchKernelGGL(push_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream), tab);
+    return launch_status();
+}
+
+extern "C" int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, const int64_t *indices, int64_t B,
+                                 int64_t T, int64_t N, int temporal, void *stream) {
+    if (n_fields == 0 || B == 0) return 0;
+    if (!fields || !indices || n_fields < 0 || B < 0 || T < 1 || N < 1) return CUSRL_E_INVALID;
+    if (n_fields > CUSRL_MAX_FIELDS) return CUSRL_E_TOO_MANY;
+    const int64_t rows = temporal ? T * B : B;
+    GatherTable tab;
+    int64_t blocks = 0;
+    int n = 0;
+    for (int i = 0; i < n_fields; ++i) {
+        const int64_t rb = fields[i].row_bytes;
+        if (rb < 0 || rb > INT32_MAX || (rb > 0 && (!fields[i].src || !fields[i].dst))) return CUSRL_E_INVALID;
+        if (rb == 0) continue;
+        tab.src[n] = static_cast<const char *>(fields[i].src);
+        tab.dst[n] = static_cast<char *>(fields[i].dst);
+        tab.row_bytes[n] = int32_t(rb);
+        int64_t ops;
+        if (rb == 1 && aligned(tab.dst[n], 4)) {
+            tab.unit[n] = 0;
+            tab.lanes_per_row[n] = 1;
+            ops = (rows + 3) / 4;
+        } else {
+            const int unit = pick_unit(tab.src[n], tab.dst[n], rb);
+            tab.unit[n] = unit;
+            tab.lanes_per_row[n] = int32_t(rb / unit);
+            ops = rows * (rb / unit);
+        }
+        tab.block_start[n] = int32_t(blocks);
+        blocks += ceil_div(ops, kGatherOpsPerBlock);
+        if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+        ++n;
+    }
+    if (n == 0) return 0;
+    tab.block_start[n] = int32_t(blocks);
+    tab.n = n;
+    hipLaunchKernelGGL(gather_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), tab, indices, B,
+                       T, N, temporal);
+    return launch_status();
+}
+
+extern "C" int64_t cusrl_flag_blocks(int64_t n) { return n <= 0 ? 0 : ceil_div(n, kFlagChunk); }
+
+extern "C" int cusrl_compact_flags(const uint8_t *flags, int64_t n, int32_t *block_counts, int recount,
+                                   int64_t *indices_out, int32_t *count_out, void *stream) {
+    if (n < 0 || !count_out) return CUSRL_E_INVALID;
+    if (n == 0) return static_cast<int>(hipMemsetAsync(count_out, 0, sizeof(int32_t), as_stream(stream)));
+    if (!flags || !block_counts || !indices_out) return CUSRL_E_INVALID;
+    const int64_t blocks = cusrl_flag_blocks(n);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    if (recount) {
+        hipLaunchKernelGGL(count_flags_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), flags, n,
+                           block_counts);
+        if (int rc = launch_status()) return rc;
+    }
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), flags, n,
+                       block_counts, indices_out, count_out);
+    return launch_status();
+}
+
+extern "C" int cusrl_scatter_rows(const void *src, const int64_t *indices, void *dst, int64_t K, int64_t row_bytes,
+                                  const int32_t *count_dev, void *stream) {
+    if (K == 0 || row_bytes == 0) return 0;
+    if (!src || !indices || !dst || K < 0 || row_bytes < 0) return CUSRL_E_INVALID;
+    const int unit = pick_unit(src, dst, row_bytes) >= 4 ? 4 : 1;
+    const int lpr = int(row_bytes / unit);
+    const int64_t blocks = ceil_div(K * lpr, kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    if (unit == 4)
+        hipLaunchKernelGGL(scatter_rows_kernel<uint32_t>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream),
+                           static_cast<const char *>(src), indices, static_cast<char *>(dst), K, lpr, row_bytes,
+                           count_dev);
+    else
+        hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream),
+                           static_cast<const char *>(src), indices, static_cast<char *>(dst), K, lpr, row_bytes,
+                           count_dev);
+    return launch_status();
+}

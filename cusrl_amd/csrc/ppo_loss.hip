@@ -1,0 +1,298 @@
+// Fused PPO objective for gfx950 (a9-a13): Normal log-prob + entropy + probability ratio, clipped surrogate,
+// (clipped) value loss and entropy bonus, forward AND backward in one pass over the minibatch.
+//
+// Reads  advantage 4 + old_logp 4 + action/mean/std 3*4A + return 4D + curr_value 4D (+ old_value 4D) bytes,
+// writes d_mean/d_std 2*4A + d_value 4D bytes per sample (264 B at A=12, D=1) — HBM-bound, ~60 flops/sample.
+//
+// Layout strategy (A % 4 == 0): the [B, A] matrices are streamed as a flat array of 16-byte chunks so that
+// every global access is a fully coalesced dwordx4 (lane i <-> chunk i), independent of the row length.  A
+// block owns 256 rows = 256*LPR chunks (LPR = A/4 chunks per row); per-chunk partial log-prob / entropy sums
+// are exchanged through LDS so that one lane per row finishes the scalar part (ratio, clipping, value loss),
+// publishes d(loss)/d(logp) through LDS, and the chunk owners (who still hold action/mean/std in registers)
+// emit the gradients.  Scalar statistics use wave64 shuffle reductions, fp64 partials per block, fixed order.
+#include "common.hpp"
+
+namespace cusrl {
+
+struct LossParams {
+    float lo, hi;            // fp32(1 - clip), fp32(1 + clip)                         ppo.py:16
+    float value_clip;        // < 0: plain MSE                                          value.py:131-135
+    float g_sur, g_ent, g_val;  // d loss / d(min term), d(entropy_b), d(sq err) incl. weights and 1/B
+    float w_sur, w_val, w_ent;
+};
+
+__device__ __forceinline__ float log_sqrt_2pi() { return 0.918938533204672741780329736406f; }  // log(sqrt(2 pi))
+__device__ __forceinline__ float entropy_const() { return 1.418938533204672741780329736406f; }  // 0.5 + 0.5 log(2 pi)
+
+// Per-row scalar part shared by both kernels.  Returns d(loss)/d(logp_row).
+__device__ __forceinline__ float row_terms(float logp, float entropy, float old_logp, float adv, const LossParams &p,
+                                           double &sur_acc, double &ent_acc, float &ratio_out, float &lr_out) {
+    const float lr = logp - old_logp;                 // action_logp_ratio        common.py:35
+    const float ratio = expf(lr);                     // action_prob_ratio        common.py:41
+    const float s1 = adv * ratio;                     // ppo.py:14
+    const float rc = fminf(fmaxf(ratio, p.lo), p.hi); // clamp                    ppo.py:16
+    const float s2 = adv * rc;
+    sur_acc += double(fminf(s1, s2));
+    ent_acc += double(entropy);
+    const bool inside = ratio >= p.lo && ratio <= p.hi;
+    float d_ratio;  // autograd of min(): ties split evenly, clamp passes on the closed interval
+    if (s1 < s2)
+        d_ratio = adv;
+    else if (s1 > s2)
+        d_ratio = inside ? adv : 0.0f;
+    else
+        d_ratio = 0.5f * adv + (inside ? 0.5f * adv : 0.0f);
+    ratio_out = ratio;
+    lr_out = lr;
+    return p.g_sur * d_ratio * ratio;
+}
+
+__device__ __forceinline__ void value_terms(const float *__restrict__ ret, const float *__restrict__ curr_value,
+                                            const float *__restrict__ old_value, float *__restrict__ d_value,
+                                            int64_t row, int D, const LossParams &p, double &val_acc) {
+    for (int d = 0; d < D; ++d) {
+        const int64_t i = row * D + d;
+        const float cv = curr_value[i], R = ret[i];
+        const float e1 = cv - R, l1 = e1 * e1, g1 = 2.0f * e1;
+        float g;
+        if (p.value_clip < 0.0f) {
+            val_acc += double(l1);  // mse_loss(return, curr_value)             value.py:132
+            g = g1;
+        } else {
+            const float c = p.value_clip, v = old_value[i];
+            const float dv = cv - v;
+            const float dvc = fminf(fmaxf(dv, -c), c);
+            const float e2 = (v + dvc) - R, l2 = e2 * e2;   // value.py:85-89
+            const float g2 = (dv >= -c && dv <= c) ? 2.0f * e2 : 0.0f;
+            val_acc += double(fmaxf(l1, l2));
+            g = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * (g1 + g2));
+        }
+        if (d_value) d_value[i] = p.g_val * g;
+    }
+}
+
+__device__ __forceinline__ void write_block_partials(double val_acc, double sur_acc, double ent_acc,
+                                                     double *__restrict__ partials) {
+    __shared__ double scratch[kWavesPerBlock];
+    const double v = block_sum(val_acc, scratch);
+    const double s = block_sum(sur_acc, scratch);
+    const double e = block_sum(ent_acc, scratch);
+    if (threadIdx.x == 0) {
+        partials[int64_t(blockIdx.x) * 3 + 0] = v;
+        partials[int64_t(blockIdx.x) * 3 + 1] = s;
+        partials[int64_t(blockIdx.x) * 3 + 2] = e;
+    }
+}
+
+constexpr int kRowsPerBlock = kBlock;
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
+    const float *__restrict__ advantage, const float *__restrict__ old_logp, const float *__restrict__ action,
+    const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ ret,
+    const float *__restrict__ curr_value, const float *__restrict__ old_value, int64_t B, int D, LossParams p,
+    float *__restrict__ logp_out, float *__restrict__ entropy_out, float *__restrict__ lr_out,
+    float *__restrict__ ratio_out, float *__restrict__ d_mean, float *__restrict__ d_std,
+    float *__restrict__ d_value, double *__restrict__ partials) {
+    __shared__ float lp_part[kRowsPerBlock * LPR];
+    __shared__ float en_part[kRowsPerBlock * LPR];
+    __shared__ float dlp_row[kRowsPerBlock];
+    const int64_t row0 = int64_t(blockIdx.x) * kRowsPerBlock;
+    const int64_t chunk0 = row0 * LPR;
+    const int64_t total_chunks = B * LPR;
+    const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(action);
+    const float4 *__restrict__ m4 = reinterpret_cast<const float4 *>(mean);
+    const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(std);
+
+    float4 x[LPR], mu[LPR], sg[LPR];
+#pragma unroll
+    for (int k = 0; k < LPR; ++k) {
+        const int64_t q = chunk0 + k * kBlock + threadIdx.x;
+        if (q < total_chunks) {
+            x[k] = x4[q];
+            mu[k] = m4[q];
+            sg[k] = s4[q];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LPR; ++k) {
+        const int64_t q = chunk0 + k * kBlock + threadIdx.x;
+        float lp = 0.0f, en = 0.0f;
+        if (q < total_chunks) {
+            const float xs[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+            const float ms[4] = {mu[k].x, mu[k].y, mu[k].z, mu[k].w};
+            const float ss[4] = {sg[k].x, sg[k].y, sg[k].z, sg[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float diff = xs[j] - ms[j], ls = logf(ss[j]);
+                // -((x - mu)^2) / (2 sigma^2) - log(sigma) - log(sqrt(2 pi))     distribution.py:207-209
+                lp += -(diff * diff) / (2.0f * (ss[j] * ss[j])) - ls - log_sqrt_2pi();
+                en += entropy_const() + ls;  // distribution.py:211-213
+            }
+        }
+        lp_part[k * kBlock + threadIdx.x] = lp;
+        en_part[k * kBlock + threadIdx.x] = en;
+    }
+    __syncthreads();
+
+    double val_acc = 0.0, sur_acc = 0.0, ent_acc = 0.0;
+    {
+        const int64_t row = row0 + threadIdx.x;
+        float dlp = 0.0f;
+        if (row < B) {
+            float logp = 0.0f, entropy = 0.0f;
+#pragma unroll
+            for (int j = 0; j < LPR; ++j) {
+                logp += lp_part[threadIdx.x * LPR + j];
+                entropy += en_part[threadIdx.x * LPR + j];
+            }
+            float ratio, lr;
+            dlp = row_terms(logp, entropy, old_logp[row], advantage[row], p, sur_acc, ent_acc, ratio, lr);
+            if (logp_out) logp_out[row] = logp;
+            if (entropy_out) entropy_out[row] = entropy;
+            if (lr_out) lr_out[row] = lr;
+            if (ratio_out) ratio_out[row] = ratio;
+            value_terms(ret, curr_value, old_value, d_value, row, D, p, val_acc);
+        }
+        dlp_row[threadIdx.x] = dlp;
+    }
+    __syncthreads();
+
+    float4 *__restrict__ dm4 = reinterpret_cast<float4 *>(d_mean);
+    float4 *__restrict__ ds4 = reinterpret_cast<float4 *>(d_std);
+#pragma unroll
+    for (int k = 0; k < LPR; ++k) {
+        const int local = k * kBlock + threadIdx.x;
+        const int64_t q = chunk0 + local;
+        if (q < total_chunks) {
+            const float dlp = dlp_row[local / LPR];
+            const float xs[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+            const float ms[4] = {mu[k].x, mu[k].y, mu[k].z, mu[k].w};
+            const float ss[4] = {sg[k].x, sg[k].y, sg[k].z, sg[k].w};
+            float gm[4], gs[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float diff = xs[j] - ms[j], var = ss[j] * ss[j];
+                gm[j] = dlp * (diff / var);                                           // d logp / d mean
+                gs[j] = dlp * ((diff * diff) / (var * ss[j]) - 1.0f / ss[j]) + p.g_ent / ss[j];  // + d entropy / d std
+            }
+            if (d_mean) dm4[q] = make_float4(gm[0], gm[1], gm[2], gm[3]);
+            if (d_std) ds4[q] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+        }
+    }
+    write_block_partials(val_acc, sur_acc, ent_acc, partials);
+}
+
+// Any action width: one lane per row, scalar accesses.
+__global__ __launch_bounds__(kBlock) void ppo_loss_rowwise_kernel(
+    const float *__restrict__ advantage, const float *__restrict__ old_logp, const float *__restrict__ action,
+    const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ ret,
+    const float *__restrict__ curr_value, const float *__restrict__ old_value, int64_t B, int A, int D, LossParams p,
+    float *__restrict__ logp_out, float *__restrict__ entropy_out, float *__restrict__ lr_out,
+    float *__restrict__ ratio_out, float *__restrict__ d_mean, float *__restrict__ d_std,
+    float *__restrict__ d_value, double *__restrict__ partials) {
+    double val_acc = 0.0, sur_acc = 0.0, ent_acc = 0.0;
+    const int64_t row = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (row < B) {
+        float logp = 0.0f, entropy = 0.0f;
+        for (int a = 0; a < A; ++a) {
+            const int64_t i = row * A + a;
+            const float diff = action[i] - mean[i], sg = std[i], ls = logf(sg);
+            logp += -(diff * diff) / (2.0f * (sg * sg)) - ls - log_sqrt_2pi();
+            entropy += entropy_const() + ls;
+        }
+        float ratio, lr;
+        const float dlp = row_terms(logp, entropy, old_logp[row], advantage[row], p, sur_acc, ent_acc, ratio, lr);
+        if (logp_out) logp_out[row] = logp;
+        if (entropy_out) entropy_out[row] = entropy;
+        if (lr_out) lr_out[row] = lr;
+        if (ratio_out) ratio_out[row] = ratio;
+        for (int a = 0; a < A; ++a) {
+            const int64_t i = row * A + a;
+            const float diff = action[i] - mean[i], sg = std[i], var = sg * sg;
+            if (d_mean) d_mean[i] = dlp * (diff / var);
+            if (d_std) d_std[i] = dlp * ((diff * diff) / (var * sg) - 1.0f / sg) + p.g_ent / sg;
+        }
+        value_terms(ret, curr_value, old_value, d_value, row, D, p, val_acc);
+    }
+    write_block_partials(val_acc, sur_acc, ent_acc, partials);
+}
+
+__global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double *__restrict__ partials, int64_t P,
+                                                                   int64_t B, int D, LossParams p,
+                                                                   float *__restrict__ losses_out) {
+    __shared__ double scratch[kWavesPerBlock];
+    double v = 0.0, s = 0.0, e = 0.0;
+    for (int64_t i = threadIdx.x; i < P; i += kBlock) {
+        v += partials[i * 3 + 0];
+        s += partials[i * 3 + 1];
+        e += partials[i * 3 + 2];
+    }
+    v = block_sum(v, scratch);
+    s = block_sum(s, scratch);
+    e = block_sum(e, scratch);
+    if (threadIdx.x == 0) {
+        losses_out[0] = float(v / double(B * D)) * p.w_val;   // mean * weight              value.py:137
+        losses_out[1] = -float(s / double(B)) * p.w_sur;      // -mean(min(...)) * weight   ppo.py:13-18,55
+        losses_out[2] = -float(e / double(B)) * p.w_ent;      // -mean(entropy) * weight    ppo.py:83-84
+    }
+}
+
+}  // namespace cusrl
+
+using namespace cusrl;
+
+extern "C" int64_t cusrl_ppo_loss_num_partials(int64_t B) { return B <= 0 ? 0 : ceil_div(B, kRowsPerBlock); }
+
+#define CUSRL_LAUNCH_CHUNKED(LPR)                                                                                     \
+    hipLaunchKernelGGL(ppo_loss_chunked_kernel<LPR>, dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, old_logp, \
+                       action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out, entropy_out,            \
+                       logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials)
+
+extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action,
+                                      const float *mean, const float *std, const float *ret, const float *curr_value,
+                                      const float *old_value, int64_t B, int64_t A, int64_t D, double clip,
+                                      double value_clip, double w_sur, double w_val, double w_ent, float *losses_out,
+                                      float *logp_out, float *entropy_out, float *logp_ratio_out, float *ratio_out,
+                                      float *d_mean, float *d_std, float *d_value, double *partials, void *stream) {
+    if (B <= 0 || A <= 0 || D <= 0) return CUSRL_E_INVALID;
+    if (!advantage || !old_logp || !action || !mean || !std || !ret || !curr_value || !losses_out || !partials)
+        return CUSRL_E_INVALID;
+    if (value_clip >= 0.0 && !old_value) return CUSRL_E_INVALID;
+    if (A > INT32_MAX || D > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    LossParams p;
+    p.lo = float(1.0 - clip);
+    p.hi = float(1.0 + clip);
+    p.value_clip = value_clip < 0.0 ? -1.0f : float(value_clip);
+    p.g_sur = float(-w_sur / double(B));
+    p.g_ent = float(-w_ent / double(B));
+    p.g_val = float(w_val / double(B * D));
+    p.w_sur = float(w_sur);
+    p.w_val = float(w_val);
+    p.w_ent = float(w_ent);
+    hipStream_t s = as_stream(stream);
+    const int64_t blocks = cusrl_ppo_loss_num_partials(B);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    const bool chunked = A % 4 == 0 && A / 4 <= 8 && aligned(action, 16) && aligned(mean, 16) && aligned(std, 16) &&
+                         (!d_mean || aligned(d_mean, 16)) && (!d_std || aligned(d_std, 16));
+    if (chunked) {
+        switch (A / 4) {
+            case 1: CUSRL_LAUNCH_CHUNKED(1); break;
+            case 2: CUSRL_LAUNCH_CHUNKED(2); break;
+            case 3: CUSRL_LAUNCH_CHUNKED(3); break;
+            case 4: CUSRL_LAUNCH_CHUNKED(4); break;
+            case 5: CUSRL_LAUNCH_CHUNKED(5); break;
+            case 6: CUSRL_LAUNCH_CHUNKED(6); break;
+            case 7: CUSRL_LAUNCH_CHUNKED(7); break;
+            default: CUSRL_LAUNCH_CHUNKED(8); break;
+        }
+    } else {
+        hipLaunchKernelGGL(ppo_loss_rowwise_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, old_logp,
+                           action, mean, std, ret, curr_value, old_value, B, int(A), int(D), p, logp_out, entropy_out,
+                           logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials);
+    }
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, partials, blocks, B, int(D), p,
+                       losses_out);
+    return launch_status();
+}

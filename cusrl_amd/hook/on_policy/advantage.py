@@ -1,0 +1,80 @@
+"""Advantage post-processing (replaces cusrl/hook/on_policy/advantage.py:13-115).
+
+``AdvantageNormalization``: per-channel ``var_mean`` (unbiased) over all leading dims, optional cross-rank
+equal-weight merge, then ``(adv - mean) / sqrt(var + 1e-8)`` in place with a true division.  When it runs right
+after the GAE hook on a buffer, the statistics pass is free: the GAE kernel already produced the block partials.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Sequence
+from typing import Any, Literal
+
+import torch
+from torch import Tensor
+
+from cusrl_amd import ops
+from cusrl_amd.template.buffer import Buffer
+from cusrl_amd.template.hook import Hook
+from cusrl_amd.utils import distributed
+
+__all__ = ["AdvantageNormalization", "AdvantageReduction"]
+
+
+class AdvantageReduction(Hook):
+    """Collapse a multi-channel advantage to ``[..., 1]`` by (weighted) sum or mean inside ``objective``."""
+
+    def __init__(self, reduction: Literal["sum", "mean"] = "sum", weight: Sequence[float] | None = None):
+        if reduction not in ("sum", "mean"):
+            raise ValueError(f"Unsupported reduction '{reduction}'")
+        super().__init__(training_only=True)
+        self.reduction = reduction
+        self.weight: tuple[float, ...] | None = None if weight is None else tuple(weight)
+        self.register_mutable("weight")
+        self._weight_tensor: Tensor | None = None
+
+    def init(self):
+        self._weight_tensor = None if self.weight is None else self.agent.to_tensor(self.weight)
+
+    def objective(self, metadata, batch):
+        advantage: Tensor = batch["advantage"]
+        if self._weight_tensor is not None:
+            advantage = advantage * self._weight_tensor
+        reduce = advantage.sum if self.reduction == "sum" else advantage.mean
+        batch["advantage"] = reduce(-1, keepdim=True)
+
+    def update_attribute(self, name: str, value: Any):
+        super().update_attribute(name, value)
+        if name == "weight":
+            self.weight = None if value is None else tuple(value)
+            self._weight_tensor = None if value is None else self.agent.to_tensor(self.weight)
+
+
+class AdvantageNormalization(Hook):
+    def __init__(self, mini_batch_wise: bool = False, synchronize: bool = True):
+        super().__init__(training_only=True)
+        self.mini_batch_wise = mini_batch_wise
+        self.synchronize = synchronize
+
+    def pre_update(self, buffer):
+        if self.mini_batch_wise:
+            return
+        derived = buffer.take_derived("advantage") if isinstance(buffer, Buffer) else None
+        self.normalize_(buffer["advantage"], derived)
+
+    def objective(self, metadata, batch):
+        if self.mini_batch_wise:
+            self.normalize_(batch["advantage"])
+
+    @torch.no_grad()
+    def normalize_(self, advantage: Tensor, derived=None):
+        channels = advantage.shape[-1]
+        count = advantage.numel() // channels
+        if derived is not None and derived[0] == "stat_partials" and derived[2] == count:
+            partials = derived[1]  # emitted by the GAE launch for exactly this tensor
+        else:
+            partials = ops.col_stats(advantage)
+        var, mean = ops.adv_stats_finalize(partials, count)
+        if self.synchronize:
+            distributed.reduce_mean_var_(mean, var)
+        ops.normalize_(advantage, mean, var, 1e-8)

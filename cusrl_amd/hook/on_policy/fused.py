@@ -1,0 +1,159 @@
+"""One-launch PPO objective behind the per-hook plugin API.
+
+The reference evaluates the PPO objective as four independent hooks — ``ValueLoss`` (value.py:121-137),
+``OnPolicyPreparation`` (common.py:29-43), ``PpoSurrogateLoss`` (ppo.py:50-55), ``EntropyLoss`` (ppo.py:82-84) —
+each a chain of small torch ops, summed in ``ActorCritic._train_step`` (actor_critic.py:309) and differentiated
+by autograd op by op.  On MI355X that is ~40 launch-bound kernels per minibatch over 24 576 x 12 floats.
+
+Here the four hooks keep their names, constructors and outputs, but when the composition is the stock one
+they only *register* their term with a per-step :class:`FusedPpoObjective`; once the last hook has run, one
+``cusrl_ppo_loss_fwd_bwd`` launch produces the three weighted losses, the per-sample log-prob / entropy /
+ratios the other hooks and metrics read, AND d(loss)/d(mean, std, value) — autograd then continues from the
+actor / critic heads.  Any non-stock composition (custom hooks that define ``objective``, non-Gaussian policies,
+multi-channel advantages reaching the surrogate) disables fusion and runs hook by hook with the same formulas.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+
+from cusrl_amd import ops
+
+__all__ = ["FusedPpoObjective"]
+
+
+class _FusedPpoFunction(torch.autograd.Function):
+    """total = value_loss + surrogate_loss + entropy_loss; gradients precomputed by the forward kernel."""
+
+    @staticmethod
+    def forward(ctx, mean, std, curr_value, advantage, old_logp, action, ret, old_value, clip, value_clip,
+                w_sur, w_val, w_ent, unit_grad):
+        out = ops.ppo_loss_fwd_bwd(
+            advantage, old_logp, action, mean, std, ret, curr_value, old_value,
+            clip=clip, value_clip=value_clip, w_sur=w_sur, w_val=w_val, w_ent=w_ent, want_grads=True,
+        )
+        ctx.save_for_backward(out["d_mean"], out["d_std"], out["d_value"])
+        ctx.unit_grad = unit_grad
+        ctx.shapes = (mean.shape, std.shape, curr_value.shape)
+        losses = out["losses"]
+        total = losses.sum()
+        side = (losses, out["logp"], out["entropy"], out["logp_ratio"], out["ratio"])
+        ctx.mark_non_differentiable(*side)
+        return (total, *side)
+
+    @staticmethod
+    def backward(ctx, grad_total, *_unused):
+        d_mean, d_std, d_value = ctx.saved_tensors
+        if not ctx.unit_grad:  # GradScaler (fp16 autocast) or a caller that rescales the loss
+            d_mean, d_std, d_value = d_mean * grad_total, d_std * grad_total, d_value * grad_total
+        shapes = ctx.shapes
+        return (d_mean.view(shapes[0]), d_std.view(shapes[1]), d_value.view(shapes[2]), *([None] * 11))
+
+
+def _overrides(hook, method: str) -> bool:
+    from cusrl_amd.template.hook import Hook
+
+    return getattr(type(hook), method) is not getattr(Hook, method)
+
+
+class FusedPpoObjective:
+    """Collects the terms of one minibatch step; ``resolve`` turns them into real tensors."""
+
+    def __init__(self, unit_grad: bool):
+        self.unit_grad = unit_grad
+        self.value: tuple | None = None
+        self.policy: tuple | None = None
+        self.surrogate: tuple | None = None
+        self.entropy: float | None = None
+
+    # ------------------------------------------------------------------ arming
+    @staticmethod
+    def eligible(composite) -> bool:
+        """Stock PPO composition only: exactly one each of the four term hooks (exact types, in the reference's
+        order), a Gaussian policy, and no other active hook that defines ``objective``."""
+        from cusrl_amd.hook.on_policy.advantage import AdvantageNormalization, AdvantageReduction
+        from cusrl_amd.hook.on_policy.common import OnPolicyPreparation
+        from cusrl_amd.hook.on_policy.gae import GeneralizedAdvantageEstimation
+        from cusrl_amd.hook.on_policy.ppo import EntropyLoss, PpoSurrogateLoss
+        from cusrl_amd.hook.on_policy.value import ValueLoss
+
+        agent = composite.agent
+        distribution = getattr(getattr(agent, "actor", None), "distribution", None)
+        if not getattr(distribution, "is_normal", False) or agent.device.type != "cuda":
+            return False
+        terms = (ValueLoss, OnPolicyPreparation, PpoSurrogateLoss, EntropyLoss)
+        passive = (GeneralizedAdvantageEstimation, AdvantageNormalization, AdvantageReduction)
+        order = []
+        for hook in composite:
+            if not hook.active:
+                continue
+            if type(hook) in terms:
+                order.append(type(hook))
+            elif _overrides(hook, "objective") and type(hook) not in passive:
+                return False
+        return tuple(order) == terms
+
+    @classmethod
+    def arm(cls, composite, batch) -> "FusedPpoObjective | None":
+        agent = composite.agent
+        if getattr(agent, "inference_mode", False) or not torch.is_grad_enabled():
+            return None
+        if not getattr(agent, "fuse_objective", True):
+            return None
+        key = tuple(hook.active for hook in composite)
+        cached = getattr(composite, "_fusion_cache", None)
+        if cached is None or cached[0] != key:
+            cached = composite._fusion_cache = (key, cls.eligible(composite))
+        if not cached[1]:
+            return None
+        context = cls(unit_grad=not agent.grad_scaler_enabled)
+        agent._fused_objective = context
+        return context
+
+    @staticmethod
+    def disarm(composite):
+        composite.agent._fused_objective = None
+
+    @staticmethod
+    def current(hook) -> "FusedPpoObjective | None":
+        return getattr(getattr(hook, "agent", None), "_fused_objective", None)
+
+    # ------------------------------------------------------------------ term registration (called by the hooks)
+    def add_value(self, curr_value, old_value, ret, weight: float, loss_clip: float | None):
+        self.value = (curr_value, old_value, ret, weight, loss_clip)
+        return {"value_loss": None}
+
+    def add_policy(self, action_dist, action, old_logp):
+        self.policy = (action_dist, action, old_logp)
+
+    def add_surrogate(self, advantage, clip_ratio: float, weight: float):
+        self.surrogate = (advantage, clip_ratio, weight)
+        return {"surrogate_loss": None}
+
+    def add_entropy(self, weight: float):
+        self.entropy = weight
+        return {"entropy_loss": None}
+
+    # ------------------------------------------------------------------ the launch
+    def resolve(self, objectives, batch: dict[str, Any]):
+        if any(term is None for term in (self.value, self.policy, self.surrogate, self.entropy)):
+            raise RuntimeError("fused PPO objective armed but a term hook did not report; this is a bug")
+        curr_value, old_value, ret, w_val, value_clip = self.value
+        action_dist, action, old_logp = self.policy
+        advantage, clip, w_sur = self.surrogate
+        total, losses, logp, entropy, logp_ratio, ratio = _FusedPpoFunction.apply(
+            action_dist["mean"], action_dist["std"], curr_value, advantage, old_logp, action, ret, old_value,
+            clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad,
+        )
+        batch["curr_action_logp"] = logp
+        batch["curr_entropy"] = entropy
+        batch["action_logp_ratio"] = logp_ratio
+        batch["action_prob_ratio"] = ratio
+        value_loss, surrogate_loss, entropy_loss = losses.unbind(0)
+        objectives["value_loss"] = value_loss
+        objectives["surrogate_loss"] = surrogate_loss
+        objectives["entropy_loss"] = entropy_loss
+        objectives.total = total
+        objectives.fused_keys = ("value_loss", "surrogate_loss", "entropy_loss")

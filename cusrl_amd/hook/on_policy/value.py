@@ -1,0 +1,111 @@
+"""Critic bootstrap target and value loss (replaces cusrl/hook/on_policy/value.py:14-144).
+
+``ValueComputation.pre_update`` builds ``next_value`` with ONE HIP launch for the shift / last-step / terminated
+logic and an ordered on-device compaction of the truncated slots; only the critic GEMMs stay in torch.  The single
+host read (the truncated count) replaces the reference's ``truncated.any()`` sync (value.py:71).
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from cusrl_amd import ops
+from cusrl_amd.hook.on_policy.fused import FusedPpoObjective
+from cusrl_amd.template.buffer import Buffer
+from cusrl_amd.template.hook import Hook
+from cusrl_amd.utils.misc import get_first
+from cusrl_amd.utils.nest import map_nested
+
+__all__ = ["ValueComputation", "ValueLoss"]
+
+
+class ValueComputation(Hook):
+    def __init__(self, *, termination_value: float = 0.0, bootstrap_truncated_states: bool = True):
+        super().__init__()
+        self.termination_value = termination_value
+        self.bootstrap_truncated_states = bootstrap_truncated_states
+        self._critic_memory = None
+
+    def init(self):
+        if self.agent.environment_spec.final_state_is_missing:
+            self.bootstrap_truncated_states = False
+
+    def post_act(self, transition):
+        state = get_first(transition, "state", "observation")
+        with self.agent.autocast():
+            value, next_memory = self.agent.critic(state, memory=self._critic_memory, sequential=False)
+        transition["value"] = value
+        transition["critic_memory"] = self._critic_memory
+        transition["next_critic_memory"] = next_memory
+        self._critic_memory = next_memory
+
+    def post_step(self, transition):
+        self.agent.critic.reset_memory(self._critic_memory, transition["done"])
+
+    @torch.no_grad()
+    def pre_update(self, buffer: Buffer):
+        critic = self.agent.critic
+        value: Tensor = buffer["value"]
+        next_value = buffer.field("next_value", value)
+        next_state: Tensor = get_first(buffer, "next_state", "next_observation")
+        terminated, truncated = buffer["terminated"], buffer["truncated"]
+        T, N = value.shape[:2]
+
+        with self.agent.autocast():
+            last_value = critic.evaluate(next_state[-1], memory=self._critic_memory)
+        counts = ops.next_value(
+            value, terminated, truncated, last_value.float(), self.termination_value,
+            truncated_uses_own_value=not self.bootstrap_truncated_states, out=next_value,
+        )
+        if not self.bootstrap_truncated_states:
+            return
+        slots, count = ops.compact_flags(truncated, counts)
+        k = int(count.item())  # the one device->host read of pre_update
+        if k == 0:
+            return
+        slots = slots[:k]
+        (truncated_next_state,) = ops.gather_rows([next_state], slots, T, N)
+        next_memory = buffer.get("next_critic_memory")
+        if next_memory is not None:
+            next_memory = map_nested(lambda m: ops.gather_rows([m], slots, T, N)[0], next_memory)
+        with self.agent.autocast():
+            truncated_next_value = critic.evaluate(truncated_next_state, memory=next_memory)
+        ops.scatter_rows(truncated_next_value.float(), slots, next_value)
+
+
+def _clipped_value_loss(value: Tensor, curr_value: Tensor, return_: Tensor, loss_clip: float) -> Tensor:
+    clipped = value + (curr_value - value).clamp(-loss_clip, loss_clip)
+    return torch.max((curr_value - return_).square(), (clipped - return_).square()).mean()
+
+
+class ValueLoss(Hook):
+    def __init__(self, weight: float = 0.5, loss_clip: float | None = None):
+        if weight <= 0:
+            raise ValueError("'weight' must be positive")
+        if loss_clip is not None and loss_clip <= 0:
+            raise ValueError("'loss_clip' must be positive or None")
+        super().__init__()
+        self.weight: float = weight
+        self.loss_clip: float | None = loss_clip
+        self.register_mutable("weight")
+        self.register_mutable("loss_clip")
+
+    def objective(self, metadata, batch):
+        state = get_first(batch, "state", "observation")
+        curr_value = self.agent.critic.evaluate(state, memory=batch.get("critic_memory"), done=batch["done"])
+        batch["curr_value"] = curr_value
+        if (fused := FusedPpoObjective.current(self)) is not None:
+            return fused.add_value(curr_value, batch["value"], batch["return"], self.weight, self.loss_clip)
+        if self.loss_clip is None:
+            loss = nn.functional.mse_loss(batch["return"], curr_value)
+        else:
+            loss = _clipped_value_loss(batch["value"], curr_value, batch["return"], self.loss_clip)
+        return {"value_loss": loss * self.weight}
+
+    def post_objective(self, metadata, batch):
+        curr_value: Tensor = batch["curr_value"]
+        self.agent.record(value=curr_value.sum(dim=-1))
+        if (dim := curr_value.size(-1)) != 1:
+            with torch.no_grad():
+                self.agent.record(**{f"value.{i}": curr_value[..., i] for i in range(dim)})

@@ -1,0 +1,151 @@
+"""Policy and value networks (counterparts of cusrl/nn/module/actor.py:26-274 and critic.py:27-101): a backbone
+``Module`` followed by a distribution head (actor) or an fp32 value head (critic)."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Callable
+
+import torch
+from torch import Tensor, nn
+
+from cusrl_amd.nn.distribution import Distribution
+from cusrl_amd.nn.module import Module, ModuleFactory
+
+__all__ = ["Actor", "Value"]
+
+
+@dataclass(slots=True)
+class ActorFactory(ModuleFactory):
+    backbone_factory: Callable[[int | None, int | None], Module]
+    distribution_factory: Callable[[int | None, int | None], Distribution]
+    latent_dim: int | None = None
+
+    def __call__(self, input_dim: int | None = None, output_dim: int | None = None):
+        backbone = self.backbone_factory(input_dim, self.latent_dim)
+        return Actor(backbone, self.distribution_factory(backbone.output_dim, output_dim))
+
+
+class Actor(Module):
+    Factory = ActorFactory
+
+    def __init__(self, backbone: Module, distribution: Distribution):
+        super().__init__(backbone.input_dim, distribution.output_dim, backbone.is_recurrent)
+        self.backbone: Module = backbone.rnn_compatible()
+        self.distribution: Distribution = distribution
+        self.latent_dim = self.backbone.output_dim
+        self.backbone_kwargs: dict[str, Any] = {}
+        self.distribution_kwargs: dict[str, Any] = {}
+
+    def clear_intermediate_repr(self):
+        super().clear_intermediate_repr()
+        self.backbone.clear_intermediate_repr()
+        self.distribution.clear_intermediate_repr()
+
+    def _encode(self, observation, memory, done, backbone_kwargs):
+        kwargs = {**self.backbone_kwargs, **(backbone_kwargs or {})}
+        if done is not None:
+            kwargs["done"] = done
+        latent, memory = self.backbone(observation, memory=memory, **kwargs)
+        self.intermediate_repr["backbone.output"] = latent
+        return latent, memory
+
+    def forward(self, observation: Tensor, memory=None, done: Tensor | None = None, backbone_kwargs=None,
+                distribution_kwargs=None, forward_type: str | None = "forward", deterministic: bool = False):
+        """``forward_type``: "forward" -> (dist_params, memory); "explore" -> (dist_params, (action, logp), memory);
+        "act" / "act_deterministic" -> (action, memory)  (actor.py:69-92)."""
+        if forward_type == "forward":
+            latent, memory = self._encode(observation, memory, done, backbone_kwargs)
+            dist_kwargs = {**self.distribution_kwargs, **(distribution_kwargs or {})}
+            return self.distribution(latent, observation=observation, **dist_kwargs), memory
+        if forward_type == "act_deterministic":
+            forward_type, deterministic = "act", True
+        if forward_type not in ("explore", "act"):
+            raise ValueError(f"Unsupported 'forward_type' value: {forward_type!r}")
+        latent, memory = self._encode(observation, memory, None, backbone_kwargs)
+        dist_kwargs = {**self.distribution_kwargs, **(distribution_kwargs or {})}
+        if deterministic:
+            dist_params = self.distribution(latent, observation=observation, **dist_kwargs)
+            action = self.distribution.determine(latent, observation=observation, **dist_kwargs)
+            logp = self.distribution.compute_logp(dist_params, action)
+        else:
+            dist_params, (action, logp) = self.distribution.sample(latent, observation=observation, **dist_kwargs)
+        if forward_type == "act":
+            return action, memory
+        return dist_params, (action, logp), memory
+
+    def explore(self, observation, memory=None, deterministic=False, backbone_kwargs=None, distribution_kwargs=None):
+        return self(observation, memory=memory, deterministic=deterministic, backbone_kwargs=backbone_kwargs,
+                    distribution_kwargs=distribution_kwargs, forward_type="explore")
+
+    def act(self, observation, memory=None, deterministic=False, backbone_kwargs=None, distribution_kwargs=None):
+        return self(observation, memory=memory, deterministic=deterministic, backbone_kwargs=backbone_kwargs,
+                    distribution_kwargs=distribution_kwargs, forward_type="act")
+
+    def compute_logp(self, dist_params, action):
+        return self.distribution.compute_logp(dist_params, action)
+
+    def compute_entropy(self, dist_params):
+        return self.distribution.compute_entropy(dist_params)
+
+    def compute_kl_div(self, dist_params1, dist_params2):
+        return self.distribution.compute_kl_div(dist_params1, dist_params2)
+
+    def step_memory(self, observation, memory=None, **kwargs):
+        return self.backbone.step_memory(observation, memory, **kwargs)
+
+    def reset_memory(self, memory, done=None):
+        self.backbone.reset_memory(memory, done)
+
+
+@dataclass(slots=True)
+class ValueFactory(ModuleFactory):
+    backbone_factory: Callable[[int | None, int | None], Module]
+    value_head_factory: Callable[[int, int], nn.Module] = nn.Linear
+    latent_dim: int | None = None
+    action_aware: bool = False
+
+    def __call__(self, input_dim: int | None = None, output_dim: int | None = 1):
+        backbone = self.backbone_factory(input_dim, self.latent_dim)
+        return Value(backbone, self.value_head_factory(backbone.output_dim, output_dim), action_aware=self.action_aware)
+
+
+class Value(Module):
+    Factory = ValueFactory
+
+    def __init__(self, backbone: Module, value_head: nn.Module, action_aware: bool = False):
+        with torch.no_grad():
+            output_dim = value_head(torch.zeros(1, backbone.output_dim)).numel()
+        super().__init__(backbone.input_dim, output_dim, backbone.is_recurrent)
+        self.backbone: Module = backbone.rnn_compatible()
+        self.value_head = value_head
+        self.action_aware = action_aware
+        self.backbone_kwargs: dict[str, Any] = {}
+
+    def forward(self, state: Tensor, *, action: Tensor | None = None, memory=None, done: Tensor | None = None, **kwargs):
+        if self.action_aware:
+            if action is None:
+                raise ValueError("Action must be provided when 'action_aware' is True")
+            state = torch.cat([state, action], dim=-1)
+        kwargs = {**self.backbone_kwargs, **kwargs}
+        if done is not None:
+            kwargs["done"] = done
+        latent, memory = self.backbone(state, memory=memory, **kwargs)
+        self.intermediate_repr["backbone.output"] = latent
+        if latent.dtype == torch.float32 and not torch.is_autocast_enabled(latent.device.type):
+            return self.value_head(latent), memory
+        with torch.autocast(device_type=latent.device.type, enabled=False):
+            return self.value_head(latent.float()), memory  # the head always runs in fp32 (critic.py:87-88)
+
+    def evaluate(self, state: Tensor, *, action=None, memory=None, done=None, **kwargs) -> Tensor:
+        return self(state, action=action, memory=memory, done=done, **kwargs)[0]
+
+    def clear_intermediate_repr(self):
+        super().clear_intermediate_repr()
+        self.backbone.clear_intermediate_repr()
+
+    def step_memory(self, state, memory=None, **kwargs):
+        return self.backbone.step_memory(state, memory, **kwargs)
+
+    def reset_memory(self, memory, done=None):
+        return self.backbone.reset_memory(memory, done=done)

@@ -1,0 +1,154 @@
+"""torch.nn building blocks of the actor-critic (counterparts of cusrl/nn/module/{module,mlp}.py and
+cusrl/nn/layer/linear.py).  These stay plain PyTorch on purpose: their dense contractions run on rocBLAS /
+hipBLASLt MFMA kernels (BASELINE.json north_star); none of the judged HIP kernels lives here."""
+
+from __future__ import annotations
+
+from collections.abc import Iterable, Sequence
+from dataclasses import dataclass
+from typing import Any
+
+import torch
+from torch import nn
+from torch.nn.functional import linear
+
+from cusrl_amd.utils.nest import iterate_nested
+
+__all__ = ["LinearFp32", "Mlp", "Module", "ModuleFactory", "disable_autocast", "resolve_activation_fn"]
+
+
+def disable_autocast(device_type: str):
+    return torch.autocast(device_type=device_type, enabled=False)
+
+
+class LinearFp32(nn.Linear):
+    """Linear layer evaluated in fp32 even under autocast (layer/linear.py:12-16)."""
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if not torch.is_autocast_enabled(input.device.type) and input.dtype == torch.float32:
+            return linear(input, self.weight, self.bias)
+        with disable_autocast(input.device.type):
+            return linear(input.float(), self.weight.float(), None if self.bias is None else self.bias.float())
+
+
+class ModuleFactory:
+    def __call__(self, input_dim: int | None = None, output_dim: int | None = None) -> "Module":
+        raise NotImplementedError
+
+
+class Module(nn.Module):
+    """``nn.Module`` + declared dims, recurrent-memory helpers and an intermediate-representation dict
+    (module/module.py:35-163)."""
+
+    Factory = ModuleFactory
+
+    def __init__(self, input_dim: int | None = None, output_dim: int | None = None, is_recurrent: bool = False,
+                 like: "Module | None" = None, intermediate_repr: dict[str, Any] | None = None):
+        super().__init__()
+        if like is not None:
+            input_dim, output_dim, is_recurrent = like.input_dim, like.output_dim, like.is_recurrent
+        elif input_dim is None or output_dim is None:
+            raise ValueError("'input_dim' and 'output_dim' must be specified when 'like' is not provided")
+        elif input_dim <= 0:
+            raise ValueError("'input_dim' must be a positive integer")
+        elif output_dim <= 0:
+            raise ValueError("'output_dim' must be a positive integer")
+        self.input_dim, self.output_dim, self.is_recurrent = input_dim, output_dim, is_recurrent
+        self.intermediate_repr: dict[str, Any] = intermediate_repr or {}
+        self._rnn_compatible = False
+
+    @property
+    def device(self) -> torch.device:
+        for tensor in itertools_chain(self.parameters(), self.buffers()):
+            return tensor.device
+        return torch.device("cpu")
+
+    def step_memory(self, input, memory=None, **kwargs):
+        if not self.is_recurrent:
+            return None
+        _, *next_memory = self(input, memory=memory, **kwargs)
+        return next_memory[0]
+
+    def reset_memory(self, memory, done=None):
+        """Zero the recurrent state of finished envs in place."""
+        if memory is None:
+            return
+        if isinstance(done, torch.Tensor):
+            done = done.squeeze(-1)
+        elif done is None:
+            done = slice(None)
+        for _, tensor in iterate_nested(memory):
+            tensor[done] = 0
+
+    def clear_intermediate_repr(self):
+        self.intermediate_repr.clear()
+
+    def rnn_compatible(self):
+        """Let a feed-forward module be called like a recurrent one: ``module(x, memory=m) -> (y, m)``."""
+        if not self.is_recurrent and not self._rnn_compatible:
+            self._rnn_compatible = True
+            plain_forward = self.forward
+
+            def forward(input, **kwargs):
+                output = plain_forward(input)
+                return (output, kwargs["memory"]) if "memory" in kwargs else output
+
+            self.forward = forward
+        return self
+
+
+def itertools_chain(*iterables):
+    for it in iterables:
+        yield from it
+
+
+def resolve_activation_fn(activation_fn: str | type[nn.Module]) -> type[nn.Module]:
+    if isinstance(activation_fn, str):
+        name = activation_fn.removeprefix("torch.").removeprefix("nn.")
+        resolved = getattr(nn, name, None)
+        if resolved is None:
+            raise ValueError(f"Unknown activation function '{activation_fn}'")
+        return resolved
+    return activation_fn
+
+
+@dataclass(slots=True)
+class MlpFactory(ModuleFactory):
+    hidden_dims: Sequence[int]
+    activation_fn: str | type[nn.Module] = "ReLU"
+    ends_with_activation: bool = False
+    dropout: float = 0.0
+
+    def __call__(self, input_dim: int | None = None, output_dim: int | None = None):
+        assert input_dim is not None
+        return Mlp(input_dim, self.hidden_dims, output_dim, self.activation_fn, self.ends_with_activation, self.dropout)
+
+
+class Mlp(Module):
+    """Linear/activation stack; ``output_dim=None`` makes the last hidden width the output (module/mlp.py:31-93)."""
+
+    Factory = MlpFactory
+
+    def __init__(self, input_dim: int, hidden_dims: Iterable[int], output_dim: int | None = None,
+                 activation_fn: str | type[nn.Module] = "ReLU", ends_with_activation: bool = False, dropout: float = 0.0):
+        widths = list(hidden_dims) + ([] if output_dim is None else [output_dim])
+        if not widths:
+            raise ValueError("Mlp needs at least one layer")
+        act = resolve_activation_fn(activation_fn)
+        super().__init__(input_dim, widths[-1])
+        layers: list[nn.Module] = []
+        fan_in = input_dim
+        for i, width in enumerate(widths):
+            layers.append(nn.Linear(fan_in, width))
+            if i + 1 < len(widths) or ends_with_activation:
+                layers.append(act())
+                if dropout > 0.0:
+                    layers.append(nn.Dropout(dropout))
+            fan_in = width
+        self.layers = nn.Sequential(*layers)
+
+    def forward(self, input: torch.Tensor, **kwargs) -> torch.Tensor:
+        return self.layers(input)
+
+    def __getitem__(self, index: int) -> nn.Module:
+        return self.layers[index]

@@ -1,0 +1,335 @@
+"""Tensor-level entry points of the HIP hot path.
+
+Every function takes torch tensors that already live in HBM, passes ``data_ptr()`` + sizes + torch's
+current ``hipStream_t`` through the C ABI (``include/cusrl_hip.h``) and returns torch tensors it allocated
+with torch's caching allocator.  PyTorch is plumbing here (memory, streams); the arithmetic is in
+``cusrl_amd/csrc/*.hip``.  Non-device tensors are rejected — there is deliberately no CPU path.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Sequence
+
+import torch
+
+from cusrl_amd import _native
+from cusrl_amd._native import Field, check
+
+__all__ = [
+    "adv_stats_finalize",
+    "buffer_push",
+    "col_stats",
+    "compact_flags",
+    "gae",
+    "gather_rows",
+    "merge_mean_var",
+    "next_value",
+    "normalize_",
+    "ppo_loss_fwd_bwd",
+    "require_device",
+    "scatter_rows",
+]
+
+
+def require_device(tensor: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    if not tensor.is_cuda:
+        raise RuntimeError(
+            f"cusrl_amd: '{name}' lives on {tensor.device}; the rollout + PPO-update hot path only runs as HIP "
+            "kernels on an MI355X device tensor (no CPU fallback exists by design)"
+        )
+    return tensor
+
+
+def _f32(tensor: torch.Tensor, name: str) -> torch.Tensor:
+    require_device(tensor, name)
+    if tensor.dtype != torch.float32:
+        raise TypeError(f"'{name}' must be float32, got {tensor.dtype}")
+    return tensor if tensor.is_contiguous() else tensor.contiguous()
+
+
+def _flag(tensor: torch.Tensor, name: str) -> torch.Tensor:
+    require_device(tensor, name)
+    if tensor.dtype not in (torch.bool, torch.uint8):
+        raise TypeError(f"'{name}' must have dtype bool, got {tensor.dtype}")
+    return tensor if tensor.is_contiguous() else tensor.contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _row_bytes(tensor: torch.Tensor, lead_dims: int) -> int:
+    n = tensor.element_size()
+    for s in tensor.shape[lead_dims:]:
+        n *= s
+    return n
+
+
+# ------------------------------------------------------------------------------------------------ a1
+def buffer_push(pairs: Sequence[tuple[torch.Tensor, torch.Tensor]], cursor: int, parallelism: int) -> None:
+    """``storage[cursor] = step`` for every ``(step [N,...], storage [T,N,...])`` pair in one launch.
+
+    Replaces the per-leaf index_put chain of cusrl/template/buffer.py:134-146.
+    """
+    lib = _native.lib()
+    stream = _stream()
+    for start in range(0, len(pairs), _native.MAX_FIELDS):
+        chunk = pairs[start : start + _native.MAX_FIELDS]
+        table = (Field * len(chunk))()
+        for i, (step, storage) in enumerate(chunk):
+            table[i].src = step.data_ptr()
+            table[i].dst = storage.data_ptr()
+            table[i].row_bytes = _row_bytes(step, 1)
+        check(lib.cusrl_buffer_push(table, len(chunk), cursor, parallelism, stream), "cusrl_buffer_push")
+
+
+# ------------------------------------------------------------------------------------------------ a7 / a8
+def gather_rows(
+    storages: Sequence[torch.Tensor],
+    indices: torch.Tensor,
+    capacity: int,
+    parallelism: int,
+    temporal: bool = False,
+) -> list[torch.Tensor]:
+    """Minibatch gather of every leaf in one launch.
+
+    ``storage.flatten(0, 1)[indices]`` (cusrl/sampler/mini_batch_sampler.py:87-89) or ``storage[:, indices]``
+    (``:113-114``) for each ``[T, N, ...]`` leaf.
+    """
+    require_device(indices, "indices")
+    if indices.dtype != torch.int64:
+        raise TypeError(f"'indices' must be int64, got {indices.dtype}")
+    if not indices.is_contiguous():
+        indices = indices.contiguous()
+    batch = indices.numel()
+    lead = (capacity, batch) if temporal else (batch,)
+    outputs = [torch.empty(lead + tuple(s.shape[2:]), dtype=s.dtype, device=s.device) for s in storages]
+    if batch == 0:
+        return outputs
+    lib = _native.lib()
+    stream = _stream()
+    for start in range(0, len(storages), _native.MAX_FIELDS):
+        chunk = range(start, min(start + _native.MAX_FIELDS, len(storages)))
+        table = (Field * len(chunk))()
+        for i, k in enumerate(chunk):
+            src = storages[k]
+            if not src.is_contiguous():
+                raise ValueError("buffer leaves must be contiguous [capacity, parallelism, ...] tensors")
+            table[i].src = src.data_ptr()
+            table[i].dst = outputs[k].data_ptr()
+            table[i].row_bytes = _row_bytes(src, 2)
+        check(
+            lib.cusrl_gather_rows(table, len(chunk), indices.data_ptr(), batch, capacity, parallelism, int(temporal), stream),
+            "cusrl_gather_rows",
+        )
+    return outputs
+
+
+# ------------------------------------------------------------------------------------------------ a3
+def next_value(
+    value: torch.Tensor,
+    terminated: torch.Tensor,
+    truncated: torch.Tensor,
+    last_value: torch.Tensor,
+    termination_value: float,
+    truncated_uses_own_value: bool,
+    out: torch.Tensor,
+) -> torch.Tensor:
+    """Bootstrap target of cusrl/hook/on_policy/value.py:66-70,79-80; returns the per-block truncated counters."""
+    value = _f32(value, "value")
+    T, N, D = value.shape
+    terminated, truncated = _flag(terminated, "terminated"), _flag(truncated, "truncated")
+    last_value = _f32(last_value, "last_value")
+    if last_value.numel() != N * D or out.shape != value.shape or not out.is_contiguous():
+        raise ValueError("next_value: inconsistent shapes")
+    lib = _native.lib()
+    block_counts = torch.empty(max(int(lib.cusrl_flag_blocks(T * N)), 1), dtype=torch.int32, device=value.device)
+    check(
+        lib.cusrl_next_value(
+            value.data_ptr(), terminated.data_ptr(), truncated.data_ptr(), last_value.data_ptr(),
+            float(termination_value), int(truncated_uses_own_value), _f32(out, "next_value").data_ptr(),
+            block_counts.data_ptr(), T, N, D, _stream(),
+        ),
+        "cusrl_next_value",
+    )
+    return block_counts
+
+
+def compact_flags(flags: torch.Tensor, block_counts: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """Ascending flat slots whose flag is set + their number (device int32[1]); no host synchronisation."""
+    flags = _flag(flags, "flags")
+    n = flags.numel()
+    lib = _native.lib()
+    recount = block_counts is None
+    if recount:
+        block_counts = torch.empty(max(int(lib.cusrl_flag_blocks(n)), 1), dtype=torch.int32, device=flags.device)
+    indices = torch.empty(n, dtype=torch.int64, device=flags.device)
+    count = torch.empty(1, dtype=torch.int32, device=flags.device)
+    check(
+        lib.cusrl_compact_flags(flags.data_ptr(), n, block_counts.data_ptr(), int(recount), indices.data_ptr(), count.data_ptr(), _stream()),
+        "cusrl_compact_flags",
+    )
+    return indices, count
+
+
+def scatter_rows(src: torch.Tensor, indices: torch.Tensor, dst: torch.Tensor) -> None:
+    """``dst.flatten(0, 1)[indices] = src`` (cusrl/hook/on_policy/value.py:78)."""
+    require_device(src, "src"), require_device(dst, "dst"), require_device(indices, "indices")
+    if src.dtype != dst.dtype or indices.dtype != torch.int64 or not dst.is_contiguous():
+        raise TypeError("scatter_rows: dtype/layout mismatch")
+    src, indices = src.contiguous(), indices.contiguous()
+    K = indices.numel()
+    if K == 0:
+        return
+    check(
+        _native.lib().cusrl_scatter_rows(src.data_ptr(), indices.data_ptr(), dst.data_ptr(), K, _row_bytes(src, 1), None, _stream()),
+        "cusrl_scatter_rows",
+    )
+
+
+# ------------------------------------------------------------------------------------------------ a4
+def gae(
+    reward: torch.Tensor,
+    value: torch.Tensor,
+    next_value_: torch.Tensor,
+    done: torch.Tensor,
+    gamma: float,
+    lamda: float,
+    lamda_value: float | None,
+    advantage: torch.Tensor | None = None,
+    ret: torch.Tensor | None = None,
+    with_stats: bool = True,
+) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None]:
+    """Fused delta + backward scan + return (+ advantage {sum, sumsq} partials) — gae.py:8-20, 85-110."""
+    reward, value, next_value_ = _f32(reward, "reward"), _f32(value, "value"), _f32(next_value_, "next_value")
+    done = _flag(done, "done")
+    if reward.dim() < 2 or reward.shape != value.shape or reward.shape != next_value_.shape:
+        raise ValueError(f"gae: reward/value/next_value shapes differ: {reward.shape}, {value.shape}, {next_value_.shape}")
+    T, N = reward.shape[:2]
+    D = reward.numel() // max(T * N, 1)
+    if done.numel() != T * N:
+        raise ValueError(f"gae: 'done' must be [T, N, 1]; got {tuple(done.shape)}")
+    advantage = torch.empty_like(reward) if advantage is None else _f32(advantage, "advantage")
+    ret = torch.empty_like(reward) if ret is None else _f32(ret, "return")
+    lib = _native.lib()
+    partials = None
+    if with_stats:
+        partials = torch.empty((max(int(lib.cusrl_gae_num_partials(T, N, D)), 1), D, 2), dtype=torch.float64, device=reward.device)
+    check(
+        lib.cusrl_gae(
+            reward.data_ptr(), value.data_ptr(), next_value_.data_ptr(), done.data_ptr(), advantage.data_ptr(),
+            ret.data_ptr(), None if partials is None else partials.data_ptr(), T, N, D, float(gamma), float(lamda),
+            -1.0 if lamda_value is None else float(lamda_value), _stream(),
+        ),
+        "cusrl_gae",
+    )
+    return advantage, ret, partials
+
+
+# ------------------------------------------------------------------------------------------------ a5 / a6
+def col_stats(x: torch.Tensor) -> torch.Tensor:
+    """Per-channel {sum, sumsq} partials of ``x [..., D]`` (first pass of advantage.py:111)."""
+    x = _f32(x, "x")
+    D = x.shape[-1]
+    rows = x.numel() // max(D, 1)
+    lib = _native.lib()
+    partials = torch.empty((max(int(lib.cusrl_col_stats_num_partials(rows, D)), 1), D, 2), dtype=torch.float64, device=x.device)
+    check(lib.cusrl_col_stats(x.data_ptr(), rows, D, partials.data_ptr(), _stream()), "cusrl_col_stats")
+    return partials
+
+
+def adv_stats_finalize(partials: torch.Tensor, count: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """``var, mean`` (unbiased) from block partials, fixed summation order."""
+    P, D, _ = partials.shape
+    mean = torch.empty(D, dtype=torch.float32, device=partials.device)
+    var = torch.empty(D, dtype=torch.float32, device=partials.device)
+    check(
+        _native.lib().cusrl_stats_finalize(partials.data_ptr(), P, D, count, mean.data_ptr(), var.data_ptr(), _stream()),
+        "cusrl_stats_finalize",
+    )
+    return var, mean
+
+
+def normalize_(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """``x.sub_(mean).div_((var + eps).sqrt())`` in place (advantage.py:114-115)."""
+    require_device(x, "x")
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise TypeError("normalize_: expected a contiguous float32 tensor")
+    D = x.shape[-1]
+    check(
+        _native.lib().cusrl_normalize(x.data_ptr(), _f32(mean, "mean").data_ptr(), _f32(var, "var").data_ptr(), eps, x.numel() // max(D, 1), D, _stream()),
+        "cusrl_normalize",
+    )
+    return x
+
+
+def merge_mean_var(gathered: torch.Tensor, mean: torch.Tensor, var: torch.Tensor) -> None:
+    """Equal-weight cross-rank merge of distributed.py:175-183 from the all-gathered ``[W, 2D]`` rows."""
+    gathered = _f32(gathered, "gathered")
+    W, twoD = gathered.shape
+    check(
+        _native.lib().cusrl_merge_mean_var(gathered.data_ptr(), W, twoD // 2, _f32(mean, "mean").data_ptr(), _f32(var, "var").data_ptr(), _stream()),
+        "cusrl_merge_mean_var",
+    )
+
+
+# ------------------------------------------------------------------------------------------------ a9 - a13
+def ppo_loss_fwd_bwd(
+    advantage: torch.Tensor,
+    old_logp: torch.Tensor,
+    action: torch.Tensor,
+    mean: torch.Tensor,
+    std: torch.Tensor,
+    ret: torch.Tensor,
+    curr_value: torch.Tensor,
+    old_value: torch.Tensor | None,
+    *,
+    clip: float,
+    value_clip: float | None,
+    w_sur: float,
+    w_val: float,
+    w_ent: float,
+    want_grads: bool = True,
+) -> dict[str, torch.Tensor]:
+    """One pass: losses[3] = (value, surrogate, entropy), per-sample logp/entropy/ratios, and the gradients."""
+    advantage, old_logp = _f32(advantage, "advantage"), _f32(old_logp, "action_logp")
+    action, mean, std = _f32(action, "action"), _f32(mean, "mean"), _f32(std, "std")
+    ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
+    A = mean.shape[-1]
+    B = mean.numel() // A
+    D = ret.shape[-1]
+    if advantage.numel() != B or old_logp.numel() != B or action.shape != mean.shape or std.shape != mean.shape:
+        raise ValueError("ppo_loss: inconsistent batch shapes")
+    if ret.numel() != B * D or curr_value.shape != ret.shape:
+        raise ValueError("ppo_loss: return / value shapes differ")
+    if value_clip is not None:
+        if old_value is None:
+            raise ValueError("ppo_loss: the clipped value loss needs the old value")
+        old_value = _f32(old_value, "value")
+    dev = mean.device
+    lib = _native.lib()
+    out = {
+        "losses": torch.empty(3, dtype=torch.float32, device=dev),
+        "logp": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
+        "entropy": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
+        "logp_ratio": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
+        "ratio": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
+    }
+    if want_grads:
+        out["d_mean"], out["d_std"], out["d_value"] = torch.empty_like(mean), torch.empty_like(std), torch.empty_like(curr_value)
+    partials = torch.empty((int(lib.cusrl_ppo_loss_num_partials(B)), 3), dtype=torch.float64, device=dev)
+
+    def ptr(name):
+        return out[name].data_ptr() if name in out else None
+
+    check(
+        lib.cusrl_ppo_loss_fwd_bwd(
+            advantage.data_ptr(), old_logp.data_ptr(), action.data_ptr(), mean.data_ptr(), std.data_ptr(),
+            ret.data_ptr(), curr_value.data_ptr(), None if old_value is None or value_clip is None else old_value.data_ptr(),
+            B, A, D, float(clip), -1.0 if value_clip is None else float(value_clip), float(w_sur), float(w_val), float(w_ent),
+            ptr("losses"), ptr("logp"), ptr("entropy"), ptr("logp_ratio"), ptr("ratio"), ptr("d_mean"), ptr("d_std"), ptr("d_value"),
+            partials.data_ptr(), _stream(),
+        ),
+        "cusrl_ppo_loss_fwd_bwd",
+    )
+    return out

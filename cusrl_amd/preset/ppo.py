@@ -1,0 +1,142 @@
+"""The `ppo` preset (counterpart of cusrl/preset/ppo.py:19-182, optimizer.py:9-23): same hook order — it is
+semantics: value target -> GAE -> advantage normalisation in ``pre_update``; value loss -> policy evaluation ->
+surrogate -> entropy in ``objective``; clipping in ``pre_optim``; statistics in ``post_update`` — same field
+names and defaults, so user code composing ``PpoAgentFactory`` / ``ppo_hook_suite`` is unchanged."""
+
+from __future__ import annotations
+
+from collections.abc import Sequence
+from dataclasses import dataclass, field
+from typing import Any
+
+import torch
+
+from cusrl_amd import hook as hooks
+from cusrl_amd.nn import Actor, Mlp, NormalDist, OneHotCategoricalDist, Value
+from cusrl_amd.sampler import AutoMiniBatchSampler
+from cusrl_amd.template.actor_critic import ActorCritic, ActorCriticFactory
+from cusrl_amd.template.agent import AgentFactory
+from cusrl_amd.template.environment import EnvironmentSpec
+from cusrl_amd.template.hook import Hook
+from cusrl_amd.template.optimizer import OptimizerFactory
+
+__all__ = ["AdamFactory", "PpoAgentFactory", "ppo_hook_suite"]
+
+
+class AdamFactory(OptimizerFactory):
+    def __init__(self, defaults: dict[str, Any] | None = None, group_overrides=None, param_filter=None):
+        super().__init__("Adam", defaults=defaults, group_overrides=group_overrides, param_filter=param_filter)
+
+
+def ppo_hook_suite(
+    orthogonal_init: bool = True,
+    normalize_observation: bool = False,
+    gae_gamma: float = 0.99,
+    gae_lamda: float = 0.95,
+    gae_lamda_value: float | None = None,
+    normalize_advantage: bool = True,
+    value_loss_weight: float = 0.5,
+    value_loss_clip: float | None = None,
+    surrogate_clip_ratio: float = 0.2,
+    surrogate_loss_weight: float = 1.0,
+    entropy_loss_weight: float = 0.01,
+    max_grad_norm: float | None = 1.0,
+    grad_clip_groups: dict[str, float] | None = None,
+    desired_kl_divergence: float | None = None,
+    max_kl_divergence: float | None = None,
+    empty_cuda_cache: bool = False,
+) -> list[Hook]:
+    if normalize_observation:
+        raise NotImplementedError("ObservationNormalization is SURVEY.md §8f rank 3 (next), not built yet")
+    if desired_kl_divergence is not None:
+        raise NotImplementedError("AdaptiveLRSchedule is host-side scalar control, out of scope (SURVEY.md §2 row 3)")
+    suite = [
+        hooks.ModuleInitialization(init_actor=orthogonal_init, init_critic=orthogonal_init),
+        hooks.ValueComputation(),
+        hooks.GeneralizedAdvantageEstimation(gamma=gae_gamma, lamda=gae_lamda, lamda_value=gae_lamda_value),
+        hooks.AdvantageNormalization() if normalize_advantage else None,
+        hooks.ValueLoss(weight=value_loss_weight, loss_clip=value_loss_clip),
+        hooks.OnPolicyPreparation(),
+        hooks.PpoSurrogateLoss(clip_ratio=surrogate_clip_ratio, weight=surrogate_loss_weight),
+        hooks.EntropyLoss(weight=entropy_loss_weight),
+        hooks.GradientClipping(max_grad_norm, grad_clip_groups),
+        hooks.OnPolicyStatistics(sampler=AutoMiniBatchSampler()),
+    ]
+    return [h for h in suite if h is not None]
+
+
+def get_distribution_factory(action_space_type: str, **kwargs):
+    if action_space_type == "continuous":
+        return NormalDist.Factory(**kwargs)
+    if action_space_type == "discrete":
+        return OneHotCategoricalDist.Factory()
+    raise ValueError(f"Unsupported action space type '{action_space_type}'")
+
+
+@dataclass(kw_only=True)
+class PpoAgentFactory(AgentFactory):
+    num_steps_per_update: int = 24
+    actor_hidden_dims: Sequence[int] = (256, 128)
+    critic_hidden_dims: Sequence[int] = (256, 128)
+    activation_fn: str | type[torch.nn.Module] = "ReLU"
+    action_space_type: str = "continuous"
+    lr: float = 2e-4
+    sampler_epochs: int = 5
+    sampler_mini_batches: int = 4
+    orthogonal_init: bool = True
+    init_distribution_std: float | None = None
+    normalize_observation: bool = False
+    gae_gamma: float = 0.99
+    gae_lamda: float = 0.95
+    gae_lamda_value: float | None = None
+    normalize_advantage: bool = True
+    value_loss_weight: float = 0.5
+    value_loss_clip: float | None = None
+    surrogate_clip_ratio: float = 0.2
+    surrogate_loss_weight: float = 1.0
+    entropy_loss_weight: float = 0.01
+    max_grad_norm: float | None = 1.0
+    grad_clip_groups: dict[str, float] = field(default_factory=dict)
+    desired_kl_divergence: float | None = None
+    max_kl_divergence: float | None = None
+    optimizer_kwargs: dict[str, Any] = field(default_factory=dict)
+    """Extra torch.optim.Adam kwargs (extension), e.g. ``{"fused": True}`` for the single-kernel Adam."""
+
+    def to_underlying(self) -> ActorCriticFactory:
+        def backbone(dims):
+            return Mlp.Factory(hidden_dims=dims, activation_fn=self.activation_fn, ends_with_activation=True)
+
+        return ActorCriticFactory(
+            num_steps_per_update=self.num_steps_per_update,
+            actor_factory=Actor.Factory(
+                backbone_factory=backbone(self.actor_hidden_dims),
+                distribution_factory=get_distribution_factory(self.action_space_type, init_std=self.init_distribution_std),
+            ),
+            critic_factory=Value.Factory(backbone_factory=backbone(self.critic_hidden_dims)),
+            optimizer_factory=AdamFactory(defaults={"lr": self.lr, **self.optimizer_kwargs}),
+            sampler=AutoMiniBatchSampler(num_epochs=self.sampler_epochs, num_mini_batches=self.sampler_mini_batches),
+            hooks=ppo_hook_suite(
+                orthogonal_init=self.orthogonal_init,
+                normalize_observation=self.normalize_observation,
+                gae_gamma=self.gae_gamma,
+                gae_lamda=self.gae_lamda,
+                gae_lamda_value=self.gae_lamda_value,
+                normalize_advantage=self.normalize_advantage,
+                value_loss_weight=self.value_loss_weight,
+                value_loss_clip=self.value_loss_clip,
+                surrogate_clip_ratio=self.surrogate_clip_ratio,
+                surrogate_loss_weight=self.surrogate_loss_weight,
+                entropy_loss_weight=self.entropy_loss_weight,
+                max_grad_norm=self.max_grad_norm,
+                grad_clip_groups=self.grad_clip_groups,
+                desired_kl_divergence=self.desired_kl_divergence,
+                max_kl_divergence=self.max_kl_divergence,
+            ),
+            name=self.name,
+            device=self.device,
+            compile=self.compile,
+            autocast=self.autocast,
+        )
+
+    def __call__(self, environment_spec: EnvironmentSpec) -> ActorCritic:
+        return self.to_underlying()(environment_spec)

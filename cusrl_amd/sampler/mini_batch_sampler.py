@@ -1,0 +1,107 @@
+"""Shuffled minibatch iteration over a full buffer (cusrl/sampler/mini_batch_sampler.py:12-140).
+
+Index semantics are the reference's, bit for bit: one ``torch.randperm(S)`` from the GLOBAL generator of the
+permutation device per call, re-drawn in place (``out=``) for every later epoch when ``shuffle``;
+``mini_batch_size = S // num_mini_batches`` (floor — tail indices are dropped); minibatch ``j`` is the slice
+``[j*B, (j+1)*B)``; flat index ``i`` addresses slot ``(t, n) = (i // N, i % N)``.  The permutation device defaults
+to the buffer's device, exactly like the reference (``device=buffer.device``), so a GPU run consumes torch's
+Philox stream and a CPU-generator run (``permutation_device="cpu"``) reproduces the CPU reference's mt19937
+stream on a GPU buffer (indices are then uploaded, 8 B per sample).  The gather of all leaves is one HIP launch.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Sequence
+from typing import Any
+
+import torch
+
+from cusrl_amd.template.buffer import Buffer, Sampler
+
+__all__ = ["AutoMiniBatchSampler", "MiniBatchSampler", "TemporalMiniBatchSampler"]
+
+
+class MiniBatchSampler(Sampler):
+    temporal = False
+
+    def __init__(
+        self,
+        num_epochs: int = 1,
+        num_mini_batches: int | Sequence[int] = 1,
+        shuffle: bool = True,
+        *,
+        permutation_device: str | torch.device | None = None,
+    ):
+        if num_epochs <= 0:
+            raise ValueError("'num_epochs' must be positive")
+        self.num_epochs = num_epochs
+        if isinstance(num_mini_batches, int):
+            if num_mini_batches <= 0:
+                raise ValueError("'num_mini_batches' must be positive")
+            self.num_mini_batches: int | tuple[int, ...] = num_mini_batches
+        else:
+            self.num_mini_batches = tuple(num_mini_batches)
+            if len(self.num_mini_batches) != num_epochs:
+                raise ValueError(
+                    "'num_mini_batches' must be an integer or a sequence of integers with length "
+                    f"equal to 'num_epochs' ({num_epochs}); got {len(self.num_mini_batches)} values"
+                )
+            if any(v <= 0 for v in self.num_mini_batches):
+                raise ValueError("'num_mini_batches' values must be positive")
+        self.shuffle = shuffle
+        self.permutation_device = None if permutation_device is None else torch.device(permutation_device)
+
+    def __call__(self, buffer: Buffer):
+        if not (buffer.full and buffer.cursor == 0):
+            raise RuntimeError("MiniBatchSampler requires a full buffer with cursor reset to 0")
+        num_samples = self._get_num_samples(buffer)
+        perm_device = self.permutation_device or buffer.device
+        staged = perm_device != buffer.device
+        epoch_indices = torch.randperm(num_samples, device=perm_device)
+        device_indices = epoch_indices.to(buffer.device, non_blocking=True) if staged else epoch_indices
+        for epoch in range(self.num_epochs):
+            count = self.num_mini_batches if isinstance(self.num_mini_batches, int) else self.num_mini_batches[epoch]
+            if count > num_samples:
+                raise ValueError(f"'num_mini_batches' ({count}) cannot exceed the number of samples ({num_samples})")
+            size = num_samples // count
+            if self.shuffle and epoch > 0:
+                torch.randperm(num_samples, device=perm_device, out=epoch_indices)
+                if staged:
+                    device_indices = epoch_indices.to(buffer.device, non_blocking=True)
+            for j in range(count):
+                metadata = {
+                    "epoch_index": epoch,
+                    "mini_batch_index": j,
+                    "total_epochs": self.num_epochs,
+                    "total_mini_batches": count,
+                    "temporal": self.temporal,
+                }
+                yield metadata, buffer.gather(device_indices[j * size : (j + 1) * size], temporal=self.temporal)
+
+    def _get_num_samples(self, buffer: Buffer) -> int:
+        return buffer.capacity * buffer.get_parallelism()
+
+
+class TemporalMiniBatchSampler(MiniBatchSampler):
+    """Permutes env ids and yields whole ``[T, n_envs/mb, ...]`` sequences (``:92-114``)."""
+
+    temporal = True
+
+    def _get_num_samples(self, buffer: Buffer) -> int:
+        return buffer.get_parallelism()
+
+
+class AutoMiniBatchSampler(Sampler):
+    """Temporal sampling iff some top-level field name ends with ``memory`` (``:136-140``)."""
+
+    def __init__(self, num_epochs: int = 1, num_mini_batches: int | Sequence[int] = 1, shuffle: bool = True,
+                 *, permutation_device: str | torch.device | None = None):
+        self.num_epochs = num_epochs
+        self.num_mini_batches = num_mini_batches
+        self.shuffle = shuffle
+        self.permutation_device = permutation_device
+
+    def __call__(self, buffer: Buffer):
+        temporal = any(key.split(".")[0].endswith("memory") for key in buffer)
+        cls = TemporalMiniBatchSampler if temporal else MiniBatchSampler
+        return cls(self.num_epochs, self.num_mini_batches, self.shuffle, permutation_device=self.permutation_device)(buffer)

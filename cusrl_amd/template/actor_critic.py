@@ -1,0 +1,232 @@
+"""Actor-critic agent: rollout into the HBM buffer, then minibatch PPO-style updates driven by hooks
+(counterpart of cusrl/template/actor_critic.py:23-320; the ONNX/JIT export part is out of scope).
+
+Differences that matter on MI355X (semantics unchanged):
+* ``buffer.push`` is one HIP launch per env step; minibatches come from one gather launch (template/buffer.py);
+* gradients live in ONE flat fp32 buffer (``FlatGradients``): ``zero_grad`` is a single memset, the per-step
+  data-parallel all-reduce (RCCL over xGMI) needs no pack / unpack copies, and norm clipping is one reduction;
+* the loss is ``Objectives.loss()`` — the fused kernel's pre-summed total when the stock PPO hooks are fused,
+  otherwise the reference's left-fold ``sum(objectives.values())``.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Iterable, Mapping
+from dataclasses import dataclass
+from typing import Any
+
+import torch
+
+from cusrl_amd.nn.actor import Actor, Value
+from cusrl_amd.template.agent import Agent, AgentFactory, preserve_io_format
+from cusrl_amd.template.buffer import Buffer, Sampler
+from cusrl_amd.template.environment import EnvironmentSpec
+from cusrl_amd.template.hook import Hook, HookComposite
+from cusrl_amd.template.optimizer import OptimizerFactory, build_optimizer
+from cusrl_amd.utils.distributed import FlatGradients, broadcast_parameters, reduce_gradients
+
+__all__ = ["ActorCritic", "ActorCriticFactory", "HookList"]
+
+
+class HookList(list):
+    """List of hooks with by-name attribute access (actor_critic.py:23-62)."""
+
+    def to_dict(self):
+        return {hook.name: hook for hook in self}
+
+    @classmethod
+    def from_dict(cls, data: dict[str, Hook]) -> "HookList":
+        return cls(hook.name_(name) for name, hook in data.items())
+
+    def __getattr__(self, name: str) -> Any:
+        for hook in self:
+            if hook.name == name:
+                return hook
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+    @classmethod
+    def coerce(cls, data: Any) -> "HookList":
+        if isinstance(data, dict):
+            return cls.from_dict(data)
+        if isinstance(data, (list, tuple)):
+            return cls(data)
+        raise TypeError(f"Unsupported hooks payload: {type(data)!r}")
+
+
+@dataclass(kw_only=True)
+class ActorCriticFactory(AgentFactory):
+    actor_factory: Any
+    critic_factory: Any
+    optimizer_factory: OptimizerFactory | Mapping[str, OptimizerFactory]
+    sampler: Sampler
+    hooks: list
+
+    def __post_init__(self):
+        self.hooks = HookList.coerce(self.hooks)
+
+    def __call__(self, environment_spec: EnvironmentSpec) -> "ActorCritic":
+        return ActorCritic(
+            environment_spec=environment_spec, actor_factory=self.actor_factory, critic_factory=self.critic_factory,
+            optimizer_factory=self.optimizer_factory, sampler=self.sampler, hooks=self.hooks,
+            num_steps_per_update=self.num_steps_per_update, name=self.name, device=self.device, compile=self.compile,
+            autocast=self.autocast,
+        )
+
+    def register_hook(self, hook: Hook, index: int | None = None, before: str | None = None, after: str | None = None):
+        """Insert ``hook`` at ``index``, or relative to a named hook; append by default (``:97-136``)."""
+        if (index is not None) + (before is not None) + (after is not None) > 1:
+            raise ValueError("Only one of index, before, or after can be specified")
+        if before is not None:
+            index = self.get_hook_index(before)
+        elif after is not None:
+            index = self.get_hook_index(after) + 1
+        elif index is None:
+            index = len(self.hooks)
+        self.hooks.insert(index, hook)
+        return self
+
+    def get_hook(self, hook_name: str) -> Hook:
+        return self.hooks[self.get_hook_index(hook_name)]
+
+    def get_hook_index(self, hook_name: str) -> int:
+        for i, hook in enumerate(self.hooks):
+            if hook.name == hook_name:
+                return i
+        raise ValueError(f"No hook named '{hook_name}' is registered")
+
+
+class ActorCritic(Agent):
+    Factory = ActorCriticFactory
+    MODULES = ["actor", "critic", "hook"]
+    STATEFULS = ["optimizer", "grad_scaler"]
+
+    def __init__(self, environment_spec: EnvironmentSpec, actor_factory, critic_factory, optimizer_factory,
+                 sampler: Sampler, hooks: Iterable[Hook], num_steps_per_update: int, name: str = "Agent",
+                 device=None, compile: bool | str = False, autocast=False):
+        super().__init__(environment_spec, num_steps_per_update, name, device, compile, autocast)
+        self.value_dim = environment_spec.reward_dim
+        self.buffer_capacity = num_steps_per_update
+        self.actor_factory, self.critic_factory, self.optimizer_factory = actor_factory, critic_factory, optimizer_factory
+        self.fuse_objective = True
+        self._fused_objective = None
+
+        self.hook = HookComposite(hooks)
+        self.hook.pre_init(self)
+        self.actor: Actor = actor_factory(self.observation_dim, self.action_dim)
+        action_aware = getattr(critic_factory, "action_aware", False)
+        self.critic: Value = critic_factory(self.state_dim + self.action_dim * action_aware, self.value_dim)
+        self.buffer = Buffer(self.buffer_capacity, self.parallelism, device=self.device)
+        self.sampler = sampler
+        self.grad_scaler = torch.GradScaler(device=self.device.type, enabled=self.grad_scaler_enabled)
+        self.actor_memory = None
+        self.hook.init()
+
+        self.actor = self.setup_module(self.actor)
+        self.critic = self.setup_module(self.critic)
+        if self.compile:
+            raise NotImplementedError("cusrl_amd replaces torch.compile with hand-written HIP kernels + hipGraphs")
+        self.optimizer = build_optimizer(optimizer_factory, self.named_parameters())
+        self.flat_gradients: FlatGradients | None = None
+        if isinstance(self.optimizer, torch.optim.Optimizer) and not self.grad_scaler_enabled:
+            self.flat_gradients = FlatGradients(self.optimizer)
+        self._set_training_mode(False)
+        self.hook.post_init()
+        broadcast_parameters(self.parameters())
+        self.hook.apply_schedule(0)
+
+    def _save_transition(self, *, _clone: bool = True, **fields):
+        """Store non-None fields as device tensors.  ``_clone`` keeps the reference's defensive copy
+        (agent.py:257-261) for values that must survive an ``env.step`` before they are pushed (observation, state,
+        recurrent memory); values pushed into the buffer right away are stored as they are."""
+        for key, value in fields.items():
+            if value is None:
+                continue
+            try:
+                self.transition[key] = self.to_nested_tensor(value) if _clone else self._as_nested_tensor(value)
+            except Exception as error:
+                raise ValueError(f"Failed to convert transition field '{key}' to a tensor") from error
+
+    def _as_nested_tensor(self, value):
+        if isinstance(value, (tuple, list)):
+            return tuple(self._as_nested_tensor(v) for v in value)
+        if isinstance(value, Mapping):
+            return {k: self._as_nested_tensor(v) for k, v in value.items()}
+        return torch.as_tensor(value, device=self.device)
+
+    @torch.no_grad()
+    @preserve_io_format
+    def act(self, observation, state=None):
+        self.transition.clear()
+        self._save_transition(observation=observation, state=state)
+        self.hook.pre_act(self.transition)
+        with self.autocast():
+            action_dist, (action, action_logp), next_memory = self.actor.explore(
+                self.transition["observation"], memory=self.actor_memory, deterministic=self.deterministic,
+                backbone_kwargs={"sequential": False},
+            )
+        self._save_transition(actor_memory=self.actor_memory)
+        self.transition.update(action_dist=action_dist, action=action, action_logp=action_logp)
+        self.actor_memory = next_memory
+        self.hook.post_act(self.transition)
+        return self.transition["action"]
+
+    @torch.no_grad()
+    def step(self, next_observation, reward, terminated, truncated, next_state=None, **kwargs) -> bool:
+        self._save_transition(_clone=False, next_observation=next_observation, next_state=next_state, reward=reward,
+                              terminated=terminated, truncated=truncated, **kwargs)
+        transition = self.transition
+        if transition["terminated"].dtype != torch.bool:
+            raise TypeError("'terminated' must have dtype bool")
+        if transition["truncated"].dtype != torch.bool:
+            raise TypeError("'truncated' must have dtype bool")
+        transition["done"] = transition["terminated"] | transition["truncated"]
+        self.hook.post_step(transition)
+        if not self.inference_mode:
+            self.buffer.push(transition)  # a1: every leaf of the transition in one HIP launch
+        self.actor.reset_memory(self.actor_memory, transition["done"])
+        ready = super().step(next_observation, reward, terminated, truncated, next_state, **kwargs)
+        return ready and self.hook.should_update(transition)
+
+    def update(self):
+        self.hook.pre_update(self.buffer)  # a3-a6: next_value, GAE, advantage normalisation
+        with self._training_mode():
+            for metadata, batch in self.sampler(self.buffer):  # a7/a8
+                self._train_step(metadata, batch)
+        self.hook.post_update()
+        self.hook.apply_schedule(self.iteration + 1)
+        return super().update()
+
+    def _zero_grad(self):
+        if self.flat_gradients is not None:
+            self.flat_gradients.zero()
+        else:
+            self.optimizer.zero_grad()
+
+    def _train_step(self, metadata: dict[str, Any], batch: dict[str, Any]):
+        self.actor.clear_intermediate_repr()
+        self.critic.clear_intermediate_repr()
+        self.hook.pre_objective(metadata, batch)
+        with self.autocast():
+            objectives = self.hook.objective(metadata, batch)  # a9-a13
+        if objectives is not None:
+            loss = objectives.loss() if hasattr(objectives, "loss") else sum(objectives.values())
+            self._zero_grad()
+            self.grad_scaler.scale(loss).backward()
+            self.grad_scaler.unscale_(self.optimizer)
+            reduce_gradients(self.optimizer, self.flat_gradients)  # a14
+            self.hook.pre_optim(self.optimizer)
+            self.grad_scaler.step(self.optimizer)
+            self.grad_scaler.update()
+            self.hook.post_optim()
+            self.record(**objectives)
+        self.hook.post_objective(metadata, batch)
+
+    def set_iteration(self, iteration: int):
+        if iteration != self.iteration:
+            super().set_iteration(iteration)
+            self.hook.apply_schedule(self.iteration)
+
+    def resize_buffer(self, capacity: int):
+        if self.buffer_capacity != capacity:
+            self.buffer_capacity = capacity
+            self.buffer.resize(capacity)

@@ -1,0 +1,204 @@
+"""Rollout buffer on HBM with one-launch append and one-launch minibatch gather.
+
+Same public surface as ``cusrl.template.Buffer`` / ``Sampler`` (cusrl/template/buffer.py:16-207): circular
+``[capacity, parallelism, ...]`` leaves keyed by the dotted path of a nested field, ``push`` / ``sample`` /
+mapping access, identical validation messages.  What differs is how bytes move:
+
+* ``push`` collects every leaf of the transition and issues ONE ``cusrl_buffer_push`` launch (the reference
+  issues one index_put per leaf per step, buffer.py:146);
+* ``gather`` (used by the minibatch samplers) issues ONE ``cusrl_gather_rows`` launch for all leaves (the
+  reference runs one advanced-indexing kernel per leaf per minibatch, mini_batch_sampler.py:77,89).
+
+Leaves are laid out exactly as the reference does — contiguous ``[T, N, C]`` with the env axis second — so the
+env axis is unit-stride for C = 1 leaves (reward, value, flags) and rows are C*4 contiguous bytes otherwise.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Callable, Iterator, Mapping, MutableMapping, Sequence
+from typing import Any
+
+import torch
+
+from cusrl_amd import ops
+from cusrl_amd.utils.config import device as resolve_device
+from cusrl_amd.utils.nest import get_schema, iterate_nested, reconstruct_nested
+
+__all__ = ["Buffer", "Sampler"]
+
+
+class Buffer(MutableMapping):
+    def __init__(self, capacity: int, parallelism: int, device: str | torch.device | None = None):
+        self.capacity: int = capacity
+        self.parallelism: int = parallelism
+        self.device = resolve_device(device)
+        self.cursor = 0
+        self.full = False
+        self.schema: dict[str, Any] = {}
+        self.storage: dict[str, torch.Tensor] = {}
+        # by-products of a kernel that remain valid until someone else touches the field (e.g. the advantage
+        # {sum, sumsq} partials the GAE kernel emits for the normalisation hook)
+        self._derived: dict[str, Any] = {}
+
+    # ------------------------------------------------------------------ bookkeeping
+    def get_parallelism(self) -> int:
+        return self.parallelism
+
+    def clear(self):
+        self.cursor = 0
+        self.full = False
+        self.storage.clear()
+        self.schema.clear()
+        self._derived.clear()
+
+    def reset_cursor(self):
+        self.cursor = 0
+
+    def resize(self, capacity: int):
+        if capacity != self.capacity:
+            self.clear()
+            self.capacity = capacity
+
+    # ------------------------------------------------------------------ mapping protocol (top-level field names)
+    def __iter__(self):
+        yield from self.schema
+
+    def __len__(self):
+        return len(self.schema)
+
+    def __contains__(self, key):
+        return key in self.schema
+
+    def __getitem__(self, key):
+        # hands out the storage tensors themselves: in-place edits by hooks are visible (advantage.py:102)
+        self._derived.pop(key, None)
+        return reconstruct_nested(self.storage, self.schema[key])
+
+    def get(self, key, default=None):
+        if (schema := self.schema.get(key)) is None:
+            return default
+        self._derived.pop(key, None)
+        return reconstruct_nested(self.storage, schema)
+
+    def __setitem__(self, name, data):
+        """Register or overwrite a whole field; every leaf must be ``[capacity, parallelism, ...]``."""
+        if data is None:
+            return
+        self._check_schema(name, data)
+        self._derived.pop(name, None)
+        for key, value in iterate_nested(data, name):
+            value = self._as_tensor(value)
+            self._validate_field_shape(key, value.shape)
+            storage = self.storage.get(key)
+            if storage is None:
+                storage = self.storage[key] = torch.zeros_like(value, device=self.device)
+            if storage.data_ptr() != value.data_ptr():
+                storage.copy_(value)
+
+    def __delitem__(self, name: str):
+        if name not in self.schema:
+            raise KeyError(f"Field '{name}' was not found")
+        for _, key in iterate_nested(self.schema[name]):
+            del self.storage[key]
+        del self.schema[name]
+        self._derived.pop(name, None)
+
+    # ------------------------------------------------------------------ extensions used by the HIP hooks
+    def field(self, name: str, like: torch.Tensor) -> torch.Tensor:
+        """Storage tensor of the single-leaf field ``name``, allocated (uninitialised) like ``like`` on first use,
+        so kernels write their results straight into buffer-owned memory (no ``copy_`` as in buffer.py:101)."""
+        storage = self.storage.get(name)
+        if storage is None:
+            self._validate_field_shape(name, like.shape)
+            storage = self.storage[name] = torch.empty_like(like, device=self.device)
+            self.schema[name] = name
+        self._derived.pop(name, None)
+        return storage
+
+    def set_derived(self, name: str, value: Any):
+        self._derived[name] = value
+
+    def take_derived(self, name: str) -> Any:
+        return self._derived.pop(name, None)
+
+    # ------------------------------------------------------------------ a1: append one step
+    def push(self, data: Mapping[str, Any]):
+        """Append one time step of every field; each leaf is ``[parallelism, ...]``.
+
+        The first write of a leaf fixes its nested schema and allocates ``[capacity, parallelism, ...]`` with the
+        pushed dtype; ``None`` fields are skipped; after ``capacity`` pushes the buffer is ``full`` and the
+        cursor wraps to 0 (buffer.py:124-151).
+        """
+        pairs = []
+        for name, nested_value in data.items():
+            if nested_value is None:
+                continue
+            self._check_schema(name, nested_value)
+            self._derived.pop(name, None)
+            for key, value in iterate_nested(nested_value, name):
+                value = self._as_tensor(value)
+                storage = self.storage.get(key)
+                if storage is None:
+                    self._validate_step_shape(key, value.shape)
+                    storage = self.storage[key] = value.new_zeros(self.capacity, *value.shape)
+                elif value.shape != storage.shape[1:]:
+                    raise ValueError(
+                        f"Shape mismatch for field '{key}': expected {tuple(storage.shape[1:])}, got {tuple(value.shape)}"
+                    )
+                if value.dtype != storage.dtype:
+                    value = value.to(storage.dtype)
+                if not value.is_contiguous():
+                    value = value.contiguous()
+                pairs.append((value, storage))
+        if pairs:
+            ops.require_device(pairs[0][1], "buffer storage")
+            ops.buffer_push(pairs, self.cursor, self.parallelism)
+        self.cursor += 1
+        if self.cursor == self.capacity:
+            self.full = True
+            self.cursor = 0
+
+    # ------------------------------------------------------------------ a7/a8: sampling
+    def sample(self, sampler: Callable[[str, torch.Tensor], torch.Tensor]) -> dict[str, Any]:
+        """Generic per-leaf callback form of the reference (buffer.py:153-162)."""
+        batch = {key: sampler(key, tensor) for key, tensor in self.storage.items()}
+        return reconstruct_nested(batch, self.schema)
+
+    def gather(self, indices: torch.Tensor, temporal: bool = False) -> dict[str, Any]:
+        """``flatten(0, 1)[indices]`` (or ``[:, indices]`` when ``temporal``) of EVERY leaf in one launch."""
+        keys = list(self.storage)
+        outputs = ops.gather_rows([self.storage[k] for k in keys], indices, self.capacity, self.parallelism, temporal)
+        return reconstruct_nested(dict(zip(keys, outputs)), self.schema)
+
+    # ------------------------------------------------------------------ validation (messages as in the reference)
+    def _as_tensor(self, data) -> torch.Tensor:
+        return torch.as_tensor(data, device=self.device)
+
+    def _validate_step_shape(self, name: str, shape: Sequence[int]):
+        if len(shape) < 2:
+            raise ValueError(f"A step of field '{name}' must have shape [parallelism, ...]")
+        if shape[0] != self.parallelism:
+            raise ValueError(f"Parallelism mismatch for field '{name}': expected {self.parallelism}, got {shape[0]}")
+
+    def _validate_field_shape(self, name: str, shape: Sequence[int]):
+        if len(shape) < 3:
+            raise ValueError(f"Field '{name}' must have shape [capacity, parallelism, ...]")
+        if shape[0] != self.capacity:
+            raise ValueError(f"Capacity mismatch for field '{name}': expected {self.capacity}, got {shape[0]}")
+        if shape[1] != self.parallelism:
+            raise ValueError(f"Parallelism mismatch for field '{name}': expected {self.parallelism}, got {shape[1]}")
+
+    def _check_schema(self, name: str, data):
+        current = get_schema(data, name)
+        known = self.schema.get(name)
+        if known is None:
+            self.schema[name] = current
+        elif known != current:
+            raise ValueError(f"Schema mismatch for field '{name}': expected '{known}', got '{current}'")
+
+
+class Sampler:
+    """Base sampler: one batch = the whole buffer, no copy (buffer.py:193-207)."""
+
+    def __call__(self, buffer: Buffer) -> Iterator[tuple[dict[str, Any], dict[str, Any]]]:
+        yield {}, buffer.sample(lambda _name, tensor: tensor)

@@ -1,0 +1,194 @@
+"""Outer training loop (counterpart of cusrl/template/trainer.py:33-416): rollout until the agent asks for an
+update, update, log.  Checkpointing goes through an optional logger object with ``save_checkpoint``; version
+dumps, trial folders and console boxes of the reference are out of scope."""
+
+from __future__ import annotations
+
+from collections.abc import Callable, Iterable, Mapping
+from typing import Any
+
+import torch
+
+from cusrl_amd.template.agent import Agent, AgentFactory
+from cusrl_amd.template.environment import Environment, get_done_indices, update_observation_and_state
+from cusrl_amd.utils import distributed
+from cusrl_amd.utils.timing import Timer
+
+__all__ = ["EnvironmentStats", "Trainer", "TrainerHook"]
+
+
+class EnvironmentStats:
+    """Per-env episode return / length accumulators and a ring of the last finished episodes (``:33-113``)."""
+
+    def __init__(self, num_envs: int, reward_dim: int = 1, buffer_size: int = 100, device=None):
+        self.num_envs, self.reward_dim = num_envs, reward_dim
+        self.device = torch.device("cpu" if device is None else device)
+        zeros = lambda *shape: torch.zeros(shape, device=self.device)  # noqa: E731
+        self.episode_rew, self.episode_len = zeros(num_envs, reward_dim), zeros(num_envs, 1)
+        self.rew_buffer, self.len_buffer = zeros(buffer_size, reward_dim), zeros(buffer_size, 1)
+        self.reward = zeros(reward_dim)
+        self.num_episodes = self.total_steps = self.num_steps = 0
+
+    def track_step(self, reward):
+        reward = torch.as_tensor(reward, device=self.device)
+        self.total_steps += self.num_envs
+        self.episode_rew += reward
+        self.episode_len += 1
+        self.reward += reward.mean(dim=0)
+        self.num_steps += 1
+
+    def clear_step_info(self):
+        self.reward.zero_()
+        self.num_steps = 0
+
+    def track_episode(self, indices):
+        rew, length = self.episode_rew[indices], self.episode_len[indices]
+        count = rew.size(0)
+        slot = (torch.arange(count, device=self.device) + self.num_episodes) % self.rew_buffer.size(0)
+        self.rew_buffer[slot], self.len_buffer[slot] = rew, length
+        self.num_episodes += count
+        self.episode_rew[indices] = 0.0
+        self.episode_len[indices] = 0.0
+
+    @property
+    def mean_step_reward(self):
+        mean = self.reward / self.num_steps if self.num_steps else self.reward
+        return tuple(mean.tolist()) if self.reward_dim > 1 else mean.item()
+
+    @property
+    def mean_episode_reward(self):
+        if self.num_episodes == 0:
+            return 0.0 if self.reward_dim == 1 else (0.0,) * self.reward_dim
+        mean = self.rew_buffer[: self.num_episodes].mean(dim=0)
+        return tuple(mean.tolist()) if self.reward_dim > 1 else mean.item()
+
+    @property
+    def mean_episode_length(self) -> float:
+        return 0.0 if self.num_episodes == 0 else self.len_buffer[: self.num_episodes].mean().item()
+
+    def state_dict(self) -> dict:
+        return {"num_episodes": self.num_episodes, "total_steps": self.total_steps}
+
+    def load_state_dict(self, state_dict: dict):
+        if state_dict:
+            self.total_steps = state_dict["total_steps"]
+
+
+class TrainerHook:
+    trainer: "Trainer"
+
+    def init(self, trainer: "Trainer"):
+        self.trainer = trainer
+
+    def pre_log_info(self, info: dict[str, float]): ...
+
+    def post_update(self): ...
+
+
+class Trainer:
+    Hook = TrainerHook
+
+    def __init__(self, environment: Environment | Callable[[], Environment], agent_factory: AgentFactory,
+                 logger_factory: Callable[[], Any] | None = None, num_iterations: int = 1000,
+                 init_iteration: int | None = None, checkpoint_interval: int = 50, checkpoint_path: str | None = None,
+                 trial_metadata: Mapping[str, Any] | None = None, verbose: bool = True, hooks: Iterable[TrainerHook] = ()):
+        self.logger = None if logger_factory is None else logger_factory()
+        self.environment = environment if isinstance(environment, Environment) else environment()
+        self.agent: Agent = agent_factory.from_environment(self.environment)
+        self.hooks = tuple(hooks)
+        for hook in self.hooks:
+            hook.init(self)
+        self.stats = EnvironmentStats(self.environment.num_instances, self.environment.spec.reward_dim,
+                                      device=self.environment.spec.device)
+        self.verbose = verbose and distributed.is_main_process()
+        self.iteration = 0
+        if checkpoint_path is not None:
+            checkpoint = torch.load(checkpoint_path, map_location=self.agent.device)
+            self.agent.load_state_dict(checkpoint["agent"])
+            self.environment.load_state_dict(checkpoint["environment"])
+            self.stats.load_state_dict(checkpoint.get("stats", {}))
+            self.iteration = checkpoint["iteration"]
+        if init_iteration is not None:
+            self.iteration = init_iteration
+        self.agent.set_iteration(self.iteration)
+        self.num_iterations = num_iterations
+        self.checkpoint_interval = checkpoint_interval
+        self.trial_metadata = dict(trial_metadata or {})
+        self.timer = Timer(self.agent.device)
+        self.last_info: dict[str, float] = {}
+
+    def run_training_loop(self):
+        try:
+            with self.timer.record("environment"):
+                observation, state, _ = self.environment.reset(randomize_episode_progress=True)
+            while self.iteration < self.num_iterations:
+                observation, state = self._rollout_and_update(observation, state)
+                self.iteration += 1
+                if self.logger is not None and self.iteration % self.checkpoint_interval == 0:
+                    self._save_checkpoint()
+        finally:
+            self.environment.close()
+
+    def _rollout_and_update(self, observation, state):
+        agent, env, timer = self.agent, self.environment, self.timer
+        while True:
+            with timer.record("agent"):
+                action = agent.act(observation, state)
+            with timer.record("environment"):
+                next_observation, next_state, reward, terminated, truncated, info = env.step(action)
+                self.stats.track_step(reward)
+            with timer.record("agent"):
+                ready = agent.step(next_observation, reward, terminated, truncated, next_state, **info)
+            with timer.record("environment"):
+                if done_indices := get_done_indices(terminated, truncated):
+                    if not env.spec.autoreset:
+                        init_observation, init_state, _ = env.reset(indices=done_indices)
+                        next_observation, next_state = update_observation_and_state(
+                            next_observation, next_state, done_indices, init_observation, init_state)
+                    self.stats.track_episode(done_indices)
+            observation, state = next_observation, next_state
+            if ready:
+                break
+        with timer.record("agent"):
+            agent_info = agent.update()
+        self._log_info(agent_info)
+        for hook in self.hooks:
+            hook.post_update()
+        return observation, state
+
+    def _save_checkpoint(self):
+        if self.logger is None or not distributed.is_main_process():
+            return
+        self.logger.save_checkpoint(
+            {"agent": self.agent.state_dict(), "environment": self.environment.state_dict(),
+             "iteration": self.iteration, "stats": self.stats.state_dict()}, iteration=self.iteration)
+
+    def _log_info(self, info: dict[str, float]):
+        for key, value in self.environment.get_metrics().items():
+            info[f"Environment/{key}"] = value
+        info["Metric/episode_length"] = self.stats.mean_episode_length
+        episode_reward, step_reward = self.stats.mean_episode_reward, self.stats.mean_step_reward
+        if isinstance(episode_reward, tuple):
+            info.update({f"Metric/episode_reward.{i}": v for i, v in enumerate(episode_reward)})
+            info.update({f"Metric/reward.{i}": v for i, v in enumerate(step_reward)})
+        else:
+            info["Metric/episode_reward"], info["Metric/reward"] = episode_reward, step_reward
+        info["Perf/environment_time"] = self.timer["environment"]
+        info["Perf/agent_time"] = self.timer["agent"]
+        info = distributed.average_dict(info)
+        world = distributed.world_size()
+        steps = self.stats.num_steps * self.environment.num_instances * world
+        info["Perf/environment_step"] = self.stats.total_steps * world
+        info["Perf/environment_fps"] = steps / max(info["Perf/environment_time"], 1e-12)
+        info["Perf/agent_fps"] = steps / max(info["Perf/agent_time"], 1e-12)
+        for hook in self.hooks:
+            hook.pre_log_info(info)
+        if self.logger is not None:
+            self.logger.log(info, self.iteration + 1)
+        if self.verbose:
+            print(f"[iteration {self.iteration + 1}/{self.num_iterations}] episode_len={info['Metric/episode_length']:.2f} "
+                  f"reward={info['Metric/reward'] if 'Metric/reward' in info else float('nan'):.4f} "
+                  f"env_time={info['Perf/environment_time']:.4f}s agent_time={info['Perf/agent_time']:.4f}s")
+        self.last_info = info
+        self.timer.clear()
+        self.stats.clear_step_info()

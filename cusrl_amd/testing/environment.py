@@ -1,0 +1,54 @@
+"""Synthetic vectorised environments.
+
+``SyntheticEnvironment`` is the benchmark task of BASELINE.json / SURVEY.md §8d: observations and rewards are
+i.i.d. N(0, 1), ``terminated ~ Bernoulli(0.01)``, ``truncated ~ Bernoulli(0.005)``, no privileged state, manual
+reset returning fresh N(0, 1) rows — everything generated on the env's device from torch's global generator.
+``DummyTorchEnvironment`` mirrors cusrl/testing/environment.py:39-63 (10 % / 10 % termination / truncation).
+"""
+
+from __future__ import annotations
+
+import torch
+
+from cusrl_amd.template.environment import Environment
+from cusrl_amd.utils.config import device as resolve_device
+
+__all__ = ["DummyTorchEnvironment", "SyntheticEnvironment"]
+
+
+class SyntheticEnvironment(Environment):
+    def __init__(self, num_instances: int = 4096, observation_dim: int = 48, action_dim: int = 12, *,
+                 state_dim: int | None = None, reward_dim: int = 1, terminate_prob: float = 0.01,
+                 truncate_prob: float = 0.005, device=None, **properties):
+        device = resolve_device(device)
+        super().__init__(observation_dim, action_dim, num_instances=num_instances, state_dim=state_dim,
+                         reward_dim=reward_dim, device=device, **properties)
+        self.device = device
+        self.terminate_prob, self.truncate_prob = terminate_prob, truncate_prob
+
+    def _randn(self, rows: int, cols: int | None):
+        return None if cols is None else torch.randn(rows, cols, device=self.device)
+
+    def reset(self, *, indices=None, randomize_episode_progress: bool = False):
+        rows = self.num_instances if indices is None else len(indices)
+        return self._randn(rows, self.observation_dim), self._randn(rows, self.state_dim), {}
+
+    def step(self, action):
+        assert isinstance(action, torch.Tensor) and action.shape == (self.num_instances, self.action_dim)
+        n = self.num_instances
+        flags = torch.rand(2, n, 1, device=self.device)
+        return (
+            self._randn(n, self.observation_dim),
+            self._randn(n, self.state_dim),
+            self._randn(n, self.spec.reward_dim),
+            flags[0] < self.terminate_prob,
+            flags[1] < self.truncate_prob,
+            {},
+        )
+
+
+class DummyTorchEnvironment(SyntheticEnvironment):
+    def __init__(self, *args, **kwargs):
+        kwargs.setdefault("terminate_prob", 0.1)
+        kwargs.setdefault("truncate_prob", 0.1)
+        super().__init__(*args, **kwargs)

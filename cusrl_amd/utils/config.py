@@ -1,0 +1,71 @@
+"""Process-wide device / rank configuration (counterpart of cusrl/utils/config.py:13-200).
+
+One process drives one MI355X.  Rank, local rank and world size come from the ``torchrun`` environment
+(``RANK`` / ``LOCAL_RANK`` / ``WORLD_SIZE``); on PyTorch-ROCm the ``nccl`` backend IS RCCL, so collectives
+run over xGMI; CPU-only processes (tests) use ``gloo``.
+"""
+
+from __future__ import annotations
+
+import atexit
+import os
+
+import torch
+
+__all__ = ["CONFIG", "configure_distributed", "device", "is_autocast_available"]
+
+
+class _Config:
+    def __init__(self):
+        self.cuda = torch.cuda.is_available()
+        self.seed: int | None = None
+        env = os.environ
+        self.distributed = "LOCAL_RANK" in env
+        self.rank = int(env.get("RANK", 0)) if self.distributed else 0
+        self.local_rank = int(env.get("LOCAL_RANK", 0)) if self.distributed else 0
+        self.world_size = int(env.get("WORLD_SIZE", 1)) if self.distributed else 1
+        self.local_world_size = int(env.get("LOCAL_WORLD_SIZE", self.world_size)) if self.distributed else 1
+        self._device = torch.device(f"cuda:{self.local_rank}" if self.cuda else "cpu")
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    @device.setter
+    def device(self, value):
+        self._device = torch.device(value)
+
+    def set_device(self, value):
+        self.device = value
+
+
+CONFIG = _Config()
+
+
+def device(device: str | torch.device | None = None) -> torch.device:
+    """The given device, or the process default when ``None``."""
+    return CONFIG.device if device is None else torch.device(device)
+
+
+def is_autocast_available() -> bool:
+    return CONFIG.cuda and torch.amp.autocast_mode.is_autocast_available(CONFIG.device.type)
+
+
+def configure_distributed(backend: str | None = None, **kwargs) -> bool:
+    """Lazily create the default process group; returns whether this is a multi-process job."""
+    if not CONFIG.distributed:
+        return False
+    if not torch.distributed.is_initialized():
+        if backend is None:
+            backend = "nccl" if CONFIG.device.type == "cuda" else "gloo"  # nccl == RCCL on ROCm
+        if CONFIG.device.type == "cuda":
+            torch.cuda.set_device(CONFIG.device)
+            kwargs.setdefault("device_id", CONFIG.device)
+        torch.distributed.init_process_group(backend=backend, world_size=CONFIG.world_size, rank=CONFIG.rank, **kwargs)
+    return True
+
+
+@atexit.register
+def _shutdown():
+    if CONFIG.distributed and torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()

@@ -1,0 +1,204 @@
+"""Data-parallel collectives of the hot path (counterpart of cusrl/utils/distributed.py:35-188).
+
+Process model: one rank per MI355X (``torchrun``), envs sharded per rank, manual gradient averaging.  On
+PyTorch-ROCm ``backend="nccl"`` is RCCL over the xGMI mesh.  Every message here is latency-bound (<= 5 MB,
+SURVEY.md §5), so the design goal is the fewest, copy-free collectives:
+
+* ``reduce_gradients`` all-reduces ONE flat fp32 buffer.  With a :class:`FlatGradients` view installed
+  (``ActorCritic`` does this) the parameters' ``.grad`` tensors alias that buffer, so there is no ``cat`` before
+  and no copy-back after the collective (the reference does both, distributed.py:153-161).
+* ``reduce_mean_var_`` all-gathers ``cat(mean, var)`` (8 bytes per rank for D = 1) and merges with the
+  reference's equal-weight formula (distributed.py:175-183) — as a HIP kernel on device tensors.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Iterable
+from typing import Any, TypeVar
+
+import numpy as np
+import torch
+
+from cusrl_amd.utils.config import CONFIG, configure_distributed
+
+__all__ = [
+    "FlatGradients",
+    "average_dict",
+    "barrier",
+    "broadcast_parameters",
+    "enabled",
+    "gather_obj",
+    "gather_stack",
+    "is_main_process",
+    "local_rank",
+    "print_rank0",
+    "rank",
+    "reduce_gradients",
+    "reduce_mean_",
+    "reduce_mean_var_",
+    "world_size",
+]
+
+_T = TypeVar("_T")
+
+
+def enabled() -> bool:
+    return CONFIG.distributed
+
+
+def rank() -> int:
+    return CONFIG.rank
+
+
+def local_rank() -> int:
+    return CONFIG.local_rank
+
+
+def world_size() -> int:
+    return CONFIG.world_size
+
+
+def is_main_process() -> bool:
+    return CONFIG.rank == 0
+
+
+def print_rank0(*args, **kwargs):
+    if CONFIG.rank == 0:
+        print(*args, **kwargs)
+
+
+def barrier():
+    if configure_distributed():
+        torch.distributed.barrier()
+
+
+def gather_obj(obj: _T) -> list[_T]:
+    if not configure_distributed():
+        return [obj]
+    out: list[Any] = [None] * CONFIG.world_size
+    torch.distributed.all_gather_object(out, obj)
+    return out
+
+
+def average_dict(info: dict[str, float]) -> dict[str, float]:
+    """Rank-average every key that at least one rank reported (trainer.py:387)."""
+    if not configure_distributed():
+        return info
+    gathered = gather_obj(info)
+    keys = {key for item in gathered for key in item}
+    result = {}
+    for key in keys:
+        values = [item[key] for item in gathered if item.get(key) is not None]
+        if values:
+            result[key] = float(np.mean(values))
+    return result
+
+
+def broadcast_parameters(parameters: Iterable[torch.nn.Parameter]):
+    """Rank 0's parameters to every rank, as ONE flat broadcast instead of one per tensor."""
+    if not configure_distributed():
+        return
+    params = [p for p in parameters]
+    if not params:
+        return
+    flat = torch.cat([p.data.reshape(-1) for p in params])
+    torch.distributed.broadcast(flat, src=0)
+    offset = 0
+    for p in params:
+        n = p.numel()
+        p.data.copy_(flat[offset : offset + n].view_as(p.data))
+        offset += n
+
+
+def gather_stack(tensor: torch.Tensor) -> torch.Tensor:
+    """``[W, *tensor.shape]`` with every rank's tensor."""
+    if not configure_distributed():
+        return tensor.unsqueeze(0)
+    if torch.distributed.get_backend() == torch.distributed.Backend.GLOO:
+        parts = [torch.empty_like(tensor) for _ in range(CONFIG.world_size)]
+        torch.distributed.all_gather(parts, tensor)
+        return torch.stack(parts, dim=0)
+    out = tensor.new_empty(CONFIG.world_size, *tensor.shape)
+    torch.distributed.all_gather_into_tensor(out, tensor)
+    return out
+
+
+def reduce_mean_(tensor: torch.Tensor) -> torch.Tensor:
+    """In-place cross-rank average (RCCL ``AVG``; Gloo has no AVG, so SUM then divide)."""
+    if not configure_distributed():
+        return tensor
+    if torch.distributed.get_backend() == torch.distributed.Backend.GLOO:
+        torch.distributed.all_reduce(tensor, op=torch.distributed.ReduceOp.SUM)
+        return tensor.div_(CONFIG.world_size)
+    torch.distributed.all_reduce(tensor, op=torch.distributed.ReduceOp.AVG)
+    return tensor
+
+
+def reduce_mean_var_(mean: torch.Tensor, var: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """Equal-weight merge of per-rank statistics into ``mean`` / ``var`` in place."""
+    if not configure_distributed():
+        return mean, var
+    gathered = gather_stack(torch.cat((mean, var), dim=0))  # [W, 2D]
+    if mean.is_cuda:
+        from cusrl_amd import ops
+
+        ops.merge_mean_var(gathered, mean, var)
+    else:  # host-side statistics (CPU process groups in tests): same formula, same order
+        all_means, all_vars = gathered.chunk(2, -1)
+        torch.mean(all_means, dim=0, out=mean)
+        torch.mean(all_vars + (all_means - mean).square(), dim=0, out=var)
+    return mean, var
+
+
+class FlatGradients:
+    """One contiguous fp32 buffer that every parameter's ``.grad`` aliases.
+
+    ``zero()`` replaces ``optimizer.zero_grad()`` with a single memset and keeps the aliases alive, so the
+    per-step gradient all-reduce is one collective on one registered buffer with no packing traffic.
+    """
+
+    def __init__(self, optimizer: torch.optim.Optimizer):
+        self.params = [p for group in optimizer.param_groups for p in group["params"] if p.requires_grad]
+        device = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.buffer = torch.zeros(total, dtype=torch.float32, device=device)
+        self.views = []
+        offset = 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("FlatGradients expects fp32 master parameters")
+            n = p.numel()
+            self.views.append(self.buffer[offset : offset + n].view_as(p))
+            offset += n
+        self.attach()
+
+    def attach(self):
+        for p, view in zip(self.params, self.views):
+            p.grad = view
+
+    def intact(self) -> bool:
+        return all(p.grad is view for p, view in zip(self.params, self.views))
+
+    def zero(self):
+        if not self.intact():
+            self.attach()
+        self.buffer.zero_()
+
+
+def reduce_gradients(optimizer: torch.optim.Optimizer, flat: FlatGradients | None = None):
+    """Average gradients across ranks (actor_critic.py:314)."""
+    if not configure_distributed():
+        return
+    if flat is not None and flat.intact():
+        reduce_mean_(flat.buffer)
+        return
+    params = [p for group in optimizer.param_groups for p in group["params"] if p.grad is not None]
+    if not params:
+        return
+    grads = torch.cat([p.grad.reshape(-1) for p in params])
+    reduce_mean_(grads)
+    offset = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(grads[offset : offset + n].view_as(p.grad))
+        offset += n

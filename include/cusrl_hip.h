@@ -1,0 +1,130 @@
+/*
+ * cusrl_hip.h — C ABI of libcusrl_hip.so: the MI355X (gfx950) rollout + PPO-update hot path.
+ *
+ * Drop-in boundary.  The reference (chengruiz/cusrl) has no FFI: its hot path is
+ * chains of PyTorch ops behind a Python plugin API (Buffer / Sampler / Hook).  Each entry point below
+ * replaces the torch-op chain of ONE reference function, cited as file:line relative to the
+ * reference repo root; the Python host (cusrl_amd/) keeps the reference's class and method names
+ * and binds these symbols with ctypes (INTEGRATION.md shows the binding a cusrl maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked "host";
+ *   - the caller owns all memory (no allocation, no hidden synchronisation, no host<->device copies);
+ *   - every launch goes to `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative CUSRL_E_* code;
+ *   - tensors are contiguous, row-major, fp32 unless stated; flags are 1-byte bools;
+ *   - layouts follow the reference Buffer: a leaf is [T, N, C] (capacity, parallelism, channels),
+ *     a "slot" is one (t, n) pair, its flat index is t * N + n (buffer.py:124-151).
+ */
+#ifndef CUSRL_HIP_H
+#define CUSRL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUSRL_ABI_VERSION 1
+#define CUSRL_MAX_FIELDS 24 /* leaves per push / gather launch; larger tables are split by the host */
+
+#define CUSRL_E_INVALID (-1)     /* NULL pointer, negative size, inconsistent arguments */
+#define CUSRL_E_TOO_MANY (-2)    /* n_fields > CUSRL_MAX_FIELDS */
+#define CUSRL_E_UNSUPPORTED (-3) /* shape outside what the kernels handle */
+
+/* One leaf of a multi-leaf copy.  `row_bytes` = bytes of one slot (C * element size). */
+typedef struct {
+    const void *src;
+    void *dst;
+    int64_t row_bytes;
+} cusrl_field_t;
+
+int cusrl_abi_version(void);
+/* Human-readable text for a return code (host string, static storage). */
+const char *cusrl_error_string(int code);
+
+/* ---- a1  Buffer.push — cusrl/template/buffer.py:124-151 (`storage[cursor] = value` per leaf) ----
+ * fields[i].src = step leaf [N, row_bytes];  fields[i].dst = storage leaf base [T, N, row_bytes].
+ * Copies every leaf's step into slot row `cursor` in ONE launch.  `fields` is a HOST array. */
+int cusrl_buffer_push(const cusrl_field_t *fields, int n_fields, int64_t cursor, int64_t N, void *stream);
+
+/* ---- a3  ValueComputation.pre_update — cusrl/hook/on_policy/value.py:56-82 ----
+ * next_value[:-1] = value[1:]; next_value[-1] = last_value [N,D]; next_value[terminated] = termination_value;
+ * truncated slots: mode 0 = left for the caller to bootstrap (value.py:72-78), mode 1 = value[truncated]
+ * (value.py:79-80).  Also counts truncated slots per block into `block_counts`
+ * (cusrl_flag_blocks(T*N) int32 entries) for cusrl_compact_flags. */
+int cusrl_next_value(const float *value, const uint8_t *terminated, const uint8_t *truncated,
+                     const float *last_value, float termination_value, int truncated_mode, float *next_value,
+                     int32_t *block_counts, int64_t T, int64_t N, int64_t D, void *stream);
+
+/* Number of per-block counters cusrl_next_value / cusrl_compact_flags use for `n` flags. */
+int64_t cusrl_flag_blocks(int64_t n);
+
+/* Ordered stream compaction of a flag array (replaces `next_state[truncated]` boolean-mask indexing,
+ * value.py:75): indices_out[0..count) = ascending flat slots with flags != 0, *count_out = count.
+ * `block_counts` must have been filled by cusrl_next_value over the same flags, or pass recount != 0
+ * to have this call count first. */
+int cusrl_compact_flags(const uint8_t *flags, int64_t n, int32_t *block_counts, int recount,
+                        int64_t *indices_out, int32_t *count_out, void *stream);
+
+/* dst[indices[k], :] = src[k, :] for k < K (row_bytes per row): `next_value[truncated] = critic(...)`,
+ * value.py:78.  If count_dev != NULL the effective K is min(K, *count_dev) read on the device. */
+int cusrl_scatter_rows(const void *src, const int64_t *indices, void *dst, int64_t K, int64_t row_bytes,
+                       const int32_t *count_dev, void *stream);
+
+/* ---- a4  GAE(lambda) + return — cusrl/hook/on_policy/gae.py:8-20, 85-110 ----
+ * delta = (r + nv*gamma) - v;  A[T-1] = delta;  A[t] = delta[t] + ((done[t] ? 0 : gamma*lamda) * A[t+1])
+ * (separate multiply and add, bit-exact with the reference);  ret = value + A, or value + A' where A' is the
+ * same scan with lamda_value when lamda_value >= 0 (pass < 0 for None).  done is [T,N,1].
+ * stat_partials (optional): [cusrl_gae_num_partials(T,N,D)] rows of {sum, sumsq} per channel, i.e.
+ * double[num_partials][D][2], of the advantage — consumed by cusrl_stats_finalize (fuses the statistics
+ * pass of advantage.py:111 into the scan). */
+int cusrl_gae(const float *reward, const float *value, const float *next_value, const uint8_t *done,
+              float *advantage, float *ret, double *stat_partials, int64_t T, int64_t N, int64_t D,
+              double gamma, double lamda, double lamda_value, void *stream);
+int64_t cusrl_gae_num_partials(int64_t T, int64_t N, int64_t D);
+
+/* ---- a5  AdvantageNormalization.normalize_ — cusrl/hook/on_policy/advantage.py:108-115 ----
+ * Column statistics of x [rows, D] as per-block {sum, sumsq} partials (double[num_partials][D][2]). */
+int cusrl_col_stats(const float *x, int64_t rows, int64_t D, double *stat_partials, void *stream);
+int64_t cusrl_col_stats_num_partials(int64_t rows, int64_t D);
+/* mean[d], var[d] (unbiased, correction = 1, like torch.var_mean) from partials, fixed summation order. */
+int cusrl_stats_finalize(const double *stat_partials, int64_t num_partials, int64_t D, int64_t count,
+                         float *mean, float *var, void *stream);
+/* x = (x - mean) / sqrt(var + eps) in place, true division (advantage.py:114-115). */
+int cusrl_normalize(float *x, const float *mean, const float *var, float eps, int64_t rows, int64_t D,
+                    void *stream);
+
+/* ---- a6  reduce_mean_var_ merge — cusrl/utils/distributed.py:175-183 ----
+ * gathered = [W, 2*D] rows of cat(mean_r, var_r) (the all_gather result); writes the equal-weight merge
+ * mean = avg_r mean_r, var = avg_r (var_r + (mean_r - mean)^2) into mean[D], var[D]. */
+int cusrl_merge_mean_var(const float *gathered, int64_t W, int64_t D, float *mean, float *var, void *stream);
+
+/* ---- a7/a8  minibatch gather — cusrl/sampler/mini_batch_sampler.py:87-89, 113-114; buffer.py:153-162 ----
+ * For every leaf i: temporal == 0:  dst_i[b]       = src_i.flatten(0,1)[indices[b]]      b < B
+ *                   temporal != 0:  dst_i[t, b]    = src_i[t, indices[b]]                t < T, b < B
+ * All leaves in ONE launch; `fields` is a HOST array; indices are int64 (torch.randperm's dtype). */
+int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, const int64_t *indices, int64_t B, int64_t T,
+                      int64_t N, int temporal, void *stream);
+
+/* ---- a9-a13  PPO objective, forward + backward ----
+ * common.py:29-43 (Normal log-prob / entropy / ratio), ppo.py:10-18,50-55 (clipped surrogate),
+ * value.py:85-89,121-137 (MSE or clipped value loss), ppo.py:82-84 (entropy bonus),
+ * actor_critic.py:309 (sum).  Shapes: advantage, old_logp [B,1]; action, mean, std [B,A];
+ * ret, curr_value, old_value [B,D] (old_value may be NULL when value_clip < 0 = None).
+ * Outputs: losses_out[3] = {value_loss, surrogate_loss, entropy_loss} (already weighted);
+ * logp_out, entropy_out, logp_ratio_out, ratio_out [B] (each optional);
+ * d_mean, d_std [B,A], d_value [B,D] = d(value_loss + surrogate_loss + entropy_loss)/d(.) .
+ * partials: double[cusrl_ppo_loss_num_partials(B)][3] workspace. */
+int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action, const float *mean,
+                           const float *std, const float *ret, const float *curr_value, const float *old_value,
+                           int64_t B, int64_t A, int64_t D, double clip, double value_clip, double w_sur,
+                           double w_val, double w_ent, float *losses_out, float *logp_out, float *entropy_out,
+                           float *logp_ratio_out, float *ratio_out, float *d_mean, float *d_std, float *d_value,
+                           double *partials, void *stream);
+int64_t cusrl_ppo_loss_num_partials(int64_t B);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUSRL_HIP_H */

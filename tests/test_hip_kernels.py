@@ -1,0 +1,273 @@
+"""GPU parity of every HIP kernel against the CPU oracle and the reference goldens, through the C ABI.
+
+Bar (BASELINE.json north_star): bit-exact for index / byte / copy work and for the GAE recurrence;
+1e-5 relative fp32 for reductions and losses (tolerances written at each assert).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    from cusrl_amd import ops as _ops
+
+    return _ops
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def cases(npz):
+    return range(int(npz["num_cases"]))
+
+
+# ------------------------------------------------------------------------------------------------ a1 push
+@pytest.mark.parametrize("N", [1, 7, 64, 4096])
+def test_push_all_leaves_bit_exact(ops, N):
+    rng = np.random.default_rng(N)
+    T = 5
+    leaves = {
+        "observation": rng.standard_normal((N, 48)).astype(np.float32),
+        "action": rng.standard_normal((N, 12)).astype(np.float32),
+        "reward": rng.standard_normal((N, 1)).astype(np.float32),
+        "done": rng.random((N, 1)) < 0.3,
+        "odd": rng.integers(0, 255, (N, 3)).astype(np.uint8),
+        "index": rng.integers(0, 1 << 40, (N, 1)).astype(np.int64),
+        "half": rng.standard_normal((N, 5)).astype(np.float16),
+    }
+    storages = {k: torch.zeros((T,) + v.shape, dtype=torch.from_numpy(v).dtype, device=DEV) for k, v in leaves.items()}
+    expect = {k: np.zeros((T,) + v.shape, v.dtype) for k, v in leaves.items()}
+    for cursor in (3, 0, 4):
+        step = {k: (v ^ (cursor % 2 == 1)) if v.dtype == bool else (v + cursor).astype(v.dtype) for k, v in leaves.items()}
+        ops.buffer_push([(dev(step[k]), storages[k]) for k in leaves], cursor, N)
+        for k in leaves:
+            oracle.buffer_push(step[k], expect[k], cursor)
+    for k in leaves:
+        assert np.array_equal(host(storages[k]), expect[k]), k
+
+
+def test_push_unaligned_views(ops):
+    base = torch.arange(0, 4 * 9 + 1, dtype=torch.float32, device=DEV)
+    step = base[1:].view(4, 9)  # 4-byte aligned only
+    storage = torch.zeros(3, 4, 9, device=DEV)
+    ops.buffer_push([(step, storage)], 1, 4)
+    assert torch.equal(storage[1], step) and not storage[0].any() and not storage[2].any()
+
+
+# ------------------------------------------------------------------------------------------------ a7/a8 gather
+@pytest.mark.parametrize("T,N,B", [(24, 64, 384), (3, 5, 15), (2, 4099, 1000), (1, 1, 1)])
+def test_gather_every_leaf_bit_exact(ops, T, N, B):
+    rng = np.random.default_rng(T * N)
+    leaves = [
+        rng.standard_normal((T, N, 48)).astype(np.float32),
+        rng.standard_normal((T, N, 12)).astype(np.float32),
+        rng.standard_normal((T, N, 1)).astype(np.float32),
+        rng.random((T, N, 1)) < 0.5,
+        rng.integers(0, 1 << 40, (T, N, 1)).astype(np.int64),
+        rng.integers(0, 255, (T, N, 3)).astype(np.uint8),
+        rng.standard_normal((T, N, 2, 3)).astype(np.float32),
+    ]
+    idx = rng.permutation(T * N)[:B].astype(np.int64)
+    outs = ops.gather_rows([dev(x) for x in leaves], dev(idx), T, N, temporal=False)
+    for x, out in zip(leaves, outs):
+        assert np.array_equal(host(out), oracle.gather_rows(x, idx)), x.shape
+    env_idx = rng.permutation(N)[: max(N // 2, 1)].astype(np.int64)
+    outs = ops.gather_rows([dev(x) for x in leaves], dev(env_idx), T, N, temporal=True)
+    for x, out in zip(leaves, outs):
+        assert np.array_equal(host(out), oracle.gather_rows(x, env_idx, temporal=True)), x.shape
+
+
+def test_gather_full_size_is_a_permutation(ops):
+    # config-2 size: 24 x 4096 slots, 4 minibatches of 24576 — size-independent property: each slot exactly once
+    T, N = 24, 4096
+    flat = torch.arange(T * N, dtype=torch.int64, device=DEV).view(T, N, 1)
+    obs = torch.randn(T, N, 48, device=DEV)
+    flags = torch.rand(T, N, 1, device=DEV) < 0.1
+    perm = torch.randperm(T * N, device=DEV)
+    got = []
+    for j in range(4):
+        idx = perm[j * 24576 : (j + 1) * 24576]
+        f, o, b = ops.gather_rows([flat, obs, flags], idx, T, N)
+        assert torch.equal(f.squeeze(-1), idx)
+        assert torch.equal(o, obs.flatten(0, 1)[idx]) and torch.equal(b, flags.flatten(0, 1)[idx])
+        got.append(f)
+    assert torch.equal(torch.cat(got).squeeze(-1).sort().values, torch.arange(T * N, device=DEV))
+
+
+def test_gather_more_than_max_fields(ops):
+    T, N = 2, 8
+    leaves = [torch.randn(T, N, k % 5 + 1, device=DEV) for k in range(30)]
+    idx = torch.randperm(T * N, device=DEV)[:9]
+    for x, out in zip(leaves, ops.gather_rows(leaves, idx, T, N)):
+        assert torch.equal(out, x.flatten(0, 1)[idx])
+
+
+# ------------------------------------------------------------------------------------------------ a3 next_value
+def test_next_value_vs_reference_goldens(ops, golden):
+    g = golden("next_value")
+
+    def critic(state, D):
+        base = 0.25 * state.sum(-1, keepdim=True) + 0.5 * state[..., :1]
+        return torch.cat([base * (d + 1) for d in range(D)], dim=-1)
+
+    for i in cases(g):
+        p = f"c{i}_"
+        value, nobs = dev(g[p + "value"]), dev(g[p + "next_observation"])
+        term, trunc = dev(g[p + "terminated"]), dev(g[p + "truncated"])
+        term_value, bootstrap = g[p + "params"]
+        T, N, D = value.shape
+        out = torch.full_like(value, float("nan"))
+        counts = ops.next_value(value, term, trunc, critic(nobs[-1], D), float(term_value), not bootstrap, out)
+        indices, count = ops.compact_flags(trunc, counts)
+        k = int(count.item())
+        expect_idx = np.flatnonzero(g[p + "truncated"].reshape(-1))
+        assert k == expect_idx.size and np.array_equal(host(indices[:k]), expect_idx)
+        if bootstrap and k:
+            (rows,) = ops.gather_rows([nobs], indices[:k], T, N)
+            ops.scatter_rows(critic(rows, D), indices[:k], out)
+        np.testing.assert_allclose(host(out), g[p + "next_value"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 4096, 4097, 98304, 1_000_003])
+def test_compact_flags_ordered(ops, n):
+    rng = np.random.default_rng(n)
+    flags = rng.random(n) < 0.07
+    indices, count = ops.compact_flags(dev(flags) if n else torch.zeros(0, dtype=torch.bool, device=DEV))
+    k = int(count.item())
+    assert k == int(flags.sum()) and np.array_equal(host(indices[:k]), np.flatnonzero(flags))
+
+
+# ------------------------------------------------------------------------------------------------ a4/a5 GAE
+def test_gae_bit_exact_vs_reference_goldens(ops, golden):
+    g = golden("gae")
+    for i in cases(g):
+        p = f"c{i}_"
+        gamma, lamda, lv = g[p + "params"]
+        adv, ret, partials = ops.gae(dev(g[p + "reward"]), dev(g[p + "value"]), dev(g[p + "next_value"]),
+                                     dev(g[p + "done"]), gamma, lamda, None if lv < 0 else lv)
+        assert np.array_equal(host(adv), g[p + "advantage"]), f"case {i}: advantage not bit-exact"
+        assert np.array_equal(host(ret), g[p + "return"]), f"case {i}: return not bit-exact"
+        T, N, D = g[p + "reward"].shape
+        if T * N < 2:
+            continue
+        var, mean = ops.adv_stats_finalize(partials, T * N)
+        np.testing.assert_allclose(host(mean), g[p + "mean"], rtol=1e-5, atol=1e-6)  # 1e-5 rel fp32
+        np.testing.assert_allclose(host(var), g[p + "var"], rtol=1e-5)
+        ops.normalize_(adv, mean, var)
+        np.testing.assert_allclose(host(adv), g[p + "normalized"], rtol=1e-5, atol=1e-6)
+        # standalone statistics kernel agrees with the fused one
+        var2, mean2 = ops.adv_stats_finalize(ops.col_stats(dev(g[p + "advantage"])), T * N)
+        np.testing.assert_allclose(host(var2), host(var), rtol=1e-6)
+        np.testing.assert_allclose(host(mean2), host(mean), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("T,N,D", [(24, 4096, 1), (24, 4098, 1), (24, 1000, 2), (3, 5, 4), (1, 64, 1), (40, 256, 1)])
+@pytest.mark.parametrize("lamda_value", [None, 0.9])
+def test_gae_bit_exact_vs_oracle(ops, T, N, D, lamda_value):
+    rng = np.random.default_rng(T + N + D)
+    reward = rng.standard_normal((T, N, D)).astype(np.float32)
+    value = rng.standard_normal((T, N, D)).astype(np.float32)
+    nv = rng.standard_normal((T, N, D)).astype(np.float32)
+    done = rng.random((T, N, 1)) < 0.05
+    adv, ret, partials = ops.gae(dev(reward), dev(value), dev(nv), dev(done), 0.99, 0.95, lamda_value)
+    oadv, oret = oracle.gae(reward, done, value, nv, 0.99, 0.95, lamda_value)
+    assert np.array_equal(host(adv), oadv) and np.array_equal(host(ret), oret)
+    var, mean = ops.adv_stats_finalize(partials, T * N)
+    ovar, omean = oracle.var_mean(oadv)
+    np.testing.assert_allclose(host(mean), omean, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(var), ovar, rtol=1e-5)
+    # given identical statistics the apply step is bit-exact (true division, correctly rounded sqrt)
+    ops.normalize_(adv, dev(omean), dev(ovar))
+    assert np.array_equal(host(adv), oracle.normalize(oadv, omean, ovar))
+
+
+def test_gae_propagates_nonfinite_like_reference(ops):
+    # 0 * inf = nan in the reference's `not_done * c * A[t+1]`; the kernel multiplies too instead of selecting
+    reward = np.zeros((3, 4, 1), np.float32)
+    reward[2, 1] = np.inf
+    done = np.zeros((3, 4, 1), bool)
+    done[1, 1] = True
+    zeros = np.zeros_like(reward)
+    adv, _, _ = ops.gae(dev(reward), dev(zeros), dev(zeros), dev(done), 0.9, 0.9, None)
+    oadv, _ = oracle.gae(reward, done, zeros, zeros, 0.9, 0.9)
+    assert np.array_equal(host(adv), oadv, equal_nan=True)
+
+
+def test_merge_mean_var_vs_reference_goldens(ops, golden):
+    g = golden("merge_mean_var")
+    for i in cases(g):
+        p = f"c{i}_"
+        gathered = dev(np.concatenate([g[p + "means"], g[p + "vars"]], axis=-1))
+        D = g[p + "means"].shape[1]
+        mean, var = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+        ops.merge_mean_var(gathered, mean, var)
+        np.testing.assert_allclose(host(mean), g[p + "mean"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(host(var), g[p + "var"], rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ a9-a13 loss
+def test_ppo_loss_vs_reference_goldens(ops, golden):
+    g = golden("losses")
+    for i in cases(g):
+        p = f"c{i}_"
+        clip, vclip, w_sur, w_val, w_ent = g[p + "params"]
+        out = ops.ppo_loss_fwd_bwd(
+            dev(g[p + "advantage"]), dev(g[p + "old_logp"]), dev(g[p + "action"]), dev(g[p + "mean"]), dev(g[p + "std"]),
+            dev(g[p + "ret"]), dev(g[p + "curr_value"]), dev(g[p + "old_value"]), clip=clip,
+            value_clip=None if vclip < 0 else vclip, w_sur=w_sur, w_val=w_val, w_ent=w_ent)
+        B = g[p + "mean"].shape[0]
+        scale = 1.0 / B
+        np.testing.assert_allclose(host(out["logp"]), g[p + "logp"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(host(out["entropy"]), g[p + "entropy"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(host(out["ratio"]), g[p + "ratio"], rtol=2e-5)
+        np.testing.assert_allclose(host(out["logp_ratio"]), g[p + "logp_ratio"], rtol=1e-5, atol=1e-5)
+        losses = host(out["losses"])
+        np.testing.assert_allclose(losses[0], g[p + "value_loss"], rtol=1e-5)  # 1e-5 rel fp32
+        np.testing.assert_allclose(losses[1], g[p + "surrogate"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(losses[2], g[p + "entropy_loss"], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(host(out["d_mean"]), g[p + "d_mean"], rtol=1e-4, atol=1e-6 * scale)
+        np.testing.assert_allclose(host(out["d_std"]), g[p + "d_std"], rtol=1e-4, atol=1e-5 * scale)
+        np.testing.assert_allclose(host(out["d_value"]), g[p + "d_value"], rtol=1e-5, atol=1e-7 * scale)
+
+
+@pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 7, 1), (513, 32, 2), (3, 40, 1), (255, 4, 3)])
+@pytest.mark.parametrize("vclip", [None, 0.2])
+def test_ppo_loss_vs_oracle(ops, B, A, D, vclip):
+    rng = np.random.default_rng(B + A)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    mean, action, adv, ret = f(B, A), f(B, A), f(B, 1), f(B, D)
+    std = (rng.random((B, A)) + 0.5).astype(np.float32)
+    action = mean + std * action  # actions drawn from the policy, so ratios stay O(1) like in training
+    curr_value, old_value = ret + 0.3 * f(B, D), ret + 0.3 * f(B, D)
+    old_logp, _ = oracle.normal_logp_entropy(action, mean + 0.02 * f(B, A), std)
+    kw = dict(clip=0.2, value_clip=vclip, w_sur=1.0, w_val=0.5, w_ent=0.01)
+    out = ops.ppo_loss_fwd_bwd(*(dev(x) for x in (adv, old_logp, action, mean, std, ret, curr_value, old_value)), **kw)
+    ref = oracle.ppo_loss(adv, old_logp, action, mean, std, ret, curr_value, old_value, **kw)
+    np.testing.assert_allclose(host(out["losses"]), ref["losses"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(host(out["logp"]), ref["logp"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(out["ratio"]), ref["ratio"], rtol=1e-4)
+    # gradients: rows whose ratio sits within 1e-5 of a clip bound may legitimately fall on either side
+    ratio = ref["ratio"].ravel()
+    safe = (np.abs(ratio - 0.8) > 1e-4) & (np.abs(ratio - 1.2) > 1e-4)
+    np.testing.assert_allclose(host(out["d_mean"])[safe], ref["d_mean"][safe], rtol=1e-3, atol=1e-6 / B)
+    np.testing.assert_allclose(host(out["d_std"])[safe], ref["d_std"][safe], rtol=1e-3, atol=1e-5 / B)
+    np.testing.assert_allclose(host(out["d_value"]), ref["d_value"], rtol=1e-4, atol=1e-7 / B)
+
+
+def test_hot_path_rejects_cpu_tensors(ops):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gae(torch.zeros(2, 2, 1), torch.zeros(2, 2, 1), torch.zeros(2, 2, 1), torch.zeros(2, 2, 1, dtype=torch.bool), 0.9, 0.9, None)
