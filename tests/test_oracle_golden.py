@@ -179,3 +179,47 @@ def test_loss_known_answers_from_reference_tests():
     assert out["losses"][1] == pytest.approx(0.2, rel=1e-5)
     # test_ppo.py:28-32 form: entropy loss = -mean(entropy) * w
     assert out["losses"][2] == pytest.approx(-0.5 * (0.5 + 0.5 * np.log(2 * np.pi)), rel=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ torch port
+def _load_port(g, tag):
+    import torch
+
+    from oracle.torch_ppo import TorchPpo
+
+    kw = dict(zip((str(k) for k in g[tag + "_factory_keys"]), g[tag + "_factory_vals"]))
+    port = TorchPpo(
+        16, 8, 8, num_steps_per_update=int(kw["num_steps_per_update"]), hidden=(32, 16), epochs=int(kw["sampler_epochs"]),
+        mini_batches=int(kw["sampler_mini_batches"]),
+        lamda_value=kw.get("gae_lamda_value"), value_clip=kw.get("value_loss_clip"),
+    )
+    named = dict(list(port.actor.named_parameters(prefix="actor")) + list(port.critic.named_parameters(prefix="critic")))
+    assert list(named) == [str(n) for n in g[tag + "_param_names"]]
+    with torch.no_grad():
+        for name, param in named.items():
+            param.copy_(torch.from_numpy(g[f"{tag}_param0/{name}"]))
+    for key in g[tag + "_buffer_keys"]:
+        port.storage[str(key)] = torch.from_numpy(g[f"{tag}_buffer_in/{key}"].copy())
+    return port
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_torch_port_replays_reference_update(golden, tag):
+    """The CPU baseline path (oracle/torch_ppo.py) reproduces one full reference ``agent.update()``:
+    permutations bit-exact, losses / gradients / parameters within 1e-5."""
+    torch = pytest.importorskip("torch")
+    g = golden("update_trace")
+    port = _load_port(g, tag)
+    port.trace = {k: [] for k in ("indices", "objectives", "grads_unclipped", "grads", "params_after")}
+    torch.manual_seed(99)
+    metrics = port.update()
+    assert np.array_equal(torch.stack(port.trace["indices"]).numpy(), g[tag + "_indices"])  # bit-exact permutations
+    for key in ("next_value", "advantage", "return"):
+        np.testing.assert_allclose(port.storage[key].numpy(), g[f"{tag}_buffer_out/{key}"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(torch.stack(port.trace["objectives"]).numpy(), g[tag + "_objectives"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(torch.stack(port.trace["grads_unclipped"]).numpy(), g[tag + "_grads_unclipped"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(torch.stack(port.trace["grads"]).numpy(), g[tag + "_grads"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(torch.stack(port.trace["params_after"]).numpy(), g[tag + "_params_after"], rtol=1e-5, atol=1e-6)
+    ref = dict(zip((str(k) for k in g[tag + "_metric_keys"]), g[tag + "_metric_vals"]))
+    np.testing.assert_allclose(metrics["kl_divergence"].item(), ref["Agent/kl_divergence"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(metrics["action_std"].item(), ref["Agent/action_std"], rtol=1e-5)
