@@ -1,0 +1,68 @@
+"""Worker for tests/test_distributed_cpu.py: one rank of a world_size-2 gloo job (launched by torchrun)."""
+
+import json
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+import cusrl_amd as cusrl  # noqa: E402  (reads RANK / LOCAL_RANK / WORLD_SIZE at import)
+from cusrl_amd.utils import distributed  # noqa: E402
+
+
+def main(out_dir: str):
+    cusrl.config.set_device("cpu")
+    assert distributed.enabled() and distributed.world_size() == 2
+    rank = distributed.rank()
+    result = {"rank": rank}
+
+    # per-rank seeding: seed + rank (cusrl/utils/misc.py:163)
+    cusrl.set_global_seed(7)
+    result["first_randperm"] = torch.randperm(16).tolist()
+
+    # a6: advantage statistics merge across ranks (equal-weight formula)
+    mean = torch.tensor([1.0 + rank, -2.0 * rank])
+    var = torch.tensor([0.5 + rank, 2.0])
+    result["local_mean"], result["local_var"] = mean.tolist(), var.tolist()
+    distributed.reduce_mean_var_(mean, var)
+    result["merged_mean"], result["merged_var"] = mean.tolist(), var.tolist()
+
+    # a14: flat gradient averaging, with and without the aliasing flat buffer
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))
+    optimizer = torch.optim.SGD(model.parameters(), lr=0.1)
+    flat = distributed.FlatGradients(optimizer)
+    flat.zero()
+    loss = model(torch.full((5, 3), float(rank + 1))).square().sum()
+    loss.backward()
+    assert flat.intact()
+    local = flat.buffer.clone()
+    distributed.reduce_gradients(optimizer, flat)
+    result["flat_local"], result["flat_reduced"] = local.tolist(), flat.buffer.tolist()
+    for p in model.parameters():
+        p.grad = None
+    model(torch.full((5, 3), float(rank + 1))).square().sum().backward()
+    distributed.reduce_gradients(optimizer)  # reference-style cat / all-reduce / copy-back path
+    result["cat_reduced"] = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).tolist()
+
+    # parameter broadcast from rank 0
+    torch.manual_seed(100 + rank)
+    other = torch.nn.Linear(3, 2)
+    before = torch.cat([p.detach().reshape(-1) for p in other.parameters()]).tolist()
+    distributed.broadcast_parameters(other.parameters())
+    result["params_before"] = before
+    result["params_after"] = torch.cat([p.detach().reshape(-1) for p in other.parameters()]).tolist()
+
+    result["averaged"] = distributed.average_dict({"shared": float(rank), f"only{rank}": 1.0})
+    result["gathered"] = distributed.gather_obj(rank * 10)
+    result["stack"] = distributed.gather_stack(torch.tensor([float(rank)])).tolist()
+    distributed.barrier()
+    Path(out_dir, f"rank{rank}.json").write_text(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

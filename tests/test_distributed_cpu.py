@@ -1,0 +1,65 @@
+"""world_size-2 gloo run on CPU of every collective on the hot path: advantage-statistics merge,
+flat gradient averaging (aliasing buffer and cat/copy-back forms), parameter broadcast, metric averaging."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def ranks(tmp_path_factory):
+    out = tmp_path_factory.mktemp("dist")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "tests" / "_dist_worker.py"), str(out)]
+    done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
+    return [json.loads((out / f"rank{r}.json").read_text()) for r in range(2)]
+
+
+def test_ranks_are_seeded_differently(ranks):
+    assert ranks[0]["first_randperm"] != ranks[1]["first_randperm"]
+    assert ranks[0]["first_randperm"] == oracle.Mt19937(7).randperm(16).tolist()
+    assert ranks[1]["first_randperm"] == oracle.Mt19937(8).randperm(16).tolist()
+
+
+def test_advantage_statistics_merge_matches_the_oracle(ranks):
+    means = np.array([r["local_mean"] for r in ranks], np.float32)
+    vars_ = np.array([r["local_var"] for r in ranks], np.float32)
+    mean, var = oracle.merge_mean_var(means, vars_)
+    for r in ranks:  # every rank ends with the same merged statistics
+        np.testing.assert_allclose(r["merged_mean"], mean, rtol=1e-6)
+        np.testing.assert_allclose(r["merged_var"], var, rtol=1e-6)
+    # equal-weight formula: var = avg(var_r + (mean_r - mean)^2), not the pooled variance
+    np.testing.assert_allclose(var, (vars_ + (means - means.mean(0)) ** 2).mean(0), rtol=1e-6)
+
+
+def test_gradient_averaging_flat_and_reference_style_agree(ranks):
+    expect = (np.array(ranks[0]["flat_local"]) + np.array(ranks[1]["flat_local"])) / 2
+    for r in ranks:
+        np.testing.assert_allclose(r["flat_reduced"], expect, rtol=1e-6)
+        np.testing.assert_allclose(r["cat_reduced"], expect, rtol=1e-6)
+
+
+def test_parameter_broadcast_and_metric_averaging(ranks):
+    assert ranks[0]["params_before"] != ranks[1]["params_before"]
+    assert ranks[0]["params_after"] == ranks[0]["params_before"] == ranks[1]["params_after"]
+    for r in ranks:
+        assert r["averaged"] == {"shared": 0.5, "only0": 1.0, "only1": 1.0}
+        assert r["gathered"] == [0, 10] and r["stack"] == [[0.0], [1.0]]

@@ -1,0 +1,273 @@
+"""CPU-side checks (no GPU, no compute through the HIP library): the C ABI loads and exports every declared symbol,
+host-side validation mirrors the reference's error behaviour, the plugin surface composes like the reference's, and the
+hot path refuses to run anywhere but on the GPU."""
+
+import re
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import cusrl_amd as cusrl
+from cusrl_amd import _native
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def test_library_exports_every_symbol_declared_in_the_header():
+    header = (ROOT / "include" / "cusrl_hip.h").read_text()
+    declared = set(re.findall(r"\b(cusrl_[a-z0-9_]+)\s*\(", header))
+    declared -= {"cusrl_field_t"}
+    lib = _native.lib()
+    for symbol in declared:
+        assert hasattr(lib, symbol), f"{symbol} declared in include/cusrl_hip.h but not exported"
+    assert declared == set(_native.EXPORTED_SYMBOLS)
+    assert lib.cusrl_abi_version() == _native.ABI_VERSION
+    assert b"invalid" in lib.cusrl_error_string(-1) and lib.cusrl_error_string(0) == b"success"
+
+
+def test_size_helpers_and_argument_validation_without_a_gpu():
+    lib = _native.lib()
+    assert lib.cusrl_flag_blocks(0) == 0 and lib.cusrl_flag_blocks(1) == 1 and lib.cusrl_flag_blocks(4097) == 2
+    assert lib.cusrl_gae_num_partials(24, 4096, 1) == 16
+    assert lib.cusrl_ppo_loss_num_partials(24576) == 96
+    assert lib.cusrl_col_stats_num_partials(98304, 1) == 24
+    # invalid arguments are rejected on the host before any launch
+    assert lib.cusrl_gae(None, None, None, None, None, None, None, 2, 2, 1, 0.9, 0.9, -1.0, None) == -1
+    assert lib.cusrl_buffer_push(None, 99, 0, 1, None) == -1
+    table = (_native.Field * 30)()
+    assert lib.cusrl_buffer_push(table, 30, 0, 1, None) == -2
+
+
+def test_hot_path_refuses_cpu_tensors():
+    from cusrl_amd import ops
+
+    x = torch.zeros(2, 3, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gae(x, x, x, torch.zeros(2, 3, 1, dtype=torch.bool), 0.99, 0.95, None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.normalize_(x, torch.zeros(1), torch.ones(1))
+    buffer = cusrl.Buffer(capacity=2, parallelism=1, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        buffer.push({"terminated": torch.tensor([[True]])})
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cusrl.hook.GeneralizedAdvantageEstimation().pre_update(
+            {"reward": x, "value": x, "next_value": x, "done": torch.zeros(2, 3, 1, dtype=torch.bool)})
+
+
+# ------------------------------------------------------------------------------------------------ Buffer (test_buffer.py)
+def test_buffer_setitem_accepts_numpy_arrays():
+    buffer = cusrl.Buffer(capacity=3, parallelism=2, device="cpu")
+    buffer["observation"] = np.arange(6, dtype=np.float32).reshape(3, 2, 1)
+    observation = buffer["observation"]
+    assert isinstance(observation, torch.Tensor) and observation.shape == (3, 2, 1) and observation.device.type == "cpu"
+    assert "observation" in buffer and list(buffer) == ["observation"] and len(buffer) == 1
+    del buffer["observation"]
+    with pytest.raises(KeyError):
+        del buffer["observation"]
+
+
+def test_buffer_validation_messages():
+    buffer = cusrl.Buffer(capacity=3, parallelism=2, device="cpu")
+    with pytest.raises(ValueError, match=r"\[parallelism, \.\.\.\]"):
+        buffer.push({"observation": torch.tensor([1.0])})
+    with pytest.raises(ValueError, match="Parallelism mismatch"):
+        buffer.push({"observation": torch.zeros(3, 1)})
+    with pytest.raises(ValueError, match=r"\[capacity, parallelism, \.\.\.\]"):
+        buffer["observation"] = torch.tensor([1.0, 2.0, 3.0])
+    with pytest.raises(ValueError, match="Capacity mismatch"):
+        buffer["observation"] = torch.zeros(2, 2, 1)
+    buffer["nested"] = {"a": torch.zeros(3, 2, 1), "b": (torch.zeros(3, 2, 2),)}
+    assert set(buffer.storage) == {"nested.a", "nested.b.0"}
+    with pytest.raises(ValueError, match="Schema mismatch"):
+        buffer["nested"] = {"a": torch.zeros(3, 2, 1)}
+    buffer.resize(5)
+    assert buffer.capacity == 5 and not buffer.storage and buffer.cursor == 0 and not buffer.full
+
+
+# ------------------------------------------------------------------------------------------------ samplers
+def test_mini_batch_sampler_validation():
+    with pytest.raises(ValueError, match="'num_epochs' must be positive"):
+        cusrl.MiniBatchSampler(num_epochs=0)
+    with pytest.raises(ValueError, match="'num_mini_batches' must be positive"):
+        cusrl.MiniBatchSampler(num_mini_batches=0)
+    with pytest.raises(ValueError, match="'num_mini_batches' values must be positive"):
+        cusrl.MiniBatchSampler(num_epochs=2, num_mini_batches=[1, 0])
+    with pytest.raises(ValueError, match="length"):
+        cusrl.MiniBatchSampler(num_epochs=2, num_mini_batches=[1])
+    buffer = cusrl.Buffer(capacity=2, parallelism=1, device="cpu")
+    buffer["observation"] = torch.zeros(2, 1, 1)
+    with pytest.raises(RuntimeError, match="full buffer"):
+        next(iter(cusrl.MiniBatchSampler()(buffer)))
+    metadata, batch = next(iter(cusrl.Sampler()(buffer)))
+    assert metadata == {} and batch["observation"] is buffer.storage["observation"]
+
+
+# ------------------------------------------------------------------------------------------------ hooks
+@pytest.mark.parametrize("kwargs", [{"gamma": -0.1}, {"gamma": 1.0}, {"lamda": -0.1}, {"lamda": 1.1}, {"lamda_value": 1.1}])
+def test_gae_validates_discount_parameters(kwargs):
+    with pytest.raises(ValueError):
+        cusrl.hook.GeneralizedAdvantageEstimation(**kwargs)
+
+
+@pytest.mark.parametrize("factory", [
+    lambda: cusrl.hook.PpoSurrogateLoss(clip_ratio=0.0),
+    lambda: cusrl.hook.PpoSurrogateLoss(weight=-1.0),
+    lambda: cusrl.hook.EntropyLoss(weight=-1.0),
+    lambda: cusrl.hook.ValueLoss(weight=0.0),
+    lambda: cusrl.hook.ValueLoss(loss_clip=0.0),
+    lambda: cusrl.hook.GradientClipping(max_grad_norm=-1.0),
+    lambda: cusrl.hook.GradientClipping(groups={"": 1.0}),
+    lambda: cusrl.hook.AdvantageReduction(reduction="max"),
+])
+def test_hooks_validate_configuration(factory):
+    with pytest.raises(ValueError):
+        factory()
+
+
+def test_hook_names_mutables_and_composite():
+    hook = cusrl.hook.GeneralizedAdvantageEstimation()
+    assert hook.name == "generalized_advantage_estimation" and hook.training_only and hook.active
+    hook.update_attribute("gamma", 0.5)
+    assert hook.gamma == 0.5
+    with pytest.raises(ValueError, match="not mutable"):
+        hook.update_attribute("recompute", True)
+    assert cusrl.hook.PpoSurrogateLoss().name == "ppo_surrogate_loss"
+    from cusrl_amd.template.hook import HookComposite
+
+    with pytest.raises(RuntimeError, match="already exists"):
+        HookComposite([cusrl.hook.EntropyLoss(), cusrl.hook.EntropyLoss()])
+    with pytest.raises(TypeError):
+        HookComposite([object()])
+    composite = HookComposite([cusrl.hook.EntropyLoss(), cusrl.hook.ValueLoss().active_(False)])
+    composite.pre_init(SimpleNamespace(inference_mode=True))
+    assert [h.name for h in composite.active_hooks()] == []  # training-only skipped in inference, inactive skipped
+    composite.agent.inference_mode = False
+    assert [h.name for h in composite.active_hooks()] == ["entropy_loss"]
+    assert composite["value_loss"].weight == 0.5
+
+
+def test_advantage_reduction_is_plain_tensor_math():
+    hook = cusrl.hook.AdvantageReduction(reduction="sum", weight=(1.0, 2.0))
+    hook.agent = SimpleNamespace(to_tensor=lambda value: torch.as_tensor(value, dtype=torch.float32))
+    hook.init()
+    batch = {"advantage": torch.tensor([[1.0, 2.0], [3.0, 4.0]])}
+    hook.objective({}, batch)
+    assert torch.allclose(batch["advantage"], torch.tensor([[5.0], [11.0]]))
+    hook.update_attribute("weight", (0.5, 0.5))
+    batch = {"advantage": torch.tensor([[2.0, 6.0]])}
+    hook.objective({}, batch)
+    assert torch.allclose(batch["advantage"], torch.tensor([[4.0]]))
+
+
+def test_ppo_preset_hook_order_and_register_hook():
+    factory = cusrl.preset.PpoAgentFactory().to_underlying()
+    assert [h.name for h in factory.hooks] == [
+        "module_initialization", "value_computation", "generalized_advantage_estimation", "advantage_normalization",
+        "value_loss", "on_policy_preparation", "ppo_surrogate_loss", "entropy_loss", "gradient_clipping",
+        "on_policy_statistics",
+    ]
+
+    class Probe(cusrl.Hook):
+        pass
+
+    factory.register_hook(Probe().name_("a"), before="value_loss")
+    factory.register_hook(Probe().name_("b"), after="entropy_loss")
+    factory.register_hook(Probe().name_("c"))
+    names = [h.name for h in factory.hooks]
+    assert names.index("a") == names.index("value_loss") - 1 and names.index("b") == names.index("entropy_loss") + 1
+    assert names[-1] == "c" and factory.hooks.gradient_clipping.max_grad_norm == 1.0
+    with pytest.raises(ValueError, match="Only one of"):
+        factory.register_hook(Probe(), index=0, before="a")
+    with pytest.raises(ValueError, match="No hook named"):
+        factory.get_hook("missing")
+    assert cusrl.preset.PpoAgentFactory().sampler_epochs == 5 and cusrl.preset.PpoAgentFactory().num_steps_per_update == 24
+
+
+def test_agent_builds_on_cpu_with_reference_parameter_layout():
+    spec = cusrl.EnvironmentSpec(48, 12, num_instances=4, device="cpu")
+    agent = cusrl.preset.PpoAgentFactory(device="cpu").to_underlying()(spec)
+    names = [n for n, _ in agent.named_parameters()]
+    assert names[:3] == ["actor.backbone.layers.0.weight", "actor.backbone.layers.0.bias", "actor.backbone.layers.2.weight"]
+    assert names[-2:] == ["critic.value_head.weight", "critic.value_head.bias"] and len(names) == 13
+    assert sum(p.numel() for p in agent.parameters()) == 92569  # 13 tensors, 92 569 parameters
+    assert agent.flat_gradients.buffer.numel() == 92569 and agent.flat_gradients.intact()
+    groups = agent.optimizer.param_groups
+    assert groups[0]["param_names"] == names
+    # orthogonal init: zero biases, small policy head
+    assert not agent.actor.backbone.layers[0].bias.any()
+    assert agent.actor.distribution.mean_head.weight.norm() < agent.actor.backbone.layers[2].weight.norm()
+    with pytest.raises(TypeError, match="'terminated' must have dtype bool"):
+        agent.act(torch.zeros(4, 48))
+        agent.step(torch.zeros(4, 48), torch.zeros(4, 1), torch.zeros(4, 1), torch.zeros(4, 1, dtype=torch.bool))
+
+
+def test_optimizer_factory_groups_and_names():
+    model = torch.nn.ModuleDict({"actor": torch.nn.Linear(2, 2), "critic": torch.nn.Linear(2, 1)})
+    factory = cusrl.OptimizerFactory("Adam", defaults={"lr": 1e-3}, group_overrides=[("critic", {"lr": 1e-2})])
+    optimizer = factory(model.named_parameters())
+    by_lr = {g["lr"]: g["param_names"] for g in optimizer.param_groups}
+    assert by_lr[1e-2] == ["critic.weight", "critic.bias"] and by_lr[1e-3] == ["actor.weight", "actor.bias"]
+    with pytest.raises(ValueError, match="No trainable parameters"):
+        cusrl.OptimizerFactory("Adam", param_filter="nothing")(model.named_parameters())
+    with pytest.raises(ValueError, match="not assigned"):
+        cusrl.template.build_optimizer(cusrl.OptimizerFactory("Adam", param_filter="actor"), model.named_parameters())
+
+
+# ------------------------------------------------------------------------------------------------ utils
+def test_nest_roundtrip():
+    from cusrl_amd.utils.nest import flatten_nested, get_schema, iterate_nested, map_nested, reconstruct_nested
+
+    data = {"a": 1, "b": {"c": [10, 20], "d": 30}, "e": (40,)}
+    assert list(iterate_nested(data)) == [("a", 1), ("b.c.0", 10), ("b.c.1", 20), ("b.d", 30), ("e.0", 40)]
+    assert get_schema({"a": 1, "b": {"c": 2}}) == {"a": "a", "b": {"c": "b.c"}}
+    assert get_schema([10, 20, {"key": 30}]) == ["0", "1", {"key": "2.key"}]
+    assert reconstruct_nested(flatten_nested(data), get_schema(data)) == data
+    assert reconstruct_nested({"a": 10, "b.c": 20, "b.d": 30}, {"a": "a", "b": ("b.c", "b.d")}) == {"a": 10, "b": (20, 30)}
+    assert map_nested(lambda v: v * 2, data)["b"]["c"] == [20, 40]
+    assert dict(iterate_nested({"x": {"y": 1}}, "p")) == {"p.x.y": 1}
+
+
+def test_metrics_weighted_mean():
+    metrics = cusrl.utils.Metrics()
+    metrics.record(loss=torch.tensor([1.0, 3.0]))       # mean 2 over 2 samples
+    metrics.record({"loss": torch.tensor([7.0, 7.0, 7.0])}, skipped=None)  # mean 7 over 3 samples
+    assert metrics.summary("Agent") == {"Agent/loss": pytest.approx(5.0)}
+    metrics.clear()
+    assert metrics.summary() == {}
+
+
+def test_timer_sections_accumulate():
+    timer = cusrl.utils.Timer("cpu")
+    with timer.record("agent"):
+        pass
+    with timer.record("agent"):
+        pass
+    assert timer["agent"] >= 0.0
+    with pytest.raises(RuntimeError, match="has not been started"):
+        timer.stop("missing")
+    timer.start("x")
+    with pytest.raises(RuntimeError, match="already been started"):
+        timer.start("x")
+
+
+def test_distributed_helpers_are_local_no_ops_in_a_single_process():
+    from cusrl_amd.utils import distributed
+
+    assert not distributed.enabled() and distributed.world_size() == 1 and distributed.rank() == 0
+    mean, var = torch.tensor([1.0]), torch.tensor([2.0])
+    assert distributed.reduce_mean_var_(mean, var) == (mean, var)
+    assert distributed.gather_stack(mean).shape == (1, 1)
+    assert distributed.average_dict({"a": 1.0}) == {"a": 1.0}
+    assert distributed.gather_obj("x") == ["x"]
+    distributed.barrier()
+
+
+def test_set_global_seed_is_rank_offset_and_reproducible():
+    cusrl.set_global_seed(42)
+    a = torch.randperm(8)
+    cusrl.set_global_seed(42)
+    assert torch.equal(a, torch.randperm(8)) and cusrl.config.seed == 42
