@@ -40,6 +40,7 @@ def parse_args():
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-kernel-pass", action="store_true")
     parser.add_argument("--cpu-seconds", type=float, default=15.0)
+    parser.add_argument("--eager", action="store_true", help="disable hipGraph replay (compile=False)")
     return parser.parse_args()
 
 
@@ -138,7 +139,8 @@ def run_gpu(args, rank, world):
         cusrl.utils.configure_distributed()
     cusrl.set_global_seed(42)
     env = cusrl.testing.SyntheticEnvironment(args.envs_per_gpu, OBS_DIM, ACT_DIM, device=device)
-    factory = cusrl.preset.PpoAgentFactory(optimizer_kwargs={"fused": True})
+    # compile=True = hipGraph replay of the act step and the minibatch steps (cusrl_amd/template/graphs.py)
+    factory = cusrl.preset.PpoAgentFactory(compile=not args.eager, optimizer_kwargs={"fused": True, "capturable": True})
     trainer = cusrl.Trainer(env, factory, num_iterations=10**9, verbose=False)
     agent = trainer.agent
 
@@ -219,6 +221,7 @@ def run_gpu(args, rank, world):
             "envs_per_gpu": args.envs_per_gpu,
             "env_steps_per_iteration": steps_per_iteration,
             "parallelism": f"dp{world}",
+            "hipgraph": not args.eager,
         },
         "ppo_update_ms": round(update_ms, 3),
         "roofline": {

@@ -113,7 +113,8 @@ class PpoAgentFactory(AgentFactory):
                 distribution_factory=get_distribution_factory(self.action_space_type, init_std=self.init_distribution_std),
             ),
             critic_factory=Value.Factory(backbone_factory=backbone(self.critic_hidden_dims)),
-            optimizer_factory=AdamFactory(defaults={"lr": self.lr, **self.optimizer_kwargs}),
+            optimizer_factory=AdamFactory(defaults={
+                "lr": self.lr, **({"capturable": True, "fused": True} if self.compile else {}), **self.optimizer_kwargs}),
             sampler=AutoMiniBatchSampler(num_epochs=self.sampler_epochs, num_mini_batches=self.sampler_mini_batches),
             hooks=ppo_hook_suite(
                 orthogonal_init=self.orthogonal_init,

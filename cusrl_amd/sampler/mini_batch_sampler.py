@@ -51,7 +51,9 @@ class MiniBatchSampler(Sampler):
         self.shuffle = shuffle
         self.permutation_device = None if permutation_device is None else torch.device(permutation_device)
 
-    def __call__(self, buffer: Buffer):
+    def iter_indices(self, buffer: Buffer):
+        """Yield ``(metadata, device index slice)`` per minibatch — the permutation logic of ``__call__`` without
+        the gather, so a captured hipGraph can own the gather (template/graphs.py)."""
         if not (buffer.full and buffer.cursor == 0):
             raise RuntimeError("MiniBatchSampler requires a full buffer with cursor reset to 0")
         num_samples = self._get_num_samples(buffer)
@@ -76,7 +78,11 @@ class MiniBatchSampler(Sampler):
                     "total_mini_batches": count,
                     "temporal": self.temporal,
                 }
-                yield metadata, buffer.gather(device_indices[j * size : (j + 1) * size], temporal=self.temporal)
+                yield metadata, device_indices[j * size : (j + 1) * size]
+
+    def __call__(self, buffer: Buffer):
+        for metadata, indices in self.iter_indices(buffer):
+            yield metadata, buffer.gather(indices, temporal=self.temporal)
 
     def _get_num_samples(self, buffer: Buffer) -> int:
         return buffer.capacity * buffer.get_parallelism()
@@ -101,7 +107,13 @@ class AutoMiniBatchSampler(Sampler):
         self.shuffle = shuffle
         self.permutation_device = permutation_device
 
-    def __call__(self, buffer: Buffer):
+    def _dispatch(self, buffer: Buffer) -> MiniBatchSampler:
         temporal = any(key.split(".")[0].endswith("memory") for key in buffer)
         cls = TemporalMiniBatchSampler if temporal else MiniBatchSampler
-        return cls(self.num_epochs, self.num_mini_batches, self.shuffle, permutation_device=self.permutation_device)(buffer)
+        return cls(self.num_epochs, self.num_mini_batches, self.shuffle, permutation_device=self.permutation_device)
+
+    def __call__(self, buffer: Buffer):
+        return self._dispatch(buffer)(buffer)
+
+    def iter_indices(self, buffer: Buffer):
+        return self._dispatch(buffer).iter_indices(buffer)

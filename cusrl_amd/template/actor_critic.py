@@ -123,9 +123,20 @@ class ActorCritic(Agent):
 
         self.actor = self.setup_module(self.actor)
         self.critic = self.setup_module(self.critic)
-        if self.compile:
-            raise NotImplementedError("cusrl_amd replaces torch.compile with hand-written HIP kernels + hipGraphs")
         self.optimizer = build_optimizer(optimizer_factory, self.named_parameters())
+        self._graphed_act = None
+        self._graphed_steps: dict[tuple, Any] = {}
+        if self.compile:
+            # `compile=True` = hipGraph replay of the act step and of every minibatch step (template/graphs.py)
+            if self.device.type != "cuda":
+                raise RuntimeError("compile=True captures hipGraphs and needs a GPU device")
+            if any(not group.get("capturable", False) for group in self.optimizer.param_groups):
+                raise ValueError("compile=True needs a graph-capturable optimizer, e.g. Adam(capturable=True, fused=True)")
+            from cusrl_amd.template.graphs import GraphedAct
+
+            self._graph_stream = torch.cuda.Stream(device=self.device)
+            self._graph_pool = torch.cuda.graph_pool_handle()
+            self._graphed_act = GraphedAct(self)
         self.flat_gradients: FlatGradients | None = None
         if isinstance(self.optimizer, torch.optim.Optimizer) and not self.grad_scaler_enabled:
             self.flat_gradients = FlatGradients(self.optimizer)
@@ -156,6 +167,11 @@ class ActorCritic(Agent):
     @torch.no_grad()
     @preserve_io_format
     def act(self, observation, state=None):
+        if self._graphed_act is not None:
+            observation_t = torch.as_tensor(observation, device=self.device)
+            state_t = None if state is None else torch.as_tensor(state, device=self.device)
+            if self._graphed_act.supported(observation_t, state_t):
+                return self._graphed_act.run(observation_t, state_t)
         self.transition.clear()
         self._save_transition(observation=observation, state=state)
         self.hook.pre_act(self.transition)
@@ -190,8 +206,19 @@ class ActorCritic(Agent):
     def update(self):
         self.hook.pre_update(self.buffer)  # a3-a6: next_value, GAE, advantage normalisation
         with self._training_mode():
-            for metadata, batch in self.sampler(self.buffer):  # a7/a8
-                self._train_step(metadata, batch)
+            if self.compile and hasattr(self.sampler, "iter_indices"):
+                from cusrl_amd.template.graphs import GraphedTrainStep
+
+                for metadata, indices in self.sampler.iter_indices(self.buffer):
+                    key = (metadata["mini_batch_index"], metadata["temporal"], indices.numel())
+                    if (step := self._graphed_steps.get(key)) is None:
+                        step = self._graphed_steps[key] = GraphedTrainStep(self, key[0], key[1])
+                    step.run(metadata, indices)
+                for step in self._graphed_steps.values():
+                    step.flush_metrics()
+            else:
+                for metadata, batch in self.sampler(self.buffer):  # a7/a8
+                    self._train_step(metadata, batch)
         self.hook.post_update()
         self.hook.apply_schedule(self.iteration + 1)
         return super().update()

@@ -1,0 +1,214 @@
+"""hipGraph capture of the two launch-bound inner loops (what ``compile=True`` means in cusrl_amd).
+
+The reference offers ``compile=True`` = ``torch.compile`` of actor / critic / hook objective
+(cusrl/template/actor_critic.py:217-220, hook.py:396-399).  On MI355X the inner loops are not FLOP-bound but
+launch-bound — one minibatch step is ≈ 75 kernels of a few µs each, one ``act`` ≈ 26 — so instead of a tracing
+compiler the same knob captures them into HIP graphs and replays them:
+
+* :class:`GraphedTrainStep` — one per minibatch slot ``j``: graph A = gather of every buffer leaf (HIP kernel) →
+  critic / actor forward → fused PPO objective (HIP kernel) → zero flat gradients → backward; then the gradient
+  all-reduce runs EAGERLY between the graphs (RCCL stays outside capture); graph B = clipping → Adam → metric taps.
+* :class:`GraphedAct` — ``pre_act`` hooks → ``actor.explore`` (sampling included: torch's graph-safe Philox state)
+  → ``post_act`` hooks (critic value).
+
+Protocol per graph: first use runs eagerly on the capture stream (warm-up of rocBLAS workspaces and allocator,
+and it IS the real step), second use captures and replays, later uses replay.  Hooks must be capture-safe: no host
+synchronisation and no Python side effects other than ``agent.record`` inside the captured phases — true for every
+stock hook.  Anything else keeps ``compile=False`` (eager), which is the default.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+
+from cusrl_amd.utils.metrics import MetricTap
+
+__all__ = ["GraphedAct", "GraphedTrainStep"]
+
+
+class _Capture:
+    """A captured region + the metric taps recorded while capturing it."""
+
+    def __init__(self, agent):
+        self.agent = agent
+        self.graph: torch.cuda.CUDAGraph | None = None
+        self.tap_names: list[str] = []
+        self.tap_counts: list[int] = []
+        self.accumulator: torch.Tensor | None = None
+        self.replays = 0
+
+    MAX_TAPS = 64
+
+    def capture(self, fn, stream: torch.cuda.Stream, pool=None):
+        tap = MetricTap()
+        self.agent.metrics.tap(tap)
+        # persistent (allocated outside the capture, so replays do not re-zero it); taps accumulate into it in-graph
+        self.accumulator = torch.zeros(self.MAX_TAPS, dtype=torch.float32, device=self.agent.device)
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, stream=stream, pool=pool):
+                result = fn()
+                if tap.values:
+                    if len(tap.values) > self.MAX_TAPS:
+                        raise RuntimeError(f"more than {self.MAX_TAPS} metrics recorded inside one captured phase")
+                    self.accumulator[: len(tap.values)].add_(torch.stack(tap.values))
+        finally:
+            self.agent.metrics.tap(None)
+        self.tap_names, self.tap_counts = tap.names, tap.counts
+        self.graph = graph
+        return result
+
+    def replay(self):
+        self.graph.replay()
+        self.replays += 1
+
+    def flush_metrics(self):
+        """Fold the accumulated taps into the agent's metrics (one host copy) and reset."""
+        if self.accumulator is None or self.replays == 0 or not self.tap_names:
+            self.replays = 0
+            return
+        sums = self.accumulator.tolist()
+        self.accumulator.zero_()
+        for name, count, total in zip(self.tap_names, self.tap_counts, sums):
+            self.agent.metrics.add_resolved(name, total * count, count * self.replays)
+        self.replays = 0
+
+
+class GraphedTrainStep:
+    def __init__(self, agent, slot: int, temporal: bool):
+        self.agent = agent
+        self.slot = slot
+        self.temporal = temporal
+        self.state = 0  # 0: cold, 1: warmed, 2: captured
+        self.stream = agent._graph_stream
+        self.static_indices: torch.Tensor | None = None
+        self.metadata: dict[str, Any] | None = None
+        self.forward_backward = _Capture(agent)
+        self.optimize = _Capture(agent)
+        self.carry: dict[str, Any] = {}
+
+    # the two phases, written once and used for the eager warm-up, the capture and (implicitly) the replays
+    def _phase_a(self):
+        agent = self.agent
+        batch = agent.buffer.gather(self.static_indices, temporal=self.temporal)
+        agent.actor.clear_intermediate_repr()
+        agent.critic.clear_intermediate_repr()
+        agent.hook.pre_objective(self.metadata, batch)
+        with agent.autocast():
+            objectives = agent.hook.objective(self.metadata, batch)
+        if objectives is not None:
+            loss = objectives.loss()
+            agent._zero_grad()
+            agent.grad_scaler.scale(loss).backward()
+            agent.grad_scaler.unscale_(agent.optimizer)
+        self.carry = {"batch": batch, "objectives": objectives}
+
+    def _phase_b(self):
+        agent = self.agent
+        batch, objectives = self.carry["batch"], self.carry["objectives"]
+        if objectives is not None:
+            agent.hook.pre_optim(agent.optimizer)
+            agent.grad_scaler.step(agent.optimizer)
+            agent.grad_scaler.update()
+            agent.hook.post_optim()
+            agent.record(**objectives)
+        agent.hook.post_objective(self.metadata, batch)
+
+    def run(self, metadata: dict[str, Any], indices: torch.Tensor):
+        from cusrl_amd.utils.distributed import reduce_gradients
+
+        agent = self.agent
+        if self.static_indices is None or self.static_indices.shape != indices.shape:
+            self.static_indices = torch.empty_like(indices)
+            self.state = 0
+        self.static_indices.copy_(indices)
+        self.metadata = dict(metadata)
+        if self.state == 2:
+            self.forward_backward.replay()
+            reduce_gradients(agent.optimizer, agent.flat_gradients)
+            self.optimize.replay()
+            return
+        if self.state == 0:  # eager on the capture stream: warms rocBLAS / allocator and performs this real step
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._phase_a()
+                reduce_gradients(agent.optimizer, agent.flat_gradients)
+                self._phase_b()
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.carry = {}
+            self.state = 1
+            return
+        self.forward_backward.capture(self._phase_a, self.stream, pool=agent._graph_pool)
+        self.optimize.capture(self._phase_b, self.stream, pool=agent._graph_pool)
+        self.state = 2
+        self.forward_backward.replay()
+        reduce_gradients(agent.optimizer, agent.flat_gradients)
+        self.optimize.replay()
+
+    def flush_metrics(self):
+        self.forward_backward.flush_metrics()
+        self.optimize.flush_metrics()
+
+
+class GraphedAct:
+    """``pre_act`` → ``actor.explore`` → ``post_act`` as one replay; the observation goes through a static buffer
+    (this copy replaces the defensive clone the reference makes of every observation, agent.py:257-261)."""
+
+    def __init__(self, agent):
+        self.agent = agent
+        self.state = 0
+        self.stream = agent._graph_stream
+        self.static_observation: torch.Tensor | None = None
+        self.static_state: torch.Tensor | None = None
+        self.capture = _Capture(agent)
+        self.transition: dict[str, Any] = {}
+
+    def _body(self):
+        agent = self.agent
+        transition = agent.transition
+        transition.clear()
+        transition["observation"] = self.static_observation
+        if self.static_state is not None:
+            transition["state"] = self.static_state
+        agent.hook.pre_act(transition)
+        with agent.autocast():
+            action_dist, (action, action_logp), _ = agent.actor.explore(
+                transition["observation"], memory=None, deterministic=agent.deterministic,
+                backbone_kwargs={"sequential": False},
+            )
+        transition.update(action_dist=action_dist, action=action, action_logp=action_logp)
+        agent.hook.post_act(transition)
+
+    def supported(self, observation, state) -> bool:
+        agent = self.agent
+        return (isinstance(observation, torch.Tensor) and observation.is_cuda and not agent.actor.is_recurrent
+                and not agent.critic.is_recurrent and not agent.inference_mode)
+
+    def run(self, observation: torch.Tensor, state: torch.Tensor | None) -> torch.Tensor:
+        agent = self.agent
+        if self.static_observation is None or self.static_observation.shape != observation.shape:
+            self.static_observation = torch.empty_like(observation)
+            self.static_state = None if state is None else torch.empty_like(state)
+            self.state = 0
+        self.static_observation.copy_(observation)
+        if state is not None:
+            self.static_state.copy_(state)
+        if self.state == 2:
+            self.capture.replay()
+            agent.transition.clear()
+            agent.transition.update(self.transition)
+            return agent.transition["action"]
+        if self.state == 0:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._body()
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.state = 1
+            return agent.transition["action"]
+        self.capture.capture(self._body, self.stream, pool=agent._graph_pool)
+        self.transition = dict(agent.transition)
+        self.state = 2
+        self.capture.replay()
+        return agent.transition["action"]

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Stand-alone timing of every HIP kernel of the hot path: back-to-back launches between one HIP-event pair
+(so the stream is never host-starved), at the BASELINE config-2 size and at a roofline-scale size.
+
+    python scripts/kernel_bench.py [--envs 4096 1048576] [--json out.json]
+
+Prints achieved GB/s = algorithmic bytes / average launch time, and the fraction of the 8 TB/s peak.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+import torch  # noqa: E402
+
+from cusrl_amd import ops  # noqa: E402
+
+PEAK = 8000.0
+DEV = "cuda:0"
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) * 1e3 / iters  # us
+
+
+def bench_size(N, T=24, obs=48, act=12, mbs=4):
+    S = T * N
+    B = S // mbs
+    iters = 200 if N <= 16384 else 10
+    f = lambda *shape: torch.randn(*shape, device=DEV)  # noqa: E731
+    flag = lambda p: torch.rand(T, N, 1, device=DEV) < p  # noqa: E731
+    rows = {}
+
+    # ---- push: the 11 leaves of the ppo transition
+    step = {"observation": f(N, obs), "mean": f(N, act), "std": f(N, act), "action": f(N, act), "logp": f(N, 1),
+            "value": f(N, 1), "next_observation": f(N, obs), "reward": f(N, 1),
+            "terminated": torch.rand(N, 1, device=DEV) < 0.01, "truncated": torch.rand(N, 1, device=DEV) < 0.01,
+            "done": torch.rand(N, 1, device=DEV) < 0.02}
+    storage = {k: torch.zeros((T,) + v.shape, dtype=v.dtype, device=DEV) for k, v in step.items()}
+    pairs = [(step[k], storage[k]) for k in step]
+    push_bytes = sum(2 * v.numel() * v.element_size() for v in step.values())
+    cursor = [0]
+
+    def push():
+        ops.buffer_push(pairs, cursor[0], N)
+        cursor[0] = (cursor[0] + 1) % T
+
+    rows["push (1 step, 11 leaves)"] = (timeit(push, iters), push_bytes)
+
+    # ---- pre_update kernels
+    reward, value, nv = f(T, N, 1), f(T, N, 1), f(T, N, 1)
+    done, term, trunc = flag(0.015), flag(0.01), flag(0.005)
+    adv, ret, out = torch.empty_like(reward), torch.empty_like(reward), torch.empty_like(reward)
+    last = f(N, 1)
+    rows["next_value"] = (timeit(lambda: ops.next_value(value, term, trunc, last, 0.0, False, out), iters), S * 10)
+    rows["gae + return + stats"] = (timeit(lambda: ops.gae(reward, value, nv, done, 0.99, 0.95, None, adv, ret), iters), S * 21)
+    rows["gae two lambdas"] = (timeit(lambda: ops.gae(reward, value, nv, done, 0.99, 0.95, 0.98, adv, ret), iters), S * 21)
+    mean, var = torch.zeros(1, device=DEV), torch.ones(1, device=DEV)
+    rows["normalize"] = (timeit(lambda: ops.normalize_(adv, mean, var), iters), S * 8)
+    rows["col_stats"] = (timeit(lambda: ops.col_stats(adv), iters), S * 4)
+    rows["compact_flags (recount)"] = (timeit(lambda: ops.compact_flags(trunc), iters), S * 2)
+
+    # ---- gather: every leaf of the buffer at update time (555 B / slot)
+    leaves = [f(T, N, obs), f(T, N, act), f(T, N, act), f(T, N, act), f(T, N, 1), f(T, N, 1), f(T, N, obs), f(T, N, 1),
+              term, trunc, done, f(T, N, 1), f(T, N, 1), f(T, N, 1)]
+    perm = torch.randperm(S, device=DEV)
+    idx = perm[:B]
+    row = sum(x[0, 0].numel() * x.element_size() for x in leaves)
+    rows[f"gather all leaves (B={B})"] = (timeit(lambda: ops.gather_rows(leaves, idx, T, N), iters), B * (2 * row + 8))
+    small = [leaves[0], leaves[3], leaves[4], leaves[5], leaves[11], leaves[12]]
+    row_small = sum(x[0, 0].numel() * x.element_size() for x in small)
+    rows["gather ppo-minimal leaves"] = (timeit(lambda: ops.gather_rows(small, idx, T, N), iters), B * (2 * row_small + 8))
+
+    # ---- fused loss
+    a = dict(advantage=f(B, 1), old_logp=f(B, 1) - 12, action=f(B, act), mean=f(B, act), std=torch.rand(B, act, device=DEV) + 0.5,
+             ret=f(B, 1), curr_value=f(B, 1), old_value=f(B, 1))
+    kw = dict(clip=0.2, value_clip=None, w_sur=1.0, w_val=0.5, w_ent=0.01)
+    loss_bytes = B * (8 + 3 * 4 * act + 8 + 2 * 4 * act + 4 + 16)
+    rows[f"ppo loss fwd+bwd (B={B})"] = (timeit(lambda: ops.ppo_loss_fwd_bwd(*a.values(), **kw), iters), loss_bytes)
+
+    # ---- reference points: a plain device copy of the same bytes (what the memory system gives a streaming kernel)
+    big = torch.empty(max(S * 21 // 8, 1024), dtype=torch.float32, device=DEV)
+    dst = torch.empty_like(big)
+    rows["torch copy_ (same bytes as gae)"] = (timeit(lambda: dst.copy_(big), iters), big.numel() * 8)
+    return rows
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--envs", type=int, nargs="+", default=[4096, 1048576])
+    parser.add_argument("--json", type=str, default=None)
+    args = parser.parse_args()
+    report = {}
+    for N in args.envs:
+        rows = bench_size(N)
+        print(f"\n== N = {N} envs, T = 24 ==")
+        print(f"{'kernel':42s} {'us/launch':>10s} {'MB':>9s} {'GB/s':>9s} {'% of 8TB/s':>10s}")
+        report[str(N)] = {}
+        for name, (us, nbytes) in rows.items():
+            gbs = nbytes / us / 1e3
+            print(f"{name:42s} {us:10.2f} {nbytes / 1e6:9.2f} {gbs:9.1f} {100 * gbs / PEAK:9.1f}%")
+            report[str(N)][name] = {"us": round(us, 3), "bytes": int(nbytes), "GBps": round(gbs, 1), "frac": round(gbs / PEAK, 4)}
+    if args.json:
+        Path(args.json).write_text(json.dumps(report, indent=1))
+
+
+if __name__ == "__main__":
+    main()
