@@ -393,7 +393,9 @@ extern "C" int cusrl_gae(const float *reward, const float *value, const float *n
     const float c_val = two ? float(gamma * lamda_value) : c_adv;
     const int64_t C = N * D;
     hipStream_t s = as_stream(stream);
-    if (gae_vec4(reward, value, next_value, done, advantage, ret, N, D)) {
+    // 4 columns per lane only when that still fills the chip (>= 256 blocks); small rollouts (config 2: 4096 envs)
+    // are latency-bound and want every lane they can get
+    if (gae_vec4(reward, value, next_value, done, advantage, ret, N, D) && C >= int64_t(4) * kBlock * 256) {
         const int64_t blocks = ceil_div(C / 4, kBlock);
         // the host sizes `stat_partials` with cusrl_gae_num_partials (>= blocks); unused rows are zeroed
         if (stat_partials) {

@@ -7,40 +7,53 @@
 namespace cusrl {
 
 // --------------------------------------------------------------------------------------------- push
-constexpr int kPushUnroll = 2;                                 // independent 16 B transactions per lane
-constexpr int64_t kPushBlockBytes = int64_t(kBlock) * 16 * kPushUnroll;
+constexpr int64_t kPushBlockBytes = int64_t(kBlock) * 16 * 2;  // two independent 16 B transactions per lane
+
+// Leaf table passed BY VALUE in the kernarg segment.  Kernarg reads are scalar loads that miss to (host-visible)
+// kernarg memory with microsecond latency, so the layout and the lookup are built for at most TWO dependent round
+// trips per wave: (1) `n` + the whole block_start[] prefix array (104 B, fetched by a few wide independent
+// s_loads, the block->leaf search is branch-free over all entries), (2) the one 24 B descriptor of the leaf found.
+// (A first version walked the prefix array with a dependent load per entry: 13 serial misses = 17-30 us per launch.)
+struct PushLeaf {
+    const char *src;
+    char *dst;
+    int64_t bytes;
+};
 
 struct PushTable {
-    const char *src[CUSRL_MAX_FIELDS];
-    char *dst[CUSRL_MAX_FIELDS];
-    int64_t bytes[CUSRL_MAX_FIELDS];
-    int32_t block_start[CUSRL_MAX_FIELDS + 1];
-    int32_t vec[CUSRL_MAX_FIELDS];  // 16 / 4 / 1 bytes per lane access
     int32_t n;
+    int32_t block_start[CUSRL_MAX_FIELDS + 1];
+    PushLeaf leaf[CUSRL_MAX_FIELDS];
 };
+
+template <typename Table>
+__device__ __forceinline__ int find_leaf(const Table &tab, int blk) {
+    int f = 0;
+#pragma unroll
+    for (int i = 1; i < CUSRL_MAX_FIELDS; ++i) f += (i < tab.n && blk >= tab.block_start[i]) ? 1 : 0;
+    return f;
+}
 
 __global__ __launch_bounds__(kBlock) void push_kernel(const PushTable tab) {
     const int blk = blockIdx.x;
-    int f = 0;
-    while (f + 1 < tab.n && blk >= tab.block_start[f + 1]) ++f;  // wave-uniform scan of <= 24 entries
-    const char *__restrict__ src = tab.src[f];
-    char *__restrict__ dst = tab.dst[f];
-    const int64_t total = tab.bytes[f];
+    const int f = find_leaf(tab, blk);
+    const PushLeaf leaf = tab.leaf[f];
+    const char *__restrict__ src = leaf.src;
+    char *__restrict__ dst = leaf.dst;
+    const int64_t total = leaf.bytes;
     const int64_t begin = int64_t(blk - tab.block_start[f]) * kPushBlockBytes;
     const int64_t end = min(begin + kPushBlockBytes, total);
-    const int vec = tab.vec[f];
-    if (vec == 16) {
-        uint4 regs[kPushUnroll];
-        int64_t offs[kPushUnroll];
-#pragma unroll
-        for (int u = 0; u < kPushUnroll; ++u) {
-            offs[u] = begin + (int64_t(u) * kBlock + threadIdx.x) * 16;
-            if (offs[u] < end) regs[u] = *reinterpret_cast<const uint4 *>(src + offs[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < kPushUnroll; ++u)
-            if (offs[u] < end) *reinterpret_cast<uint4 *>(dst + offs[u]) = regs[u];
-    } else if (vec == 4) {
+    const uintptr_t align = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | uintptr_t(total);
+    if ((align & 15) == 0) {
+        const int64_t o0 = begin + int64_t(threadIdx.x) * 16;
+        const int64_t o1 = o0 + int64_t(kBlock) * 16;
+        uint4 r0, r1;
+        const bool p0 = o0 < end, p1 = o1 < end;
+        if (p0) r0 = *reinterpret_cast<const uint4 *>(src + o0);
+        if (p1) r1 = *reinterpret_cast<const uint4 *>(src + o1);
+        if (p0) *reinterpret_cast<uint4 *>(dst + o0) = r0;
+        if (p1) *reinterpret_cast<uint4 *>(dst + o1) = r1;
+    } else if ((align & 3) == 0) {
         for (int64_t o = begin + int64_t(threadIdx.x) * 4; o < end; o += int64_t(kBlock) * 4)
             *reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(src + o);
     } else {
@@ -52,14 +65,19 @@ __global__ __launch_bounds__(kBlock) void push_kernel(const PushTable tab) {
 constexpr int kGatherItems = 4;                       // lane-ops per thread, all loads issued before any store
 constexpr int kGatherOpsPerBlock = kBlock * kGatherItems;
 
-struct GatherTable {
-    const char *src[CUSRL_MAX_FIELDS];
-    char *dst[CUSRL_MAX_FIELDS];
-    int32_t row_bytes[CUSRL_MAX_FIELDS];
-    int32_t unit[CUSRL_MAX_FIELDS];           // bytes per lane-op: 16 / 8 / 4 / 2 / 1;  0 = "four 1-byte rows packed"
-    int32_t lanes_per_row[CUSRL_MAX_FIELDS];  // row_bytes / unit
-    int32_t block_start[CUSRL_MAX_FIELDS + 1];
+struct GatherLeaf {
+    const char *src;
+    char *dst;
+    int32_t row_bytes;
+    int32_t unit;           // bytes per lane-op: 16 / 8 / 4 / 2 / 1;  0 = "four 1-byte rows packed"
+    int32_t lanes_per_row;  // row_bytes / unit
+    int32_t pad;
+};
+
+struct GatherTable {  // same two-round-trip kernarg layout as PushTable
     int32_t n;
+    int32_t block_start[CUSRL_MAX_FIELDS + 1];
+    GatherLeaf leaf[CUSRL_MAX_FIELDS];
 };
 
 template <typename V>
@@ -100,13 +118,13 @@ __device__ __forceinline__ void gather_unit(const char *__restrict__ src, char *
 __global__ __launch_bounds__(kBlock) void gather_kernel(const GatherTable tab, const int64_t *__restrict__ idx,
                                                         int64_t B, int64_t T, int64_t N, int temporal) {
     const int blk = blockIdx.x;
-    int f = 0;
-    while (f + 1 < tab.n && blk >= tab.block_start[f + 1]) ++f;
-    const char *__restrict__ src = tab.src[f];
-    char *__restrict__ dst = tab.dst[f];
-    const int unit = tab.unit[f];
-    const int lpr = tab.lanes_per_row[f];
-    const int64_t row_bytes = tab.row_bytes[f];
+    const int f = find_leaf(tab, blk);
+    const GatherLeaf leaf = tab.leaf[f];
+    const char *__restrict__ src = leaf.src;
+    char *__restrict__ dst = leaf.dst;
+    const int unit = leaf.unit;
+    const int lpr = leaf.lanes_per_row;
+    const int64_t row_bytes = leaf.row_bytes;
     const int64_t rows = temporal ? T * B : B;
     const int64_t op0 = int64_t(blk - tab.block_start[f]) * kGatherOpsPerBlock + threadIdx.x;
     const bool temp = temporal != 0;
@@ -252,12 +270,9 @@ extern "C" int cusrl_buffer_push(const cusrl_field_t *fields, int n_fields, int6
         const int64_t bytes = N * fields[i].row_bytes;
         if (fields[i].row_bytes < 0 || (bytes > 0 && (!fields[i].src || !fields[i].dst))) return CUSRL_E_INVALID;
         if (bytes == 0) continue;
-        tab.src[n] = static_cast<const char *>(fields[i].src);
-        tab.dst[n] = static_cast<char *>(fields[i].dst) + cursor * bytes;
-        tab.bytes[n] = bytes;
-        tab.vec[n] = (bytes % 16 == 0 && aligned(tab.src[n], 16) && aligned(tab.dst[n], 16))  ? 16
-                     : (bytes % 4 == 0 && aligned(tab.src[n], 4) && aligned(tab.dst[n], 4)) ? 4
-                                                                                             : 1;
+        tab.leaf[n].src = static_cast<const char *>(fields[i].src);
+        tab.leaf[n].dst = static_cast<char *>(fields[i].dst) + cursor * bytes;
+        tab.leaf[n].bytes = bytes;
         tab.block_start[n] = blocks;
         const int64_t nb = ceil_div(bytes, kPushBlockBytes);
         if (nb + blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
@@ -265,7 +280,7 @@ extern "C" int cusrl_buffer_push(const cusrl_field_t *fields, int n_fields, int6
         ++n;
     }
     if (n == 0) return 0;
-    tab.block_start[n] = blocks;
+    for (int i = n; i <= CUSRL_MAX_FIELDS; ++i) tab.block_start[i] = blocks;
     tab.n = n;
     hipLaunchKernelGGL(push_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream), tab);
     return launch_status();
@@ -284,18 +299,20 @@ extern "C" int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, cons
         const int64_t rb = fields[i].row_bytes;
         if (rb < 0 || rb > INT32_MAX || (rb > 0 && (!fields[i].src || !fields[i].dst))) return CUSRL_E_INVALID;
         if (rb == 0) continue;
-        tab.src[n] = static_cast<const char *>(fields[i].src);
-        tab.dst[n] = static_cast<char *>(fields[i].dst);
-        tab.row_bytes[n] = int32_t(rb);
+        GatherLeaf &leaf = tab.leaf[n];
+        leaf.src = static_cast<const char *>(fields[i].src);
+        leaf.dst = static_cast<char *>(fields[i].dst);
+        leaf.row_bytes = int32_t(rb);
+        leaf.pad = 0;
         int64_t ops;
-        if (rb == 1 && aligned(tab.dst[n], 4)) {
-            tab.unit[n] = 0;
-            tab.lanes_per_row[n] = 1;
+        if (rb == 1 && aligned(leaf.dst, 4)) {
+            leaf.unit = 0;
+            leaf.lanes_per_row = 1;
             ops = (rows + 3) / 4;
         } else {
-            const int unit = pick_unit(tab.src[n], tab.dst[n], rb);
-            tab.unit[n] = unit;
-            tab.lanes_per_row[n] = int32_t(rb / unit);
+            const int unit = pick_unit(leaf.src, leaf.dst, rb);
+            leaf.unit = unit;
+            leaf.lanes_per_row = int32_t(rb / unit);
             ops = rows * (rb / unit);
         }
         tab.block_start[n] = int32_t(blocks);
@@ -304,7 +321,7 @@ extern "C" int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, cons
         ++n;
     }
     if (n == 0) return 0;
-    tab.block_start[n] = int32_t(blocks);
+    for (int i = n; i <= CUSRL_MAX_FIELDS; ++i) tab.block_start[i] = int32_t(blocks);
     tab.n = n;
     hipLaunchKernelGGL(gather_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), tab, indices, B,
                        T, N, temporal);

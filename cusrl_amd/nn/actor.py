@@ -10,7 +10,7 @@ import torch
 from torch import Tensor, nn
 
 from cusrl_amd.nn.distribution import Distribution
-from cusrl_amd.nn.module import Module, ModuleFactory
+from cusrl_amd.nn.module import Linear, Module, ModuleFactory
 
 __all__ = ["Actor", "Value"]
 
@@ -101,7 +101,7 @@ class Actor(Module):
 @dataclass(slots=True)
 class ValueFactory(ModuleFactory):
     backbone_factory: Callable[[int | None, int | None], Module]
-    value_head_factory: Callable[[int, int], nn.Module] = nn.Linear
+    value_head_factory: Callable[[int, int], nn.Module] = Linear  # nn.Linear + wide-batch weight gradient
     latent_dim: int | None = None
     action_aware: bool = False
 

@@ -14,11 +14,63 @@ from torch.nn.functional import linear
 
 from cusrl_amd.utils.nest import iterate_nested
 
-__all__ = ["LinearFp32", "Mlp", "Module", "ModuleFactory", "disable_autocast", "resolve_activation_fn"]
+__all__ = ["Linear", "LinearFp32", "Mlp", "Module", "ModuleFactory", "disable_autocast", "resolve_activation_fn"]
 
 
 def disable_autocast(device_type: str):
     return torch.autocast(device_type=device_type, enabled=False)
+
+
+class _WideBatchLinear(torch.autograd.Function):
+    """``linear(x, w, b)`` whose weight gradient is shaped for 256 CUs.
+
+    dW = dY^T X has a tiny output (e.g. 128 x 256) and a huge reduction dim (the minibatch, 24 576): as ONE GEMM it
+    yields a few dozen output tiles, i.e. most of the chip idles (rocBLAS picks no split-K here: 84 us measured).
+    Splitting the batch into S slabs turns it into a batched GEMM with S x more workgroups plus a tiny sum — still a
+    rocBLAS/hipBLASLt MFMA GEMM, just with enough parallelism.  Forward and dX are unchanged.
+    """
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, splits):
+        ctx.save_for_backward(input, weight)
+        ctx.splits = splits
+        ctx.has_bias = bias is not None
+        return linear(input, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight = ctx.saved_tensors
+        grad_input = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            grad_input = grad_output @ weight
+        if ctx.needs_input_grad[1]:
+            rows, splits = input.shape[0], ctx.splits
+            gy = grad_output.reshape(splits, rows // splits, -1)
+            grad_weight = torch.bmm(gy.transpose(1, 2), input.reshape(splits, rows // splits, -1)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = grad_output.sum(0)
+        return grad_input, grad_weight, grad_bias, None
+
+
+def _batch_splits(rows: int) -> int:
+    """Largest power-of-two slab count (<= 32) that divides the batch and leaves >= 1024 rows per slab."""
+    splits = 1
+    while splits < 32 and rows % (splits * 2) == 0 and rows // (splits * 2) >= 1024:
+        splits *= 2
+    return splits
+
+
+class Linear(nn.Linear):
+    """``nn.Linear`` (same parameters, same state-dict keys) with the wide-batch weight-gradient path on the GPU."""
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if (input.dim() == 2 and input.is_cuda and input.shape[0] >= 4096 and torch.is_grad_enabled()
+                and self.weight.requires_grad and input.dtype == self.weight.dtype
+                and not torch.is_autocast_enabled("cuda")):
+            splits = _batch_splits(input.shape[0])
+            if splits > 1:
+                return _WideBatchLinear.apply(input, self.weight, self.bias, splits)
+        return linear(input, self.weight, self.bias)
 
 
 class LinearFp32(nn.Linear):
@@ -26,7 +78,7 @@ class LinearFp32(nn.Linear):
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         if not torch.is_autocast_enabled(input.device.type) and input.dtype == torch.float32:
-            return linear(input, self.weight, self.bias)
+            return Linear.forward(self, input)
         with disable_autocast(input.device.type):
             return linear(input.float(), self.weight.float(), None if self.bias is None else self.bias.float())
 
@@ -139,7 +191,7 @@ class Mlp(Module):
         layers: list[nn.Module] = []
         fan_in = input_dim
         for i, width in enumerate(widths):
-            layers.append(nn.Linear(fan_in, width))
+            layers.append(Linear(fan_in, width))
             if i + 1 < len(widths) or ends_with_activation:
                 layers.append(act())
                 if dropout > 0.0:

@@ -224,10 +224,21 @@ class ActorCritic(Agent):
         return super().update()
 
     def _zero_grad(self):
-        if self.flat_gradients is not None:
-            self.flat_gradients.zero()
-        else:
+        if self.flat_gradients is None:
             self.optimizer.zero_grad()
+        elif not self.flat_gradients.intact():
+            self.flat_gradients.attach()
+
+    def _backward(self, loss: torch.Tensor):
+        """Gradients of ``loss`` into ``p.grad``.  With the flat gradient buffer the per-parameter gradients are
+        concatenated into it by ONE kernel (no memset, no 13 accumulate launches per step); otherwise this is the
+        reference's ``scaled_loss.backward()`` (actor_critic.py:311-312)."""
+        flat = self.flat_gradients
+        if flat is None:
+            self.grad_scaler.scale(loss).backward()
+            return
+        grads = torch.autograd.grad(loss, flat.params, allow_unused=True, materialize_grads=True)
+        torch.cat([grad.reshape(-1) for grad in grads], out=flat.buffer)
 
     def _train_step(self, metadata: dict[str, Any], batch: dict[str, Any]):
         self.actor.clear_intermediate_repr()
@@ -238,7 +249,7 @@ class ActorCritic(Agent):
         if objectives is not None:
             loss = objectives.loss() if hasattr(objectives, "loss") else sum(objectives.values())
             self._zero_grad()
-            self.grad_scaler.scale(loss).backward()
+            self._backward(loss)
             self.grad_scaler.unscale_(self.optimizer)
             reduce_gradients(self.optimizer, self.flat_gradients)  # a14
             self.hook.pre_optim(self.optimizer)

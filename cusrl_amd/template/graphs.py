@@ -101,7 +101,7 @@ class GraphedTrainStep:
         if objectives is not None:
             loss = objectives.loss()
             agent._zero_grad()
-            agent.grad_scaler.scale(loss).backward()
+            agent._backward(loss)
             agent.grad_scaler.unscale_(agent.optimizer)
         self.carry = {"batch": batch, "objectives": objectives}
 
