@@ -49,6 +49,8 @@ _SIGNATURES = {
         [_P] * 8 + [c_int64] * 3 + [c_double] * 5 + [_P] * 8 + [_P, _P],
     ),
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
+    "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
+    "cusrl_episode_stats": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1,0 +1,119 @@
+// Rollout-side kernels for gfx950: fused Normal sample + log-prob (a12, acting side) and one-launch episode
+// statistics (removes the per-step device->host sync of the reference trainer loop).
+#include "common.hpp"
+
+namespace cusrl {
+
+__device__ __forceinline__ float log_sqrt_2pi_r() { return 0.918938533204672741780329736406f; }
+
+// One lane per row for any A; rows are short (A = 12 -> 48 B) and the batch is one env step (N rows), so this is
+// latency-bound, not bandwidth-bound.  A % 4 == 0 rows are read as 16 B chunks.
+template <bool kVec4>
+__global__ __launch_bounds__(kBlock) void normal_sample_logp_kernel(const float *__restrict__ mean,
+                                                                    const float *__restrict__ std,
+                                                                    const float *__restrict__ eps,
+                                                                    float *__restrict__ action,
+                                                                    float *__restrict__ logp, int64_t B, int A) {
+    const int64_t row = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (row >= B) return;
+    float lp = 0.0f;
+    if constexpr (kVec4) {
+        const float4 *m4 = reinterpret_cast<const float4 *>(mean + row * A);
+        const float4 *s4 = reinterpret_cast<const float4 *>(std + row * A);
+        const float4 *e4 = reinterpret_cast<const float4 *>(eps + row * A);
+        float4 *a4 = reinterpret_cast<float4 *>(action + row * A);
+        for (int c = 0; c < A / 4; ++c) {
+            const float4 m = m4[c], s = s4[c], e = e4[c];
+            const float ms[4] = {m.x, m.y, m.z, m.w}, ss[4] = {s.x, s.y, s.z, s.w}, es[4] = {e.x, e.y, e.z, e.w};
+            float as[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                as[j] = ms[j] + es[j] * ss[j];  // rsample: loc + eps * scale
+                const float diff = as[j] - ms[j];
+                lp += -(diff * diff) / (2.0f * (ss[j] * ss[j])) - logf(ss[j]) - log_sqrt_2pi_r();
+            }
+            a4[c] = make_float4(as[0], as[1], as[2], as[3]);
+        }
+    } else {
+        for (int a = 0; a < A; ++a) {
+            const int64_t i = row * A + a;
+            const float act = mean[i] + eps[i] * std[i];
+            const float diff = act - mean[i];
+            action[i] = act;
+            lp += -(diff * diff) / (2.0f * (std[i] * std[i])) - logf(std[i]) - log_sqrt_2pi_r();
+        }
+    }
+    logp[row] = lp;
+}
+
+__global__ __launch_bounds__(kBlock) void episode_stats_kernel(const float *__restrict__ reward,
+                                                               const uint8_t *__restrict__ done,
+                                                               float *__restrict__ episode_rew,
+                                                               float *__restrict__ episode_len,
+                                                               float *__restrict__ ring_rew,
+                                                               float *__restrict__ ring_len,
+                                                               unsigned long long *__restrict__ num_episodes,
+                                                               double *__restrict__ step_reward_sum, int64_t N, int D,
+                                                               int64_t R) {
+    __shared__ double scratch[kWavesPerBlock];
+    const int64_t n = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const bool active = n < N;
+    const bool finished = active && done[n] != 0;
+    unsigned long long slot = 0;
+    float len = 0.0f;
+    if (active) len = episode_len[n] + 1.0f;
+    if (finished) {
+        slot = atomicAdd(num_episodes, 1ull) % (unsigned long long)R;  // ticket = position in the ring
+        ring_len[slot] = len;
+    }
+    for (int d = 0; d < D; ++d) {
+        float r = 0.0f;
+        if (active) {
+            r = reward[n * D + d];
+            const float total = episode_rew[n * D + d] + r;
+            if (finished) ring_rew[slot * D + d] = total;
+            episode_rew[n * D + d] = finished ? 0.0f : total;
+        }
+        const double block_total = block_sum(double(r), scratch);
+        if (threadIdx.x == 0) atomicAdd(step_reward_sum + d, block_total);
+    }
+    if (active) episode_len[n] = finished ? 0.0f : len;
+}
+
+}  // namespace cusrl
+
+using namespace cusrl;
+
+extern "C" int cusrl_normal_sample_logp(const float *mean, const float *std, const float *eps, float *action,
+                                        float *logp, int64_t B, int64_t A, void *stream) {
+    if (B < 0 || A <= 0) return CUSRL_E_INVALID;
+    if (B == 0) return 0;
+    if (!mean || !std || !eps || !action || !logp) return CUSRL_E_INVALID;
+    if (A > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    const int64_t blocks = ceil_div(B, kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    const bool vec4 = A % 4 == 0 && aligned(mean, 16) && aligned(std, 16) && aligned(eps, 16) && aligned(action, 16);
+    if (vec4)
+        hipLaunchKernelGGL(normal_sample_logp_kernel<true>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream),
+                           mean, std, eps, action, logp, B, int(A));
+    else
+        hipLaunchKernelGGL(normal_sample_logp_kernel<false>, dim3(uint32_t(blocks)), dim3(kBlock), 0,
+                           as_stream(stream), mean, std, eps, action, logp, B, int(A));
+    return launch_status();
+}
+
+extern "C" int cusrl_episode_stats(const float *reward, const uint8_t *done, float *episode_rew, float *episode_len,
+                                   float *ring_rew, float *ring_len, uint64_t *num_episodes, double *step_reward_sum,
+                                   int64_t N, int64_t D, int64_t R, void *stream) {
+    if (N < 0 || D <= 0 || R <= 0) return CUSRL_E_INVALID;
+    if (N == 0) return 0;
+    if (!reward || !done || !episode_rew || !episode_len || !ring_rew || !ring_len || !num_episodes || !step_reward_sum)
+        return CUSRL_E_INVALID;
+    if (D > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    const int64_t blocks = ceil_div(N, kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(episode_stats_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), reward, done,
+                       episode_rew, episode_len, ring_rew, ring_len,
+                       reinterpret_cast<unsigned long long *>(num_episodes), step_reward_sum, N, int(D), R);
+    return launch_status();
+}

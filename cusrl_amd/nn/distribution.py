@@ -126,6 +126,13 @@ class _Normal(Distribution):
 
     def sample_from_dist(self, dist_params):
         mean, std = self._ms(dist_params)
+        if mean.is_cuda and not torch.is_grad_enabled():
+            # acting path: eps from torch's generator (the reference's random stream), then ONE HIP launch for
+            # action = mean + eps * std and its log-prob instead of ~12 elementwise / reduction launches
+            from cusrl_amd import ops
+
+            eps = torch.empty(mean.shape, dtype=mean.dtype, device=mean.device).normal_()
+            return ops.normal_sample_logp(mean, std, eps)
         with disable_autocast(mean.device.type):
             # same draw as Normal.rsample(): mean + std * N(0, 1) from the global generator of mean's device
             sample = mean + torch.empty(mean.shape, dtype=mean.dtype, device=mean.device).normal_() * std

@@ -20,10 +20,12 @@ __all__ = [
     "buffer_push",
     "col_stats",
     "compact_flags",
+    "episode_stats",
     "gae",
     "gather_rows",
     "merge_mean_var",
     "next_value",
+    "normal_sample_logp",
     "normalize_",
     "ppo_loss_fwd_bwd",
     "require_device",
@@ -333,3 +335,35 @@ def ppo_loss_fwd_bwd(
         "cusrl_ppo_loss_fwd_bwd",
     )
     return out
+
+
+# ------------------------------------------------------------------------------------------------ rollout side
+def normal_sample_logp(mean: torch.Tensor, std: torch.Tensor, eps: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """``action = mean + eps * std`` and ``log_prob(action).sum(-1, keepdim=True)`` in one launch
+    (cusrl/nn/module/distribution.py:198-205)."""
+    mean, std, eps = _f32(mean, "mean"), _f32(std, "std"), _f32(eps, "eps")
+    if std.shape != mean.shape or eps.shape != mean.shape:
+        raise ValueError("normal_sample_logp: shape mismatch")
+    A = mean.shape[-1]
+    B = mean.numel() // A
+    action = torch.empty_like(mean)
+    logp = torch.empty(mean.shape[:-1] + (1,), dtype=torch.float32, device=mean.device)
+    check(
+        _native.lib().cusrl_normal_sample_logp(mean.data_ptr(), std.data_ptr(), eps.data_ptr(), action.data_ptr(), logp.data_ptr(), B, A, _stream()),
+        "cusrl_normal_sample_logp",
+    )
+    return action, logp
+
+
+def episode_stats(reward, done, episode_rew, episode_len, ring_rew, ring_len, num_episodes, step_reward_sum) -> None:
+    """One-launch ``EnvironmentStats.track_step`` + ``track_episode`` (cusrl/template/trainer.py:54-76), no host sync."""
+    reward = _f32(reward, "reward")
+    done = _flag(done, "done")
+    N, D = reward.shape
+    check(
+        _native.lib().cusrl_episode_stats(
+            reward.data_ptr(), done.data_ptr(), episode_rew.data_ptr(), episode_len.data_ptr(), ring_rew.data_ptr(),
+            ring_len.data_ptr(), num_episodes.data_ptr(), step_reward_sum.data_ptr(), N, D, ring_len.numel(), _stream(),
+        ),
+        "cusrl_episode_stats",
+    )

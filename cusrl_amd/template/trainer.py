@@ -18,17 +18,40 @@ __all__ = ["EnvironmentStats", "Trainer", "TrainerHook"]
 
 
 class EnvironmentStats:
-    """Per-env episode return / length accumulators and a ring of the last finished episodes (``:33-113``)."""
+    """Per-env episode return / length accumulators and a ring of the last finished episodes (``:33-113``).
+
+    On a GPU env everything is device-resident and ``track(reward, done)`` is ONE HIP launch
+    (``cusrl_episode_stats``) with no host round trip; on CPU / NumPy envs it is the reference's torch-op form.
+    """
 
     def __init__(self, num_envs: int, reward_dim: int = 1, buffer_size: int = 100, device=None):
-        self.num_envs, self.reward_dim = num_envs, reward_dim
+        self.num_envs, self.reward_dim, self.buffer_size = num_envs, reward_dim, buffer_size
         self.device = torch.device("cpu" if device is None else device)
-        zeros = lambda *shape: torch.zeros(shape, device=self.device)  # noqa: E731
+        self.on_device = self.device.type == "cuda"
+        zeros = lambda *shape, **kw: torch.zeros(shape, device=self.device, **kw)  # noqa: E731
         self.episode_rew, self.episode_len = zeros(num_envs, reward_dim), zeros(num_envs, 1)
         self.rew_buffer, self.len_buffer = zeros(buffer_size, reward_dim), zeros(buffer_size, 1)
         self.reward = zeros(reward_dim)
-        self.num_episodes = self.total_steps = self.num_steps = 0
+        self.total_steps = self.num_steps = 0
+        self._num_episodes = 0
+        if self.on_device:
+            self._episodes_dev = zeros(1, dtype=torch.int64)
+            self._reward_sum = zeros(reward_dim, dtype=torch.float64)
 
+    # ---- device path: one launch per env step
+    def track(self, reward: torch.Tensor, done: torch.Tensor):
+        from cusrl_amd import ops
+
+        self.total_steps += self.num_envs
+        self.num_steps += 1
+        ops.episode_stats(reward, done, self.episode_rew, self.episode_len, self.rew_buffer, self.len_buffer,
+                          self._episodes_dev, self._reward_sum)
+
+    @property
+    def num_episodes(self) -> int:
+        return int(self._episodes_dev.item()) if self.on_device else self._num_episodes
+
+    # ---- host path (reference form)
     def track_step(self, reward):
         reward = torch.as_tensor(reward, device=self.device)
         self.total_steps += self.num_envs
@@ -37,34 +60,42 @@ class EnvironmentStats:
         self.reward += reward.mean(dim=0)
         self.num_steps += 1
 
-    def clear_step_info(self):
-        self.reward.zero_()
-        self.num_steps = 0
-
     def track_episode(self, indices):
         rew, length = self.episode_rew[indices], self.episode_len[indices]
         count = rew.size(0)
-        slot = (torch.arange(count, device=self.device) + self.num_episodes) % self.rew_buffer.size(0)
+        slot = (torch.arange(count, device=self.device) + self._num_episodes) % self.buffer_size
         self.rew_buffer[slot], self.len_buffer[slot] = rew, length
-        self.num_episodes += count
+        self._num_episodes += count
         self.episode_rew[indices] = 0.0
         self.episode_len[indices] = 0.0
 
+    def clear_step_info(self):
+        self.reward.zero_()
+        if self.on_device:
+            self._reward_sum.zero_()
+        self.num_steps = 0
+
     @property
     def mean_step_reward(self):
-        mean = self.reward / self.num_steps if self.num_steps else self.reward
+        if self.on_device:
+            total = (self._reward_sum / self.num_envs).float()
+        else:
+            total = self.reward
+        mean = total / self.num_steps if self.num_steps else total
         return tuple(mean.tolist()) if self.reward_dim > 1 else mean.item()
 
     @property
     def mean_episode_reward(self):
-        if self.num_episodes == 0:
+        count = min(self.num_episodes, self.buffer_size)
+        if count == 0:
             return 0.0 if self.reward_dim == 1 else (0.0,) * self.reward_dim
-        mean = self.rew_buffer[: self.num_episodes].mean(dim=0)
+        mean = self.rew_buffer[:count].mean(dim=0)
         return tuple(mean.tolist()) if self.reward_dim > 1 else mean.item()
 
     @property
     def mean_episode_length(self) -> float:
-        return 0.0 if self.num_episodes == 0 else self.len_buffer[: self.num_episodes].mean().item()
+        count = min(self.num_episodes, self.buffer_size)
+        return 0.0 if count == 0 else self.len_buffer[:count].mean().item()
 
     def state_dict(self) -> dict:
         return {"num_episodes": self.num_episodes, "total_steps": self.total_steps}
@@ -130,22 +161,35 @@ class Trainer:
             self.environment.close()
 
     def _rollout_and_update(self, observation, state):
-        agent, env, timer = self.agent, self.environment, self.timer
+        agent, env, timer, stats = self.agent, self.environment, self.timer, self.stats
         while True:
             with timer.record("agent"):
                 action = agent.act(observation, state)
             with timer.record("environment"):
                 next_observation, next_state, reward, terminated, truncated, info = env.step(action)
-                self.stats.track_step(reward)
+                if not stats.on_device:
+                    stats.track_step(reward)
             with timer.record("agent"):
                 ready = agent.step(next_observation, reward, terminated, truncated, next_state, **info)
             with timer.record("environment"):
-                if done_indices := get_done_indices(terminated, truncated):
+                if stats.on_device:
+                    # device-resident bookkeeping: one launch, and a host round trip only if the env needs indices
+                    done = agent.transition.get("done")
+                    if not isinstance(done, torch.Tensor) or done.device != stats.device:
+                        done = torch.as_tensor(terminated, device=stats.device) | torch.as_tensor(truncated, device=stats.device)
+                    stats.track(torch.as_tensor(reward, device=stats.device), done)
+                    if not env.spec.autoreset:
+                        done_indices = done.squeeze(-1).nonzero().reshape(-1)  # index tensor (allowed by the contract)
+                        if done_indices.numel():
+                            init_observation, init_state, _ = env.reset(indices=done_indices)
+                            next_observation, next_state = update_observation_and_state(
+                                next_observation, next_state, done_indices, init_observation, init_state)
+                elif done_indices := get_done_indices(terminated, truncated):
                     if not env.spec.autoreset:
                         init_observation, init_state, _ = env.reset(indices=done_indices)
                         next_observation, next_state = update_observation_and_state(
                             next_observation, next_state, done_indices, init_observation, init_state)
-                    self.stats.track_episode(done_indices)
+                    stats.track_episode(done_indices)
             observation, state = next_observation, next_state
             if ready:
                 break

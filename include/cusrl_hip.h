@@ -124,6 +124,24 @@ int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const 
                            double *partials, void *stream);
 int64_t cusrl_ppo_loss_num_partials(int64_t B);
 
+/* ---- rollout-side: sampling and episode statistics ----
+ * Normal sample + log-prob of the sample in one pass — cusrl/nn/module/distribution.py:198-205 (`rsample`, then
+ * `log_prob(sample).sum(-1, keepdim)`): action = mean + eps * std with eps ~ N(0,1) supplied by the caller (drawn
+ * from torch's generator so the random stream is the reference's); logp[B] as in cusrl_ppo_loss_fwd_bwd. */
+int cusrl_normal_sample_logp(const float *mean, const float *std, const float *eps, float *action, float *logp,
+                             int64_t B, int64_t A, void *stream);
+
+/* EnvironmentStats.track_step + track_episode — cusrl/template/trainer.py:54-76, in one launch and without the
+ * host round trip of `get_done_indices(...).tolist()` (environment.py:356-362):
+ *   episode_rew[n] += reward[n]; episode_len[n] += 1; step_reward_sum[d] += sum_n reward[n,d];
+ *   for done[n]: slot = (num_episodes++) % R; ring_rew[slot] = episode_rew[n]; ring_len[slot] = episode_len[n];
+ *                episode_rew[n] = 0; episode_len[n] = 0.
+ * reward, episode_rew [N,D]; done [N] bytes; episode_len [N]; ring_rew [R,D]; ring_len [R];
+ * num_episodes: device uint64[1]; step_reward_sum: device double[D]. */
+int cusrl_episode_stats(const float *reward, const uint8_t *done, float *episode_rew, float *episode_len,
+                        float *ring_rew, float *ring_len, uint64_t *num_episodes, double *step_reward_sum,
+                        int64_t N, int64_t D, int64_t R, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

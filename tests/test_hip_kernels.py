@@ -271,3 +271,67 @@ def test_ppo_loss_vs_oracle(ops, B, A, D, vclip):
 def test_hot_path_rejects_cpu_tensors(ops):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.gae(torch.zeros(2, 2, 1), torch.zeros(2, 2, 1), torch.zeros(2, 2, 1), torch.zeros(2, 2, 1, dtype=torch.bool), 0.9, 0.9, None)
+
+
+# ------------------------------------------------------------------------------------------------ rollout side
+@pytest.mark.parametrize("B,A", [(4096, 12), (7, 5), (1, 1), (1000, 32)])
+def test_normal_sample_logp_vs_oracle(ops, B, A):
+    rng = np.random.default_rng(B * A)
+    mean = rng.standard_normal((B, A)).astype(np.float32)
+    std = (rng.random((B, A)) + 0.3).astype(np.float32)
+    eps = rng.standard_normal((B, A)).astype(np.float32)
+    action, logp = ops.normal_sample_logp(dev(mean), dev(std), dev(eps))
+    expect = mean + eps * std  # Normal.rsample(): loc + eps * scale, separately rounded
+    assert np.array_equal(host(action), expect)
+    ref_logp, _ = oracle.normal_logp_entropy(expect, mean, std)
+    np.testing.assert_allclose(host(logp), ref_logp, rtol=1e-5, atol=1e-5)
+    assert logp.shape == (B, 1)
+
+
+def test_sampling_consumes_the_same_random_stream_as_rsample(ops):
+    from cusrl_amd.nn import NormalDist
+
+    dist = NormalDist(4, 3).to(DEV)
+    params = {"mean": torch.randn(64, 3, device=DEV), "std": torch.rand(64, 3, device=DEV) + 0.5}
+    torch.manual_seed(123)
+    with torch.no_grad():
+        action, logp = dist.sample_from_dist(params)
+    torch.manual_seed(123)
+    reference = torch.distributions.Normal(params["mean"], params["std"], validate_args=False)
+    expect = reference.rsample()
+    assert torch.equal(action, expect)
+    assert torch.allclose(logp, reference.log_prob(expect).sum(-1, keepdim=True), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,D,R", [(4096, 1, 100), (50, 2, 100), (300, 1, 16)])
+def test_episode_stats_one_launch_matches_reference_bookkeeping(ops, N, D, R):
+    rng = np.random.default_rng(N + D)
+    episode_rew = torch.zeros(N, D, device=DEV)
+    episode_len = torch.zeros(N, 1, device=DEV)
+    ring_rew, ring_len = torch.zeros(R, D, device=DEV), torch.zeros(R, 1, device=DEV)
+    count = torch.zeros(1, dtype=torch.int64, device=DEV)
+    reward_sum = torch.zeros(D, dtype=torch.float64, device=DEV)
+    h_rew, h_len = np.zeros((N, D), np.float32), np.zeros((N, 1), np.float32)
+    finished, total, h_sum = [], 0, np.zeros(D)
+    for step in range(6):
+        reward = rng.standard_normal((N, D)).astype(np.float32)
+        done = rng.random((N, 1)) < 0.02
+        ops.episode_stats(dev(reward), dev(done), episode_rew, episode_len, ring_rew, ring_len, count, reward_sum)
+        h_rew += reward
+        h_len += 1
+        h_sum += reward.astype(np.float64).sum(0)
+        for n in np.flatnonzero(done):
+            finished.append((h_rew[n].copy(), float(h_len[n, 0])))
+            h_rew[n] = 0
+            h_len[n] = 0
+        total += int(done.sum())
+    assert int(count.item()) == total
+    assert np.array_equal(host(episode_rew), h_rew) and np.array_equal(host(episode_len), h_len)
+    np.testing.assert_allclose(host(reward_sum), h_sum, rtol=1e-12)
+    if total <= R:  # ring holds exactly the finished episodes (slot order within one step is by atomic ticket)
+        got = sorted((tuple(round(float(v), 4) for v in r), l) for r, l in zip(host(ring_rew)[:total], host(ring_len)[:total, 0].tolist()))
+        want = sorted((tuple(round(float(v), 4) for v in r), l) for r, l in finished)
+        assert got == want
+    else:  # more finished than ring slots: every slot holds some finished episode
+        lens = {l for _, l in finished}
+        assert set(host(ring_len)[:, 0].tolist()) <= lens
