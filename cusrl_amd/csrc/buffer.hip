@@ -80,39 +80,103 @@ struct GatherTable {  // same two-round-trip kernarg layout as PushTable
     GatherLeaf leaf[CUSRL_MAX_FIELDS];
 };
 
+// Memory-level parallelism is the whole game here (every access is a dependent idx -> row -> store chain and, at
+// config-2 sizes, the launch is latency-bound): loads are never predicated — out-of-range lane-ops are CLAMPED to
+// the last valid op so the compiler can issue all index loads of a lane back to back, then all row loads, and only
+// then the stores.  (Predicated loads made it wait after every single load: 27-40 us per 27 MB launch.)
+// One empty asm statement that "uses and redefines" every loaded register: the loads must all be issued (and
+// waited for) before it, the stores can only come after it.
+__device__ __forceinline__ void pin_loaded(uint4 (&r)[kGatherItems]) {
+    static_assert(kGatherItems == 4, "operand list below is written for 4 items");
+    asm volatile(""
+                 : "+v"(r[0].x), "+v"(r[0].y), "+v"(r[0].z), "+v"(r[0].w), "+v"(r[1].x), "+v"(r[1].y), "+v"(r[1].z),
+                   "+v"(r[1].w), "+v"(r[2].x), "+v"(r[2].y), "+v"(r[2].z), "+v"(r[2].w), "+v"(r[3].x), "+v"(r[3].y),
+                   "+v"(r[3].z), "+v"(r[3].w));
+}
+__device__ __forceinline__ void pin_loaded(uint2 (&r)[kGatherItems]) {
+    asm volatile(""
+                 : "+v"(r[0].x), "+v"(r[0].y), "+v"(r[1].x), "+v"(r[1].y), "+v"(r[2].x), "+v"(r[2].y), "+v"(r[3].x),
+                   "+v"(r[3].y));
+}
+__device__ __forceinline__ void pin_loaded(uint32_t (&r)[kGatherItems]) {
+    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+}
+__device__ __forceinline__ void pin_loaded(uint16_t (&r)[kGatherItems]) {
+    uint32_t t[4] = {r[0], r[1], r[2], r[3]};
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+    for (int i = 0; i < 4; ++i) r[i] = uint16_t(t[i]);
+}
+__device__ __forceinline__ void pin_loaded(uint8_t (&r)[kGatherItems]) {
+    uint32_t t[4] = {r[0], r[1], r[2], r[3]};
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+    for (int i = 0; i < 4; ++i) r[i] = uint8_t(t[i]);
+}
+
 template <typename V>
 __device__ __forceinline__ void gather_unit(const char *__restrict__ src, char *__restrict__ dst,
                                             const int64_t *__restrict__ idx, int64_t ops, int64_t op0, int lpr,
                                             int64_t row_bytes, int64_t B, int64_t N, bool temporal) {
-    V regs[kGatherItems];
-    int64_t dst_off[kGatherItems];
+    int64_t row[kGatherItems], col[kGatherItems], src_row[kGatherItems];
 #pragma unroll
     for (int it = 0; it < kGatherItems; ++it) {
-        const int64_t op = op0 + int64_t(it) * kBlock;
-        dst_off[it] = -1;
-        if (op < ops) {
-            int64_t r, c;
-            if (lpr == 1) {
-                r = op;
-                c = 0;
-            } else {
-                r = op / lpr;
-                c = op - r * lpr;
-            }
-            int64_t src_row;
-            if (temporal) {
-                const int64_t t = r / B, b = r - t * B;
-                src_row = t * N + idx[b];
-            } else {
-                src_row = idx[r];
-            }
-            regs[it] = *reinterpret_cast<const V *>(src + src_row * row_bytes + c * int64_t(sizeof(V)));
-            dst_off[it] = r * row_bytes + c * int64_t(sizeof(V));
+        const int64_t op = min(op0 + int64_t(it) * kBlock, ops - 1);
+        if (lpr == 1) {
+            row[it] = op;
+            col[it] = 0;
+        } else {
+            row[it] = op / lpr;
+            col[it] = op - row[it] * lpr;
         }
     }
+    if (temporal) {
+#pragma unroll
+        for (int it = 0; it < kGatherItems; ++it) {
+            const int64_t t = row[it] / B, b = row[it] - t * B;
+            src_row[it] = t * N + idx[b];
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < kGatherItems; ++it) src_row[it] = idx[row[it]];
+    }
+    V regs[kGatherItems];
 #pragma unroll
     for (int it = 0; it < kGatherItems; ++it)
-        if (dst_off[it] >= 0) *reinterpret_cast<V *>(dst + dst_off[it]) = regs[it];
+        regs[it] = *reinterpret_cast<const V *>(src + src_row[it] * row_bytes + col[it] * int64_t(sizeof(V)));
+    pin_loaded(regs);  // all row loads are in flight before the first store (hipcc otherwise re-interleaves
+                       // load / wait / store per item, i.e. one exposed memory latency per item)
+    // stores are unconditional as well: a clamped lane-op rewrites the last element with the identical bytes, which
+    // keeps the whole body branch-free (with masked stores LLVM sinks each load into its store's block again)
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it)
+        *reinterpret_cast<V *>(dst + row[it] * row_bytes + col[it] * int64_t(sizeof(V))) = regs[it];
+}
+
+// 1-byte leaves (terminated / truncated / done): one lane gathers 4 consecutive output rows (4 index loads, then 4
+// byte loads, all unpredicated) and issues a single 4-byte store instead of four byte stores.
+__device__ __forceinline__ void gather_bytes_packed(const char *__restrict__ src, char *__restrict__ dst,
+                                                    const int64_t *__restrict__ idx, int64_t rows, int64_t op,
+                                                    int64_t B, int64_t N, bool temporal) {
+    const int64_t r0 = op * 4;
+    if (r0 >= rows) return;
+    int64_t src_row[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t r = min(r0 + j, rows - 1);
+        if (temporal) {
+            const int64_t t = r / B, b = r - t * B;
+            src_row[j] = t * N + idx[b];
+        } else {
+            src_row[j] = idx[r];
+        }
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) packed |= uint32_t(uint8_t(src[src_row[j]])) << (8 * j);
+    if (r0 + 4 <= rows) {
+        *reinterpret_cast<uint32_t *>(dst + r0) = packed;
+    } else {
+        for (int j = 0; r0 + j < rows; ++j) dst[r0 + j] = char(packed >> (8 * j));
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void gather_kernel(const GatherTable tab, const int64_t *__restrict__ idx,
@@ -126,40 +190,12 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const GatherTable tab, c
     const int lpr = leaf.lanes_per_row;
     const int64_t row_bytes = leaf.row_bytes;
     const int64_t rows = temporal ? T * B : B;
-    const int64_t op0 = int64_t(blk - tab.block_start[f]) * kGatherOpsPerBlock + threadIdx.x;
     const bool temp = temporal != 0;
-    if (unit == 0) {
-        // 1-byte leaves (terminated / truncated / done): one lane gathers 4 consecutive output rows and
-        // issues a single 4-byte store instead of four byte stores.
-        const int64_t ops = (rows + 3) / 4;
-#pragma unroll
-        for (int it = 0; it < kGatherItems; ++it) {
-            const int64_t op = op0 + int64_t(it) * kBlock;
-            if (op >= ops) break;
-            const int64_t r0 = op * 4;
-            uint32_t packed = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t r = r0 + j;
-                if (r < rows) {
-                    int64_t src_row;
-                    if (temp) {
-                        const int64_t t = r / B, b = r - t * B;
-                        src_row = t * N + idx[b];
-                    } else {
-                        src_row = idx[r];
-                    }
-                    packed |= uint32_t(uint8_t(src[src_row])) << (8 * j);
-                }
-            }
-            if (r0 + 4 <= rows) {
-                *reinterpret_cast<uint32_t *>(dst + r0) = packed;
-            } else {
-                for (int j = 0; r0 + j < rows; ++j) dst[r0 + j] = char(packed >> (8 * j));
-            }
-        }
+    if (unit == 0) {  // one packed lane-op per lane: kBlock ops per block
+        gather_bytes_packed(src, dst, idx, rows, int64_t(blk - tab.block_start[f]) * kBlock + threadIdx.x, B, N, temp);
         return;
     }
+    const int64_t op0 = int64_t(blk - tab.block_start[f]) * kGatherOpsPerBlock + threadIdx.x;
     const int64_t ops = rows * lpr;
     switch (unit) {
         case 16: gather_unit<uint4>(src, dst, idx, ops, op0, lpr, row_bytes, B, N, temp); break;
@@ -316,7 +352,7 @@ extern "C" int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, cons
             ops = rows * (rb / unit);
         }
         tab.block_start[n] = int32_t(blocks);
-        blocks += ceil_div(ops, kGatherOpsPerBlock);
+        blocks += ceil_div(ops, leaf.unit == 0 ? kBlock : kGatherOpsPerBlock);
         if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
         ++n;
     }
