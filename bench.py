@@ -41,90 +41,43 @@ def parse_args():
     parser.add_argument("--no-kernel-pass", action="store_true")
     parser.add_argument("--cpu-seconds", type=float, default=15.0)
     parser.add_argument("--eager", action="store_true", help="disable hipGraph replay (compile=False)")
+    parser.add_argument("--no-observer", action="store_true", help="do not bracket eager launches with HIP events")
+    parser.add_argument("--autoreset", action="store_true",
+                        help="env resets finished instances itself (no per-step index read-back in the trainer)")
     return parser.parse_args()
 
 
-class EventRecorder:
-    """HIP-event pairs around calls of named ``cusrl_amd.ops`` functions, recorded on torch's current stream (the
-    stream every kernel of the path is launched on)."""
-
-    def __init__(self):
-        self.pending: dict[str, list] = {}
-        self.bytes: dict[str, float] = {}
-        self.originals: dict[str, object] = {}
-
-    def wrap(self, ops, name, bytes_fn):
-        original = getattr(ops, name)
-        self.originals[name] = original
-        pending = self.pending.setdefault(name, [])
-
-        def timed(*args, **kwargs):
-            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            start.record()
-            result = original(*args, **kwargs)
-            end.record()
-            pending.append((start, end, bytes_fn(*args, **kwargs)))
-            return result
-
-        setattr(ops, name, timed)
-
-    def unwrap(self, ops):
-        for name, original in self.originals.items():
-            setattr(ops, name, original)
-        self.originals.clear()
-
-    def summary(self):
-        torch.cuda.synchronize()
-        out = {}
-        for name, records in self.pending.items():
-            if not records:
-                continue
-            total_ms = sum(s.elapsed_time(e) for s, e, _ in records)
-            total_bytes = sum(b for _, _, b in records)
-            avg_us = total_ms * 1e3 / len(records)
-            gbs = total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
-            out[name] = {
-                "launches": len(records),
-                "avg_us": round(avg_us, 3),
-                "bytes_per_launch": int(total_bytes / len(records)),
-                "achieved_GBps": round(gbs, 1),
-                "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
-            }
-        return out
+KERNEL_NAMES = {
+    "cusrl_gather_rows": "cusrl::gather_kernel",
+    "cusrl_buffer_push": "cusrl::push_kernel",
+    "cusrl_gae": "cusrl::gae_kernel",
+    "cusrl_next_value": "cusrl::next_value_kernel",
+    "cusrl_normalize": "cusrl::normalize_kernel",
+    "cusrl_ppo_loss_fwd_bwd": "cusrl::ppo_loss_chunked_kernel<3> (+ finalize)",
+    "cusrl_normal_sample_logp": "cusrl::normal_sample_logp_kernel",
+    "cusrl_episode_stats": "cusrl::episode_stats_kernel",
+}
 
 
-def _row_bytes(t, lead):
-    n = t.element_size()
-    for s in t.shape[lead:]:
-        n *= s
-    return n
-
-
-# algorithmic bytes of one call (SURVEY.md §8d accounting: every byte the op must read + write once)
-def gather_bytes(storages, indices, capacity, parallelism, temporal=False):
-    rows = indices.numel() * (capacity if temporal else 1)
-    return rows * sum(2 * _row_bytes(s, 2) for s in storages) + indices.numel() * 8
-
-
-def push_bytes(pairs, cursor, parallelism):
-    return sum(2 * step.numel() * step.element_size() for step, _ in pairs)
-
-
-def gae_bytes(reward, value, next_value, done, *a, **k):
-    return reward.numel() * (3 * 4 + 2 * 4) + done.numel()
-
-
-def next_value_bytes(value, terminated, truncated, *a, **k):
-    return value.numel() * 8 + terminated.numel() * 2
-
-
-def normalize_bytes(x, *a, **k):
-    return x.numel() * 8
-
-
-def loss_bytes(advantage, old_logp, action, mean, std, ret, curr_value, old_value, **k):
-    B, A, D = advantage.numel(), mean.shape[-1], ret.shape[-1]
-    return B * (4 + 4 + 3 * 4 * A + 2 * 4 * D + 2 * 4 * A + 4 * D + 4 * 4)  # + logp/entropy/ratio side outputs
+def summarize(observer):
+    """Per C-ABI entry: launches, average HIP-event time, algorithmic bytes and achieved GB/s."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, records in observer.records.items():
+        if not records:
+            continue
+        total_ms = sum(s.elapsed_time(e) for s, e, _ in records)
+        total_bytes = sum(b for _, _, b in records)
+        gbs = total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+        out[name] = {
+            "kernel": KERNEL_NAMES.get(name, name),
+            "launches": len(records),
+            "avg_us": round(total_ms * 1e3 / len(records), 3),
+            "bytes_per_launch": int(total_bytes / len(records)),
+            "achieved_GBps": round(gbs, 1),
+            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+        }
+    return out
 
 
 def run_gpu(args, rank, world):
@@ -138,7 +91,7 @@ def run_gpu(args, rank, world):
     if world > 1:
         cusrl.utils.configure_distributed()
     cusrl.set_global_seed(42)
-    env = cusrl.testing.SyntheticEnvironment(args.envs_per_gpu, OBS_DIM, ACT_DIM, device=device)
+    env = cusrl.testing.SyntheticEnvironment(args.envs_per_gpu, OBS_DIM, ACT_DIM, device=device, autoreset=args.autoreset)
     # compile=True = hipGraph replay of the act step and the minibatch steps (cusrl_amd/template/graphs.py)
     factory = cusrl.preset.PpoAgentFactory(compile=not args.eager, optimizer_kwargs={"fused": True, "capturable": True})
     trainer = cusrl.Trainer(env, factory, num_iterations=10**9, verbose=False)
@@ -168,9 +121,12 @@ def run_gpu(args, rank, world):
         observation, state = trainer._rollout_and_update(observation, state)
         trainer.iteration += 1
 
-    # ---- timed region: exactly `steps` iterations; the dominant kernel is bracketed by HIP events live
-    recorder = EventRecorder()
-    recorder.wrap(ops, "gather_rows", gather_bytes)
+    # ---- timed region: exactly `steps` iterations.  The dominant kernel (minibatch gather) is bracketed by HIP
+    # events live: 20 of its 21 launches per iteration replay inside hipGraphs (not observable from the host); the
+    # 21st — the statistics pass over the whole buffer, same kernel, 2x the rows — is launched eagerly and timed.
+    observer = ops.LaunchObserver(only={"cusrl_gather_rows"})
+    if not args.no_observer:
+        ops.set_launch_observer(observer)
     update_events.clear()
     barrier()
     t0 = time.perf_counter()
@@ -179,8 +135,9 @@ def run_gpu(args, rank, world):
         trainer.iteration += 1
     barrier()
     elapsed = time.perf_counter() - t0
-    recorder.unwrap(ops)
-    dominant = recorder.summary()["gather_rows"]
+    ops.set_launch_observer(None)
+    live = summarize(observer)
+    dominant = live.get("cusrl_gather_rows", {"achieved_GBps": 0.0, "bytes_per_launch": 0, "avg_us": 0.0, "launches": 0})
     update_ms = sum(s.elapsed_time(e) for s, e in update_events) / max(len(update_events), 1)
 
     if world > 1:
@@ -190,16 +147,17 @@ def run_gpu(args, rank, world):
 
     kernels = {}
     if not args.no_kernel_pass:
-        full = EventRecorder()
-        for name, fn in (("buffer_push", push_bytes), ("gather_rows", gather_bytes), ("gae", gae_bytes),
-                         ("next_value", next_value_bytes), ("normalize_", normalize_bytes),
-                         ("ppo_loss_fwd_bwd", loss_bytes)):
-            full.wrap(ops, name, fn)
+        # every HIP kernel of the path, launched eagerly (graph replay off) so each launch can be bracketed
+        agent.compile = False
+        saved_act, agent._graphed_act = agent._graphed_act, None
+        full = ops.LaunchObserver()
+        ops.set_launch_observer(full)
         for _ in range(3):
             observation, state = trainer._rollout_and_update(observation, state)
             trainer.iteration += 1
-        full.unwrap(ops)
-        kernels = full.summary()
+        ops.set_launch_observer(None)
+        agent.compile, agent._graphed_act = not args.eager, saved_act
+        kernels = summarize(full)
 
     steps_per_iteration = args.envs_per_gpu * HORIZON * world
     result = {
@@ -222,11 +180,13 @@ def run_gpu(args, rank, world):
             "env_steps_per_iteration": steps_per_iteration,
             "parallelism": f"dp{world}",
             "hipgraph": not args.eager,
+            "autoreset": args.autoreset,
         },
         "ppo_update_ms": round(update_ms, 3),
         "roofline": {
             "bound": "hbm",
-            "kernel": "cusrl::gather_kernel (minibatch gather of all buffer leaves, one launch)",
+            "kernel": "cusrl::gather_kernel (all 14 buffer leaves in one launch; timed: the eager whole-buffer launch "
+                      "of the statistics pass, 98304 rows; the 20 in-graph minibatch launches move 24576 rows each)",
             "achieved": dominant["achieved_GBps"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

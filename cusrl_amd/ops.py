@@ -16,6 +16,7 @@ from cusrl_amd import _native
 from cusrl_amd._native import Field, check
 
 __all__ = [
+    "LaunchObserver",
     "adv_stats_finalize",
     "buffer_push",
     "col_stats",
@@ -30,7 +31,48 @@ __all__ = [
     "ppo_loss_fwd_bwd",
     "require_device",
     "scatter_rows",
+    "set_launch_observer",
 ]
+
+
+class LaunchObserver:
+    """Optional HIP-event bracketing of individual launches, placed directly around the C call (after all host-side
+    preparation), on the stream the kernel is launched on.  Used by ``bench.py``; ``None`` in normal operation."""
+
+    def __init__(self, only: set[str] | None = None):
+        # timing events are not free on this stack (~20-40 us of stream bubble per pair): observe few launches
+        self.only = only
+        self.records: dict[str, list[tuple[torch.cuda.Event, torch.cuda.Event, int]]] = {}
+        self._open: torch.cuda.Event | None = None
+
+    def begin(self):
+        self._open = torch.cuda.Event(enable_timing=True)
+        self._open.record()
+
+    def end(self, name: str, nbytes: int):
+        event = torch.cuda.Event(enable_timing=True)
+        event.record()
+        self.records.setdefault(name, []).append((self._open, event, nbytes))
+
+
+_observer: LaunchObserver | None = None
+
+
+def set_launch_observer(observer: LaunchObserver | None) -> None:
+    global _observer
+    _observer = observer
+
+
+def _observed(name: str, nbytes_fn, call) -> None:
+    """Run ``call()`` (a single C-ABI launch returning its status) with optional event bracketing."""
+    observer = _observer
+    if observer is None or (observer.only is not None and name not in observer.only) or torch.cuda.is_current_stream_capturing():
+        check(call(), name)
+        return
+    observer.begin()
+    status = call()
+    observer.end(name, nbytes_fn())
+    check(status, name)
 
 
 def require_device(tensor: torch.Tensor, name: str = "tensor") -> torch.Tensor:
@@ -82,7 +124,11 @@ def buffer_push(pairs: Sequence[tuple[torch.Tensor, torch.Tensor]], cursor: int,
             table[i].src = step.data_ptr()
             table[i].dst = storage.data_ptr()
             table[i].row_bytes = _row_bytes(step, 1)
-        check(lib.cusrl_buffer_push(table, len(chunk), cursor, parallelism, stream), "cusrl_buffer_push")
+        _observed(
+            "cusrl_buffer_push",
+            lambda: sum(2 * step.numel() * step.element_size() for step, _ in chunk),
+            lambda: lib.cusrl_buffer_push(table, len(chunk), cursor, parallelism, stream),
+        )
 
 
 # ------------------------------------------------------------------------------------------------ a7 / a8
@@ -120,9 +166,11 @@ def gather_rows(
             table[i].src = src.data_ptr()
             table[i].dst = outputs[k].data_ptr()
             table[i].row_bytes = _row_bytes(src, 2)
-        check(
-            lib.cusrl_gather_rows(table, len(chunk), indices.data_ptr(), batch, capacity, parallelism, int(temporal), stream),
+        rows = batch * (capacity if temporal else 1)
+        _observed(
             "cusrl_gather_rows",
+            lambda: rows * sum(2 * _row_bytes(storages[k], 2) for k in chunk) + batch * 8,
+            lambda: lib.cusrl_gather_rows(table, len(chunk), indices.data_ptr(), batch, capacity, parallelism, int(temporal), stream),
         )
     return outputs
 
@@ -146,13 +194,14 @@ def next_value(
         raise ValueError("next_value: inconsistent shapes")
     lib = _native.lib()
     block_counts = torch.empty(max(int(lib.cusrl_flag_blocks(T * N)), 1), dtype=torch.int32, device=value.device)
-    check(
-        lib.cusrl_next_value(
-            value.data_ptr(), terminated.data_ptr(), truncated.data_ptr(), last_value.data_ptr(),
-            float(termination_value), int(truncated_uses_own_value), _f32(out, "next_value").data_ptr(),
-            block_counts.data_ptr(), T, N, D, _stream(),
-        ),
+    out_ptr = _f32(out, "next_value").data_ptr()
+    _observed(
         "cusrl_next_value",
+        lambda: T * N * (8 * D + 2),
+        lambda: lib.cusrl_next_value(
+            value.data_ptr(), terminated.data_ptr(), truncated.data_ptr(), last_value.data_ptr(),
+            float(termination_value), int(truncated_uses_own_value), out_ptr, block_counts.data_ptr(), T, N, D, _stream(),
+        ),
     )
     return block_counts
 
@@ -217,13 +266,14 @@ def gae(
     partials = None
     if with_stats:
         partials = torch.empty((max(int(lib.cusrl_gae_num_partials(T, N, D)), 1), D, 2), dtype=torch.float64, device=reward.device)
-    check(
-        lib.cusrl_gae(
+    _observed(
+        "cusrl_gae",
+        lambda: T * N * (20 * D + 1),
+        lambda: lib.cusrl_gae(
             reward.data_ptr(), value.data_ptr(), next_value_.data_ptr(), done.data_ptr(), advantage.data_ptr(),
             ret.data_ptr(), None if partials is None else partials.data_ptr(), T, N, D, float(gamma), float(lamda),
             -1.0 if lamda_value is None else float(lamda_value), _stream(),
         ),
-        "cusrl_gae",
     )
     return advantage, ret, partials
 
@@ -258,9 +308,11 @@ def normalize_(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, eps: floa
     if x.dtype != torch.float32 or not x.is_contiguous():
         raise TypeError("normalize_: expected a contiguous float32 tensor")
     D = x.shape[-1]
-    check(
-        _native.lib().cusrl_normalize(x.data_ptr(), _f32(mean, "mean").data_ptr(), _f32(var, "var").data_ptr(), eps, x.numel() // max(D, 1), D, _stream()),
+    mean, var = _f32(mean, "mean"), _f32(var, "var")
+    _observed(
         "cusrl_normalize",
+        lambda: x.numel() * 8,
+        lambda: _native.lib().cusrl_normalize(x.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, x.numel() // max(D, 1), D, _stream()),
     )
     return x
 
@@ -324,15 +376,16 @@ def ppo_loss_fwd_bwd(
     def ptr(name):
         return out[name].data_ptr() if name in out else None
 
-    check(
-        lib.cusrl_ppo_loss_fwd_bwd(
+    _observed(
+        "cusrl_ppo_loss_fwd_bwd",
+        lambda: B * (8 + 12 * A + 8 * D + (8 * A + 4 * D if want_grads else 0) + 16 + (4 * D if value_clip is not None else 0)),
+        lambda: lib.cusrl_ppo_loss_fwd_bwd(
             advantage.data_ptr(), old_logp.data_ptr(), action.data_ptr(), mean.data_ptr(), std.data_ptr(),
             ret.data_ptr(), curr_value.data_ptr(), None if old_value is None or value_clip is None else old_value.data_ptr(),
             B, A, D, float(clip), -1.0 if value_clip is None else float(value_clip), float(w_sur), float(w_val), float(w_ent),
             ptr("losses"), ptr("logp"), ptr("entropy"), ptr("logp_ratio"), ptr("ratio"), ptr("d_mean"), ptr("d_std"), ptr("d_value"),
             partials.data_ptr(), _stream(),
         ),
-        "cusrl_ppo_loss_fwd_bwd",
     )
     return out
 
@@ -348,9 +401,10 @@ def normal_sample_logp(mean: torch.Tensor, std: torch.Tensor, eps: torch.Tensor)
     B = mean.numel() // A
     action = torch.empty_like(mean)
     logp = torch.empty(mean.shape[:-1] + (1,), dtype=torch.float32, device=mean.device)
-    check(
-        _native.lib().cusrl_normal_sample_logp(mean.data_ptr(), std.data_ptr(), eps.data_ptr(), action.data_ptr(), logp.data_ptr(), B, A, _stream()),
+    _observed(
         "cusrl_normal_sample_logp",
+        lambda: B * (16 * A + 4),
+        lambda: _native.lib().cusrl_normal_sample_logp(mean.data_ptr(), std.data_ptr(), eps.data_ptr(), action.data_ptr(), logp.data_ptr(), B, A, _stream()),
     )
     return action, logp
 
@@ -360,10 +414,11 @@ def episode_stats(reward, done, episode_rew, episode_len, ring_rew, ring_len, nu
     reward = _f32(reward, "reward")
     done = _flag(done, "done")
     N, D = reward.shape
-    check(
-        _native.lib().cusrl_episode_stats(
+    _observed(
+        "cusrl_episode_stats",
+        lambda: N * (12 * D + 9),
+        lambda: _native.lib().cusrl_episode_stats(
             reward.data_ptr(), done.data_ptr(), episode_rew.data_ptr(), episode_len.data_ptr(), ring_rew.data_ptr(),
             ring_len.data_ptr(), num_episodes.data_ptr(), step_reward_sum.data_ptr(), N, D, ring_len.numel(), _stream(),
         ),
-        "cusrl_episode_stats",
     )

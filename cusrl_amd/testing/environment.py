@@ -19,10 +19,10 @@ __all__ = ["DummyTorchEnvironment", "SyntheticEnvironment"]
 class SyntheticEnvironment(Environment):
     def __init__(self, num_instances: int = 4096, observation_dim: int = 48, action_dim: int = 12, *,
                  state_dim: int | None = None, reward_dim: int = 1, terminate_prob: float = 0.01,
-                 truncate_prob: float = 0.005, device=None, **properties):
+                 truncate_prob: float = 0.005, device=None, autoreset: bool = False, **properties):
         device = resolve_device(device)
         super().__init__(observation_dim, action_dim, num_instances=num_instances, state_dim=state_dim,
-                         reward_dim=reward_dim, device=device, **properties)
+                         reward_dim=reward_dim, device=device, autoreset=autoreset, **properties)
         self.device = device
         self.terminate_prob, self.truncate_prob = terminate_prob, truncate_prob
 
@@ -37,6 +37,8 @@ class SyntheticEnvironment(Environment):
         assert isinstance(action, torch.Tensor) and action.shape == (self.num_instances, self.action_dim)
         n = self.num_instances
         flags = torch.rand(2, n, 1, device=self.device)
+        # with autoreset=True a finished instance restarts from a fresh N(0, 1) observation — which the i.i.d.
+        # next observation below already is, so no masked overwrite is needed
         return (
             self._randn(n, self.observation_dim),
             self._randn(n, self.state_dim),
