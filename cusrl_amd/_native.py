@@ -51,6 +51,8 @@ _SIGNATURES = {
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
     "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
     "cusrl_episode_stats": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, _P]),
+    "cusrl_relu_bwd_colsum": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
+    "cusrl_colsum_num_partials": (c_int64, [c_int64, c_int64]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

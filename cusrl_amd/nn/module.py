@@ -14,7 +14,7 @@ from torch.nn.functional import linear
 
 from cusrl_amd.utils.nest import iterate_nested
 
-__all__ = ["Linear", "LinearFp32", "Mlp", "Module", "ModuleFactory", "disable_autocast", "resolve_activation_fn"]
+__all__ = ["Linear", "LinearFp32", "linear_act", "Mlp", "Module", "ModuleFactory", "disable_autocast", "resolve_activation_fn"]
 
 
 def disable_autocast(device_type: str):
@@ -22,55 +22,85 @@ def disable_autocast(device_type: str):
 
 
 class _WideBatchLinear(torch.autograd.Function):
-    """``linear(x, w, b)`` whose weight gradient is shaped for 256 CUs.
+    """``linear(x, w, b)`` (optionally + ReLU in the GEMM epilogue) with a backward shaped for 256 CUs.
 
-    dW = dY^T X has a tiny output (e.g. 128 x 256) and a huge reduction dim (the minibatch, 24 576): as ONE GEMM it
-    yields a few dozen output tiles, i.e. most of the chip idles (rocBLAS picks no split-K here: 84 us measured).
-    Splitting the batch into S slabs turns it into a batched GEMM with S x more workgroups plus a tiny sum — still a
-    rocBLAS/hipBLASLt MFMA GEMM, just with enough parallelism.  Forward and dX are unchanged.
+    * forward with ``relu``: ``torch._addmm_activation`` — bias and ReLU run in the hipBLASLt epilogue (the separate
+      ReLU launch costs as much as the GEMM itself for the 48 -> 256 layer: 29.9 us vs 16.3 us measured);
+    * dW = dY^T X has a tiny output (e.g. 128 x 256) and a huge reduction dim (the minibatch, 24 576): as ONE GEMM it
+      yields a few dozen output tiles, i.e. most of the chip idles (rocBLAS picks no split-K here: 84 us measured).
+      Splitting the batch into S slabs turns it into a batched GEMM with S x more workgroups plus a tiny sum
+      (17 + 4 us) — still a rocBLAS/hipBLASLt MFMA GEMM, just with enough parallelism;
+    * ReLU mask and bias gradient come from ONE HIP pass (``cusrl_relu_bwd_colsum``) instead of threshold_backward +
+      a column-sum reduction (35 us -> ~15 us for [24576, 256]).
     """
 
     @staticmethod
-    def forward(ctx, input, weight, bias, splits):
-        ctx.save_for_backward(input, weight)
-        ctx.splits = splits
-        ctx.has_bias = bias is not None
-        return linear(input, weight, bias)
+    def forward(ctx, input, weight, bias, splits, relu):
+        if relu:
+            output = torch._addmm_activation(bias, input, weight.t())
+            ctx.save_for_backward(input, weight, output)
+        else:
+            output = linear(input, weight, bias)
+            ctx.save_for_backward(input, weight)
+        ctx.splits, ctx.relu, ctx.has_bias = splits, relu, bias is not None
+        return output
 
     @staticmethod
     def backward(ctx, grad_output):
-        input, weight = ctx.saved_tensors
-        grad_input = grad_weight = grad_bias = None
+        from cusrl_amd import ops
+
+        if ctx.relu:
+            input, weight, output = ctx.saved_tensors
+            grad_output, grad_bias = ops.relu_backward_bias(grad_output.contiguous(), output)
+        else:
+            input, weight = ctx.saved_tensors
+            grad_bias = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                _, grad_bias = ops.relu_backward_bias(grad_output.contiguous(), None)
+        grad_input = grad_weight = None
         if ctx.needs_input_grad[0]:
             grad_input = grad_output @ weight
         if ctx.needs_input_grad[1]:
             rows, splits = input.shape[0], ctx.splits
-            gy = grad_output.reshape(splits, rows // splits, -1)
-            grad_weight = torch.bmm(gy.transpose(1, 2), input.reshape(splits, rows // splits, -1)).sum(0)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            grad_bias = grad_output.sum(0)
-        return grad_input, grad_weight, grad_bias, None
+            if splits > 1:
+                gy = grad_output.reshape(splits, rows // splits, -1)
+                grad_weight = torch.bmm(gy.transpose(1, 2), input.reshape(splits, rows // splits, -1)).sum(0)
+            else:
+                grad_weight = grad_output.t() @ input
+        return grad_input, grad_weight, grad_bias, None, None
 
 
 def _batch_splits(rows: int) -> int:
     """Largest power-of-two slab count (<= 32) that divides the batch and leaves >= 1024 rows per slab."""
+    if rows < 4096:
+        return 1
     splits = 1
     while splits < 32 and rows % (splits * 2) == 0 and rows // (splits * 2) >= 1024:
         splits *= 2
     return splits
 
 
+def _device_fp32(input: torch.Tensor, weight: torch.Tensor) -> bool:
+    return (input.dim() == 2 and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32
+            and not torch.is_autocast_enabled("cuda"))
+
+
+def linear_act(input: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, relu: bool = False) -> torch.Tensor:
+    """``relu?(linear(input, weight, bias))`` through the MI355X-shaped paths when the data is fp32 on the GPU."""
+    if _device_fp32(input, weight) and (bias is not None or not relu):
+        if torch.is_grad_enabled() and (weight.requires_grad or input.requires_grad):
+            return _WideBatchLinear.apply(input, weight, bias, _batch_splits(input.shape[0]), relu)
+        if relu:
+            return torch._addmm_activation(bias, input, weight.t())
+    output = linear(input, weight, bias)
+    return torch.relu(output) if relu else output
+
+
 class Linear(nn.Linear):
-    """``nn.Linear`` (same parameters, same state-dict keys) with the wide-batch weight-gradient path on the GPU."""
+    """``nn.Linear`` (same parameters, same state-dict keys) routed through :func:`linear_act`."""
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        if (input.dim() == 2 and input.is_cuda and input.shape[0] >= 4096 and torch.is_grad_enabled()
-                and self.weight.requires_grad and input.dtype == self.weight.dtype
-                and not torch.is_autocast_enabled("cuda")):
-            splits = _batch_splits(input.shape[0])
-            if splits > 1:
-                return _WideBatchLinear.apply(input, self.weight, self.bias, splits)
-        return linear(input, self.weight, self.bias)
+        return linear_act(input, self.weight, self.bias)
 
 
 class LinearFp32(nn.Linear):
@@ -200,7 +230,19 @@ class Mlp(Module):
         self.layers = nn.Sequential(*layers)
 
     def forward(self, input: torch.Tensor, **kwargs) -> torch.Tensor:
-        return self.layers(input)
+        layers = self.layers
+        if not (input.is_cuda and input.dim() == 2):
+            return layers(input)
+        x, i, n = input, 0, len(layers)
+        while i < n:  # Linear followed by ReLU runs as one GEMM with the ReLU in its epilogue
+            module = layers[i]
+            if type(module) is Linear and i + 1 < n and type(layers[i + 1]) is nn.ReLU:
+                x = linear_act(x, module.weight, module.bias, relu=True)
+                i += 2
+            else:
+                x = module(x)
+                i += 1
+        return x
 
     def __getitem__(self, index: int) -> nn.Module:
         return self.layers[index]

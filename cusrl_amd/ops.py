@@ -29,6 +29,7 @@ __all__ = [
     "normal_sample_logp",
     "normalize_",
     "ppo_loss_fwd_bwd",
+    "relu_backward_bias",
     "require_device",
     "scatter_rows",
     "set_launch_observer",
@@ -422,3 +423,29 @@ def episode_stats(reward, done, episode_rew, episode_len, ring_rew, ring_len, nu
             ring_len.data_ptr(), num_episodes.data_ptr(), step_reward_sum.data_ptr(), N, D, ring_len.numel(), _stream(),
         ),
     )
+
+
+# ------------------------------------------------------------------------------------------------ MLP backward epilogue
+def relu_backward_bias(grad_output: torch.Tensor, output: torch.Tensor | None) -> tuple[torch.Tensor, torch.Tensor]:
+    """``(grad_output * (output > 0), masked.sum(0))`` in one pass; with ``output=None`` just the column sums
+    (bias gradient of a linear layer, with or without the ReLU that follows it)."""
+    grad_output = _f32(grad_output, "grad_output")
+    H = grad_output.shape[-1]
+    rows = grad_output.numel() // H
+    lib = _native.lib()
+    partials = torch.empty((max(int(lib.cusrl_colsum_num_partials(rows, H)), 1), H), dtype=torch.float32, device=grad_output.device)
+    colsum = torch.empty(H, dtype=torch.float32, device=grad_output.device)
+    chunkable = H % 4 == 0 and H // 4 <= 256 and 256 % (H // 4) == 0
+    if output is None and not chunkable and H > 1:
+        return grad_output, grad_output.sum(0)  # narrow odd widths (e.g. a 12-wide policy head): torch's reduce is fine
+    if output is None:
+        grad_in, out_ptr, in_ptr = grad_output, None, None
+    else:
+        output = _f32(output, "output")
+        grad_in = torch.empty_like(grad_output)
+        out_ptr, in_ptr = output.data_ptr(), grad_in.data_ptr()
+    check(
+        lib.cusrl_relu_bwd_colsum(grad_output.data_ptr(), out_ptr, in_ptr, partials.data_ptr(), colsum.data_ptr(), rows, H, _stream()),
+        "cusrl_relu_bwd_colsum",
+    )
+    return grad_in, colsum

@@ -142,6 +142,15 @@ int cusrl_episode_stats(const float *reward, const uint8_t *done, float *episode
                         float *ring_rew, float *ring_len, uint64_t *num_episodes, double *step_reward_sum,
                         int64_t N, int64_t D, int64_t R, void *stream);
 
+/* ---- MLP backward epilogues (callers of the path: torch.nn.Linear / ReLU backward of the actor-critic) ----
+ * Bias gradient = column sums of grad [rows, H]; with `output` != NULL the ReLU backward mask is applied first
+ * (grad_in = grad * (output > 0), written to grad_in) and the column sums are taken of the masked gradient, i.e.
+ * threshold_backward + sum(0) of autograd in one pass.  partials: float[cusrl_colsum_num_partials(rows, H)][H]
+ * workspace; colsum: float[H] (fixed summation order: deterministic). */
+int cusrl_relu_bwd_colsum(const float *grad, const float *output, float *grad_in, float *partials, float *colsum,
+                          int64_t rows, int64_t H, void *stream);
+int64_t cusrl_colsum_num_partials(int64_t rows, int64_t H);
+
 #ifdef __cplusplus
 }
 #endif

@@ -335,3 +335,38 @@ def test_episode_stats_one_launch_matches_reference_bookkeeping(ops, N, D, R):
     else:  # more finished than ring slots: every slot holds some finished episode
         lens = {l for _, l in finished}
         assert set(host(ring_len)[:, 0].tolist()) <= lens
+
+
+# ------------------------------------------------------------------------------------------------ MLP backward epilogue
+@pytest.mark.parametrize("rows,H", [(24576, 256), (24576, 128), (24576, 12), (24576, 1), (100, 32), (7, 5), (1, 4), (4097, 64)])
+@pytest.mark.parametrize("mask", [True, False])
+def test_relu_backward_bias_matches_autograd(ops, rows, H, mask):
+    torch.manual_seed(rows + H)
+    grad = torch.randn(rows, H, device=DEV)
+    output = torch.relu(torch.randn(rows, H, device=DEV)) if mask else None
+    grad_in, colsum = ops.relu_backward_bias(grad, output)
+    expect = torch.ops.aten.threshold_backward(grad, output, 0) if mask else grad
+    assert torch.equal(grad_in, expect)  # the mask is exact
+    ref = expect.double().sum(0)
+    # fp32 accumulation over `rows` terms of magnitude ~1: 1e-5 relative to the column's absolute mass
+    torch.testing.assert_close(colsum.double(), ref, rtol=1e-5, atol=1e-5 * float(expect.abs().sum(0).max()))
+
+
+def test_fused_linear_paths_match_plain_autograd():
+    from cusrl_amd.nn.module import Mlp
+
+    torch.manual_seed(0)
+    for rows in (64, 8192):
+        mlp = Mlp(48, (256, 128), ends_with_activation=True).to(DEV)
+        x = torch.randn(rows, 48, device=DEV, requires_grad=True)
+        mlp(x).square().sum().backward()
+        got = [p.grad.clone() for p in mlp.parameters()] + [x.grad.clone()]
+        for p in mlp.parameters():
+            p.grad = None
+        x.grad = None
+        mlp.layers(x).square().sum().backward()  # plain nn.Sequential path: addmm, relu, autograd backward
+        want = [p.grad for p in mlp.parameters()] + [x.grad]
+        for g, w in zip(got, want):
+            torch.testing.assert_close(g, w, rtol=2e-4, atol=1e-4 * float(w.abs().max()))
+        with torch.no_grad():
+            assert torch.equal(mlp(x), mlp.layers(x))
