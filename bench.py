@@ -80,6 +80,16 @@ def summarize(observer):
     return out
 
 
+def pmc_traffic(envs_per_gpu):
+    """HBM bytes of the timed launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
+    passes, FETCH_SIZE doubled per the gfx950 correction — profiles/r01/pmc_summary.json, scripts/gpu_pmc.sh).
+    Counters cannot be read from inside this process, so the committed measurement of the same launch is quoted."""
+    path = ROOT / "profiles" / "r01" / "pmc_summary.json"
+    if envs_per_gpu != NUM_ENVS or not path.exists():
+        return None
+    return json.loads(path.read_text())["gather_whole_buffer"]["hbm_traffic_bytes_corrected"]
+
+
 def run_gpu(args, rank, world):
     import cusrl_amd as cusrl
     from cusrl_amd import ops
@@ -146,18 +156,16 @@ def run_gpu(args, rank, world):
         elapsed = float(t.item())
 
     kernels = {}
-    if not args.no_kernel_pass:
-        # every HIP kernel of the path, launched eagerly (graph replay off) so each launch can be bracketed
-        agent.compile = False
-        saved_act, agent._graphed_act = agent._graphed_act, None
-        full = ops.LaunchObserver()
-        ops.set_launch_observer(full)
-        for _ in range(3):
-            observation, state = trainer._rollout_and_update(observation, state)
-            trainer.iteration += 1
-        ops.set_launch_observer(None)
-        agent.compile, agent._graphed_act = not args.eager, saved_act
-        kernels = summarize(full)
+    if not args.no_kernel_pass and rank == 0:
+        # every HIP kernel of the path stand-alone at this workload's sizes, replayed from a hipGraph between one
+        # HIP-event pair (bracketing each eager launch with events costs a 10-40 us stream bubble per pair and would
+        # dominate these 3-10 us kernels); scripts/kernel_bench.py also reports the roofline-scale size (1M envs)
+        sys.path.insert(0, str(ROOT / "scripts"))
+        import kernel_bench
+
+        for name, (us, nbytes) in kernel_bench.bench_size(args.envs_per_gpu, iters=100).items():
+            kernels[name] = {"avg_us": round(us, 2), "bytes_per_launch": int(nbytes),
+                             "achieved_GBps": round(nbytes / us / 1e3, 1), "frac_of_hbm_peak": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
 
     steps_per_iteration = args.envs_per_gpu * HORIZON * world
     result = {
@@ -191,7 +199,7 @@ def run_gpu(args, rank, world):
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(dominant["achieved_GBps"] / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic(args.envs_per_gpu),
             "bytes_per_launch": dominant["bytes_per_launch"],
             "avg_us": dominant["avg_us"],
             "launches": dominant["launches"],

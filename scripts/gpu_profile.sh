@@ -17,3 +17,24 @@ grep "^{" /tmp/prof_$TAG.log > "$R/gpurun_out/$TAG/bench_line.json" < /dev/null
 ls -la "$R/gpurun_out/$TAG" < /dev/null
 F=$(find "$OUT" -name "*kernel_stats.csv" < /dev/null | head -1)
 if [ -n "$F" ]; then head -50 "$F" | cut -c1-220; else echo "no kernel_stats.csv"; find "$OUT" -type f < /dev/null | head; fi
+# per (kernel, grid size) averages of the cusrl kernels from the raw dispatch trace (the stats CSV averages mix sizes)
+T=$(find "$OUT" -name "*kernel_trace.csv" < /dev/null | head -1)
+if [ -n "$T" ]; then
+python3 - "$T" "$R/gpurun_out/$TAG/cusrl_kernels_by_grid.csv" <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: [0, 0, 10**18, 0])
+with open(sys.argv[1]) as f:
+    for row in csv.DictReader(f):
+        name = row["Kernel_Name"]
+        if "cusrl::" not in name:
+            continue
+        key = (name.split("(")[0], int(row.get("Grid_Size", row.get("Grid_Size_X", 0))))
+        d = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+        a = acc[key]; a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+with open(sys.argv[2], "w") as f:
+    f.write("kernel,grid_size_threads,calls,avg_ns,min_ns,max_ns\n")
+    for (name, grid), (n, tot, lo, hi) in sorted(acc.items()):
+        f.write(f"\"{name}\",{grid},{n},{tot / n:.0f},{lo},{hi}\n")
+print(open(sys.argv[2]).read())
+PY
+fi

@@ -24,26 +24,61 @@ PEAK = 8000.0
 DEV = "cuda:0"
 
 
+USE_GRAPH = True
+
+
 def timeit(fn, iters):
+    """Average device time per call.  With USE_GRAPH the calls are replayed from a captured hipGraph so the Python /
+    ctypes launch overhead (10-40 us per call, larger than the kernels at config-2 size) is not what is timed."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(iters):
+    if not USE_GRAPH:
+        start.record()
+        for _ in range(iters):
+            fn()
+        end.record()
+        torch.cuda.synchronize()
+        return start.elapsed_time(end) * 1e3 / iters  # us
+    per_graph = 10
+    stream, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
         fn()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=stream):
+        for _ in range(per_graph):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    replays = max(iters // per_graph, 1)
+    start.record()
+    for _ in range(replays):
+        graph.replay()
     end.record()
     torch.cuda.synchronize()
-    return start.elapsed_time(end) * 1e3 / iters  # us
+    return start.elapsed_time(end) * 1e3 / (replays * per_graph)
 
 
-def bench_size(N, T=24, obs=48, act=12, mbs=4):
+class _Rows(dict):
+    """name -> (us, bytes); measurements whose name does not match ``only`` are skipped without launching."""
+
+    def __init__(self, only, iters):
+        super().__init__()
+        self.only, self.iters = only, iters
+
+    def measure(self, name, fn, nbytes):
+        if self.only is None or self.only in name:
+            self[name] = (timeit(fn, self.iters), nbytes)
+
+
+def bench_size(N, T=24, obs=48, act=12, mbs=4, only=None, iters=None):
     S = T * N
     B = S // mbs
-    iters = 200 if N <= 16384 else 10
+    iters = iters or (200 if N <= 16384 else 10)
     f = lambda *shape: torch.randn(*shape, device=DEV)  # noqa: E731
     flag = lambda p: torch.rand(T, N, 1, device=DEV) < p  # noqa: E731
-    rows = {}
+    rows = _Rows(only, iters)
 
     # ---- push: the 11 leaves of the ppo transition
     step = {"observation": f(N, obs), "mean": f(N, act), "std": f(N, act), "action": f(N, act), "logp": f(N, 1),
@@ -59,20 +94,20 @@ def bench_size(N, T=24, obs=48, act=12, mbs=4):
         ops.buffer_push(pairs, cursor[0], N)
         cursor[0] = (cursor[0] + 1) % T
 
-    rows["push (1 step, 11 leaves)"] = (timeit(push, iters), push_bytes)
+    rows.measure("push (1 step, 11 leaves)", push, push_bytes)
 
     # ---- pre_update kernels
     reward, value, nv = f(T, N, 1), f(T, N, 1), f(T, N, 1)
     done, term, trunc = flag(0.015), flag(0.01), flag(0.005)
     adv, ret, out = torch.empty_like(reward), torch.empty_like(reward), torch.empty_like(reward)
     last = f(N, 1)
-    rows["next_value"] = (timeit(lambda: ops.next_value(value, term, trunc, last, 0.0, False, out), iters), S * 10)
-    rows["gae + return + stats"] = (timeit(lambda: ops.gae(reward, value, nv, done, 0.99, 0.95, None, adv, ret), iters), S * 21)
-    rows["gae two lambdas"] = (timeit(lambda: ops.gae(reward, value, nv, done, 0.99, 0.95, 0.98, adv, ret), iters), S * 21)
+    rows.measure("next_value", lambda: ops.next_value(value, term, trunc, last, 0.0, False, out), S * 10)
+    rows.measure("gae + return + stats", lambda: ops.gae(reward, value, nv, done, 0.99, 0.95, None, adv, ret), S * 21)
+    rows.measure("gae two lambdas", lambda: ops.gae(reward, value, nv, done, 0.99, 0.95, 0.98, adv, ret), S * 21)
     mean, var = torch.zeros(1, device=DEV), torch.ones(1, device=DEV)
-    rows["normalize"] = (timeit(lambda: ops.normalize_(adv, mean, var), iters), S * 8)
-    rows["col_stats"] = (timeit(lambda: ops.col_stats(adv), iters), S * 4)
-    rows["compact_flags (recount)"] = (timeit(lambda: ops.compact_flags(trunc), iters), S * 2)
+    rows.measure("normalize", lambda: ops.normalize_(adv, mean, var), S * 8)
+    rows.measure("col_stats", lambda: ops.col_stats(adv), S * 4)
+    rows.measure("compact_flags (recount)", lambda: ops.compact_flags(trunc), S * 2)
 
     # ---- gather: every leaf of the buffer at update time (555 B / slot)
     leaves = [f(T, N, obs), f(T, N, act), f(T, N, act), f(T, N, act), f(T, N, 1), f(T, N, 1), f(T, N, obs), f(T, N, 1),
@@ -80,22 +115,22 @@ def bench_size(N, T=24, obs=48, act=12, mbs=4):
     perm = torch.randperm(S, device=DEV)
     idx = perm[:B]
     row = sum(x[0, 0].numel() * x.element_size() for x in leaves)
-    rows[f"gather all leaves (B={B})"] = (timeit(lambda: ops.gather_rows(leaves, idx, T, N), iters), B * (2 * row + 8))
+    rows.measure(f"gather all leaves (B={B})", lambda: ops.gather_rows(leaves, idx, T, N), B * (2 * row + 8))
     small = [leaves[0], leaves[3], leaves[4], leaves[5], leaves[11], leaves[12]]
     row_small = sum(x[0, 0].numel() * x.element_size() for x in small)
-    rows["gather ppo-minimal leaves"] = (timeit(lambda: ops.gather_rows(small, idx, T, N), iters), B * (2 * row_small + 8))
+    rows.measure("gather ppo-minimal leaves", lambda: ops.gather_rows(small, idx, T, N), B * (2 * row_small + 8))
 
     # ---- fused loss
     a = dict(advantage=f(B, 1), old_logp=f(B, 1) - 12, action=f(B, act), mean=f(B, act), std=torch.rand(B, act, device=DEV) + 0.5,
              ret=f(B, 1), curr_value=f(B, 1), old_value=f(B, 1))
     kw = dict(clip=0.2, value_clip=None, w_sur=1.0, w_val=0.5, w_ent=0.01)
     loss_bytes = B * (8 + 3 * 4 * act + 8 + 2 * 4 * act + 4 + 16)
-    rows[f"ppo loss fwd+bwd (B={B})"] = (timeit(lambda: ops.ppo_loss_fwd_bwd(*a.values(), **kw), iters), loss_bytes)
+    rows.measure(f"ppo loss fwd+bwd (B={B})", lambda: ops.ppo_loss_fwd_bwd(*a.values(), **kw), loss_bytes)
 
     # ---- reference points: a plain device copy of the same bytes (what the memory system gives a streaming kernel)
     big = torch.empty(max(S * 21 // 8, 1024), dtype=torch.float32, device=DEV)
     dst = torch.empty_like(big)
-    rows["torch copy_ (same bytes as gae)"] = (timeit(lambda: dst.copy_(big), iters), big.numel() * 8)
+    rows.measure("torch copy_ (same bytes as gae)", lambda: dst.copy_(big), big.numel() * 8)
     return rows
 
 
@@ -103,10 +138,16 @@ def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--envs", type=int, nargs="+", default=[4096, 1048576])
     parser.add_argument("--json", type=str, default=None)
+    parser.add_argument("--only", type=str, default=None, help="substring filter on row names (PMC passes)")
+    parser.add_argument("--iters", type=int, default=None)
+    parser.add_argument("--mbs", type=int, default=4, help="minibatches per epoch (1 = gather the whole buffer)")
+    parser.add_argument("--eager", action="store_true", help="time eager launches (includes host launch overhead)")
     args = parser.parse_args()
+    global USE_GRAPH
+    USE_GRAPH = not args.eager
     report = {}
     for N in args.envs:
-        rows = bench_size(N)
+        rows = bench_size(N, mbs=args.mbs, only=args.only, iters=args.iters)
         print(f"\n== N = {N} envs, T = 24 ==")
         print(f"{'kernel':42s} {'us/launch':>10s} {'MB':>9s} {'GB/s':>9s} {'% of 8TB/s':>10s}")
         report[str(N)] = {}
