@@ -41,6 +41,7 @@ def parse_args():
     parser.add_argument("--no-kernel-pass", action="store_true")
     parser.add_argument("--cpu-seconds", type=float, default=15.0)
     parser.add_argument("--eager", action="store_true", help="disable hipGraph replay (compile=False)")
+    parser.add_argument("--no-timer", action="store_true", help="replace the trainer's section timer by a no-op (diagnostic)")
     parser.add_argument("--no-observer", action="store_true", help="do not bracket eager launches with HIP events")
     parser.add_argument("--autoreset", action="store_true",
                         help="env resets finished instances itself (no per-step index read-back in the trainer)")
@@ -106,6 +107,11 @@ def run_gpu(args, rank, world):
     factory = cusrl.preset.PpoAgentFactory(compile=not args.eager, optimizer_kwargs={"fused": True, "capturable": True})
     trainer = cusrl.Trainer(env, factory, num_iterations=10**9, verbose=False)
     agent = trainer.agent
+    if args.no_timer:
+        from contextlib import nullcontext
+
+        trainer.timer.record = lambda name: nullcontext()
+        trainer.timer.__class__.__getitem__ = lambda self, name: 1.0
 
     update_events = []
     original_update = agent.update
