@@ -1,4 +1,5 @@
 from cusrl_amd.hook.control import ModuleInitialization
+from cusrl_amd.hook.mdp import ObservationNormalization
 from cusrl_amd.hook.on_policy import (
     AdvantageNormalization,
     AdvantageReduction,
@@ -19,6 +20,7 @@ __all__ = [
     "GeneralizedAdvantageEstimation",
     "GradientClipping",
     "ModuleInitialization",
+    "ObservationNormalization",
     "OnPolicyPreparation",
     "OnPolicyStatistics",
     "PpoSurrogateLoss",

@@ -73,6 +73,7 @@ class FusedPpoObjective:
     def eligible(composite) -> bool:
         """Stock PPO composition only: exactly one each of the four term hooks (exact types, in the reference's
         order), a Gaussian policy, and no other active hook that defines ``objective``."""
+        from cusrl_amd.hook.mdp.observation import ObservationNormalization
         from cusrl_amd.hook.on_policy.advantage import AdvantageNormalization, AdvantageReduction
         from cusrl_amd.hook.on_policy.common import OnPolicyPreparation
         from cusrl_amd.hook.on_policy.gae import GeneralizedAdvantageEstimation
@@ -84,7 +85,7 @@ class FusedPpoObjective:
         if not getattr(distribution, "is_normal", False) or agent.device.type != "cuda":
             return False
         terms = (ValueLoss, OnPolicyPreparation, PpoSurrogateLoss, EntropyLoss)
-        passive = (GeneralizedAdvantageEstimation, AdvantageNormalization, AdvantageReduction)
+        passive = (GeneralizedAdvantageEstimation, AdvantageNormalization, AdvantageReduction, ObservationNormalization)
         order = []
         for hook in composite:
             if not hook.active:

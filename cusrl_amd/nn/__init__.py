@@ -1,6 +1,7 @@
 from cusrl_amd.nn.actor import Actor, Value
 from cusrl_amd.nn.distribution import AdaptiveNormalDist, Distribution, NormalDist, OneHotCategoricalDist
 from cusrl_amd.nn.module import LinearFp32, Mlp, Module, ModuleFactory
+from cusrl_amd.nn.rms import RunningMeanStd
 
 __all__ = [
     "Actor",
@@ -12,5 +13,6 @@ __all__ = [
     "ModuleFactory",
     "NormalDist",
     "OneHotCategoricalDist",
+    "RunningMeanStd",
     "Value",
 ]

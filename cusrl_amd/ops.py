@@ -29,8 +29,11 @@ __all__ = [
     "normal_sample_logp",
     "normalize_",
     "ppo_loss_fwd_bwd",
+    "masked_col_stats",
     "relu_backward_bias",
     "require_device",
+    "rms_merge_",
+    "rms_normalize",
     "scatter_rows",
     "set_launch_observer",
 ]
@@ -449,3 +452,53 @@ def relu_backward_bias(grad_output: torch.Tensor, output: torch.Tensor | None) -
         "cusrl_relu_bwd_colsum",
     )
     return grad_in, colsum
+
+
+# ------------------------------------------------------------------------------------------------ running statistics
+def masked_col_stats(x: torch.Tensor, mask: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``mean_var_count`` (population variance) of the rows of ``x [rows, C]`` whose ``mask`` byte is set
+    (cusrl/nn/utils/normalization.py:15-50 after the ``observation[indices]`` select of observation.py:206-208);
+    the count stays on the device (double[1]) — no host synchronisation."""
+    x = _f32(x, "input")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if mask is not None:
+        mask = _flag(mask, "mask")
+        if mask.numel() != rows:
+            raise ValueError("masked_col_stats: mask must have one entry per row")
+    lib = _native.lib()
+    dev = x.device
+    partials = torch.empty((max(int(lib.cusrl_masked_stats_num_partials(rows, C)), 1), C + 1, 2), dtype=torch.float64, device=dev)
+    mean, var = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.float64, device=dev)
+    check(
+        lib.cusrl_masked_col_stats(x.data_ptr(), None if mask is None else mask.data_ptr(), rows, C, partials.data_ptr(),
+                                   mean.data_ptr(), var.data_ptr(), count.data_ptr(), _stream()),
+        "cusrl_masked_col_stats",
+    )
+    return mean, var, count
+
+
+def rms_merge_(mean, var, std, count, batch_mean, batch_var, batch_count, eps: float, max_count: float | None) -> None:
+    """In-place Chan merge of batch statistics into running statistics (normalization.py:80-93, rms.py:163-167)."""
+    check(
+        _native.lib().cusrl_rms_merge(
+            _f32(mean, "mean").data_ptr(), _f32(var, "var").data_ptr(), _f32(std, "std").data_ptr(), count.data_ptr(),
+            _f32(batch_mean, "batch_mean").data_ptr(), _f32(batch_var, "batch_var").data_ptr(), batch_count.data_ptr(),
+            float(eps), -1.0 if max_count is None else float(max_count), mean.numel(), _stream(),
+        ),
+        "cusrl_rms_merge",
+    )
+
+
+def rms_normalize(x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, clamp: float | None) -> torch.Tensor:
+    """``((x - mean) / std).clamp(-clamp, clamp)`` as one launch (rms.py:198-203)."""
+    x = _f32(x, "input")
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    check(
+        _native.lib().cusrl_rms_normalize(x.data_ptr(), _f32(mean, "mean").data_ptr(), _f32(std, "std").data_ptr(),
+                                          -1.0 if clamp is None else float(clamp), out.data_ptr(), x.numel() // C, C, _stream()),
+        "cusrl_rms_normalize",
+    )
+    return out

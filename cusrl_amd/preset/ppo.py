@@ -46,12 +46,11 @@ def ppo_hook_suite(
     max_kl_divergence: float | None = None,
     empty_cuda_cache: bool = False,
 ) -> list[Hook]:
-    if normalize_observation:
-        raise NotImplementedError("ObservationNormalization is SURVEY.md §8f rank 3 (next), not built yet")
     if desired_kl_divergence is not None:
         raise NotImplementedError("AdaptiveLRSchedule is host-side scalar control, out of scope (SURVEY.md §2 row 3)")
     suite = [
         hooks.ModuleInitialization(init_actor=orthogonal_init, init_critic=orthogonal_init),
+        hooks.ObservationNormalization() if normalize_observation else None,
         hooks.ValueComputation(),
         hooks.GeneralizedAdvantageEstimation(gamma=gae_gamma, lamda=gae_lamda, lamda_value=gae_lamda_value),
         hooks.AdvantageNormalization() if normalize_advantage else None,

@@ -151,6 +151,27 @@ int cusrl_relu_bwd_colsum(const float *grad, const float *output, float *grad_in
                           int64_t rows, int64_t H, void *stream);
 int64_t cusrl_colsum_num_partials(int64_t rows, int64_t H);
 
+/* ---- running observation statistics ----
+ * cusrl/nn/utils/normalization.py:15-50 `mean_var_count` of x [rows, C] restricted to rows with mask != 0 (mask may
+ * be NULL = all rows; replaces the host-synchronising boolean-mask select of hook/mdp/observation.py:206-208):
+ * batch_mean[C], batch_var[C] (population variance, correction = 0), batch_count (device double[1]);
+ * an empty selection yields mean 0, var 1, count 0 like the reference.
+ * partials: double[cusrl_masked_stats_num_partials(rows, C)][C + 1][2] workspace. */
+int cusrl_masked_col_stats(const float *x, const uint8_t *mask, int64_t rows, int64_t C, double *partials,
+                           float *batch_mean, float *batch_var, double *batch_count, void *stream);
+int64_t cusrl_masked_stats_num_partials(int64_t rows, int64_t C);
+
+/* cusrl/nn/utils/normalization.py:80-93 `merge_mean_var_` + cusrl/nn/layer/rms.py:163-167: merge batch statistics into
+ * the running mean / var (weights count : batch_count), std = sqrt(var + eps), count += batch_count (capped at
+ * max_count when max_count > 0); a zero batch_count leaves everything unchanged.  count, batch_count: device double[1]. */
+int cusrl_rms_merge(float *mean, float *var, float *std, double *count, const float *batch_mean,
+                    const float *batch_var, const double *batch_count, float eps, double max_count, int64_t C,
+                    void *stream);
+
+/* cusrl/nn/layer/rms.py:198-203 `normalize`: out = clamp((x - mean) / std, -clamp, clamp) (clamp <= 0: no clamp). */
+int cusrl_rms_normalize(const float *x, const float *mean, const float *std, float clamp, float *out, int64_t rows,
+                        int64_t C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -393,6 +393,67 @@ def make_update_trace(cusrl):
     np.savez_compressed(HERE / "update_trace.npz", **out)
 
 
+# ------------------------------------------------------------------------------- observation normalisation
+def make_obs_norm(cusrl):
+    """ObservationNormalization pre_act / post_step over a short rollout
+    (hook/mdp/observation.py:159-246, nn/layer/rms.py:136-206, nn/utils/normalization.py:15-93)."""
+    from types import SimpleNamespace  # noqa: PLC0415
+
+    out = dict(META)
+    gen = torch.Generator().manual_seed(31)
+    idx = 0
+    for N, C, S, with_state, max_count in [(64, 48, 0, False, None), (16, 5, 7, True, None), (8, 3, 0, False, 40)]:
+        spec = cusrl.EnvironmentSpec(C, 2, state_dim=S if with_state else None, num_instances=N)
+        agent = SimpleNamespace(environment_spec=spec, observation_dim=C, state_dim=S if with_state else C,
+                                has_state=with_state, inference_mode=False, setup_module=lambda m: m,
+                                to_tensor=torch.as_tensor)
+        hook = cusrl.hook.ObservationNormalization(max_count=max_count)
+        hook.pre_init(agent)
+        hook.init()
+        steps = 6
+        p = f"c{idx}_"
+        out[p + "params"] = np.array([N, C, S if with_state else 0, steps, -1 if max_count is None else max_count])
+        observation = torch.randn(N, C, generator=gen) * 3 + 1
+        state = torch.randn(N, S, generator=gen) * 0.5 - 2 if with_state else None
+        for t in range(steps):
+            tr = {"observation": observation.clone()}
+            if with_state:
+                tr["state"] = state.clone()
+            hook.pre_act(tr)
+            out[p + f"obs_in_{t}"] = np_(observation)
+            out[p + f"obs_out_{t}"] = np_(tr["observation"])
+            if with_state:
+                out[p + f"state_in_{t}"] = np_(state)
+                out[p + f"state_out_{t}"] = np_(tr["state"])
+            next_observation = torch.randn(N, C, generator=gen) * (3 + t) + 1
+            next_state = torch.randn(N, S, generator=gen) * 0.5 - 2 if with_state else None
+            done = torch.rand(N, 1, generator=gen) < 0.3
+            tr.update(next_observation=next_observation.clone(), done=done)
+            if with_state:
+                tr["next_state"] = next_state.clone()
+            hook.post_step(tr)
+            out[p + f"next_in_{t}"] = np_(next_observation)
+            out[p + f"next_out_{t}"] = np_(tr["next_observation"])
+            out[p + f"done_{t}"] = np_(done)
+            out[p + f"mean_{t}"] = np_(hook.observation_rms.mean)
+            out[p + f"var_{t}"] = np_(hook.observation_rms.var)
+            out[p + f"count_{t}"] = np.array(hook.observation_rms.count)
+            if with_state:
+                out[p + f"next_state_in_{t}"] = np_(next_state)
+                out[p + f"next_state_out_{t}"] = np_(tr["next_state"])
+                out[p + f"state_mean_{t}"] = np_(hook.state_rms.mean)
+                out[p + f"state_var_{t}"] = np_(hook.state_rms.var)
+            # reset finished envs with fresh observations (what the trainer does)
+            fresh = torch.randn(N, C, generator=gen) * 0.1
+            observation = torch.where(done, fresh, next_observation)
+            if with_state:
+                state = torch.where(done, torch.randn(N, S, generator=gen), next_state)
+        idx += 1
+    out["num_cases"] = np.array(idx)
+    np.savez_compressed(HERE / "obs_norm.npz", **out)
+    print("obs_norm.npz:", idx, "cases")
+
+
 def main():
     cusrl = import_reference()
     cusrl.config.set_device("cpu")
@@ -402,6 +463,7 @@ def main():
     make_losses(cusrl)
     make_merge(cusrl)
     make_update_trace(cusrl)
+    make_obs_norm(cusrl)
     leaked = list(REFERENCE.rglob("__pycache__"))
     assert not leaked, f"bytecode leaked into the reference tree: {leaked[:3]}"
 
