@@ -6,7 +6,10 @@ gather, PPO objective forward+backward) runs as hand-written HIP kernels for gfx
 """
 
 from cusrl_amd import hook, nn, preset, sampler, template, testing, utils
-from cusrl_amd.nn import Actor, AdaptiveNormalDist, Distribution, LinearFp32, Mlp, Module, ModuleFactory, NormalDist, OneHotCategoricalDist, Value
+from cusrl_amd.nn import (
+    Actor, AdaptiveNormalDist, Distribution, Gru, LinearFp32, Lstm, Mlp, Module, ModuleFactory, NormalDist,
+    OneHotCategoricalDist, Rnn, RunningMeanStd, Value,
+)
 from cusrl_amd.sampler import AutoMiniBatchSampler, MiniBatchSampler, TemporalMiniBatchSampler
 from cusrl_amd.template import (
     ActorCritic,
@@ -35,8 +38,10 @@ __all__ = [
     "Distribution",
     "Environment",
     "EnvironmentSpec",
+    "Gru",
     "Hook",
     "LinearFp32",
+    "Lstm",
     "MiniBatchSampler",
     "Mlp",
     "Module",
@@ -44,6 +49,8 @@ __all__ = [
     "NormalDist",
     "OneHotCategoricalDist",
     "OptimizerFactory",
+    "Rnn",
+    "RunningMeanStd",
     "Sampler",
     "TemporalMiniBatchSampler",
     "Trainer",

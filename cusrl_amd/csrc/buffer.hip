@@ -278,11 +278,27 @@ __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(const char *__rest
                                                               char *__restrict__ dst, int64_t K, int lpr,
                                                               int64_t row_bytes, const int32_t *__restrict__ count_dev) {
     const int64_t limit = count_dev ? min(K, int64_t(*count_dev)) : K;
-    const int64_t op = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (op >= limit * lpr) return;
-    const int64_t k = op / lpr, c = op - k * lpr;
-    *reinterpret_cast<V *>(dst + indices[k] * row_bytes + c * int64_t(sizeof(V))) =
-        *reinterpret_cast<const V *>(src + k * row_bytes + c * int64_t(sizeof(V)));
+    const int64_t ops = limit * lpr;
+    if (ops <= 0) return;
+    // same shape as the gather: clamped, unpredicated, index loads -> row loads -> stores (duplicates are identical)
+    const int64_t op0 = int64_t(blockIdx.x) * kGatherOpsPerBlock + threadIdx.x;
+    int64_t row[kGatherItems], col[kGatherItems], dst_row[kGatherItems];
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it) {
+        const int64_t op = min(op0 + int64_t(it) * kBlock, ops - 1);
+        row[it] = lpr == 1 ? op : op / lpr;
+        col[it] = op - row[it] * lpr;
+    }
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it) dst_row[it] = indices[row[it]];
+    V regs[kGatherItems];
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it)
+        regs[it] = *reinterpret_cast<const V *>(src + row[it] * row_bytes + col[it] * int64_t(sizeof(V)));
+    pin_loaded(regs);
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it)
+        *reinterpret_cast<V *>(dst + dst_row[it] * row_bytes + col[it] * int64_t(sizeof(V))) = regs[it];
 }
 
 static int pick_unit(const void *a, const void *b, int64_t row_bytes) {
@@ -383,21 +399,24 @@ extern "C" int cusrl_compact_flags(const uint8_t *flags, int64_t n, int32_t *blo
     return launch_status();
 }
 
+#define CUSRL_LAUNCH_SCATTER(V)                                                                                      \
+    hipLaunchKernelGGL(scatter_rows_kernel<V>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream),           \
+                       static_cast<const char *>(src), indices, static_cast<char *>(dst), K, lpr, row_bytes, count_dev)
+
 extern "C" int cusrl_scatter_rows(const void *src, const int64_t *indices, void *dst, int64_t K, int64_t row_bytes,
                                   const int32_t *count_dev, void *stream) {
     if (K == 0 || row_bytes == 0) return 0;
     if (!src || !indices || !dst || K < 0 || row_bytes < 0) return CUSRL_E_INVALID;
-    const int unit = pick_unit(src, dst, row_bytes) >= 4 ? 4 : 1;
+    const int unit = pick_unit(src, dst, row_bytes);
     const int lpr = int(row_bytes / unit);
-    const int64_t blocks = ceil_div(K * lpr, kBlock);
+    const int64_t blocks = ceil_div(K * lpr, kGatherOpsPerBlock);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
-    if (unit == 4)
-        hipLaunchKernelGGL(scatter_rows_kernel<uint32_t>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream),
-                           static_cast<const char *>(src), indices, static_cast<char *>(dst), K, lpr, row_bytes,
-                           count_dev);
-    else
-        hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream),
-                           static_cast<const char *>(src), indices, static_cast<char *>(dst), K, lpr, row_bytes,
-                           count_dev);
+    switch (unit) {
+        case 16: CUSRL_LAUNCH_SCATTER(uint4); break;
+        case 8: CUSRL_LAUNCH_SCATTER(uint2); break;
+        case 4: CUSRL_LAUNCH_SCATTER(uint32_t); break;
+        case 2: CUSRL_LAUNCH_SCATTER(uint16_t); break;
+        default: CUSRL_LAUNCH_SCATTER(uint8_t); break;
+    }
     return launch_status();
 }

@@ -1,0 +1,148 @@
+"""Recurrent backbones (counterpart of cusrl/nn/module/rnn.py:21-449): ``nn.GRU`` / ``nn.LSTM`` / ``nn.RNN`` (MIOpen on the
+GPU) behind one wrapper that keeps memories as ``[N, layers * hidden]`` tensors (a dict ``{"hidden", "cell"}`` for LSTM),
+steps one env step at a time during rollout and, on temporal minibatches, cuts the batch at episode boundaries so every
+segment restarts from a zero memory (done-split layout from cusrl_amd/nn/recurrent.py — HIP kernels)."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any
+
+import torch
+from torch import Tensor, nn
+
+from cusrl_amd.nn import recurrent
+from cusrl_amd.nn.module import Module, ModuleFactory
+from cusrl_amd.utils.nest import map_nested
+
+__all__ = ["Gru", "Lstm", "Rnn"]
+
+
+def _to_layers(memory: Tensor, layers: int, hidden: int) -> Tensor:
+    """``[N, layers * hidden]`` -> ``[layers, N, hidden]`` (what torch's RNNs take)."""
+    return memory.reshape(memory.size(0), layers, hidden).transpose(0, 1).contiguous()
+
+
+def _from_layers(state: Tensor) -> Tensor:
+    return state.transpose(0, 1).reshape(state.size(1), -1)
+
+
+class _Gru(nn.GRU):
+    def forward(self, input, memory=None):
+        if memory is None:
+            output, hn = super().forward(input)
+        else:
+            output, hn = super().forward(input, _to_layers(memory, self.num_layers, self.hidden_size))
+        return output, _from_layers(hn)
+
+
+class _VanillaRnn(nn.RNN):
+    def forward(self, input, memory=None):
+        if memory is None:
+            output, hn = super().forward(input)
+        else:
+            output, hn = super().forward(input, _to_layers(memory, self.num_layers, self.hidden_size))
+        return output, _from_layers(hn)
+
+
+class _Lstm(nn.LSTM):
+    def forward(self, input, memory=None):
+        if memory is None:
+            output, (hn, cn) = super().forward(input)
+        else:
+            h0 = _to_layers(memory["hidden"], self.num_layers, self.hidden_size)
+            c0 = _to_layers(memory["cell"], self.num_layers, self.hidden_size)
+            output, (hn, cn) = super().forward(input, (h0, c0))
+        return output, {"hidden": _from_layers(hn), "cell": _from_layers(cn)}
+
+
+@dataclass
+class RnnFactory(ModuleFactory):
+    module_type: str
+    hidden_size: int
+    num_layers: int = 1
+    nonlinearity: str = "tanh"
+    bias: bool = True
+    dropout: float = 0.0
+
+    def __call__(self, input_dim: int | None = None, output_dim: int | None = None):
+        assert input_dim is not None
+        kind = self.module_type.lower()
+        common = dict(input_size=input_dim, hidden_size=self.hidden_size, num_layers=self.num_layers, bias=self.bias,
+                      dropout=self.dropout)
+        if kind in ("rnn", "vanilla"):
+            core = _VanillaRnn(nonlinearity=self.nonlinearity, **common)
+        elif kind == "lstm":
+            core = _Lstm(**common)
+        elif kind == "gru":
+            core = _Gru(**common)
+        else:
+            raise ValueError(f"Unsupported RNN module class '{self.module_type}'")
+        return Rnn(core, output_dim=output_dim)
+
+
+class Rnn(Module):
+    Factory = RnnFactory
+
+    def __init__(self, rnn: nn.Module, output_dim: int | None = None):
+        super().__init__(rnn.input_size, output_dim or rnn.hidden_size, is_recurrent=True)
+        self.rnn = rnn
+        self.output_proj = nn.Linear(rnn.hidden_size, output_dim) if output_dim else nn.Identity()
+
+    def forward(self, input: Tensor, memory: Any = None, *, done: Tensor | None = None, sequential: bool = True,
+                pack_sequence: bool = False, **kwargs):
+        """``input`` is ``[L, N, C]`` (``sequential``) or ``[N, C]``; with ``done [L, N, 1]`` the memory restarts from zero
+        after every finished episode inside the batch (rnn.py:206-253)."""
+        if sequential and input.dim() >= 3:
+            memory = recurrent.select_initial_memory(memory, input.shape[:-1])
+        if done is not None:
+            if not sequential:
+                raise ValueError("'done' can be provided only when 'sequential' is True")
+            if pack_sequence:
+                raise NotImplementedError("packed sequences (final-state recovery) are not built; PPO does not use them")
+            latent, memory = self._forward_sequence(input, memory, done)
+        else:
+            latent, memory = self._forward_tensor(input, memory, sequential=sequential)
+        return self.output_proj(latent), memory
+
+    def _forward_tensor(self, input: Tensor, memory: Any = None, sequential: bool = True):
+        shape = input.shape
+        if input.dim() < 3:
+            flat = input.reshape(1, -1, input.size(-1))
+            if memory is not None:
+                memory = map_nested(lambda m: m.reshape(flat.size(1), -1), memory)
+        else:
+            flat = input.reshape(input.size(0) if sequential else 1, -1, input.size(-1))
+            if memory is not None:
+                memory = map_nested(lambda m: m.flatten(0, -2), memory)
+        latent, out_memory = self.rnn(flat, memory)
+        latent = latent.reshape(*shape[:-1], latent.size(-1))
+        if out_memory is not None:
+            batch_dims = shape[(1 if sequential and len(shape) > 2 else 0):-1]
+            out_memory = map_nested(lambda m: m.reshape(*batch_dims, m.size(-1)), out_memory)
+        return latent, out_memory
+
+    def _forward_sequence(self, input: Tensor, memory: Any, done: Tensor):
+        layout = recurrent.compute_sequence_layout(done)
+        padded_input, _ = recurrent.split_and_pad_sequences(input, done, layout)
+        scattered = recurrent.scatter_memory(memory, done, layout)
+        padded_latent, _ = self._forward_tensor(padded_input, scattered)
+        # the RNN also consumed padded steps, so its final state is not the state at each episode's last valid step
+        return recurrent.unpad_and_merge_sequences(padded_latent, layout), None
+
+    def step_memory(self, input: Tensor, memory: Any = None, sequential: bool = True, **kwargs):
+        if sequential and input.dim() >= 3:
+            memory = recurrent.select_initial_memory(memory, input.shape[:-1])
+        return self._forward_tensor(input, memory, sequential=sequential)[1]
+
+
+class Gru(Rnn):
+    def __init__(self, input_dim: int, hidden_size: int, num_layers: int = 1, bias: bool = True, dropout: float = 0.0,
+                 output_dim: int | None = None):
+        super().__init__(_Gru(input_dim, hidden_size, num_layers, bias=bias, dropout=dropout), output_dim=output_dim)
+
+
+class Lstm(Rnn):
+    def __init__(self, input_dim: int, hidden_size: int, num_layers: int = 1, bias: bool = True, dropout: float = 0.0,
+                 output_dim: int | None = None):
+        super().__init__(_Lstm(input_dim, hidden_size, num_layers, bias=bias, dropout=dropout), output_dim=output_dim)

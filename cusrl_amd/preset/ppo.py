@@ -12,7 +12,7 @@ from typing import Any
 import torch
 
 from cusrl_amd import hook as hooks
-from cusrl_amd.nn import Actor, Mlp, NormalDist, OneHotCategoricalDist, Value
+from cusrl_amd.nn import Actor, Mlp, NormalDist, OneHotCategoricalDist, Rnn, Value
 from cusrl_amd.sampler import AutoMiniBatchSampler
 from cusrl_amd.template.actor_critic import ActorCritic, ActorCriticFactory
 from cusrl_amd.template.agent import AgentFactory
@@ -20,7 +20,7 @@ from cusrl_amd.template.environment import EnvironmentSpec
 from cusrl_amd.template.hook import Hook
 from cusrl_amd.template.optimizer import OptimizerFactory
 
-__all__ = ["AdamFactory", "PpoAgentFactory", "ppo_hook_suite"]
+__all__ = ["AdamFactory", "PpoAgentFactory", "RecurrentPpoAgentFactory", "ppo_hook_suite"]
 
 
 class AdamFactory(OptimizerFactory):
@@ -140,3 +140,25 @@ class PpoAgentFactory(AgentFactory):
 
     def __call__(self, environment_spec: EnvironmentSpec) -> ActorCritic:
         return self.to_underlying()(environment_spec)
+
+
+@dataclass(kw_only=True)
+class RecurrentPpoAgentFactory(PpoAgentFactory):
+    """PPO with GRU / LSTM actor and critic (counterpart of cusrl/preset/ppo.py:185-298): same hook suite; the sampler
+    switches to whole-sequence (temporal) minibatches because the buffer holds ``*_memory`` leaves."""
+
+    rnn_type: str = "LSTM"
+    actor_num_layers: int = 2
+    actor_hidden_size: int = 256
+    critic_num_layers: int = 2
+    critic_hidden_size: int = 256
+
+    def to_underlying(self) -> ActorCriticFactory:
+        underlying = super().to_underlying()
+        underlying.actor_factory = Actor.Factory(
+            backbone_factory=Rnn.Factory(self.rnn_type, num_layers=self.actor_num_layers, hidden_size=self.actor_hidden_size),
+            distribution_factory=get_distribution_factory(self.action_space_type, init_std=self.init_distribution_std),
+        )
+        underlying.critic_factory = Value.Factory(
+            backbone_factory=Rnn.Factory(self.rnn_type, num_layers=self.critic_num_layers, hidden_size=self.critic_hidden_size))
+        return underlying

@@ -206,7 +206,8 @@ class ActorCritic(Agent):
     def update(self):
         self.hook.pre_update(self.buffer)  # a3-a6: next_value, GAE, advantage normalisation
         with self._training_mode():
-            if self.compile and hasattr(self.sampler, "iter_indices"):
+            recurrent = self.actor.is_recurrent or self.critic.is_recurrent  # dynamic sequence counts: not capturable
+            if self.compile and hasattr(self.sampler, "iter_indices") and not recurrent:
                 from cusrl_amd.template.graphs import GraphedTrainStep
 
                 for metadata, indices in self.sampler.iter_indices(self.buffer):

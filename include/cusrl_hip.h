@@ -172,6 +172,24 @@ int cusrl_rms_merge(float *mean, float *var, float *std, double *count, const fl
 int cusrl_rms_normalize(const float *x, const float *mean, const float *std, float clamp, float *out, int64_t rows,
                         int64_t C, void *stream);
 
+/* ---- recurrent BPTT data movement ----
+ * Done-split sequence layout of a temporal batch — cusrl/nn/utils/recurrent.py:63-92 (`compute_sequence_lengths`),
+ * :215-252 (`split_and_pad_sequences`), :160-199 (`scatter_memory`).  done is [L, N] bytes (the last step always ends
+ * a sequence).  Sequences are numbered env-major (all segments of env 0 in time order, then env 1, ...).
+ *  phase 1  cusrl_sequence_count: sequences per env -> exclusive prefix within each block of 256 envs
+ *           (env_prefix[N] int32), block totals (block_totals[cusrl_sequence_blocks(N)] int32) and the total number
+ *           of sequences Ns (num_sequences, device int32[1]) — the host reads Ns to size the padded tensors;
+ *  phase 2  cusrl_sequence_layout: dest[t*N + n] = pos * Ns + seq (int64: row of slot (t, n) inside the padded
+ *           [L, Ns] layout), first_seq[n] = index of env n's first sequence, and mask[pos * Ns + seq] = 1 for valid
+ *           padded positions (mask [L, Ns] bytes must be zeroed by the caller).
+ * Packing / unpacking any [L, N, ...] tensor is then cusrl_scatter_rows / cusrl_gather_rows with `dest`. */
+int cusrl_sequence_count(const uint8_t *done, int64_t L, int64_t N, int32_t *env_prefix, int32_t *block_totals,
+                         int32_t *num_sequences, void *stream);
+int64_t cusrl_sequence_blocks(int64_t N);
+int cusrl_sequence_layout(const uint8_t *done, int64_t L, int64_t N, const int32_t *env_prefix,
+                          const int32_t *block_totals, int64_t Ns, int64_t *dest, int64_t *first_seq, uint8_t *mask,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -454,6 +454,62 @@ def make_obs_norm(cusrl):
     print("obs_norm.npz:", idx, "cases")
 
 
+# ------------------------------------------------------------------------------------------- recurrent BPTT
+def make_recurrent(cusrl):
+    """done-split sequence packing (nn/utils/recurrent.py:63-272) and the GRU / LSTM
+    ``Rnn`` wrapper on temporal minibatches (nn/module/rnn.py:237-299)."""
+    from cusrl.nn.utils import recurrent as R  # noqa: PLC0415
+
+    out = dict(META)
+    gen = torch.Generator().manual_seed(404)
+    idx = 0
+    for L, N, C, H, p_done in [(6, 5, 3, 4, 0.3), (24, 16, 8, 6, 0.05), (3, 1, 2, 2, 0.5), (8, 7, 4, 4, 0.0), (5, 4, 2, 3, 1.0)]:
+        x = torch.randn(L, N, C, generator=gen)
+        done = torch.rand(L, N, 1, generator=gen) < p_done
+        memory = torch.randn(N, H, generator=gen)
+        padded, mask = R.split_and_pad_sequences(x, done)
+        assert torch.equal(R.unpad_and_merge_sequences(padded, mask), x)
+        p = f"c{idx}_"
+        out[p + "x"], out[p + "done"], out[p + "memory"] = np_(x), np_(done), np_(memory)
+        out[p + "padded"], out[p + "mask"] = np_(padded), np_(mask)
+        out[p + "scattered"] = np_(R.scatter_memory(memory, done))
+        out[p + "sequence_lengths"] = np_(R.compute_sequence_lengths(done))
+        out[p + "sequence_indices"] = np_(R.compute_sequence_indices(done))
+        idx += 1
+    out["num_cases"] = np.array(idx)
+    # Rnn wrapper: single step, sequence without done, sequence with done (zero-initialised segments)
+    for kind in ("GRU", "LSTM"):
+        torch.manual_seed(9)
+        rnn = cusrl.Rnn.Factory(kind, hidden_size=8, num_layers=2)(5)
+        L, N = 7, 6
+        x = torch.randn(L, N, 5, generator=gen)
+        done = torch.rand(L, N, 1, generator=gen) < 0.2
+        p = kind.lower() + "_"
+        for k, v in rnn.state_dict().items():
+            out[p + "param/" + k] = np_(v)
+        out[p + "param_names"] = np.array(list(rnn.state_dict().keys()))
+        out[p + "x"], out[p + "done"] = np_(x), np_(done)
+        with torch.no_grad():
+            memory = None
+            stepwise = []
+            memories = []
+            for t in range(L):  # rollout: one step at a time, memory reset where done
+                flat = (lambda m: np_(torch.cat([m["hidden"], m["cell"]], -1))) if kind == "LSTM" else np_
+                memories.append(np.zeros((N, 16 * (2 if kind == "LSTM" else 1)), np.float32) if memory is None else flat(memory))
+                y, memory = rnn(x[t], memory=memory, sequential=False)
+                stepwise.append(np_(y))
+                rnn.reset_memory(memory, done[t])
+            out[p + "stepwise"] = np.stack(stepwise)
+            out[p + "memories"] = np.stack(memories)
+            initial = None
+            y_seq, _ = rnn(x, memory=initial, done=done)
+            out[p + "sequence_with_done"] = np_(y_seq)
+            y_plain, last = rnn(x, memory=None)
+            out[p + "sequence_plain"] = np_(y_plain)
+    np.savez_compressed(HERE / "recurrent.npz", **out)
+    print("recurrent.npz:", idx, "cases + GRU/LSTM wrappers")
+
+
 def main():
     cusrl = import_reference()
     cusrl.config.set_device("cpu")
@@ -464,6 +520,7 @@ def main():
     make_merge(cusrl)
     make_update_trace(cusrl)
     make_obs_norm(cusrl)
+    make_recurrent(cusrl)
     leaked = list(REFERENCE.rglob("__pycache__"))
     assert not leaked, f"bytecode leaked into the reference tree: {leaked[:3]}"
 

@@ -1,0 +1,131 @@
+"""Recurrent BPTT path: done-split sequence packing and the GRU / LSTM wrapper against vectors
+recorded from the reference (golden ``recurrent.npz``): layouts and copies bit-exact, RNN outputs 1e-5."""
+
+import numpy as np
+import pytest
+import torch
+
+import cusrl_amd as cusrl
+
+DEV = "cuda:0"
+
+
+def load_rnn(g, kind, device):
+    rnn = cusrl.Rnn.Factory(kind, hidden_size=8, num_layers=2)(5)
+    names = [str(n) for n in g[f"{kind.lower()}_param_names"]]
+    assert list(rnn.state_dict().keys()) == names
+    rnn.load_state_dict({n: torch.from_numpy(g[f"{kind.lower()}_param/{n}"].copy()) for n in names})
+    return rnn.to(device)
+
+
+@pytest.mark.parametrize("kind", ["GRU", "LSTM"])
+def test_rollout_stepping_and_plain_sequences_match_reference(golden, kind):
+    """Host-side module logic (memory layout [N, layers*hidden], reset at done) — runs on CPU."""
+    g = golden("recurrent")
+    p = kind.lower() + "_"
+    rnn = load_rnn(g, kind, "cpu")
+    x, done = torch.from_numpy(g[p + "x"].copy()), torch.from_numpy(g[p + "done"].copy())
+    with torch.no_grad():
+        memory = None
+        for t in range(x.size(0)):
+            if memory is not None:
+                flat = torch.cat([memory["hidden"], memory["cell"]], -1) if kind == "LSTM" else memory
+                np.testing.assert_allclose(flat.numpy(), g[p + "memories"][t], rtol=1e-5, atol=1e-6)
+            y, memory = rnn(x[t], memory=memory, sequential=False)
+            np.testing.assert_allclose(y.numpy(), g[p + "stepwise"][t], rtol=1e-5, atol=1e-6)
+            rnn.reset_memory(memory, done[t])
+        y, _ = rnn(x, memory=None)
+        np.testing.assert_allclose(y.numpy(), g[p + "sequence_plain"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError, match="only when 'sequential'"):
+        rnn(x[0], done=done[0], sequential=False)
+
+
+@pytest.mark.gpu
+def test_sequence_packing_bit_exact_vs_reference(golden):
+    from cusrl_amd.nn import recurrent as R
+
+    g = golden("recurrent")
+    for i in range(int(g["num_cases"])):
+        p = f"c{i}_"
+        x, done = torch.from_numpy(g[p + "x"].copy()).to(DEV), torch.from_numpy(g[p + "done"].copy()).to(DEV)
+        memory = torch.from_numpy(g[p + "memory"].copy()).to(DEV)
+        padded, mask = R.split_and_pad_sequences(x, done)
+        assert np.array_equal(padded.cpu().numpy(), g[p + "padded"]), f"case {i}"
+        assert np.array_equal(mask.cpu().numpy(), g[p + "mask"])
+        assert torch.equal(R.unpad_and_merge_sequences(padded, mask), x)
+        bare_mask = mask.clone()  # no cached layout: rebuilt from the mask by ordered compaction
+        assert torch.equal(R.unpad_and_merge_sequences(padded, bare_mask), x)
+        assert np.array_equal(R.scatter_memory(memory, done).cpu().numpy(), g[p + "scattered"])
+        assert np.array_equal(R.compute_sequence_lengths(done).cpu().numpy(), g[p + "sequence_lengths"])
+        assert np.array_equal(R.compute_sequence_indices(done).cpu().numpy(), g[p + "sequence_indices"])
+    # nested (LSTM) memories and wide rows
+    done = torch.rand(24, 300, 1, device=DEV) < 0.04
+    mem = {"hidden": torch.randn(300, 512, device=DEV), "cell": torch.randn(300, 512, device=DEV)}
+    layout = R.compute_sequence_layout(done)
+    out = R.scatter_memory(mem, done, layout)
+    assert out["hidden"].shape == (layout.num_sequences, 512)
+    assert torch.equal(out["cell"][layout.first_seq], mem["cell"]) and int((out["cell"].abs().sum(-1) > 0).sum()) == 300
+    x = torch.randn(24, 300, 48, device=DEV)
+    padded, mask = R.split_and_pad_sequences(x, done, layout)
+    assert torch.equal(R.unpad_and_merge_sequences(padded, layout), x) and int(mask.sum()) == 24 * 300
+    assert not padded.transpose(0, 1)[~mask.transpose(0, 1)].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["GRU", "LSTM"])
+def test_sequences_with_episode_boundaries_match_reference(golden, kind):
+    g = golden("recurrent")
+    p = kind.lower() + "_"
+    rnn = load_rnn(g, kind, DEV)
+    x, done = torch.from_numpy(g[p + "x"].copy()).to(DEV), torch.from_numpy(g[p + "done"].copy()).to(DEV)
+    with torch.no_grad():
+        y, memory = rnn(x, memory=None, done=done)
+    assert memory is None
+    np.testing.assert_allclose(y.cpu().numpy(), g[p + "sequence_with_done"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(y.cpu().numpy(), g[p + "stepwise"], rtol=1e-5, atol=2e-6)  # == the rollout's own outputs
+    # BPTT through the scatter / gather: gradients equal those of the step-by-step evaluation with memory resets
+    x.requires_grad_(True)
+    rnn(x, memory=None, done=done)[0].square().sum().backward()
+    packed = [p.grad.clone() for p in rnn.parameters()] + [x.grad.clone()]
+    for p in rnn.parameters():
+        p.grad = None
+    x.grad = None
+    memory, outputs = None, []
+    for t in range(x.size(0)):
+        y, memory = rnn(x[t], memory=memory, sequential=False)
+        outputs.append(y)
+        keep = (~done[t]).float()
+        memory = {k: v * keep for k, v in memory.items()} if kind == "LSTM" else memory * keep
+    torch.stack(outputs).square().sum().backward()
+    for got, want in zip(packed, [p.grad for p in rnn.parameters()] + [x.grad]):
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rnn_type", ["GRU", "LSTM"])
+def test_recurrent_ppo_preset_trains(rnn_type):
+    cusrl.config.set_device(DEV)
+    cusrl.set_global_seed(2)
+
+    class Consistency(cusrl.Hook):
+        checked = 0
+
+        def objective(self, metadata, batch):
+            # cusrl_test/_helpers.py:76-94: the policy re-evaluated on the first minibatch reproduces the rollout's means
+            if metadata["epoch_index"] == 0 and metadata["mini_batch_index"] == 0:
+                assert metadata["temporal"] is True and batch["observation"].dim() == 3
+                error = (batch["curr_action_dist"]["mean"] - batch["action_dist"]["mean"]).abs().max()
+                assert error < 1e-4, f"Max error {error}"
+                Consistency.checked += 1
+
+    factory = cusrl.preset.RecurrentPpoAgentFactory(
+        rnn_type=rnn_type, actor_hidden_size=32, critic_hidden_size=32, num_steps_per_update=8, sampler_epochs=1,
+        sampler_mini_batches=1).to_underlying()
+    factory.register_hook(Consistency())
+    env = cusrl.testing.DummyTorchEnvironment(num_instances=16, observation_dim=10, action_dim=4, device=DEV)
+    trainer = cusrl.Trainer(env, factory, num_iterations=3, verbose=False)
+    trainer.run_training_loop()
+    assert Consistency.checked == 3
+    keys = set(trainer.agent.buffer.storage)
+    assert {"actor_memory", "critic_memory", "next_critic_memory"} <= {k.split(".")[0] for k in keys}
+    assert np.isfinite(trainer.last_info["Agent/value_loss"]) and np.isfinite(trainer.last_info["Agent/kl_divergence"])
