@@ -57,6 +57,8 @@ _SIGNATURES = {
     "cusrl_masked_stats_num_partials": (c_int64, [c_int64, c_int64]),
     "cusrl_rms_merge": (c_int, [_P] * 7 + [c_float, c_double, c_int64, _P]),
     "cusrl_rms_normalize": (c_int, [_P, _P, _P, c_float, _P, c_int64, c_int64, _P]),
+    "cusrl_rnd_reward": (c_int, [_P, _P, _P, _P, c_float, c_int64, c_int64, _P]),
+    "cusrl_amp_style_reward": (c_int, [_P, _P, _P, c_float, c_int64, _P]),
     "cusrl_sequence_count": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P]),
     "cusrl_sequence_blocks": (c_int64, [c_int64]),
     "cusrl_sequence_layout": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, _P, _P, _P, _P]),

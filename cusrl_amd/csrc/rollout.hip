@@ -80,9 +80,61 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const float *__re
     if (active) episode_len[n] = finished ? 0.0f : len;
 }
 
+// ---- intrinsic-reward epilogues: one launch instead of sub / square / mean / mul / add_ (RND) or
+// exp / add / reciprocal / rsub / clamp / log / neg / mul / add_ (AMP)
+__global__ __launch_bounds__(kBlock) void rnd_reward_kernel(const float *__restrict__ target,
+                                                            const float *__restrict__ prediction,
+                                                            float *__restrict__ reward, float *__restrict__ bonus_out,
+                                                            float scale, int64_t rows, int K) {
+    const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= rows) return;
+    float acc = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const float d = target[i * K + k] - prediction[i * K + k];
+        acc += d * d;
+    }
+    const float bonus = scale * (acc / float(K));  // reward_scale * (target - prediction).square().mean(-1)
+    reward[i] += bonus;
+    if (bonus_out) bonus_out[i] = bonus;
+}
+
+__global__ __launch_bounds__(kBlock) void amp_style_reward_kernel(const float *__restrict__ logit,
+                                                                  float *__restrict__ reward,
+                                                                  float *__restrict__ bonus_out, float scale,
+                                                                  int64_t rows) {
+    const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= rows) return;
+    // reward_scale * -log(clamp(1 - 1 / (1 + exp(-logit)), min=1e-4)), evaluated in the reference's order
+    const float p = 1.0f - 1.0f / (1.0f + expf(-logit[i]));
+    const float bonus = scale * -logf(fmaxf(p, 1e-4f));
+    reward[i] += bonus;
+    if (bonus_out) bonus_out[i] = bonus;
+}
+
 }  // namespace cusrl
 
 using namespace cusrl;
+
+extern "C" int cusrl_rnd_reward(const float *target, const float *prediction, float *reward, float *bonus_out,
+                                float scale, int64_t rows, int64_t K, void *stream) {
+    if (rows < 0 || K <= 0) return CUSRL_E_INVALID;
+    if (rows == 0) return 0;
+    if (!target || !prediction || !reward) return CUSRL_E_INVALID;
+    if (K > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(rnd_reward_kernel, dim3(uint32_t(ceil_div(rows, kBlock))), dim3(kBlock), 0, as_stream(stream),
+                       target, prediction, reward, bonus_out, scale, rows, int(K));
+    return launch_status();
+}
+
+extern "C" int cusrl_amp_style_reward(const float *logit, float *reward, float *bonus_out, float scale, int64_t rows,
+                                      void *stream) {
+    if (rows < 0) return CUSRL_E_INVALID;
+    if (rows == 0) return 0;
+    if (!logit || !reward) return CUSRL_E_INVALID;
+    hipLaunchKernelGGL(amp_style_reward_kernel, dim3(uint32_t(ceil_div(rows, kBlock))), dim3(kBlock), 0,
+                       as_stream(stream), logit, reward, bonus_out, scale, rows);
+    return launch_status();
+}
 
 extern "C" int cusrl_normal_sample_logp(const float *mean, const float *std, const float *eps, float *action,
                                         float *logp, int64_t B, int64_t A, void *stream) {

@@ -1,5 +1,6 @@
 from cusrl_amd.hook.control import ModuleInitialization
-from cusrl_amd.hook.mdp import ObservationNormalization
+from cusrl_amd.hook.auxiliary import AdversarialMotionPrior, RandomNetworkDistillation
+from cusrl_amd.hook.mdp import ObservationNormalization, RewardShaping
 from cusrl_amd.hook.on_policy import (
     AdvantageNormalization,
     AdvantageReduction,
@@ -14,6 +15,9 @@ from cusrl_amd.hook.on_policy import (
 )
 
 __all__ = [
+    "AdversarialMotionPrior",
+    "RandomNetworkDistillation",
+    "RewardShaping",
     "AdvantageNormalization",
     "AdvantageReduction",
     "EntropyLoss",

@@ -1,0 +1,57 @@
+"""Random Network Distillation bonus (counterpart of cusrl/hook/auxiliary/rnd.py:15-81): a frozen random target net
+and a trained predictor; the prediction error on ``next_state`` is added to the buffer's reward before the value
+target / GAE hooks run, and minimised as ``rnd_loss``.  The two MLPs stay torch modules; the reward epilogue is one HIP
+launch (``cusrl_rnd_reward``)."""
+
+from __future__ import annotations
+
+import itertools
+
+import torch
+from torch import nn
+
+from cusrl_amd.template.hook import Hook
+from cusrl_amd.utils.misc import get_first
+
+__all__ = ["RandomNetworkDistillation"]
+
+
+class RandomNetworkDistillation(Hook):
+    def __init__(self, module_factory, output_dim: int, reward_scale: float, state_indices=None):
+        super().__init__()
+        self.output_dim = output_dim
+        self.module_factory = module_factory
+        self.state_indices = slice(None) if state_indices is None else state_indices
+        self.reward_scale: float = reward_scale
+        self.register_mutable("reward_scale")
+
+    def init(self):
+        input_dim = torch.ones(1, self.agent.state_dim)[..., self.state_indices].numel()
+        target, predictor = self.module_factory(input_dim, self.output_dim), self.module_factory(input_dim, self.output_dim)
+        for module in itertools.chain(target.modules(), predictor.modules()):
+            if isinstance(module, nn.Linear):
+                nn.init.xavier_normal_(module.weight)
+                nn.init.zeros_(module.bias)
+        self.register_module("target", target)
+        self.register_module("predictor", predictor)
+        self.target.requires_grad_(False)
+        self.criterion = nn.MSELoss()
+
+    @torch.no_grad()
+    def pre_update(self, buffer):
+        next_state = get_first(buffer, "next_state", "next_observation")[..., self.state_indices]
+        flat = next_state.reshape(-1, next_state.shape[-1])
+        target, prediction = self.target(flat), self.predictor(flat)
+        reward = buffer["reward"]
+        if reward.is_cuda and reward.shape[-1] == 1 and reward.is_contiguous():
+            from cusrl_amd import ops
+
+            bonus = ops.rnd_reward_(reward, target, prediction, self.reward_scale)
+        else:  # multi-channel rewards broadcast the bonus over channels like the reference; host tensors: torch ops
+            bonus = self.reward_scale * (target - prediction).square().mean(dim=-1, keepdim=True).view(*reward.shape[:-1], 1)
+            reward.add_(bonus)
+        self.agent.record(rnd_reward=bonus)
+
+    def objective(self, metadata, batch):
+        next_state = get_first(batch, "next_state", "next_observation")[..., self.state_indices]
+        return {"rnd_loss": self.criterion(self.predictor(next_state), self.target(next_state))}

@@ -88,8 +88,13 @@ def _device_fp32(input: torch.Tensor, weight: torch.Tensor) -> bool:
 def linear_act(input: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, relu: bool = False) -> torch.Tensor:
     """``relu?(linear(input, weight, bias))`` through the MI355X-shaped paths when the data is fp32 on the GPU."""
     if _device_fp32(input, weight) and (bias is not None or not relu):
-        if torch.is_grad_enabled() and (weight.requires_grad or input.requires_grad):
+        # the custom backward is once-differentiable: only take it where it pays (wide minibatches); small batches keep
+        # torch's own double-differentiable ops (the AMP gradient penalty differentiates through the discriminator twice)
+        if torch.is_grad_enabled() and (weight.requires_grad or input.requires_grad) and input.shape[0] >= 4096:
             return _WideBatchLinear.apply(input, weight, bias, _batch_splits(input.shape[0]), relu)
+        if torch.is_grad_enabled() and (weight.requires_grad or input.requires_grad):
+            output = linear(input, weight, bias)
+            return torch.relu(output) if relu else output
         if relu:
             return torch._addmm_activation(bias, input, weight.t())
     output = linear(input, weight, bias)

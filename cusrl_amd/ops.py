@@ -18,6 +18,7 @@ from cusrl_amd._native import Field, check
 __all__ = [
     "LaunchObserver",
     "adv_stats_finalize",
+    "amp_style_reward_",
     "buffer_push",
     "col_stats",
     "compact_flags",
@@ -33,6 +34,7 @@ __all__ = [
     "relu_backward_bias",
     "require_device",
     "rms_merge_",
+    "rnd_reward_",
     "rms_normalize",
     "scatter_rows",
     "set_launch_observer",
@@ -502,3 +504,34 @@ def rms_normalize(x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, clamp:
         "cusrl_rms_normalize",
     )
     return out
+
+
+# ------------------------------------------------------------------------------------------------ intrinsic rewards
+def rnd_reward_(reward: torch.Tensor, target: torch.Tensor, prediction: torch.Tensor, scale: float) -> torch.Tensor:
+    """``reward += scale * (target - prediction).square().mean(-1, keepdim=True)`` in place, one launch; returns the
+    added bonus (cusrl/hook/auxiliary/rnd.py:71-74)."""
+    target, prediction = _f32(target, "target"), _f32(prediction, "prediction")
+    require_device(reward, "reward")
+    if reward.dtype != torch.float32 or not reward.is_contiguous() or reward.shape[-1] != 1:
+        raise TypeError("rnd_reward_: reward must be a contiguous float32 [..., 1] tensor")
+    K = target.shape[-1]
+    rows = target.numel() // K
+    if reward.numel() != rows or prediction.shape != target.shape:
+        raise ValueError("rnd_reward_: shape mismatch")
+    bonus = torch.empty_like(reward)
+    check(_native.lib().cusrl_rnd_reward(target.data_ptr(), prediction.data_ptr(), reward.data_ptr(), bonus.data_ptr(),
+                                         float(scale), rows, K, _stream()), "cusrl_rnd_reward")
+    return bonus
+
+
+def amp_style_reward_(reward: torch.Tensor, logit: torch.Tensor, scale: float) -> torch.Tensor:
+    """``reward += scale * -log(clamp(1 - sigmoid(logit), 1e-4))`` in place, one launch; returns the bonus
+    (cusrl/hook/auxiliary/amp.py:134-136)."""
+    logit = _f32(logit, "logit")
+    require_device(reward, "reward")
+    if reward.dtype != torch.float32 or not reward.is_contiguous() or reward.numel() != logit.numel():
+        raise TypeError("amp_style_reward_: reward must be a contiguous float32 tensor matching the logits")
+    bonus = torch.empty_like(reward)
+    check(_native.lib().cusrl_amp_style_reward(logit.data_ptr(), reward.data_ptr(), bonus.data_ptr(), float(scale),
+                                               logit.numel(), _stream()), "cusrl_amp_style_reward")
+    return bonus

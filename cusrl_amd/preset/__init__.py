@@ -1,3 +1,3 @@
-from cusrl_amd.preset.ppo import AdamFactory, PpoAgentFactory, RecurrentPpoAgentFactory, ppo_hook_suite
+from cusrl_amd.preset.ppo import AdamFactory, AmpAgentFactory, PpoAgentFactory, RecurrentPpoAgentFactory, ppo_hook_suite
 
-__all__ = ["AdamFactory", "PpoAgentFactory", "RecurrentPpoAgentFactory", "ppo_hook_suite"]
+__all__ = ["AdamFactory", "AmpAgentFactory", "PpoAgentFactory", "RecurrentPpoAgentFactory", "ppo_hook_suite"]

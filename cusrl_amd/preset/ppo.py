@@ -20,7 +20,7 @@ from cusrl_amd.template.environment import EnvironmentSpec
 from cusrl_amd.template.hook import Hook
 from cusrl_amd.template.optimizer import OptimizerFactory
 
-__all__ = ["AdamFactory", "PpoAgentFactory", "RecurrentPpoAgentFactory", "ppo_hook_suite"]
+__all__ = ["AdamFactory", "AmpAgentFactory", "PpoAgentFactory", "RecurrentPpoAgentFactory", "ppo_hook_suite"]
 
 
 class AdamFactory(OptimizerFactory):
@@ -161,4 +161,32 @@ class RecurrentPpoAgentFactory(PpoAgentFactory):
         )
         underlying.critic_factory = Value.Factory(
             backbone_factory=Rnn.Factory(self.rnn_type, num_layers=self.critic_num_layers, hidden_size=self.critic_hidden_size))
+        return underlying
+
+
+@dataclass(kw_only=True)
+class AmpAgentFactory(PpoAgentFactory):
+    """PPO + Adversarial Motion Priors (counterpart of cusrl/preset/amp.py:12-53): reward shaping and the AMP hook are
+    inserted before ``value_computation`` so the style reward is in the buffer when the value target is built."""
+
+    extrinsic_reward_scale: float = 1.0
+    amp_discriminator_hidden_dims: Sequence[int] = (256, 128)
+    amp_dataset_source: Any = None
+    amp_state_indices: Any = None
+    amp_batch_size: int = 512
+    amp_reward_scale: float = 1.0
+    amp_loss_weight: float = 1.0
+    amp_grad_penalty_weight: float = 5.0
+
+    def to_underlying(self) -> ActorCriticFactory:
+        underlying = super().to_underlying()
+        underlying.register_hook(hooks.RewardShaping(scale=self.extrinsic_reward_scale), before="value_computation")
+        underlying.register_hook(
+            hooks.AdversarialMotionPrior(
+                discriminator_factory=Mlp.Factory(hidden_dims=self.amp_discriminator_hidden_dims, activation_fn=self.activation_fn),
+                dataset_source=self.amp_dataset_source, state_indices=self.amp_state_indices, batch_size=self.amp_batch_size,
+                reward_scale=self.amp_reward_scale, loss_weight=self.amp_loss_weight,
+                grad_penalty_weight=self.amp_grad_penalty_weight),
+            after="reward_shaping",
+        )
         return underlying

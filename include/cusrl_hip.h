@@ -190,6 +190,15 @@ int cusrl_sequence_layout(const uint8_t *done, int64_t L, int64_t N, const int32
                           const int32_t *block_totals, int64_t Ns, int64_t *dest, int64_t *first_seq, uint8_t *mask,
                           void *stream);
 
+/* ---- intrinsic-reward epilogues ----
+ * RND, cusrl/hook/auxiliary/rnd.py:71-74: reward[i] += scale * mean_k (target[i,k] - prediction[i,k])^2 for i < rows
+ * (reward has one channel); bonus_out (optional, [rows]) receives the added term for the `rnd_reward` metric. */
+int cusrl_rnd_reward(const float *target, const float *prediction, float *reward, float *bonus_out, float scale,
+                     int64_t rows, int64_t K, void *stream);
+/* AMP, cusrl/hook/auxiliary/amp.py:134-136: reward[i] += scale * -log(max(1 - 1/(1 + exp(-logit[i])), 1e-4));
+ * bonus_out as above (`amp_reward`). */
+int cusrl_amp_style_reward(const float *logit, float *reward, float *bonus_out, float scale, int64_t rows, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

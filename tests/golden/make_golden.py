@@ -510,6 +510,69 @@ def make_recurrent(cusrl):
     print("recurrent.npz:", idx, "cases + GRU/LSTM wrappers")
 
 
+# ------------------------------------------------------------------------------------------------ RND / AMP
+def make_aux_rewards(cusrl):
+    """RandomNetworkDistillation.pre_update / objective (hook/auxiliary/rnd.py:55-81) and
+    AdversarialMotionPrior.post_step / objective (hook/auxiliary/amp.py:112-160) with fixed network weights."""
+    from types import SimpleNamespace  # noqa: PLC0415
+
+    out = dict(META)
+    gen = torch.Generator().manual_seed(77)
+    records = {}
+    agent = SimpleNamespace(state_dim=10, device=torch.device("cpu"), setup_module=lambda m: m, to_tensor=torch.as_tensor,
+                            record=lambda **kw: records.update({k: v.clone() for k, v in kw.items()}),
+                            environment_spec=SimpleNamespace(demonstration_sampler=None))
+    # --- RND
+    torch.manual_seed(3)
+    rnd = cusrl.hook.RandomNetworkDistillation(cusrl.Mlp.Factory([12, 8]), output_dim=5, reward_scale=0.25, state_indices=slice(2, 9))
+    rnd.pre_init(agent)
+    rnd.init()
+    for name, module in (("target", rnd.target), ("predictor", rnd.predictor)):
+        for k, v in module.state_dict().items():
+            out[f"rnd_{name}/{k}"] = np_(v)
+    next_obs = torch.randn(6, 9, 10, generator=gen)
+    reward = torch.randn(6, 9, 1, generator=gen)
+    buffer = {"next_observation": next_obs.clone(), "reward": reward.clone()}
+    rnd.pre_update(buffer)
+    out["rnd_next_observation"], out["rnd_reward_in"], out["rnd_reward_out"] = np_(next_obs), np_(reward), np_(buffer["reward"])
+    out["rnd_reward_metric"] = np_(records["rnd_reward"])
+    batch = {"next_observation": next_obs.flatten(0, 1)}
+    loss = rnd.objective({}, batch)["rnd_loss"]
+    loss.backward()
+    out["rnd_loss"] = np_(loss)
+    out["rnd_grad"] = np_(torch.cat([p.grad.reshape(-1) for p in rnd.predictor.parameters()]))
+    # --- AMP
+    torch.manual_seed(4)
+    dataset = torch.randn(50, 8, generator=gen)
+    amp = cusrl.hook.AdversarialMotionPrior(cusrl.Mlp.Factory([16, 8]), dataset_source=dataset.clone(), state_indices=slice(1, 5),
+                                            batch_size=None, reward_scale=0.5, loss_weight=2.0, grad_penalty_weight=5.0)
+    amp.pre_init(agent)
+    amp.init()
+    for k, v in amp.discriminator.state_dict().items():
+        out[f"amp_discriminator/{k}"] = np_(v)
+    out["amp_dataset"] = np_(dataset)
+    steps = 3
+    for t in range(steps):
+        obs, nobs = torch.randn(7, 10, generator=gen), torch.randn(7, 10, generator=gen)
+        rew = torch.randn(7, 1, generator=gen)
+        torch.manual_seed(100 + t)  # pins torch.randint inside _sample_demonstration
+        tr = {"observation": obs.clone(), "next_observation": nobs.clone(), "reward": rew.clone()}
+        amp.post_step(tr)
+        out[f"amp_obs_{t}"], out[f"amp_next_obs_{t}"], out[f"amp_reward_in_{t}"] = np_(obs), np_(nobs), np_(rew)
+        out[f"amp_reward_out_{t}"] = np_(tr["reward"])
+        out[f"amp_agent_transition_{t}"], out[f"amp_expert_transition_{t}"] = np_(tr["agent_transition"]), np_(tr["expert_transition"])
+        out[f"amp_rms_mean_{t}"], out[f"amp_rms_var_{t}"] = np_(amp.transition_rms.mean), np_(amp.transition_rms.var)
+    batch = {"agent_transition": tr["agent_transition"].clone(), "expert_transition": tr["expert_transition"].clone()}
+    losses = amp.objective({}, batch)
+    total = sum(losses.values())
+    total.backward()
+    out["amp_discrimination_loss"], out["amp_grad_penalty_loss"] = np_(losses["amp_discrimination_loss"]), np_(losses["amp_grad_penalty_loss"])
+    out["amp_grad"] = np_(torch.cat([p.grad.reshape(-1) for p in amp.discriminator.parameters()]))
+    out["amp_steps"] = np.array(steps)
+    np.savez_compressed(HERE / "aux_rewards.npz", **out)
+    print("aux_rewards.npz: RND + AMP")
+
+
 def main():
     cusrl = import_reference()
     cusrl.config.set_device("cpu")
@@ -521,6 +584,7 @@ def main():
     make_update_trace(cusrl)
     make_obs_norm(cusrl)
     make_recurrent(cusrl)
+    make_aux_rewards(cusrl)
     leaked = list(REFERENCE.rglob("__pycache__"))
     assert not leaked, f"bytecode leaked into the reference tree: {leaked[:3]}"
 
