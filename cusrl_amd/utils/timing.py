@@ -17,8 +17,8 @@ class Timer:
     """Accumulates time per named section.  On a GPU the sections are bracketed by HIP timing events resolved lazily
     (no synchronisation inside the loop).  Timing events are not free on this stack — each one is a barrier packet
     that costs the stream a bubble — so back-to-back sections SHARE their boundary event (the end of one section is
-    the start of the next when it begins within 50 us of host time) and event objects are pooled: the trainer's
-    4 sections per env step cost 5 events instead of 8."""
+    the start of the next when it begins within 50 us of host time): the trainer's 4 sections per env step cost
+    4 events instead of 8."""
 
     SHARE_WINDOW = 50e-6
 
@@ -28,12 +28,11 @@ class Timer:
         self._open: dict[str, object] = {}
         self._total: dict[str, float] = defaultdict(float)
         self._pending: dict[str, list] = defaultdict(list)
-        self._pool: list = []
         self._boundary = None
         self._boundary_time = 0.0
 
     def _event(self):
-        event = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
+        event = torch.cuda.Event(enable_timing=True)
         event.record(torch.cuda.current_stream(self.device))
         return event
 
@@ -68,9 +67,7 @@ class Timer:
         return self._total[name]
 
     def clear(self):
-        # events may be shared between sections: recycle each object once, after everything has been resolved
-        for name in list(self._pending):
-            self._resolve(name)
+        self._pending.clear()
         self._boundary = None
         self._open.clear()
         self._total.clear()
