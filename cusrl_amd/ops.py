@@ -137,6 +137,30 @@ def buffer_push(pairs: Sequence[tuple[torch.Tensor, torch.Tensor]], cursor: int,
         )
 
 
+def make_push_table(leaves: Sequence[tuple[torch.Tensor, tuple]]):
+    """Pre-filled ``cusrl_field_t`` array for a fixed set of ``(storage [T, N, ...], step shape)`` leaves: destination
+    pointers and row sizes never change between pushes, only the source pointers do."""
+    table = (Field * max(len(leaves), 1))()
+    for i, (storage, shape) in enumerate(leaves):
+        table[i].dst = storage.data_ptr()
+        row = storage.element_size()
+        for s in shape[1:]:
+            row *= s
+        table[i].row_bytes = row
+    return table
+
+
+def push_table(table, count: int, cursor: int, parallelism: int) -> None:
+    """Launch ``cusrl_buffer_push`` on a table whose ``src`` pointers were just filled."""
+    lib = _native.lib()
+    stream = _stream()
+    _observed(
+        "cusrl_buffer_push",
+        lambda: sum(2 * parallelism * table[i].row_bytes for i in range(count)),
+        lambda: lib.cusrl_buffer_push(table, count, cursor, parallelism, stream),
+    )
+
+
 # ------------------------------------------------------------------------------------------------ a7 / a8
 def gather_rows(
     storages: Sequence[torch.Tensor],

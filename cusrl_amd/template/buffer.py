@@ -27,6 +27,12 @@ from cusrl_amd.utils.nest import get_schema, iterate_nested, reconstruct_nested
 __all__ = ["Buffer", "Sampler"]
 
 
+def _native_max_fields() -> int:
+    from cusrl_amd import _native
+
+    return _native.MAX_FIELDS
+
+
 class Buffer(MutableMapping):
     def __init__(self, capacity: int, parallelism: int, device: str | torch.device | None = None):
         self.capacity: int = capacity
@@ -39,6 +45,7 @@ class Buffer(MutableMapping):
         # by-products of a kernel that remain valid until someone else touches the field (e.g. the advantage
         # {sum, sumsq} partials the GAE kernel emits for the normalisation hook)
         self._derived: dict[str, Any] = {}
+        self._push_plan = None
 
     # ------------------------------------------------------------------ bookkeeping
     def get_parallelism(self) -> int:
@@ -50,6 +57,7 @@ class Buffer(MutableMapping):
         self.storage.clear()
         self.schema.clear()
         self._derived.clear()
+        self._push_plan = None
 
     def reset_cursor(self):
         self.cursor = 0
@@ -129,6 +137,8 @@ class Buffer(MutableMapping):
         pushed dtype; ``None`` fields are skipped; after ``capacity`` pushes the buffer is ``full`` and the
         cursor wraps to 0 (buffer.py:124-151).
         """
+        if self._fast_push(data):
+            return
         pairs = []
         for name, nested_value in data.items():
             if nested_value is None:
@@ -153,10 +163,74 @@ class Buffer(MutableMapping):
         if pairs:
             ops.require_device(pairs[0][1], "buffer storage")
             ops.buffer_push(pairs, self.cursor, self.parallelism)
+        self._advance()
+        self._build_push_plan(data)
+
+    def _advance(self):
         self.cursor += 1
         if self.cursor == self.capacity:
             self.full = True
             self.cursor = 0
+
+    # ---- steady-state append: the transition has the same fields every step, so everything that does not change
+    # (schema, shapes, destination pointers, row sizes) is resolved once and a push is "fill 11 source pointers + launch"
+    def _build_push_plan(self, data: Mapping[str, Any]):
+        self._push_plan = None
+        if len(self.storage) > _native_max_fields():
+            return
+        keys, leaves = [], []
+        for name, nested_value in data.items():
+            if nested_value is None:
+                keys.append((name, None))
+                continue
+            paths = []
+            for key, value in iterate_nested(nested_value, name):
+                if not isinstance(value, torch.Tensor):
+                    return  # numpy / python inputs take the converting path
+                storage = self.storage[key]
+                paths.append((tuple(key.split(".")[1:]), storage, tuple(value.shape), value.dtype))
+            keys.append((name, get_schema(nested_value, name)))
+            leaves.append((name, paths))
+        table = ops.make_push_table([(storage, shape) for _, paths in leaves for _, storage, shape, _ in paths])
+        self._push_plan = (tuple(keys), leaves, table, {k: t.data_ptr() for k, t in self.storage.items()})
+
+    def _fast_push(self, data: Mapping[str, Any]) -> bool:
+        plan = getattr(self, "_push_plan", None)
+        if plan is None:
+            return False
+        keys, leaves, table, pointers = plan
+        if len(data) != len(keys):
+            return False
+        for (name, schema), (got_name, got) in zip(keys, data.items()):
+            if name != got_name or (schema is None) != (got is None):
+                return False
+        index = 0
+        device = self.device
+        for name, paths in leaves:
+            nested_value = data[name]
+            for path, storage, shape, dtype in paths:
+                value = nested_value
+                try:
+                    for part in path:
+                        value = value[part] if isinstance(value, Mapping) else value[int(part)]
+                except (KeyError, IndexError, TypeError, ValueError):
+                    return False
+                if (type(value) is not torch.Tensor or value.dtype != dtype or tuple(value.shape) != shape
+                        or value.device != device or not value.is_contiguous()):
+                    return False
+                table[index].src = value.data_ptr()
+                index += 1
+        # nested containers may have gained leaves the plan does not know: compare schemas only when sizes differ
+        for name, schema in keys:
+            if isinstance(schema, dict) and len(data[name]) != len(schema):
+                return False
+        if any(self.storage[k].data_ptr() != p for k, p in pointers.items()) or len(pointers) != len(self.storage):
+            return False  # a field was replaced / added behind our back
+        for name, _ in keys:
+            self._derived.pop(name, None)
+        ops.push_table(table, index, self.cursor, self.parallelism)
+        self._advance()
+        return True
 
     # ------------------------------------------------------------------ a7/a8: sampling
     def sample(self, sampler: Callable[[str, torch.Tensor], torch.Tensor]) -> dict[str, Any]:
