@@ -26,8 +26,10 @@ __device__ __forceinline__ float entropy_const() { return 1.41893853320467274178
 
 // Per-row scalar part shared by both kernels.  Returns d(loss)/d(logp_row).
 __device__ __forceinline__ float row_terms(float logp, float entropy, float old_logp, float adv, const LossParams &p,
-                                           double &sur_acc, double &ent_acc, float &ratio_out, float &lr_out) {
+                                           double &sur_acc, double &ent_acc, double &abs_lr_acc, float &ratio_out,
+                                           float &lr_out) {
     const float lr = logp - old_logp;                 // action_logp_ratio        common.py:35
+    abs_lr_acc += double(fabsf(lr));                  // metric `ratio` = |logp ratio|   common.py:47
     const float ratio = expf(lr);                     // action_prob_ratio        common.py:41
     const float s1 = adv * ratio;                     // ppo.py:14
     const float rc = fminf(fmaxf(ratio, p.lo), p.hi); // clamp                    ppo.py:16
@@ -49,10 +51,12 @@ __device__ __forceinline__ float row_terms(float logp, float entropy, float old_
 
 __device__ __forceinline__ void value_terms(const float *__restrict__ ret, const float *__restrict__ curr_value,
                                             const float *__restrict__ old_value, float *__restrict__ d_value,
-                                            int64_t row, int D, const LossParams &p, double &val_acc) {
+                                            int64_t row, int D, const LossParams &p, double &val_acc,
+                                            double &value_sum_acc) {
     for (int d = 0; d < D; ++d) {
         const int64_t i = row * D + d;
         const float cv = curr_value[i], R = ret[i];
+        value_sum_acc += double(cv);  // metric `value` = curr_value.sum(-1)        value.py:141
         const float e1 = cv - R, l1 = e1 * e1, g1 = 2.0f * e1;
         float g;
         if (p.value_clip < 0.0f) {
@@ -71,16 +75,14 @@ __device__ __forceinline__ void value_terms(const float *__restrict__ ret, const
     }
 }
 
-__device__ __forceinline__ void write_block_partials(double val_acc, double sur_acc, double ent_acc,
-                                                     double *__restrict__ partials) {
+constexpr int kLossSums = 5;  // value loss, surrogate, entropy, |logp ratio|, value
+
+__device__ __forceinline__ void write_block_partials(const double (&acc)[kLossSums], double *__restrict__ partials) {
     __shared__ double scratch[kWavesPerBlock];
-    const double v = block_sum(val_acc, scratch);
-    const double s = block_sum(sur_acc, scratch);
-    const double e = block_sum(ent_acc, scratch);
-    if (threadIdx.x == 0) {
-        partials[int64_t(blockIdx.x) * 3 + 0] = v;
-        partials[int64_t(blockIdx.x) * 3 + 1] = s;
-        partials[int64_t(blockIdx.x) * 3 + 2] = e;
+#pragma unroll
+    for (int k = 0; k < kLossSums; ++k) {
+        const double total = block_sum(acc[k], scratch);
+        if (threadIdx.x == 0) partials[int64_t(blockIdx.x) * kLossSums + k] = total;
     }
 }
 
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
     }
     __syncthreads();
 
-    double val_acc = 0.0, sur_acc = 0.0, ent_acc = 0.0;
+    double acc[kLossSums] = {0.0, 0.0, 0.0, 0.0, 0.0};
     {
         const int64_t row = row0 + threadIdx.x;
         float dlp = 0.0f;
@@ -147,12 +149,12 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
                 entropy += en_part[threadIdx.x * LPR + j];
             }
             float ratio, lr;
-            dlp = row_terms(logp, entropy, old_logp[row], advantage[row], p, sur_acc, ent_acc, ratio, lr);
+            dlp = row_terms(logp, entropy, old_logp[row], advantage[row], p, acc[1], acc[2], acc[3], ratio, lr);
             if (logp_out) logp_out[row] = logp;
             if (entropy_out) entropy_out[row] = entropy;
             if (lr_out) lr_out[row] = lr;
             if (ratio_out) ratio_out[row] = ratio;
-            value_terms(ret, curr_value, old_value, d_value, row, D, p, val_acc);
+            value_terms(ret, curr_value, old_value, d_value, row, D, p, acc[0], acc[4]);
         }
         dlp_row[threadIdx.x] = dlp;
     }
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
             if (d_std) ds4[q] = make_float4(gs[0], gs[1], gs[2], gs[3]);
         }
     }
-    write_block_partials(val_acc, sur_acc, ent_acc, partials);
+    write_block_partials(acc, partials);
 }
 
 // Any action width: one lane per row, scalar accesses.
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowwise_kernel(
     float *__restrict__ logp_out, float *__restrict__ entropy_out, float *__restrict__ lr_out,
     float *__restrict__ ratio_out, float *__restrict__ d_mean, float *__restrict__ d_std,
     float *__restrict__ d_value, double *__restrict__ partials) {
-    double val_acc = 0.0, sur_acc = 0.0, ent_acc = 0.0;
+    double acc[kLossSums] = {0.0, 0.0, 0.0, 0.0, 0.0};
     const int64_t row = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (row < B) {
         float logp = 0.0f, entropy = 0.0f;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowwise_kernel(
             entropy += entropy_const() + ls;
         }
         float ratio, lr;
-        const float dlp = row_terms(logp, entropy, old_logp[row], advantage[row], p, sur_acc, ent_acc, ratio, lr);
+        const float dlp = row_terms(logp, entropy, old_logp[row], advantage[row], p, acc[1], acc[2], acc[3], ratio, lr);
         if (logp_out) logp_out[row] = logp;
         if (entropy_out) entropy_out[row] = entropy;
         if (lr_out) lr_out[row] = lr;
@@ -213,28 +215,29 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowwise_kernel(
             if (d_mean) d_mean[i] = dlp * (diff / var);
             if (d_std) d_std[i] = dlp * ((diff * diff) / (var * sg) - 1.0f / sg) + p.g_ent / sg;
         }
-        value_terms(ret, curr_value, old_value, d_value, row, D, p, val_acc);
+        value_terms(ret, curr_value, old_value, d_value, row, D, p, acc[0], acc[4]);
     }
-    write_block_partials(val_acc, sur_acc, ent_acc, partials);
+    write_block_partials(acc, partials);
 }
 
 __global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double *__restrict__ partials, int64_t P,
                                                                    int64_t B, int D, LossParams p,
                                                                    float *__restrict__ losses_out) {
     __shared__ double scratch[kWavesPerBlock];
-    double v = 0.0, s = 0.0, e = 0.0;
-    for (int64_t i = threadIdx.x; i < P; i += kBlock) {
-        v += partials[i * 3 + 0];
-        s += partials[i * 3 + 1];
-        e += partials[i * 3 + 2];
+    double sums[kLossSums];
+#pragma unroll
+    for (int k = 0; k < kLossSums; ++k) {
+        double s = 0.0;
+        for (int64_t i = threadIdx.x; i < P; i += kBlock) s += partials[i * kLossSums + k];
+        sums[k] = block_sum(s, scratch);
     }
-    v = block_sum(v, scratch);
-    s = block_sum(s, scratch);
-    e = block_sum(e, scratch);
     if (threadIdx.x == 0) {
-        losses_out[0] = float(v / double(B * D)) * p.w_val;   // mean * weight              value.py:137
-        losses_out[1] = -float(s / double(B)) * p.w_sur;      // -mean(min(...)) * weight   ppo.py:13-18,55
-        losses_out[2] = -float(e / double(B)) * p.w_ent;      // -mean(entropy) * weight    ppo.py:83-84
+        losses_out[0] = float(sums[0] / double(B * D)) * p.w_val;   // mean * weight              value.py:137
+        losses_out[1] = -float(sums[1] / double(B)) * p.w_sur;      // -mean(min(...)) * weight   ppo.py:13-18,55
+        losses_out[2] = -float(sums[2] / double(B)) * p.w_ent;      // -mean(entropy) * weight    ppo.py:83-84
+        losses_out[3] = float(sums[3] / double(B));                 // mean |logp ratio|          common.py:47 metric
+        losses_out[4] = float(sums[2] / double(B));                 // mean entropy               common.py:48 metric
+        losses_out[5] = float(sums[4] / double(B));                 // mean value.sum(-1)         value.py:141 metric
     }
 }
 

@@ -33,4 +33,8 @@ class OnPolicyPreparation(Hook):
         return None
 
     def post_objective(self, metadata, batch):
-        self.agent.record(ratio=batch["action_logp_ratio"].abs(), entropy=batch["curr_entropy"])
+        if (reduced := batch.get("_fused_metrics")) is not None:
+            self.agent.metrics.record_reduced("ratio", *reduced["ratio"])
+            self.agent.metrics.record_reduced("entropy", *reduced["entropy"])
+        else:
+            self.agent.record(ratio=batch["action_logp_ratio"].abs(), entropy=batch["curr_entropy"])

@@ -38,7 +38,7 @@ class _FusedPpoFunction(torch.autograd.Function):
         ctx.unit_grad = unit_grad
         ctx.shapes = (mean.shape, std.shape, curr_value.shape)
         losses = out["losses"]
-        total = losses.sum()
+        total = losses[:3].sum()
         side = (losses, out["logp"], out["entropy"], out["logp_ratio"], out["ratio"])
         ctx.mark_non_differentiable(*side)
         return (total, *side)
@@ -155,7 +155,10 @@ class FusedPpoObjective:
         batch["curr_entropy"] = entropy
         batch["action_logp_ratio"] = logp_ratio
         batch["action_prob_ratio"] = ratio
-        value_loss, surrogate_loss, entropy_loss = losses.unbind(0)
+        value_loss, surrogate_loss, entropy_loss, mean_abs_ratio, mean_entropy, mean_value = losses.unbind(0)
+        # the means the hooks record after every minibatch, already reduced by the kernel (no extra launches)
+        rows = advantage.numel()
+        batch["_fused_metrics"] = {"ratio": (mean_abs_ratio, rows), "entropy": (mean_entropy, rows), "value": (mean_value, rows)}
         objectives["value_loss"] = value_loss
         objectives["surrogate_loss"] = surrogate_loss
         objectives["entropy_loss"] = entropy_loss

@@ -105,7 +105,10 @@ class ValueLoss(Hook):
 
     def post_objective(self, metadata, batch):
         curr_value: Tensor = batch["curr_value"]
-        self.agent.record(value=curr_value.sum(dim=-1))
+        if (reduced := batch.get("_fused_metrics")) is not None:
+            self.agent.metrics.record_reduced("value", *reduced["value"])
+        else:
+            self.agent.record(value=curr_value.sum(dim=-1))
         if (dim := curr_value.size(-1)) != 1:
             with torch.no_grad():
                 self.agent.record(**{f"value.{i}": curr_value[..., i] for i in range(dim)})

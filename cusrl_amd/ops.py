@@ -375,7 +375,8 @@ def ppo_loss_fwd_bwd(
     w_ent: float,
     want_grads: bool = True,
 ) -> dict[str, torch.Tensor]:
-    """One pass: losses[3] = (value, surrogate, entropy), per-sample logp/entropy/ratios, and the gradients."""
+    """One pass: losses[0:3] = (value, surrogate, entropy) weighted losses, losses[3:6] = means of |logp ratio|, entropy
+    and value (the metrics of common.py:45-49 / value.py:139-141), per-sample logp/entropy/ratios, and the gradients."""
     advantage, old_logp = _f32(advantage, "advantage"), _f32(old_logp, "action_logp")
     action, mean, std = _f32(action, "action"), _f32(mean, "mean"), _f32(std, "std")
     ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
@@ -393,7 +394,7 @@ def ppo_loss_fwd_bwd(
     dev = mean.device
     lib = _native.lib()
     out = {
-        "losses": torch.empty(3, dtype=torch.float32, device=dev),
+        "losses": torch.empty(6, dtype=torch.float32, device=dev),  # 3 weighted losses + 3 metric means
         "logp": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
         "entropy": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
         "logp_ratio": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
@@ -401,7 +402,7 @@ def ppo_loss_fwd_bwd(
     }
     if want_grads:
         out["d_mean"], out["d_std"], out["d_value"] = torch.empty_like(mean), torch.empty_like(std), torch.empty_like(curr_value)
-    partials = torch.empty((int(lib.cusrl_ppo_loss_num_partials(B)), 3), dtype=torch.float64, device=dev)
+    partials = torch.empty((int(lib.cusrl_ppo_loss_num_partials(B)), 5), dtype=torch.float64, device=dev)
 
     def ptr(name):
         return out[name].data_ptr() if name in out else None

@@ -77,6 +77,16 @@ class Metrics:
             else:
                 self._queue.setdefault(name, []).append((value, numel))
 
+    def record_reduced(self, name: str, mean: torch.Tensor, count: int):
+        """Record a value that is already the mean of ``count`` samples (0-d device tensor, e.g. a kernel output)."""
+        if count <= 0:
+            return
+        mean = mean.detach().reshape(())
+        if self._tap is not None:
+            self._tap.add(name, mean, count)
+        else:
+            self._queue.setdefault(name, []).append((mean, count))
+
     def add_resolved(self, name: str, weighted_sum: float, count: int):
         """Merge an already reduced contribution (used by graph replays: Σ mean·count and Σ count)."""
         if count > 0:

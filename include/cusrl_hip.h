@@ -112,10 +112,11 @@ int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, const int64_t *
  * value.py:85-89,121-137 (MSE or clipped value loss), ppo.py:82-84 (entropy bonus),
  * actor_critic.py:309 (sum).  Shapes: advantage, old_logp [B,1]; action, mean, std [B,A];
  * ret, curr_value, old_value [B,D] (old_value may be NULL when value_clip < 0 = None).
- * Outputs: losses_out[3] = {value_loss, surrogate_loss, entropy_loss} (already weighted);
+ * Outputs: losses_out[6] = {value_loss, surrogate_loss, entropy_loss} (already weighted) followed by the three
+ * per-minibatch metrics the hooks record — mean |logp ratio|, mean entropy, mean curr_value.sum(-1);
  * logp_out, entropy_out, logp_ratio_out, ratio_out [B] (each optional);
  * d_mean, d_std [B,A], d_value [B,D] = d(value_loss + surrogate_loss + entropy_loss)/d(.) .
- * partials: double[cusrl_ppo_loss_num_partials(B)][3] workspace. */
+ * partials: double[cusrl_ppo_loss_num_partials(B)][5] workspace. */
 int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action, const float *mean,
                            const float *std, const float *ret, const float *curr_value, const float *old_value,
                            int64_t B, int64_t A, int64_t D, double clip, double value_clip, double w_sur,

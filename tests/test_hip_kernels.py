@@ -257,7 +257,12 @@ def test_ppo_loss_vs_oracle(ops, B, A, D, vclip):
     kw = dict(clip=0.2, value_clip=vclip, w_sur=1.0, w_val=0.5, w_ent=0.01)
     out = ops.ppo_loss_fwd_bwd(*(dev(x) for x in (adv, old_logp, action, mean, std, ret, curr_value, old_value)), **kw)
     ref = oracle.ppo_loss(adv, old_logp, action, mean, std, ret, curr_value, old_value, **kw)
-    np.testing.assert_allclose(host(out["losses"]), ref["losses"], rtol=1e-5, atol=1e-7)
+    losses = host(out["losses"])
+    np.testing.assert_allclose(losses[:3], ref["losses"], rtol=1e-5, atol=1e-7)
+    # the three minibatch metrics the hooks record (common.py:45-49, value.py:139-141), reduced by the same launch
+    np.testing.assert_allclose(losses[3], np.abs(ref["logp"] - old_logp).mean(dtype=np.float64), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(losses[4], ref["entropy"].mean(dtype=np.float64), rtol=1e-5)
+    np.testing.assert_allclose(losses[5], curr_value.sum(-1).mean(dtype=np.float64), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(host(out["logp"]), ref["logp"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(host(out["ratio"]), ref["ratio"], rtol=1e-4)
     # gradients: rows whose ratio sits within 1e-5 of a clip bound may legitimately fall on either side
