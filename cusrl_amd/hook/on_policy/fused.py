@@ -35,6 +35,9 @@ class _FusedPpoFunction(torch.autograd.Function):
             clip=clip, value_clip=value_clip, w_sur=w_sur, w_val=w_val, w_ent=w_ent, want_grads=True,
         )
         ctx.save_for_backward(out["d_mean"], out["d_std"], out["d_value"])
+        # the five side outputs never receive a gradient; without this autograd would materialise a zero tensor for
+        # each of them on every backward (5 fill launches per minibatch)
+        ctx.set_materialize_grads(False)
         ctx.unit_grad = unit_grad
         ctx.shapes = (mean.shape, std.shape, curr_value.shape)
         losses = out["losses"]
@@ -45,6 +48,8 @@ class _FusedPpoFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_total, *_unused):
+        if grad_total is None:
+            return (None,) * 14
         d_mean, d_std, d_value = ctx.saved_tensors
         if not ctx.unit_grad:  # GradScaler (fp16 autocast) or a caller that rescales the loss
             d_mean, d_std, d_value = d_mean * grad_total, d_std * grad_total, d_value * grad_total

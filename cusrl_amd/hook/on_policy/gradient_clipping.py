@@ -3,7 +3,7 @@
 Parameters fall into the longest matching name prefix of ``groups`` (default group otherwise); each group is clipped
 to its own max norm and its pre-clip norm is recorded as ``grad_norm/<prefix|default>``.  When every parameter
 is in the default group and the agent keeps its gradients in one flat buffer, the norm is a single reduction over
-that buffer instead of a per-tensor foreach chain.
+that buffer (``cusrl_clip_grad_norm``: norm and scale in two launches) instead of a per-tensor foreach chain.
 """
 
 from __future__ import annotations
@@ -11,6 +11,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from cusrl_amd import ops
 from cusrl_amd.template.hook import Hook
 
 __all__ = ["GradientClipping"]
@@ -40,8 +41,7 @@ class GradientClipping(Hook):
         flat = getattr(self.agent, "flat_gradients", None)
         if not self.groups and flat is not None and flat.intact():
             if self.max_grad_norm is not None:
-                total = torch.linalg.vector_norm(flat.buffer)
-                flat.buffer.mul_((self.max_grad_norm / (total + 1e-6)).clamp_(max=1.0))  # clip_grad_norm_'s formula
+                total = ops.clip_grad_norm_(flat.buffer, self.max_grad_norm)  # two launches instead of six
                 self.agent.record(**{"grad_norm/default": total})
             return
         buckets: dict[str, list] = {"": [], **{prefix: [] for prefix in self.groups}}

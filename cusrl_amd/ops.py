@@ -481,6 +481,23 @@ def relu_backward_bias(grad_output: torch.Tensor, output: torch.Tensor | None) -
     return grad_in, colsum
 
 
+# ------------------------------------------------------------------------------------------------ gradient clipping
+def clip_grad_norm_(flat_grad: torch.Tensor, max_norm: float | None) -> torch.Tensor:
+    """``torch.nn.utils.clip_grad_norm_`` on one flat fp32 gradient buffer, in place: returns the pre-clip L2 norm
+    (0-d device tensor); ``max_norm=None`` only measures (gradient_clipping.py:67-83)."""
+    flat_grad = _f32(flat_grad, "flat_grad")
+    lib = _native.lib()
+    n = flat_grad.numel()
+    partials = torch.empty(max(int(lib.cusrl_clip_grad_norm_num_partials(n)), 1), dtype=torch.float64, device=flat_grad.device)
+    norm = torch.empty(1, dtype=torch.float32, device=flat_grad.device)
+    check(
+        lib.cusrl_clip_grad_norm(flat_grad.data_ptr(), n, -1.0 if max_norm is None else float(max_norm),
+                                 partials.data_ptr(), norm.data_ptr(), _stream()),
+        "cusrl_clip_grad_norm",
+    )
+    return norm[0]
+
+
 # ------------------------------------------------------------------------------------------------ running statistics
 def masked_col_stats(x: torch.Tensor, mask: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``mean_var_count`` (population variance) of the rows of ``x [rows, C]`` whose ``mask`` byte is set

@@ -152,6 +152,13 @@ int cusrl_relu_bwd_colsum(const float *grad, const float *output, float *grad_in
                           int64_t rows, int64_t H, void *stream);
 int64_t cusrl_colsum_num_partials(int64_t rows, int64_t H);
 
+/* ---- gradient-norm clipping (hook/on_policy/gradient_clipping.py:67-83 -> torch.nn.utils.clip_grad_norm_) ----
+ * norm_out[0] = ||grad||_2 (pre-clip, the `grad_norm/default` metric); grad *= min(max_norm / (norm + 1e-6), 1).
+ * max_norm < 0: measure only.  grad: float[n], 16-byte aligned (the flat gradient buffer every .grad aliases);
+ * partials: double[cusrl_clip_grad_norm_num_partials(n)] workspace.  Fixed summation order (deterministic). */
+int cusrl_clip_grad_norm(float *grad, int64_t n, float max_norm, double *partials, float *norm_out, void *stream);
+int64_t cusrl_clip_grad_norm_num_partials(int64_t n);
+
 /* ---- running observation statistics ----
  * cusrl/nn/utils/normalization.py:15-50 `mean_var_count` of x [rows, C] restricted to rows with mask != 0 (mask may
  * be NULL = all rows; replaces the host-synchronising boolean-mask select of hook/mdp/observation.py:206-208):

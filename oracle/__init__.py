@@ -122,6 +122,19 @@ def merge_mean_var(means, vars_):
     return mean, var
 
 
+# ------------------------------------------------------------------------------------------ gradient clipping
+def clip_grad_norm(grad, max_norm):
+    """cusrl/hook/on_policy/gradient_clipping.py:67-83 -> torch.nn.utils.clip_grad_norm_ (norm_type 2):
+    ``total = ||g||_2``; ``g * min(max_norm / (total + 1e-6), 1)`` in fp32.  Returns (clipped copy, total);
+    ``max_norm=None`` only measures."""
+    grad = _f32(grad)
+    total = np.float32(np.sqrt(np.sum(grad.astype(np.float64) ** 2)))
+    if max_norm is None:
+        return grad.copy(), total
+    coef = np.float32(max_norm) / (total + np.float32(1e-6))
+    return grad * np.minimum(coef, np.float32(1.0)), total
+
+
 # ------------------------------------------------------------------------------------------ a7/a8
 def gather_rows(storage: np.ndarray, indices, temporal: bool = False) -> np.ndarray:
     storage = np.ascontiguousarray(storage)

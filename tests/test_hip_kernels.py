@@ -357,6 +357,28 @@ def test_relu_backward_bias_matches_autograd(ops, rows, H, mask):
     torch.testing.assert_close(colsum.double(), ref, rtol=1e-5, atol=1e-5 * float(expect.abs().sum(0).max()))
 
 
+@pytest.mark.parametrize("n", [92569, 3, 65537, 4096, 0])
+@pytest.mark.parametrize("max_norm", [1.0, 1e6, None])
+def test_clip_grad_norm_vs_oracle_and_torch(ops, n, max_norm):
+    rng = np.random.default_rng(n)
+    grad = (rng.standard_normal(n) * 0.05).astype(np.float32)
+    expect, total = oracle.clip_grad_norm(grad, max_norm)
+    flat = dev(grad)
+    norm = ops.clip_grad_norm_(flat, max_norm)
+    np.testing.assert_allclose(norm.item(), total, rtol=1e-6)
+    if max_norm is None or total <= max_norm:
+        np.testing.assert_array_equal(host(flat), grad)  # coefficient clamps to exactly 1: untouched
+    else:
+        np.testing.assert_allclose(host(flat), expect, rtol=1e-6)
+    # same numbers as torch's own clip on the device
+    reference = torch.nn.Parameter(dev(grad).clone())
+    reference.grad = dev(grad).clone()
+    if max_norm is not None and n > 0:
+        ref_norm = torch.nn.utils.clip_grad_norm_([reference], max_norm)
+        np.testing.assert_allclose(norm.item(), ref_norm.item(), rtol=1e-6)
+        torch.testing.assert_close(flat, reference.grad, rtol=1e-6, atol=0)
+
+
 def test_fused_linear_paths_match_plain_autograd():
     from cusrl_amd.nn.module import Mlp
 

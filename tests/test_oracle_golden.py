@@ -223,3 +223,18 @@ def test_torch_port_replays_reference_update(golden, tag):
     ref = dict(zip((str(k) for k in g[tag + "_metric_keys"]), g[tag + "_metric_vals"]))
     np.testing.assert_allclose(metrics["kl_divergence"].item(), ref["Agent/kl_divergence"], rtol=1e-3, atol=1e-7)
     np.testing.assert_allclose(metrics["action_std"].item(), ref["Agent/action_std"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("max_norm", [0.5, 1e6])
+def test_clip_grad_norm_matches_torch_utility(max_norm):
+    """The reference's GradientClipping calls torch.nn.utils.clip_grad_norm_ (gradient_clipping.py:67-83)."""
+    import torch
+
+    rng = np.random.default_rng(7)
+    grad = rng.standard_normal(92569).astype(np.float32) * 0.01
+    param = torch.nn.Parameter(torch.zeros(grad.size))
+    param.grad = torch.from_numpy(grad.copy())
+    total = torch.nn.utils.clip_grad_norm_([param], max_norm)
+    clipped, norm = oracle.clip_grad_norm(grad, max_norm)
+    np.testing.assert_allclose(norm, total.item(), rtol=1e-6)
+    np.testing.assert_allclose(clipped, param.grad.numpy(), rtol=1e-6)
