@@ -1,0 +1,195 @@
+// Backward of a NARROW linear layer (policy-mean / value heads: out_features O <= 16, e.g. 128 -> 12 and 128 -> 1)
+// for gfx950.  autograd issues three library calls for it — dX = dY W (a [B,O]x[O,K] GEMM), dW = dY^T X (a GEMM with
+// an O x K output and the whole minibatch as reduction dim) and db = dY.sum(0) — 8 + 19 + 6 us at B = 24576, K = 128,
+// each 3-7x above its HBM floor because an O <= 16 wide operand cannot fill an MFMA tile.  With O this small the
+// products are plain FMAs on data already in registers, so ONE pass does all three: a lane owns one 16 B chunk of
+// the K axis, keeps its O x 4 slice of W and of the dW accumulator in VGPRs, streams X rows (coalesced float4,
+// 4 rows in flight), writes dX and accumulates dW / db.  HBM traffic = X read + dX write (+ dY), the floor.
+#include "common.hpp"
+
+namespace cusrl {
+
+constexpr int kHeadRowsPerBlock = 64;
+constexpr int head_batch(int O) { return O > 8 ? 2 : 4; }  // X rows in flight per lane (VGPR budget: O x 12 + ...)
+constexpr int kHeadBiasPad = 16;  // db rides behind dW in the same partial row, padded to keep float4 alignment
+
+template <int O>
+__global__ __launch_bounds__(kBlock) void narrow_linear_bwd_kernel(const float *__restrict__ grad_out,
+                                                                   const float *__restrict__ input,
+                                                                   const float *__restrict__ weight,
+                                                                   float *__restrict__ grad_input,
+                                                                   float *__restrict__ partials, int64_t rows, int K) {
+    extern __shared__ float4 red[];  // [(groups - 1)][O][lpr] dW slices, then [16][16] db parts
+    const int lpr = K / 4;
+    const int groups = kBlock / lpr;
+    const int col = threadIdx.x % lpr, sub = threadIdx.x / lpr;
+    const int64_t row0 = int64_t(blockIdx.x) * kHeadRowsPerBlock;
+    const int64_t row_end = min(row0 + kHeadRowsPerBlock, rows);
+
+    constexpr int kHeadBatch = head_batch(O);
+    float4 w[O], dw[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        w[o] = reinterpret_cast<const float4 *>(weight)[o * lpr + col];
+        dw[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t base = row0 + sub; base < row_end; base += int64_t(kHeadBatch) * groups) {
+        float4 x[kHeadBatch];
+        float g[kHeadBatch][O];
+        int64_t r[kHeadBatch];
+        bool live[kHeadBatch];
+#pragma unroll
+        for (int k = 0; k < kHeadBatch; ++k) {  // all loads of the batch first (rows past the end: clamped, zeroed)
+            const int64_t row = base + int64_t(k) * groups;
+            live[k] = row < row_end;
+            r[k] = min(row, row_end - 1);
+            x[k] = reinterpret_cast<const float4 *>(input)[r[k] * lpr + col];
+            if constexpr (O % 4 == 0) {  // a dY row is a whole number of 16 B chunks (same address in every lane)
+#pragma unroll
+                for (int o4 = 0; o4 < O / 4; ++o4) {
+                    const float4 v = reinterpret_cast<const float4 *>(grad_out)[r[k] * (O / 4) + o4];
+                    g[k][o4 * 4 + 0] = v.x, g[k][o4 * 4 + 1] = v.y, g[k][o4 * 4 + 2] = v.z, g[k][o4 * 4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int o = 0; o < O; ++o) g[k][o] = grad_out[r[k] * O + o];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kHeadBatch; ++k) {
+            float4 dx = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const float go = live[k] ? g[k][o] : 0.f;
+                dx.x = fmaf(go, w[o].x, dx.x), dx.y = fmaf(go, w[o].y, dx.y);
+                dx.z = fmaf(go, w[o].z, dx.z), dx.w = fmaf(go, w[o].w, dx.w);
+                dw[o].x = fmaf(go, x[k].x, dw[o].x), dw[o].y = fmaf(go, x[k].y, dw[o].y);
+                dw[o].z = fmaf(go, x[k].z, dw[o].z), dw[o].w = fmaf(go, x[k].w, dw[o].w);
+            }
+            if (grad_input && live[k]) reinterpret_cast<float4 *>(grad_input)[r[k] * lpr + col] = dx;
+        }
+    }
+
+    // combine the row groups of the block in fixed order: groups 1.. park their slices in LDS, group 0 adds them up
+    float *red_bias = reinterpret_cast<float *>(red + (groups - 1) * O * lpr);  // [16 row parts][16 outputs]
+    if (sub > 0) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) red[((sub - 1) * O + o) * lpr + col] = dw[o];
+    }
+    {   // db: the block's dY rows were just read (L1/L2 hits); lane (part, o) sums rows part, part + 16, ...
+        const int o = threadIdx.x & 15, part = threadIdx.x >> 4;
+        float total = 0.f;
+        if (o < O)
+            for (int64_t row = row0 + part; row < row_end; row += 16) total += grad_out[row * O + o];
+        red_bias[part * 16 + o] = total;
+    }
+    __syncthreads();
+    float *out = partials + int64_t(blockIdx.x) * (O * K + kHeadBiasPad);
+    if (sub == 0) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float4 total = dw[o];
+            for (int s = 1; s < groups; ++s) {
+                const float4 v = red[((s - 1) * O + o) * lpr + col];
+                total.x += v.x, total.y += v.y, total.z += v.z, total.w += v.w;
+            }
+            reinterpret_cast<float4 *>(out)[o * lpr + col] = total;
+        }
+    }
+    if (threadIdx.x >= kBlock - kHeadBiasPad) {  // the last 16 threads finish db (columns >= O are zero padding)
+        const int o = threadIdx.x - (kBlock - kHeadBiasPad);
+        float total = 0.f;
+        for (int part = 0; part < 16; ++part) total += red_bias[part * 16 + o];
+        out[O * K + o] = total;
+    }
+}
+
+// partials [P, H] -> out [H] (H % 4 == 0), same scheme as the bias-gradient finalize of mlp_epilogue.hip:
+// one block per 64 columns = 16 float4 lanes x 16 partial-row groups, groups combined through LDS in fixed order.
+__global__ __launch_bounds__(kBlock) void narrow_linear_finalize_kernel(const float *__restrict__ partials, int64_t P,
+                                                                        int H, float *__restrict__ out) {
+    __shared__ float4 red[kBlock];
+    const int c4 = threadIdx.x & 15, group = threadIdx.x >> 4;
+    const int h = blockIdx.x * 64 + c4 * 4;
+    float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h < H) {
+        const float4 *base = reinterpret_cast<const float4 *>(partials + h);
+        const int64_t stride = H / 4;
+        int64_t p = group;
+        for (; p + 48 < P; p += 64) {
+            const float4 a = base[p * stride], b = base[(p + 16) * stride], c = base[(p + 32) * stride],
+                         d = base[(p + 48) * stride];
+            total.x += (a.x + b.x) + (c.x + d.x), total.y += (a.y + b.y) + (c.y + d.y);
+            total.z += (a.z + b.z) + (c.z + d.z), total.w += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; p < P; p += 16) {
+            const float4 a = base[p * stride];
+            total.x += a.x, total.y += a.y, total.z += a.z, total.w += a.w;
+        }
+    }
+    red[threadIdx.x] = total;
+    __syncthreads();
+    if (group == 0 && h < H) {
+        float4 sum = red[c4];
+        for (int g = 1; g < 16; ++g) {
+            const float4 v = red[g * 16 + c4];
+            sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(out + h) = sum;
+    }
+}
+
+static bool narrow_shape_ok(int64_t K, int64_t O) {
+    if (O < 1 || O > 16 || K < 64 || K > 1024 || K % 4) return false;  // K >= 64 keeps the LDS slices < 64 KB
+    const int64_t lpr = K / 4;
+    return (lpr & (lpr - 1)) == 0;  // power of two: divides the 256-lane block
+}
+
+template <int O>
+static void launch_narrow_bwd(const float *grad_out, const float *input, const float *weight, float *grad_input,
+                              float *partials, int64_t rows, int K, int64_t blocks, hipStream_t s) {
+    const int lpr = K / 4, groups = kBlock / lpr;
+    const size_t lds = size_t(groups - 1) * O * lpr * sizeof(float4) + 256 * sizeof(float);
+    hipLaunchKernelGGL(narrow_linear_bwd_kernel<O>, dim3(uint32_t(blocks)), dim3(kBlock), lds, s, grad_out, input, weight,
+                       grad_input, partials, rows, K);
+}
+
+}  // namespace cusrl
+
+extern "C" int cusrl_narrow_linear_supported(int64_t in_features, int64_t out_features) {
+    return cusrl::narrow_shape_ok(in_features, out_features) ? 1 : 0;
+}
+
+extern "C" int64_t cusrl_narrow_linear_num_partials(int64_t rows) {
+    return rows <= 0 ? 0 : cusrl::ceil_div(rows, cusrl::kHeadRowsPerBlock);
+}
+
+extern "C" int cusrl_narrow_linear_bwd(const float *grad_out, const float *input, const float *weight,
+                                       float *grad_input, float *partials, float *grad_weight_bias, int64_t rows,
+                                       int64_t in_features, int64_t out_features, void *stream) {
+    using namespace cusrl;
+    if (!grad_out || !input || !weight || !partials || !grad_weight_bias || rows <= 0) return CUSRL_E_INVALID;
+    if (!narrow_shape_ok(in_features, out_features)) return CUSRL_E_UNSUPPORTED;
+    if (out_features % 4 == 0 && !aligned(grad_out, 16)) return CUSRL_E_UNSUPPORTED;
+    if (!aligned(input, 16) || !aligned(weight, 16) || !aligned(partials, 16) || !aligned(grad_weight_bias, 16) ||
+        (grad_input && !aligned(grad_input, 16)))
+        return CUSRL_E_UNSUPPORTED;
+    hipStream_t s = as_stream(stream);
+    const int K = int(in_features);
+    const int64_t blocks = ceil_div(rows, kHeadRowsPerBlock);
+    switch (out_features) {
+#define CUSRL_NARROW_CASE(N) \
+    case N: launch_narrow_bwd<N>(grad_out, input, weight, grad_input, partials, rows, K, blocks, s); break;
+        CUSRL_NARROW_CASE(1) CUSRL_NARROW_CASE(2) CUSRL_NARROW_CASE(3) CUSRL_NARROW_CASE(4)
+        CUSRL_NARROW_CASE(5) CUSRL_NARROW_CASE(6) CUSRL_NARROW_CASE(7) CUSRL_NARROW_CASE(8)
+        CUSRL_NARROW_CASE(9) CUSRL_NARROW_CASE(10) CUSRL_NARROW_CASE(11) CUSRL_NARROW_CASE(12)
+        CUSRL_NARROW_CASE(13) CUSRL_NARROW_CASE(14) CUSRL_NARROW_CASE(15) CUSRL_NARROW_CASE(16)
+#undef CUSRL_NARROW_CASE
+        default: return CUSRL_E_UNSUPPORTED;
+    }
+    if (int rc = launch_status()) return rc;
+    const int H = int(out_features) * K + kHeadBiasPad;
+    hipLaunchKernelGGL(narrow_linear_finalize_kernel, dim3(uint32_t(ceil_div(H, 64))), dim3(kBlock), 0, s, partials,
+                       blocks, H, grad_weight_bias);
+    return launch_status();
+}

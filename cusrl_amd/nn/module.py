@@ -31,7 +31,9 @@ class _WideBatchLinear(torch.autograd.Function):
       Splitting the batch into S slabs turns it into a batched GEMM with S x more workgroups plus a tiny sum
       (17 + 4 us) — still a rocBLAS/hipBLASLt MFMA GEMM, just with enough parallelism;
     * ReLU mask and bias gradient come from ONE HIP pass (``cusrl_relu_bwd_colsum``) instead of threshold_backward +
-      a column-sum reduction (35 us -> ~15 us for [24576, 256]).
+      a column-sum reduction (35 us -> ~15 us for [24576, 256]);
+    * a head with <= 16 outputs (policy mean, value) gets dX, dW and db from ONE streaming pass
+      (``cusrl_narrow_linear_bwd``) instead of two skinny GEMMs, a split-sum and a column sum.
     """
 
     @staticmethod
@@ -43,6 +45,7 @@ class _WideBatchLinear(torch.autograd.Function):
             output = linear(input, weight, bias)
             ctx.save_for_backward(input, weight)
         ctx.splits, ctx.relu, ctx.has_bias = splits, relu, bias is not None
+        ctx.narrow = (not relu) and input.is_contiguous() and weight.is_contiguous() and _narrow_head(weight)
         return output
 
     @staticmethod
@@ -54,6 +57,10 @@ class _WideBatchLinear(torch.autograd.Function):
             grad_output, grad_bias = ops.relu_backward_bias(grad_output.contiguous(), output)
         else:
             input, weight = ctx.saved_tensors
+            if ctx.narrow and ctx.needs_input_grad[1]:  # policy-mean / value head: dX, dW and db from one pass
+                grad_input, grad_weight, grad_bias = ops.narrow_linear_backward(
+                    grad_output.contiguous(), input, weight, need_input_grad=ctx.needs_input_grad[0])
+                return grad_input, grad_weight, (grad_bias if ctx.has_bias else None), None, None
             grad_bias = None
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 _, grad_bias = ops.relu_backward_bias(grad_output.contiguous(), None)
@@ -68,6 +75,12 @@ class _WideBatchLinear(torch.autograd.Function):
             else:
                 grad_weight = grad_output.t() @ input
         return grad_input, grad_weight, grad_bias, None, None
+
+
+def _narrow_head(weight: torch.Tensor) -> bool:
+    from cusrl_amd import ops
+
+    return weight.shape[0] <= 16 and ops.narrow_linear_supported(weight.shape[1], weight.shape[0])
 
 
 def _batch_splits(rows: int) -> int:

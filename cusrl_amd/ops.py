@@ -481,6 +481,36 @@ def relu_backward_bias(grad_output: torch.Tensor, output: torch.Tensor | None) -
     return grad_in, colsum
 
 
+# ------------------------------------------------------------------------------------------------ narrow heads
+_HEAD_PAD = 16
+
+
+def narrow_linear_supported(in_features: int, out_features: int) -> bool:
+    return bool(_native.lib().cusrl_narrow_linear_supported(in_features, out_features))
+
+
+def narrow_linear_backward(grad_output: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
+                           need_input_grad: bool = True) -> tuple[torch.Tensor | None, torch.Tensor, torch.Tensor]:
+    """``(grad_output @ weight, grad_output.T @ input, grad_output.sum(0))`` of a linear layer with at most 16
+    outputs (policy-mean / value head) in one pass over the minibatch."""
+    grad_output, input, weight = _f32(grad_output, "grad_output"), _f32(input, "input"), _f32(weight, "weight")
+    O, K = weight.shape
+    rows = input.shape[0]
+    lib = _native.lib()
+    dev = input.device
+    grad_input = torch.empty_like(input) if need_input_grad else None
+    width = O * K + _HEAD_PAD
+    partials = torch.empty((int(lib.cusrl_narrow_linear_num_partials(rows)), width), dtype=torch.float32, device=dev)
+    packed = torch.empty(width, dtype=torch.float32, device=dev)
+    check(
+        lib.cusrl_narrow_linear_bwd(grad_output.data_ptr(), input.data_ptr(), weight.data_ptr(),
+                                    None if grad_input is None else grad_input.data_ptr(), partials.data_ptr(),
+                                    packed.data_ptr(), rows, K, O, _stream()),
+        "cusrl_narrow_linear_bwd",
+    )
+    return grad_input, packed[: O * K].view(O, K), packed[O * K : O * K + O]
+
+
 # ------------------------------------------------------------------------------------------------ gradient clipping
 def clip_grad_norm_(flat_grad: torch.Tensor, max_norm: float | None) -> torch.Tensor:
     """``torch.nn.utils.clip_grad_norm_`` on one flat fp32 gradient buffer, in place: returns the pre-clip L2 norm

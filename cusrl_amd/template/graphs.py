@@ -19,6 +19,7 @@ stock hook.  Anything else keeps ``compile=False`` (eager), which is the default
 
 from __future__ import annotations
 
+import gc
 from typing import Any
 
 import torch
@@ -47,6 +48,12 @@ class _Capture:
         # persistent (allocated outside the capture, so replays do not re-zero it); taps accumulate into it in-graph
         self.accumulator = torch.zeros(self.MAX_TAPS, dtype=torch.float32, device=self.agent.device)
         graph = torch.cuda.CUDAGraph()
+        # Python's cyclic collector must not run inside the capture: finalisers of unrelated garbage (an old agent's
+        # pinned host buffers, events, graphs) issue stream operations that are illegal while capturing and abort
+        # the process.  Collect now, keep the collector off for the duration of the capture.
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.graph(graph, stream=stream, pool=pool):
                 result = fn()
@@ -55,6 +62,8 @@ class _Capture:
                         raise RuntimeError(f"more than {self.MAX_TAPS} metrics recorded inside one captured phase")
                     self.accumulator[: len(tap.values)].add_(torch.stack(tap.values))
         finally:
+            if gc_was_enabled:
+                gc.enable()
             self.agent.metrics.tap(None)
         self.tap_names, self.tap_counts = tap.names, tap.counts
         self.graph = graph

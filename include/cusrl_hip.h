@@ -152,6 +152,19 @@ int cusrl_relu_bwd_colsum(const float *grad, const float *output, float *grad_in
                           int64_t rows, int64_t H, void *stream);
 int64_t cusrl_colsum_num_partials(int64_t rows, int64_t H);
 
+/* ---- backward of a narrow linear layer (policy-mean / value heads; torch.nn.Linear backward with out_features <= 16)
+ * One pass over the minibatch produces all three gradients of y = x W^T + b:
+ *   grad_input [rows, K] = grad_out W   (skipped when NULL),   dW [O, K] = grad_out^T x,   db [O] = sum_rows grad_out.
+ * grad_weight_bias: float[O*K + 16] = dW (row-major) followed by db (then zero padding);
+ * partials: float[cusrl_narrow_linear_num_partials(rows)][O*K + 16] workspace.  Supported shapes
+ * (cusrl_narrow_linear_supported): 1 <= O <= 16, K in {64, 128, ..., 1024} a power of two; all pointers 16-byte aligned.
+ * Fixed summation order (deterministic). */
+int cusrl_narrow_linear_bwd(const float *grad_out, const float *input, const float *weight, float *grad_input,
+                            float *partials, float *grad_weight_bias, int64_t rows, int64_t in_features,
+                            int64_t out_features, void *stream);
+int64_t cusrl_narrow_linear_num_partials(int64_t rows);
+int cusrl_narrow_linear_supported(int64_t in_features, int64_t out_features);
+
 /* ---- gradient-norm clipping (hook/on_policy/gradient_clipping.py:67-83 -> torch.nn.utils.clip_grad_norm_) ----
  * norm_out[0] = ||grad||_2 (pre-clip, the `grad_norm/default` metric); grad *= min(max_norm / (norm + 1e-6), 1).
  * max_norm < 0: measure only.  grad: float[n], 16-byte aligned (the flat gradient buffer every .grad aliases);

@@ -127,6 +127,16 @@ def bench_size(N, T=24, obs=48, act=12, mbs=4, only=None, iters=None):
     loss_bytes = B * (8 + 3 * 4 * act + 8 + 2 * 4 * act + 4 + 16)
     rows.measure(f"ppo loss fwd+bwd (B={B})", lambda: ops.ppo_loss_fwd_bwd(*a.values(), **kw), loss_bytes)
 
+    # ---- MLP backward epilogues and the optimizer-side kernels of one minibatch step
+    g256, y256 = f(B, 256), torch.relu(f(B, 256))
+    rows.measure(f"relu bwd + bias grad [B,256] (B={B})", lambda: ops.relu_backward_bias(g256, y256), B * 256 * 12)
+    gm, gv, h2 = f(B, act), f(B, 1), f(B, 128)
+    wm, wv = f(act, 128), f(1, 128)
+    rows.measure(f"narrow head bwd 128->{act} (B={B})", lambda: ops.narrow_linear_backward(gm, h2, wm), B * 4 * (act + 256))
+    rows.measure(f"narrow head bwd 128->1 (B={B})", lambda: ops.narrow_linear_backward(gv, h2, wv), B * 4 * (1 + 256))
+    flat = f(92569)
+    rows.measure("clip_grad_norm (92569 floats)", lambda: ops.clip_grad_norm_(flat, 1.0), flat.numel() * 12)
+
     # ---- reference points: a plain device copy of the same bytes (what the memory system gives a streaming kernel)
     big = torch.empty(max(S * 21 // 8, 1024), dtype=torch.float32, device=DEV)
     dst = torch.empty_like(big)
