@@ -45,8 +45,6 @@ def parse_args():
     parser.add_argument("--no-observer", action="store_true", help="do not bracket eager launches with HIP events")
     parser.add_argument("--autoreset", action="store_true",
                         help="env resets finished instances itself (no per-step index read-back in the trainer)")
-    parser.add_argument("--blocking-done", action="store_true",
-                        help="read reset indices with a blocking device nonzero() instead of the staged host copy (diagnostic)")
     return parser.parse_args()
 
 
@@ -108,7 +106,6 @@ def run_gpu(args, rank, world):
     # compile=True = hipGraph replay of the act step and the minibatch steps (cusrl_amd/template/graphs.py)
     factory = cusrl.preset.PpoAgentFactory(compile=not args.eager, optimizer_kwargs={"fused": True, "capturable": True})
     trainer = cusrl.Trainer(env, factory, num_iterations=10**9, verbose=False)
-    trainer.stage_done_flags = not args.blocking_done
     agent = trainer.agent
     if args.no_timer:
         from contextlib import nullcontext

@@ -105,42 +105,6 @@ class EnvironmentStats:
             self.total_steps = state_dict["total_steps"]
 
 
-class _DoneFlagsReader:
-    """Host copy of the step's done flags without draining the stream.
-
-    ``done.nonzero()`` (what the reference's ``get_done_indices`` amounts to on device tensors) is two kernels plus a
-    blocking read-back issued AFTER the agent's step launches, so the host stalls until everything queued has run and
-    the GPU then idles while the host prepares the next step.  Here the two flag vectors are copied to pinned host
-    memory right after ``env.step`` (N bytes each, asynchronous, ordered on the stream) and an event is recorded;
-    the agent's step is then enqueued and only afterwards the event is awaited — it fired long ago, while the GPU
-    still works through the step's launches.  Beyond ``MAX_ENVS`` instances a host scan would cost more than the
-    device ``nonzero``, so the caller falls back to it.
-    """
-
-    MAX_ENVS = 1 << 16
-
-    def __init__(self, num_envs: int, device: torch.device):
-        self.device = device
-        self.flags = torch.empty((2, num_envs), dtype=torch.bool, pin_memory=True)
-        self.event = torch.cuda.Event()
-
-    @staticmethod
-    def usable(terminated, truncated, device: torch.device, num_envs: int) -> bool:
-        return (num_envs <= _DoneFlagsReader.MAX_ENVS and all(
-            isinstance(flag, torch.Tensor) and flag.device == device and flag.dtype == torch.bool
-            and flag.numel() == num_envs for flag in (terminated, truncated)))
-
-    def stage(self, terminated: torch.Tensor, truncated: torch.Tensor):
-        self.flags[0].copy_(terminated.reshape(-1), non_blocking=True)
-        self.flags[1].copy_(truncated.reshape(-1), non_blocking=True)
-        self.event.record()
-
-    def indices(self) -> torch.Tensor:
-        self.event.synchronize()
-        found = (self.flags[0] | self.flags[1]).nonzero().reshape(-1)
-        return found.to(self.device, non_blocking=True) if found.numel() else found
-
-
 class TrainerHook:
     trainer: "Trainer"
 
@@ -183,8 +147,6 @@ class Trainer:
         self.trial_metadata = dict(trial_metadata or {})
         self.timer = Timer(self.agent.device)
         self.last_info: dict[str, float] = {}
-        self._done_reader: _DoneFlagsReader | None = None
-        self.stage_done_flags = True  # False: read the reset indices with a blocking device nonzero()
 
     def run_training_loop(self):
         try:
@@ -207,13 +169,6 @@ class Trainer:
                 next_observation, next_state, reward, terminated, truncated, info = env.step(action)
                 if not stats.on_device:
                     stats.track_step(reward)
-                staged = None
-                if self.stage_done_flags and stats.on_device and not env.spec.autoreset and _DoneFlagsReader.usable(
-                        terminated, truncated, stats.device, stats.num_envs):
-                    if self._done_reader is None:
-                        self._done_reader = _DoneFlagsReader(stats.num_envs, stats.device)
-                    staged = self._done_reader
-                    staged.stage(terminated, truncated)
             with timer.record("agent"):
                 ready = agent.step(next_observation, reward, terminated, truncated, next_state, **info)
             with timer.record("environment"):
@@ -224,8 +179,9 @@ class Trainer:
                         done = torch.as_tensor(terminated, device=stats.device) | torch.as_tensor(truncated, device=stats.device)
                     stats.track(torch.as_tensor(reward, device=stats.device), done)
                     if not env.spec.autoreset:
-                        # index tensor (allowed by the contract)
-                        done_indices = staged.indices() if staged is not None else done.squeeze(-1).nonzero().reshape(-1)
+                        # index tensor (allowed by the contract).  A staged copy of the flags to pinned host memory
+                        # + event wait + host scan was measured 4 % SLOWER per iteration than this blocking nonzero.
+                        done_indices = done.squeeze(-1).nonzero().reshape(-1)
                         if done_indices.numel():
                             init_observation, init_state, _ = env.reset(indices=done_indices)
                             next_observation, next_state = update_observation_and_state(
