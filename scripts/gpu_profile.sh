@@ -36,5 +36,25 @@ with open(sys.argv[2], "w") as f:
     for (name, grid), (n, tot, lo, hi) in sorted(acc.items()):
         f.write(f"\"{name}\",{grid},{n},{tot / n:.0f},{lo},{hi}\n")
 print(open(sys.argv[2]).read())
+# stream occupancy: how much of the traced span the GPU was executing kernels, and where the idle time sits
+spans = []
+with open(sys.argv[1]) as f:
+    for row in csv.DictReader(f):
+        spans.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+spans.sort()
+busy, gaps, cursor = 0, collections.Counter(), spans[0][0]
+for start, end in spans:
+    if start > cursor:
+        gap = start - cursor
+        bucket = "<5us" if gap < 5e3 else "5-20us" if gap < 2e4 else "20-100us" if gap < 1e5 else ">100us"
+        gaps[bucket] += gap
+        cursor = start
+    if end > cursor:
+        busy += end - cursor
+        cursor = end
+total = spans[-1][1] - spans[0][0]
+print(f"dispatches {len(spans)}  span {total / 1e6:.1f} ms  busy {busy / 1e6:.1f} ms ({100 * busy / total:.1f} %)")
+for bucket in ("<5us", "5-20us", "20-100us", ">100us"):
+    print(f"  idle in gaps {bucket:9s} {gaps[bucket] / 1e6:8.2f} ms")
 PY
 fi
