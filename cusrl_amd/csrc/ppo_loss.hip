@@ -238,6 +238,8 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double 
         losses_out[3] = float(sums[3] / double(B));                 // mean |logp ratio|          common.py:47 metric
         losses_out[4] = float(sums[2] / double(B));                 // mean entropy               common.py:48 metric
         losses_out[5] = float(sums[4] / double(B));                 // mean value.sum(-1)         value.py:141 metric
+        // sum(objectives.values()) in the hooks' insertion order            actor_critic.py:309
+        losses_out[6] = (losses_out[0] + losses_out[1]) + losses_out[2];
     }
 }
 

@@ -41,7 +41,7 @@ class _FusedPpoFunction(torch.autograd.Function):
         ctx.unit_grad = unit_grad
         ctx.shapes = (mean.shape, std.shape, curr_value.shape)
         losses = out["losses"]
-        total = losses[:3].sum()
+        total = losses[6]  # (value + surrogate) + entropy, summed by the kernel
         side = (losses, out["logp"], out["entropy"], out["logp_ratio"], out["ratio"])
         ctx.mark_non_differentiable(*side)
         return (total, *side)
@@ -160,7 +160,7 @@ class FusedPpoObjective:
         batch["curr_entropy"] = entropy
         batch["action_logp_ratio"] = logp_ratio
         batch["action_prob_ratio"] = ratio
-        value_loss, surrogate_loss, entropy_loss, mean_abs_ratio, mean_entropy, mean_value = losses.unbind(0)
+        value_loss, surrogate_loss, entropy_loss, mean_abs_ratio, mean_entropy, mean_value, _ = losses.unbind(0)
         # the means the hooks record after every minibatch, already reduced by the kernel (no extra launches)
         rows = advantage.numel()
         batch["_fused_metrics"] = {"ratio": (mean_abs_ratio, rows), "entropy": (mean_entropy, rows), "value": (mean_value, rows)}

@@ -41,7 +41,12 @@ class GradientClipping(Hook):
         flat = getattr(self.agent, "flat_gradients", None)
         if not self.groups and flat is not None and flat.intact():
             if self.max_grad_norm is not None:
-                total = ops.clip_grad_norm_(flat.buffer, self.max_grad_norm)  # two launches instead of six
+                flat_optimizer = getattr(self.agent, "flat_optimizer", None)
+                if flat_optimizer is not None and flat_optimizer.optimizer is optimizer:
+                    # the flat Adam step applies the coefficient while it streams the gradient: one launch here
+                    total = flat_optimizer.defer_clip(self.max_grad_norm)
+                else:
+                    total = ops.clip_grad_norm_(flat.buffer, self.max_grad_norm)  # two launches instead of six
                 self.agent.record(**{"grad_norm/default": total})
             return
         buckets: dict[str, list] = {"": [], **{prefix: [] for prefix in self.groups}}

@@ -376,7 +376,7 @@ def ppo_loss_fwd_bwd(
     want_grads: bool = True,
 ) -> dict[str, torch.Tensor]:
     """One pass: losses[0:3] = (value, surrogate, entropy) weighted losses, losses[3:6] = means of |logp ratio|, entropy
-    and value (the metrics of common.py:45-49 / value.py:139-141), per-sample logp/entropy/ratios, and the gradients."""
+    and value (the metrics of common.py:45-49 / value.py:139-141), losses[6] = their sum, per-sample logp/entropy/ratios, and the gradients."""
     advantage, old_logp = _f32(advantage, "advantage"), _f32(old_logp, "action_logp")
     action, mean, std = _f32(action, "action"), _f32(mean, "mean"), _f32(std, "std")
     ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
@@ -394,7 +394,7 @@ def ppo_loss_fwd_bwd(
     dev = mean.device
     lib = _native.lib()
     out = {
-        "losses": torch.empty(6, dtype=torch.float32, device=dev),  # 3 weighted losses + 3 metric means
+        "losses": torch.empty(7, dtype=torch.float32, device=dev),  # 3 weighted losses, 3 metric means, total
         "logp": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
         "entropy": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
         "logp_ratio": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
@@ -526,6 +526,41 @@ def clip_grad_norm_(flat_grad: torch.Tensor, max_norm: float | None) -> torch.Te
         "cusrl_clip_grad_norm",
     )
     return norm[0]
+
+
+def grad_sumsq(flat_grad: torch.Tensor) -> torch.Tensor:
+    """Block partials (double) of ``sum(grad ** 2)`` — the pending norm that :func:`adam_step` turns into the clipping
+    coefficient while it streams the gradient."""
+    flat_grad = _f32(flat_grad, "flat_grad")
+    lib = _native.lib()
+    n = flat_grad.numel()
+    partials = torch.empty(max(int(lib.cusrl_clip_grad_norm_num_partials(n)), 1), dtype=torch.float64, device=flat_grad.device)
+    check(lib.cusrl_grad_sumsq(flat_grad.data_ptr(), n, partials.data_ptr(), _stream()), "cusrl_grad_sumsq")
+    return partials
+
+
+def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+              step: torch.Tensor, lr: torch.Tensor, ticket: torch.Tensor, *, betas: tuple[float, float], eps: float,
+              weight_decay: float, decoupled: bool, maximize: bool = False, clip_partials: torch.Tensor | None = None,
+              max_norm: float | None = None, norm_out: torch.Tensor | None = None):
+    """One Adam / AdamW step over flat fp32 buffers, in place (``step`` and ``lr`` are 1-element device tensors)."""
+    for tensor, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (step, "step"), (lr, "lr")):
+        _f32(tensor, name)
+    require_device(ticket, "ticket")
+    if ticket.dtype != torch.int32 or ticket.numel() != 1:
+        raise TypeError("'ticket' must be a 1-element int32 device tensor")
+    n = param.numel()
+    if not (grad.numel() == exp_avg.numel() == exp_avg_sq.numel() == n):
+        raise ValueError("flat optimizer buffers must have the same length")
+    check(
+        _native.lib().cusrl_adam_step(
+            param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), step.data_ptr(), lr.data_ptr(), n,
+            float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(decoupled), int(maximize),
+            None if clip_partials is None else clip_partials.data_ptr(), 0 if clip_partials is None else clip_partials.numel(),
+            -1.0 if max_norm is None else float(max_norm), None if norm_out is None else norm_out.data_ptr(),
+            ticket.data_ptr(), _stream()),
+        "cusrl_adam_step",
+    )
 
 
 # ------------------------------------------------------------------------------------------------ running statistics

@@ -138,8 +138,17 @@ class ActorCritic(Agent):
             self._graph_pool = torch.cuda.graph_pool_handle()
             self._graphed_act = GraphedAct(self)
         self.flat_gradients: FlatGradients | None = None
+        self._unit_grad: torch.Tensor | None = None
         if isinstance(self.optimizer, torch.optim.Optimizer) and not self.grad_scaler_enabled:
             self.flat_gradients = FlatGradients(self.optimizer)
+        self.flat_optimizer = None
+        if self.flat_gradients is not None and self.device.type == "cuda" and all(
+                group.get("fused") for group in self.optimizer.param_groups):
+            # a fused Adam / AdamW was asked for: step it as ONE HIP launch over flat buffers (utils/flat_optimizer.py)
+            from cusrl_amd.utils.flat_optimizer import FlatAdam
+
+            if FlatAdam.eligible(self.optimizer, self.flat_gradients):
+                self.flat_optimizer = FlatAdam(self.optimizer, self.flat_gradients)
         self._set_training_mode(False)
         self.hook.post_init()
         broadcast_parameters(self.parameters())
@@ -238,7 +247,9 @@ class ActorCritic(Agent):
         if flat is None:
             self.grad_scaler.scale(loss).backward()
             return
-        grads = torch.autograd.grad(loss, flat.params, allow_unused=True, materialize_grads=True)
+        if self._unit_grad is None or self._unit_grad.dtype != loss.dtype:
+            self._unit_grad = torch.ones((), dtype=loss.dtype, device=loss.device)  # persistent: no ones_like per step
+        grads = torch.autograd.grad(loss, flat.params, grad_outputs=self._unit_grad, allow_unused=True, materialize_grads=True)
         torch.cat([grad.reshape(-1) for grad in grads], out=flat.buffer)
 
     def _train_step(self, metadata: dict[str, Any], batch: dict[str, Any]):
@@ -259,6 +270,11 @@ class ActorCritic(Agent):
             self.hook.post_optim()
             self.record(**objectives)
         self.hook.post_objective(metadata, batch)
+
+    def load_state_dict(self, state_dict: dict[str, Any]):
+        super().load_state_dict(state_dict)
+        if self.flat_optimizer is not None:  # torch swapped the optimizer's state tensors: fold them back in
+            self.flat_optimizer.adopt_state()
 
     def set_iteration(self, iteration: int):
         if iteration != self.iteration:

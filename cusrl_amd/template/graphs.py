@@ -134,6 +134,8 @@ class GraphedTrainStep:
             self.state = 0
         self.static_indices.copy_(indices)
         self.metadata = dict(metadata)
+        if agent.flat_optimizer is not None:
+            agent.flat_optimizer.refresh()  # learning-rate changes reach the captured step through device memory
         if self.state == 2:
             self.forward_backward.replay()
             reduce_gradients(agent.optimizer, agent.flat_gradients)

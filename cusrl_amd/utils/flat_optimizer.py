@@ -1,0 +1,137 @@
+"""torch.optim.Adam / AdamW stepped as ONE HIP launch over flat buffers.
+
+The optimizer object stays the user's ``torch.optim.Adam`` (same ``param_groups``, same ``state_dict`` layout, so
+checkpoints and LR schedules keep working), but
+
+* every parameter's storage is re-pointed into one contiguous fp32 buffer (values preserved),
+* ``exp_avg`` / ``exp_avg_sq`` of every parameter are views of two more flat buffers and all ``step`` counters are
+  one shared device scalar,
+* ``optimizer.step`` becomes ``cusrl_adam_step`` over ``(params, FlatGradients.buffer, exp_avg, exp_avg_sq)``.
+
+``GradientClipping`` cooperates: instead of scaling the gradients itself it leaves the block partials of the squared
+norm with :meth:`FlatAdam.defer_clip` and the step applies ``min(max_norm / (norm + 1e-6), 1)`` while streaming the
+gradient — "clip + step" is 2 launches instead of 8 (torch: norm, add, reciprocal, mul, clamp, mul, foreach-add,
+fused-adam), and the learning rate is read from device memory so hipGraph replays follow LR schedules.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from cusrl_amd import ops
+from cusrl_amd.utils.distributed import FlatGradients
+
+__all__ = ["FlatAdam"]
+
+_SUPPORTED = (torch.optim.Adam, torch.optim.AdamW)
+_GROUP_KEYS = ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize", "decoupled_weight_decay")
+
+
+class FlatAdam:
+    @staticmethod
+    def eligible(optimizer, flat_gradients: FlatGradients | None) -> bool:
+        """Exactly Adam / AdamW, one hyper-parameter set for all groups, plain (non-amsgrad, non-differentiable)
+        fp32 parameters on the GPU whose gradients already live in ``flat_gradients``."""
+        if type(optimizer) not in _SUPPORTED or flat_gradients is None:
+            return False
+        groups = optimizer.param_groups
+        first = groups[0]
+        if any(group.get("amsgrad") or group.get("differentiable") for group in groups):
+            return False
+        if any(isinstance(group["lr"], torch.Tensor) and group["lr"].numel() != 1 for group in groups):
+            return False
+        if any(any(group.get(key) != first.get(key) for key in _GROUP_KEYS) for group in groups[1:]):
+            return False
+        params = [p for group in groups for p in group["params"] if p.requires_grad]
+        if len(params) != len(flat_gradients.params) or any(a is not b for a, b in zip(params, flat_gradients.params)):
+            return False
+        return all(p.is_cuda and p.dtype == torch.float32 for p in params)
+
+    def __init__(self, optimizer, flat_gradients: FlatGradients):
+        self.optimizer, self.gradients = optimizer, flat_gradients
+        self.params = flat_gradients.params
+        device = self.params[0].device
+        total = flat_gradients.buffer.numel()
+        flat = lambda: torch.zeros(total, dtype=torch.float32, device=device)  # noqa: E731
+        self.param_buffer, self.exp_avg, self.exp_avg_sq = flat(), flat(), flat()
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=device)
+        self.lr = torch.zeros(1, dtype=torch.float32, device=device)
+        self._lr_value: float | None = None
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=device)
+        self._pending_clip: tuple[torch.Tensor, float | None, torch.Tensor] | None = None
+        self._views: list[tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []
+        offset = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                window = slice(offset, offset + n)
+                view = self.param_buffer[window].view_as(p)
+                view.copy_(p)
+                p.data = view  # same values, storage now inside the flat buffer
+                self._views.append((view, self.exp_avg[window].view_as(p), self.exp_avg_sq[window].view_as(p)))
+                offset += n
+        self.adopt_state()
+        optimizer.step = self.step  # GradScaler(enabled=False).step(optimizer) and direct calls land here
+
+    # ------------------------------------------------------------------ state aliasing
+    def adopt_state(self):
+        """(Re-)alias ``optimizer.state`` into the flat buffers, keeping whatever values it currently holds — call
+        after ``optimizer.load_state_dict`` (torch replaces the state tensors there)."""
+        state = self.optimizer.state
+        steps = [float(state[p]["step"]) for p in self.params if p in state and "step" in state[p]]
+        with torch.no_grad():
+            self.step_count.fill_(max(steps) if steps else 0.0)
+            for p, (_, exp_avg, exp_avg_sq) in zip(self.params, self._views):
+                held = state.get(p, {})
+                if "exp_avg" in held and held["exp_avg"] is not exp_avg:
+                    exp_avg.copy_(held["exp_avg"])
+                    exp_avg_sq.copy_(held["exp_avg_sq"])
+                state[p] = {"step": self.step_count[0], "exp_avg": exp_avg, "exp_avg_sq": exp_avg_sq}
+
+    def intact(self) -> bool:
+        state = self.optimizer.state
+        return self.gradients.intact() and all(
+            p.data_ptr() == view.data_ptr() and state.get(p, {}).get("exp_avg") is exp_avg
+            for p, (view, exp_avg, _) in zip(self.params, self._views))
+
+    # ------------------------------------------------------------------ the step
+    def defer_clip(self, max_norm: float | None) -> torch.Tensor:
+        """Take over gradient clipping: launches only the squared-norm partials now; the coefficient is applied by
+        the next :meth:`step`.  Returns the device scalar that will hold the pre-clip norm after that step."""
+        norm = torch.empty(1, dtype=torch.float32, device=self.lr.device)  # one per step: metrics keep a reference
+        self._pending_clip = (ops.grad_sumsq(self.gradients.buffer), max_norm, norm)
+        return norm[0]
+
+    def _sync_lr(self, group) -> None:
+        lr = group["lr"]
+        if isinstance(lr, torch.Tensor):
+            if lr.data_ptr() != self.lr.data_ptr():
+                self.lr.copy_(lr.reshape(1))
+        elif lr != self._lr_value:  # host-side schedules: one tiny fill when the value changes, none otherwise
+            self.lr.fill_(float(lr))
+            self._lr_value = float(lr)
+
+    def refresh(self):
+        """Host-side bookkeeping that must happen OUTSIDE a captured graph before it replays (learning rate)."""
+        self._sync_lr(self.optimizer.param_groups[0])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not self.intact():
+            raise RuntimeError("FlatAdam: parameters, gradients or optimizer state were re-allocated behind its back "
+                               "(module.to(), optimizer.load_state_dict()): call adopt_state() or rebuild the agent")
+        group = self.optimizer.param_groups[0]
+        if not torch.cuda.is_current_stream_capturing():
+            self._sync_lr(group)
+        partials, max_norm, norm = self._pending_clip if self._pending_clip is not None else (None, None, None)
+        self._pending_clip = None
+        decoupled = bool(group.get("decoupled_weight_decay", False)) or isinstance(self.optimizer, torch.optim.AdamW)
+        ops.adam_step(self.param_buffer, self.gradients.buffer, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+                      self.ticket, betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"],
+                      decoupled=decoupled, maximize=bool(group.get("maximize", False)), clip_partials=partials,
+                      max_norm=max_norm, norm_out=norm)
+        return loss

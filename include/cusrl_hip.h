@@ -112,8 +112,9 @@ int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, const int64_t *
  * value.py:85-89,121-137 (MSE or clipped value loss), ppo.py:82-84 (entropy bonus),
  * actor_critic.py:309 (sum).  Shapes: advantage, old_logp [B,1]; action, mean, std [B,A];
  * ret, curr_value, old_value [B,D] (old_value may be NULL when value_clip < 0 = None).
- * Outputs: losses_out[6] = {value_loss, surrogate_loss, entropy_loss} (already weighted) followed by the three
- * per-minibatch metrics the hooks record — mean |logp ratio|, mean entropy, mean curr_value.sum(-1);
+ * Outputs: losses_out[7] = {value_loss, surrogate_loss, entropy_loss} (already weighted), the three per-minibatch
+ * metrics the hooks record — mean |logp ratio|, mean entropy, mean curr_value.sum(-1) — and the total loss
+ * (value + surrogate) + entropy that the agent differentiates (actor_critic.py:309);
  * logp_out, entropy_out, logp_ratio_out, ratio_out [B] (each optional);
  * d_mean, d_std [B,A], d_value [B,D] = d(value_loss + surrogate_loss + entropy_loss)/d(.) .
  * partials: double[cusrl_ppo_loss_num_partials(B)][5] workspace. */
@@ -171,6 +172,24 @@ int cusrl_narrow_linear_supported(int64_t in_features, int64_t out_features);
  * partials: double[cusrl_clip_grad_norm_num_partials(n)] workspace.  Fixed summation order (deterministic). */
 int cusrl_clip_grad_norm(float *grad, int64_t n, float max_norm, double *partials, float *norm_out, void *stream);
 int64_t cusrl_clip_grad_norm_num_partials(int64_t n);
+
+/* Block partials of sum(grad^2) only (the first half of cusrl_clip_grad_norm): the caller hands them to
+ * cusrl_adam_step, which applies the clipping coefficient while it streams the gradient. */
+int cusrl_grad_sumsq(const float *grad, int64_t n, double *partials, void *stream);
+
+/* ---- optimizer step on flat buffers (torch.optim.Adam / AdamW, the optimizer of cusrl/preset/ppo.py) ----
+ * One launch: step += 1; g = grad * clip (clip = min(max_norm / (||grad|| + 1e-6), 1) from `clip_partials`, or 1
+ * when NULL; max_norm < 0: norm only); AdamW: param *= 1 - lr wd, Adam: g += wd param;
+ * exp_avg += (g - exp_avg)(1 - beta1); exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) g^2;
+ * param -= lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps)   (torch's fused kernel).
+ * Hyper-parameters are doubles like torch's: 1 - beta and the bias corrections are formed in double, then rounded.
+ * param / grad / exp_avg / exp_avg_sq: float[n], 16-byte aligned; step, lr: device float[1] (hipGraph replays see
+ * schedule changes); norm_out: device float[1] or NULL (receives ||grad||, the `grad_norm` metric);
+ * ticket: device uint32[1], zero-initialised once by the caller and owned by this entry point afterwards. */
+int cusrl_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, const float *lr,
+                    int64_t n, double beta1, double beta2, double eps, double weight_decay, int decoupled_weight_decay,
+                    int maximize, const double *clip_partials, int64_t num_clip_partials, float max_norm,
+                    float *norm_out, uint32_t *ticket, void *stream);
 
 /* ---- running observation statistics ----
  * cusrl/nn/utils/normalization.py:15-50 `mean_var_count` of x [rows, C] restricted to rows with mask != 0 (mask may

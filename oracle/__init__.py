@@ -135,6 +135,28 @@ def clip_grad_norm(grad, max_norm):
     return grad * np.minimum(coef, np.float32(1.0)), total
 
 
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+              decoupled=False, grad_scale=1.0):
+    """One step of torch.optim.Adam / AdamW (the optimizer cusrl/preset/ppo.py builds), fp32 like torch's kernels:
+    returns (param, exp_avg, exp_avg_sq, step + 1).  ``grad_scale`` is the clipping coefficient applied first."""
+    f = np.float32
+    param, grad, exp_avg, exp_avg_sq = (_f32(a).copy() for a in (param, grad, exp_avg, exp_avg_sq))
+    beta1, beta2 = float(betas[0]), float(betas[1])  # python floats (doubles): 1 - beta is rounded to fp32 afterwards
+    step = step + 1
+    grad = grad * f(grad_scale)
+    if weight_decay:
+        if decoupled:
+            param = param * (f(1.0) - f(lr) * f(weight_decay))
+        else:
+            grad = grad + f(weight_decay) * param
+    exp_avg = exp_avg + (grad - exp_avg) * f(1.0 - beta1)
+    exp_avg_sq = f(beta2) * exp_avg_sq + f(1.0 - beta2) * (grad * grad)
+    step_size = f(lr / (1.0 - beta1**step))
+    denom = np.sqrt(exp_avg_sq) / f(np.sqrt(1.0 - beta2**step)) + f(eps)
+    param = param - step_size * (exp_avg / denom)
+    return param.astype(f), exp_avg.astype(f), exp_avg_sq.astype(f), step
+
+
 # ------------------------------------------------------------------------------------------ a7/a8
 def gather_rows(storage: np.ndarray, indices, temporal: bool = False) -> np.ndarray:
     storage = np.ascontiguousarray(storage)

@@ -265,6 +265,7 @@ def test_ppo_loss_vs_oracle(ops, B, A, D, vclip):
                                atol=2e-7 * float(np.abs(ref["logp"]).max()))
     np.testing.assert_allclose(losses[4], ref["entropy"].mean(dtype=np.float64), rtol=1e-5)
     np.testing.assert_allclose(losses[5], curr_value.sum(-1).mean(dtype=np.float64), rtol=1e-5, atol=1e-6)
+    assert losses[6] == np.float32(np.float32(losses[0] + losses[1]) + losses[2])  # the total the agent differentiates
     np.testing.assert_allclose(host(out["logp"]), ref["logp"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(host(out["ratio"]), ref["ratio"], rtol=1e-4)
     # gradients: rows whose ratio sits within 1e-5 of a clip bound may legitimately fall on either side
@@ -410,6 +411,36 @@ def test_narrow_head_autograd_matches_plain_linear():
         torch.nn.functional.linear(x, head.weight, head.bias).square().sum().backward()
         for a, b in zip(got, [head.weight.grad, head.bias.grad, x.grad]):
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("n", [92569, 5, 4096])
+@pytest.mark.parametrize("decoupled,weight_decay,max_norm", [(False, 0.0, 1.0), (True, 0.01, None), (False, 0.01, 0.05)])
+def test_adam_step_vs_oracle(ops, n, decoupled, weight_decay, max_norm):
+    rng = np.random.default_rng(n)
+    param = rng.standard_normal(n).astype(np.float32)
+    exp_avg, exp_avg_sq, step = np.zeros(n, np.float32), np.zeros(n, np.float32), 0
+    d_param, d_m, d_v = dev(param), dev(exp_avg), dev(exp_avg_sq)
+    d_step, d_lr = torch.zeros(1, device=DEV), torch.full((1,), 2e-4, device=DEV)
+    ticket = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for _ in range(3):
+        grad = (rng.standard_normal(n) * 0.02).astype(np.float32)
+        d_grad = dev(grad)
+        scale, norm = 1.0, None
+        if max_norm is not None:
+            clipped, total = oracle.clip_grad_norm(grad, max_norm)
+            scale = float(min(np.float32(max_norm) / (total + np.float32(1e-6)), np.float32(1.0)))
+        partials = ops.grad_sumsq(d_grad) if max_norm is not None else None
+        norm = torch.zeros(1, device=DEV) if max_norm is not None else None
+        ops.adam_step(d_param, d_grad, d_m, d_v, d_step, d_lr, ticket, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay,
+                      decoupled=decoupled, clip_partials=partials, max_norm=max_norm, norm_out=norm)
+        param, exp_avg, exp_avg_sq, step = oracle.adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=2e-4, weight_decay=weight_decay,
+                                                            decoupled=decoupled, grad_scale=scale)
+        if norm is not None:
+            np.testing.assert_allclose(norm.item(), total, rtol=1e-6)
+        assert d_step.item() == step and ticket.item() == 0
+        np.testing.assert_allclose(host(d_param), param, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(host(d_m), exp_avg, rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(host(d_v), exp_avg_sq, rtol=1e-5, atol=1e-12)
 
 
 def test_fused_linear_paths_match_plain_autograd():

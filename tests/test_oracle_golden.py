@@ -238,3 +238,25 @@ def test_clip_grad_norm_matches_torch_utility(max_norm):
     clipped, norm = oracle.clip_grad_norm(grad, max_norm)
     np.testing.assert_allclose(norm, total.item(), rtol=1e-6)
     np.testing.assert_allclose(clipped, param.grad.numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("cls_name,weight_decay", [("Adam", 0.0), ("Adam", 0.01), ("AdamW", 0.01)])
+def test_adam_step_matches_torch_optimizer(cls_name, weight_decay):
+    """cusrl/preset/ppo.py builds torch.optim.AdamW / Adam; the oracle restates one step of it."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    param = rng.standard_normal(1000).astype(np.float32)
+    reference = torch.nn.Parameter(torch.from_numpy(param.copy()))
+    optimizer = getattr(torch.optim, cls_name)([reference], lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay)
+    exp_avg, exp_avg_sq, step = np.zeros_like(param), np.zeros_like(param), 0
+    for _ in range(4):
+        grad = rng.standard_normal(1000).astype(np.float32) * 0.1
+        reference.grad = torch.from_numpy(grad.copy())
+        optimizer.step()
+        param, exp_avg, exp_avg_sq, step = oracle.adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=2e-4, weight_decay=weight_decay,
+                                                            decoupled=cls_name == "AdamW")
+        np.testing.assert_allclose(param, reference.detach().numpy(), rtol=1e-6, atol=1e-7)
+    state = optimizer.state[reference]
+    np.testing.assert_allclose(exp_avg, state["exp_avg"].numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(exp_avg_sq, state["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-10)
