@@ -21,6 +21,12 @@ class Field(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("row_bytes", c_int64)]
 
 
+class GradPiece(Structure):
+    """``cusrl_grad_piece_t`` — one parameter's slot of the flat gradient buffer and what to sum into it."""
+
+    _fields_ = [("src", c_void_p), ("offset", c_int64), ("numel", c_int64), ("splits", c_int64)]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -58,6 +64,7 @@ _SIGNATURES = {
     "cusrl_narrow_linear_supported": (c_int, [c_int64, c_int64]),
     "cusrl_clip_grad_norm": (c_int, [_P, c_int64, c_float, _P, _P, _P]),
     "cusrl_clip_grad_norm_num_partials": (c_int64, [c_int64]),
+    "cusrl_assemble_gradients": (c_int, [POINTER(GradPiece), c_int64, _P, _P]),
     "cusrl_grad_sumsq": (c_int, [_P, c_int64, _P, _P]),
     "cusrl_adam_step": (c_int, [_P] * 6 + [c_int64, c_double, c_double, c_double, c_double, c_int, c_int, _P, c_int64, c_float, _P, _P, _P]),
     "cusrl_masked_col_stats": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, _P]),

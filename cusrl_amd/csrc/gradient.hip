@@ -189,3 +189,74 @@ extern "C" int cusrl_adam_step(float *param, const float *grad, float *exp_avg, 
         param, grad, exp_avg, exp_avg_sq, step, lr, clip_partials, norm_out, ticket, n, a);
     return launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Assembly of the flat gradient buffer: every parameter's gradient lands in its slot of the one buffer that the
+// all-reduce, the clipping norm and the optimizer step work on.  A piece is `splits` stacked partial gradients
+// (the split-batch weight-gradient GEMMs leave [S, out, in] slabs: their sum IS the gradient), a plain gradient
+// (splits = 1) or nothing (splits = 0: zeros).  One launch replaces one torch.cat plus one sum(0) per split GEMM.
+namespace cusrl {
+
+struct GradPiece {
+    const float *src;
+    int64_t offset, numel;
+    int32_t splits, pad;
+};
+
+struct GradTable {
+    int32_t n;
+    int32_t block_start[CUSRL_MAX_FIELDS + 1];
+    GradPiece piece[CUSRL_MAX_FIELDS];
+};
+
+constexpr int kAssemblePerBlock = kBlock * 4;  // elements of one piece per block
+
+__global__ __launch_bounds__(kBlock) void assemble_gradients_kernel(const GradTable tab, float *__restrict__ flat) {
+    const int blk = blockIdx.x;
+    int f = 0;
+#pragma unroll
+    for (int i = 1; i < CUSRL_MAX_FIELDS; ++i) f += (i < tab.n && blk >= tab.block_start[i]) ? 1 : 0;
+    const GradPiece piece = tab.piece[f];
+    const float *__restrict__ src = piece.src;
+    const int64_t n = piece.numel;
+    const int64_t base = int64_t(blk - tab.block_start[f]) * kAssemblePerBlock + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t e = base + int64_t(k) * kBlock;
+        if (e >= n) break;
+        float total = 0.f;
+        int s = 0;
+        for (; s + 4 <= piece.splits; s += 4) {  // fixed order, four independent loads in flight
+            const float a = src[int64_t(s) * n + e], b = src[int64_t(s + 1) * n + e], c = src[int64_t(s + 2) * n + e],
+                        d = src[int64_t(s + 3) * n + e];
+            total += (a + b) + (c + d);
+        }
+        for (; s < piece.splits; ++s) total += src[int64_t(s) * n + e];
+        flat[piece.offset + e] = total;
+    }
+}
+
+}  // namespace cusrl
+
+extern "C" int cusrl_assemble_gradients(const cusrl_grad_piece_t *pieces, int64_t num_pieces, float *flat, void *stream) {
+    using namespace cusrl;
+    if (num_pieces < 0 || (num_pieces > 0 && (!pieces || !flat))) return CUSRL_E_INVALID;
+    for (int64_t first = 0; first < num_pieces; first += CUSRL_MAX_FIELDS) {
+        GradTable tab;
+        tab.n = int32_t(num_pieces - first < CUSRL_MAX_FIELDS ? num_pieces - first : CUSRL_MAX_FIELDS);
+        int64_t blocks = 0;
+        for (int i = 0; i < tab.n; ++i) {
+            const cusrl_grad_piece_t &p = pieces[first + i];
+            if (p.numel < 0 || p.offset < 0 || p.splits < 0 || (p.splits > 0 && !p.src)) return CUSRL_E_INVALID;
+            tab.block_start[i] = int32_t(blocks);
+            tab.piece[i] = GradPiece{static_cast<const float *>(p.src), p.offset, p.numel, int32_t(p.splits), 0};
+            blocks += ceil_div(p.numel, kAssemblePerBlock);
+            if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+        }
+        tab.block_start[tab.n] = int32_t(blocks);
+        if (blocks == 0) continue;
+        assemble_gradients_kernel<<<uint32_t(blocks), kBlock, 0, as_stream(stream)>>>(tab, flat);
+        if (int rc = launch_status()) return rc;
+    }
+    return 0;
+}

@@ -5,6 +5,7 @@ hipBLASLt MFMA kernels (BASELINE.json north_star); none of the judged HIP kernel
 from __future__ import annotations
 
 from collections.abc import Iterable, Sequence
+from contextlib import contextmanager
 from dataclasses import dataclass
 from typing import Any
 
@@ -19,6 +20,23 @@ __all__ = ["Linear", "LinearFp32", "linear_act", "Mlp", "Module", "ModuleFactory
 
 def disable_autocast(device_type: str):
     return torch.autocast(device_type=device_type, enabled=False)
+
+
+# While a sink is installed (ActorCritic._backward with a flat gradient buffer), split-batch weight gradients are
+# handed over as their UNSUMMED [S, out, in] slabs, keyed by the weight's storage address, and the backward returns
+# no weight gradient: the flat-buffer assembly sums the slabs straight into the parameter's slot (one launch for all
+# parameters) instead of one sum(0) launch per layer followed by a concatenation.
+_split_grad_sink: dict[int, torch.Tensor] | None = None
+
+
+@contextmanager
+def collect_split_weight_grads():
+    global _split_grad_sink
+    previous, _split_grad_sink = _split_grad_sink, {}
+    try:
+        yield _split_grad_sink
+    finally:
+        _split_grad_sink = previous
 
 
 class _WideBatchLinear(torch.autograd.Function):
@@ -71,7 +89,12 @@ class _WideBatchLinear(torch.autograd.Function):
             rows, splits = input.shape[0], ctx.splits
             if splits > 1:
                 gy = grad_output.reshape(splits, rows // splits, -1)
-                grad_weight = torch.bmm(gy.transpose(1, 2), input.reshape(splits, rows // splits, -1)).sum(0)
+                slabs = torch.bmm(gy.transpose(1, 2), input.reshape(splits, rows // splits, -1))
+                sink = _split_grad_sink
+                if sink is not None and weight.data_ptr() not in sink:
+                    sink[weight.data_ptr()] = slabs  # summed by the flat-gradient assembly
+                else:
+                    grad_weight = slabs.sum(0)
             else:
                 grad_weight = grad_output.t() @ input
         return grad_input, grad_weight, grad_bias, None, None

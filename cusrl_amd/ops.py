@@ -528,6 +528,28 @@ def clip_grad_norm_(flat_grad: torch.Tensor, max_norm: float | None) -> torch.Te
     return norm[0]
 
 
+def assemble_gradients(pieces: Sequence[tuple[torch.Tensor | None, int, int, int]], flat: torch.Tensor):
+    """Fill the flat gradient buffer in one launch.  ``pieces`` = ``(src, offset, numel, splits)`` per parameter:
+    ``src [splits, numel]`` slabs are summed into ``flat[offset : offset + numel]``; ``splits = 1`` copies a plain
+    gradient, ``src = None`` / ``splits = 0`` writes zeros."""
+    flat = _f32(flat, "flat")
+    table = (_native.GradPiece * max(len(pieces), 1))()
+    keep = []
+    for slot, (src, offset, numel, splits) in zip(table, pieces):
+        if src is None or splits == 0:
+            slot.src, slot.splits = None, 0
+        else:
+            src = _f32(src, "gradient piece")
+            if src.numel() != splits * numel:
+                raise ValueError(f"gradient piece has {src.numel()} elements, expected {splits} x {numel}")
+            if offset < 0 or offset + numel > flat.numel():
+                raise ValueError("gradient piece does not fit the flat buffer")
+            keep.append(src)
+            slot.src, slot.splits = src.data_ptr(), splits
+        slot.offset, slot.numel = offset, numel
+    check(_native.lib().cusrl_assemble_gradients(table, len(pieces), flat.data_ptr(), _stream()), "cusrl_assemble_gradients")
+
+
 def grad_sumsq(flat_grad: torch.Tensor) -> torch.Tensor:
     """Block partials (double) of ``sum(grad ** 2)`` — the pending norm that :func:`adam_step` turns into the clipping
     coefficient while it streams the gradient."""

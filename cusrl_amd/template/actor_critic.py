@@ -18,6 +18,7 @@ from typing import Any
 import torch
 
 from cusrl_amd.nn.actor import Actor, Value
+from cusrl_amd.nn.module import collect_split_weight_grads
 from cusrl_amd.template.agent import Agent, AgentFactory, preserve_io_format
 from cusrl_amd.template.buffer import Buffer, Sampler
 from cusrl_amd.template.environment import EnvironmentSpec
@@ -240,8 +241,9 @@ class ActorCritic(Agent):
             self.flat_gradients.attach()
 
     def _backward(self, loss: torch.Tensor):
-        """Gradients of ``loss`` into ``p.grad``.  With the flat gradient buffer the per-parameter gradients are
-        concatenated into it by ONE kernel (no memset, no 13 accumulate launches per step); otherwise this is the
+        """Gradients of ``loss`` into ``p.grad``.  With the flat gradient buffer the per-parameter gradients — and the
+        unsummed slabs of the split-batch weight-gradient GEMMs — are written into it by ONE kernel (no memset, no 13
+        accumulate launches, no per-layer sum(0)); otherwise this is the
         reference's ``scaled_loss.backward()`` (actor_critic.py:311-312)."""
         flat = self.flat_gradients
         if flat is None:
@@ -249,8 +251,9 @@ class ActorCritic(Agent):
             return
         if self._unit_grad is None or self._unit_grad.dtype != loss.dtype:
             self._unit_grad = torch.ones((), dtype=loss.dtype, device=loss.device)  # persistent: no ones_like per step
-        grads = torch.autograd.grad(loss, flat.params, grad_outputs=self._unit_grad, allow_unused=True, materialize_grads=True)
-        torch.cat([grad.reshape(-1) for grad in grads], out=flat.buffer)
+        with collect_split_weight_grads() as split_slabs:
+            grads = torch.autograd.grad(loss, flat.params, grad_outputs=self._unit_grad, allow_unused=True)
+        flat.assemble(grads, split_slabs)
 
     def _train_step(self, metadata: dict[str, Any], batch: dict[str, Any]):
         self.actor.clear_intermediate_repr()

@@ -184,6 +184,29 @@ class FlatGradients:
             self.attach()
         self.buffer.zero_()
 
+    def assemble(self, grads, split_slabs: dict[int, torch.Tensor] | None = None):
+        """Write every parameter's gradient into its slot with ONE launch (``cusrl_assemble_gradients``).
+        ``grads[i]`` is parameter i's gradient or None; ``split_slabs`` maps a parameter's storage address to the
+        unsummed ``[S, ...]`` partial gradients its split-batch GEMM left behind (cusrl_amd/nn/module.py)."""
+        from cusrl_amd import ops
+
+        pieces, offset = [], 0
+        for p, grad in zip(self.params, grads):
+            n = p.numel()
+            slabs = split_slabs.pop(p.data_ptr(), None) if split_slabs else None
+            if slabs is not None and grad is not None:  # the weight was used more than once in the graph
+                grad, slabs = grad + slabs.sum(0), None
+            if slabs is not None:
+                pieces.append((slabs, offset, n, slabs.shape[0]))
+            elif grad is not None:
+                pieces.append((grad, offset, n, 1))
+            else:
+                pieces.append((None, offset, n, 0))
+            offset += n
+        if split_slabs:
+            raise RuntimeError("split weight gradients were produced for tensors that are not optimizer parameters")
+        ops.assemble_gradients(pieces, self.buffer)
+
 
 def reduce_gradients(optimizer: torch.optim.Optimizer, flat: FlatGradients | None = None):
     """Average gradients across ranks (actor_critic.py:314)."""

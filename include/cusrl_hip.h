@@ -173,6 +173,18 @@ int cusrl_narrow_linear_supported(int64_t in_features, int64_t out_features);
 int cusrl_clip_grad_norm(float *grad, int64_t n, float max_norm, double *partials, float *norm_out, void *stream);
 int64_t cusrl_clip_grad_norm_num_partials(int64_t n);
 
+/* ---- flat gradient assembly (the buffer behind actor_critic.py:311-314: backward, all-reduce, clip, step) ----
+ * flat[offset .. offset + numel) = sum over `splits` stacked slabs of src [splits][numel]; splits = 1 copies a
+ * plain gradient, splits = 0 writes zeros (src ignored).  The split-batch weight-gradient GEMMs leave their
+ * [S, out, in] partial products here instead of running one sum(0) each; one launch per 24 pieces.  Fixed order. */
+typedef struct {
+    const void *src;
+    int64_t offset; /* element offset of the parameter's slot in `flat` */
+    int64_t numel;
+    int64_t splits;
+} cusrl_grad_piece_t;
+int cusrl_assemble_gradients(const cusrl_grad_piece_t *pieces, int64_t num_pieces, float *flat, void *stream);
+
 /* Block partials of sum(grad^2) only (the first half of cusrl_clip_grad_norm): the caller hands them to
  * cusrl_adam_step, which applies the clipping coefficient while it streams the gradient. */
 int cusrl_grad_sumsq(const float *grad, int64_t n, double *partials, void *stream);

@@ -443,6 +443,30 @@ def test_adam_step_vs_oracle(ops, n, decoupled, weight_decay, max_norm):
         np.testing.assert_allclose(host(d_v), exp_avg_sq, rtol=1e-5, atol=1e-12)
 
 
+def test_assemble_gradients_sums_slabs_into_slots(ops):
+    rng = np.random.default_rng(3)
+    shapes = [(16, 128 * 256), (1, 256), (16, 256 * 48), (1, 12), (0, 7), (3, 5), (1, 1)] * 5  # 35 pieces: two launches
+    flat = torch.full((sum(n for _, n in shapes) + 3,), float("nan"), device=DEV)
+    pieces, expect, offset = [], np.full(flat.numel(), np.nan, np.float32), 0
+    for splits, n in shapes:
+        src = rng.standard_normal((splits, n)).astype(np.float32) if splits else None
+        pieces.append((None if src is None else dev(src), offset, n, splits))
+        # the kernel's order: groups of four slabs (a + b) + (c + d), then the rest one by one
+        total = np.zeros(n, np.float32)
+        s = 0
+        while splits and s + 4 <= splits:
+            total = total + ((src[s] + src[s + 1]) + (src[s + 2] + src[s + 3]))
+            s += 4
+        for r in range(s, splits):
+            total = total + src[r]
+        expect[offset : offset + n] = total
+        offset += n
+    ops.assemble_gradients(pieces, flat)
+    got = host(flat)
+    assert np.isnan(got[offset:]).all()  # nothing written past the last slot
+    np.testing.assert_array_equal(got[:offset], expect[:offset])
+
+
 def test_fused_linear_paths_match_plain_autograd():
     from cusrl_amd.nn.module import Mlp
 
