@@ -59,7 +59,7 @@ _SIGNATURES = {
     "cusrl_episode_stats": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, _P]),
     "cusrl_relu_bwd_colsum": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
     "cusrl_colsum_num_partials": (c_int64, [c_int64, c_int64]),
-    "cusrl_narrow_linear_bwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, _P]),
+    "cusrl_narrow_linear_bwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_narrow_linear_num_partials": (c_int64, [c_int64]),
     "cusrl_narrow_linear_supported": (c_int, [c_int64, c_int64]),
     "cusrl_clip_grad_norm": (c_int, [_P, c_int64, c_float, _P, _P, _P]),

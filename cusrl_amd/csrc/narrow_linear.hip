@@ -13,13 +13,17 @@ constexpr int kHeadRowsPerBlock = 64;
 constexpr int head_batch(int O) { return O > 8 ? 2 : 4; }  // X rows in flight per lane (VGPR budget: O x 12 + ...)
 constexpr int kHeadBiasPad = 16;  // db rides behind dW in the same partial row, padded to keep float4 alignment
 
-template <int O>
+// kReluInput: the layer's input is a ReLU output (x > 0 <=> the ReLU passed), so the kernel also plays the ReLU's
+// backward for the producer: grad_input comes out already masked and its column sums (= the producer layer's bias
+// gradient) ride along as one more accumulator slice — the separate mask + column-sum pass over [rows, K] disappears.
+template <int O, bool kReluInput>
 __global__ __launch_bounds__(kBlock) void narrow_linear_bwd_kernel(const float *__restrict__ grad_out,
                                                                    const float *__restrict__ input,
                                                                    const float *__restrict__ weight,
                                                                    float *__restrict__ grad_input,
                                                                    float *__restrict__ partials, int64_t rows, int K) {
-    extern __shared__ float4 red[];  // [(groups - 1)][O][lpr] dW slices, then [16][16] db parts
+    extern __shared__ float4 red[];  // [(groups - 1)][O + 1][lpr] dW (+ masked-dX column sum) slices, then [16][16] db
+    constexpr int SL = O + 1;        // accumulator slices per lane: O rows of dW and the column sums of the masked dX
     const int lpr = K / 4;
     const int groups = kBlock / lpr;
     const int col = threadIdx.x % lpr, sub = threadIdx.x / lpr;
@@ -27,12 +31,11 @@ __global__ __launch_bounds__(kBlock) void narrow_linear_bwd_kernel(const float *
     const int64_t row_end = min(row0 + kHeadRowsPerBlock, rows);
 
     constexpr int kHeadBatch = head_batch(O);
-    float4 w[O], dw[O];
+    float4 w[O], dw[SL];
 #pragma unroll
-    for (int o = 0; o < O; ++o) {
-        w[o] = reinterpret_cast<const float4 *>(weight)[o * lpr + col];
-        dw[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int o = 0; o < O; ++o) w[o] = reinterpret_cast<const float4 *>(weight)[o * lpr + col];
+#pragma unroll
+    for (int o = 0; o < SL; ++o) dw[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t base = row0 + sub; base < row_end; base += int64_t(kHeadBatch) * groups) {
         float4 x[kHeadBatch];
         float g[kHeadBatch][O];
@@ -66,15 +69,20 @@ __global__ __launch_bounds__(kBlock) void narrow_linear_bwd_kernel(const float *
                 dw[o].x = fmaf(go, x[k].x, dw[o].x), dw[o].y = fmaf(go, x[k].y, dw[o].y);
                 dw[o].z = fmaf(go, x[k].z, dw[o].z), dw[o].w = fmaf(go, x[k].w, dw[o].w);
             }
+            if constexpr (kReluInput) {  // rows past the end have dx == 0: they add nothing to the sums
+                dx.x = x[k].x > 0.f ? dx.x : 0.f, dx.y = x[k].y > 0.f ? dx.y : 0.f;
+                dx.z = x[k].z > 0.f ? dx.z : 0.f, dx.w = x[k].w > 0.f ? dx.w : 0.f;
+                dw[O].x += dx.x, dw[O].y += dx.y, dw[O].z += dx.z, dw[O].w += dx.w;
+            }
             if (grad_input && live[k]) reinterpret_cast<float4 *>(grad_input)[r[k] * lpr + col] = dx;
         }
     }
 
     // combine the row groups of the block in fixed order: groups 1.. park their slices in LDS, group 0 adds them up
-    float *red_bias = reinterpret_cast<float *>(red + (groups - 1) * O * lpr);  // [16 row parts][16 outputs]
+    float *red_bias = reinterpret_cast<float *>(red + (groups - 1) * SL * lpr);  // [16 row parts][16 outputs]
     if (sub > 0) {
 #pragma unroll
-        for (int o = 0; o < O; ++o) red[((sub - 1) * O + o) * lpr + col] = dw[o];
+        for (int o = 0; o < SL; ++o) red[((sub - 1) * SL + o) * lpr + col] = dw[o];
     }
     {   // db: the block's dY rows were just read (L1/L2 hits); lane (part, o) sums rows part, part + 16, ...
         const int o = threadIdx.x & 15, part = threadIdx.x >> 4;
@@ -84,13 +92,13 @@ __global__ __launch_bounds__(kBlock) void narrow_linear_bwd_kernel(const float *
         red_bias[part * 16 + o] = total;
     }
     __syncthreads();
-    float *out = partials + int64_t(blockIdx.x) * (O * K + kHeadBiasPad);
+    float *out = partials + int64_t(blockIdx.x) * (SL * K + kHeadBiasPad);
     if (sub == 0) {
 #pragma unroll
-        for (int o = 0; o < O; ++o) {
+        for (int o = 0; o < SL; ++o) {
             float4 total = dw[o];
             for (int s = 1; s < groups; ++s) {
-                const float4 v = red[((s - 1) * O + o) * lpr + col];
+                const float4 v = red[((s - 1) * SL + o) * lpr + col];
                 total.x += v.x, total.y += v.y, total.z += v.z, total.w += v.w;
             }
             reinterpret_cast<float4 *>(out)[o * lpr + col] = total;
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void narrow_linear_bwd_kernel(const float *
         const int o = threadIdx.x - (kBlock - kHeadBiasPad);
         float total = 0.f;
         for (int part = 0; part < 16; ++part) total += red_bias[part * 16 + o];
-        out[O * K + o] = total;
+        out[SL * K + o] = total;
     }
 }
 
@@ -140,18 +148,31 @@ __global__ __launch_bounds__(kBlock) void narrow_linear_finalize_kernel(const fl
 }
 
 static bool narrow_shape_ok(int64_t K, int64_t O) {
-    if (O < 1 || O > 16 || K < 64 || K > 1024 || K % 4) return false;  // K >= 64 keeps the LDS slices < 64 KB
+    if (O < 1 || O > 16 || K < 32 || K > 1024 || K % 4) return false;
     const int64_t lpr = K / 4;
     return (lpr & (lpr - 1)) == 0;  // power of two: divides the 256-lane block
 }
 
-template <int O>
-static void launch_narrow_bwd(const float *grad_out, const float *input, const float *weight, float *grad_input,
-                              float *partials, int64_t rows, int K, int64_t blocks, hipStream_t s) {
+template <int O, bool kReluInput>
+static int launch_narrow_bwd_as(const float *grad_out, const float *input, const float *weight, float *grad_input,
+                                float *partials, int64_t rows, int K, int64_t blocks, hipStream_t s) {
     const int lpr = K / 4, groups = kBlock / lpr;
-    const size_t lds = size_t(groups - 1) * O * lpr * sizeof(float4) + 256 * sizeof(float);
-    hipLaunchKernelGGL(narrow_linear_bwd_kernel<O>, dim3(uint32_t(blocks)), dim3(kBlock), lds, s, grad_out, input, weight,
-                       grad_input, partials, rows, K);
+    const size_t lds = size_t(groups - 1) * (O + 1) * lpr * sizeof(float4) + 256 * sizeof(float);
+    if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in (the CU has 160 KB)
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&narrow_linear_bwd_kernel<O, kReluInput>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (err != hipSuccess) return int(err);
+    }
+    hipLaunchKernelGGL((narrow_linear_bwd_kernel<O, kReluInput>), dim3(uint32_t(blocks)), dim3(kBlock), lds, s, grad_out,
+                       input, weight, grad_input, partials, rows, K);
+    return launch_status();
+}
+
+template <int O>
+static int launch_narrow_bwd(const float *grad_out, const float *input, const float *weight, float *grad_input,
+                             float *partials, int64_t rows, int K, int64_t blocks, bool relu_input, hipStream_t s) {
+    return relu_input ? launch_narrow_bwd_as<O, true>(grad_out, input, weight, grad_input, partials, rows, K, blocks, s)
+                      : launch_narrow_bwd_as<O, false>(grad_out, input, weight, grad_input, partials, rows, K, blocks, s);
 }
 
 }  // namespace cusrl
@@ -165,21 +186,23 @@ extern "C" int64_t cusrl_narrow_linear_num_partials(int64_t rows) {
 }
 
 extern "C" int cusrl_narrow_linear_bwd(const float *grad_out, const float *input, const float *weight,
-                                       float *grad_input, float *partials, float *grad_weight_bias, int64_t rows,
-                                       int64_t in_features, int64_t out_features, void *stream) {
+                                       float *grad_input, float *partials, float *packed, int64_t rows,
+                                       int64_t in_features, int64_t out_features, int relu_input, void *stream) {
     using namespace cusrl;
-    if (!grad_out || !input || !weight || !partials || !grad_weight_bias || rows <= 0) return CUSRL_E_INVALID;
+    if (!grad_out || !input || !weight || !partials || !packed || rows <= 0) return CUSRL_E_INVALID;
     if (!narrow_shape_ok(in_features, out_features)) return CUSRL_E_UNSUPPORTED;
     if (out_features % 4 == 0 && !aligned(grad_out, 16)) return CUSRL_E_UNSUPPORTED;
-    if (!aligned(input, 16) || !aligned(weight, 16) || !aligned(partials, 16) || !aligned(grad_weight_bias, 16) ||
+    if (!aligned(input, 16) || !aligned(weight, 16) || !aligned(partials, 16) || !aligned(packed, 16) ||
         (grad_input && !aligned(grad_input, 16)))
         return CUSRL_E_UNSUPPORTED;
     hipStream_t s = as_stream(stream);
     const int K = int(in_features);
     const int64_t blocks = ceil_div(rows, kHeadRowsPerBlock);
+    const bool relu = relu_input != 0;
+    int rc = 0;
     switch (out_features) {
 #define CUSRL_NARROW_CASE(N) \
-    case N: launch_narrow_bwd<N>(grad_out, input, weight, grad_input, partials, rows, K, blocks, s); break;
+    case N: rc = launch_narrow_bwd<N>(grad_out, input, weight, grad_input, partials, rows, K, blocks, relu, s); break;
         CUSRL_NARROW_CASE(1) CUSRL_NARROW_CASE(2) CUSRL_NARROW_CASE(3) CUSRL_NARROW_CASE(4)
         CUSRL_NARROW_CASE(5) CUSRL_NARROW_CASE(6) CUSRL_NARROW_CASE(7) CUSRL_NARROW_CASE(8)
         CUSRL_NARROW_CASE(9) CUSRL_NARROW_CASE(10) CUSRL_NARROW_CASE(11) CUSRL_NARROW_CASE(12)
@@ -187,9 +210,9 @@ extern "C" int cusrl_narrow_linear_bwd(const float *grad_out, const float *input
 #undef CUSRL_NARROW_CASE
         default: return CUSRL_E_UNSUPPORTED;
     }
-    if (int rc = launch_status()) return rc;
-    const int H = int(out_features) * K + kHeadBiasPad;
+    if (rc) return rc;
+    const int H = (int(out_features) + 1) * K + kHeadBiasPad;
     hipLaunchKernelGGL(narrow_linear_finalize_kernel, dim3(uint32_t(ceil_div(H, 64))), dim3(kBlock), 0, s, partials,
-                       blocks, H, grad_weight_bias);
+                       blocks, H, packed);
     return launch_status();
 }

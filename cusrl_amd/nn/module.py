@@ -51,7 +51,9 @@ class _WideBatchLinear(torch.autograd.Function):
     * ReLU mask and bias gradient come from ONE HIP pass (``cusrl_relu_bwd_colsum``) instead of threshold_backward +
       a column-sum reduction (35 us -> ~15 us for [24576, 256]);
     * a head with <= 16 outputs (policy mean, value) gets dX, dW and db from ONE streaming pass
-      (``cusrl_narrow_linear_bwd``) instead of two skinny GEMMs, a split-sum and a column sum.
+      (``cusrl_narrow_linear_bwd``) instead of two skinny GEMMs, a split-sum and a column sum — and when its input
+      is the ReLU output of the layer in front, the same pass also performs that ReLU's backward mask and the
+      bias-gradient column sums of that layer, so the layer's own epilogue launch is skipped.
     """
 
     @staticmethod
@@ -59,11 +61,13 @@ class _WideBatchLinear(torch.autograd.Function):
         if relu:
             output = torch._addmm_activation(bias, input, weight.t())
             ctx.save_for_backward(input, weight, output)
+            output._cusrl_relu_output = True  # lets a narrow head behind it play this ReLU's backward (see backward)
         else:
             output = linear(input, weight, bias)
             ctx.save_for_backward(input, weight)
         ctx.splits, ctx.relu, ctx.has_bias = splits, relu, bias is not None
         ctx.narrow = (not relu) and input.is_contiguous() and weight.is_contiguous() and _narrow_head(weight)
+        ctx.input_is_relu_output = getattr(input, "_cusrl_relu_output", False)
         return output
 
     @staticmethod
@@ -72,12 +76,23 @@ class _WideBatchLinear(torch.autograd.Function):
 
         if ctx.relu:
             input, weight, output = ctx.saved_tensors
-            grad_output, grad_bias = ops.relu_backward_bias(grad_output.contiguous(), output)
+            premasked = getattr(grad_output, "_cusrl_premasked", None)
+            if premasked is not None and premasked[1] == grad_output._version and ctx.has_bias:
+                grad_bias = premasked[0]  # the head behind this ReLU already masked its dX and summed its columns
+            else:
+                grad_output, grad_bias = ops.relu_backward_bias(grad_output.contiguous(), output)
         else:
             input, weight = ctx.saved_tensors
             if ctx.narrow and ctx.needs_input_grad[1]:  # policy-mean / value head: dX, dW and db from one pass
-                grad_input, grad_weight, grad_bias = ops.narrow_linear_backward(
-                    grad_output.contiguous(), input, weight, need_input_grad=ctx.needs_input_grad[0])
+                fuse_relu = ctx.input_is_relu_output and ctx.needs_input_grad[0]
+                grad_input, grad_weight, grad_bias, masked_colsum = ops.narrow_linear_backward(
+                    grad_output.contiguous(), input, weight, need_input_grad=ctx.needs_input_grad[0], relu_input=fuse_relu)
+                if fuse_relu:
+                    # The input is a ReLU output, so masking dX by (input > 0) here IS that ReLU's backward (it is
+                    # idempotent, so the producer may safely repeat it).  Tell the producer — through the tensor it
+                    # will receive as grad_output — that the mask and the bias-gradient column sums are done; the
+                    # version stamp voids the note if autograd accumulates another consumer's gradient in place.
+                    grad_input._cusrl_premasked = (masked_colsum, grad_input._version)
                 return grad_input, grad_weight, (grad_bias if ctx.has_bias else None), None, None
             grad_bias = None
             if ctx.has_bias and ctx.needs_input_grad[2]:

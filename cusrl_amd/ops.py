@@ -490,25 +490,28 @@ def narrow_linear_supported(in_features: int, out_features: int) -> bool:
 
 
 def narrow_linear_backward(grad_output: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
-                           need_input_grad: bool = True) -> tuple[torch.Tensor | None, torch.Tensor, torch.Tensor]:
+                           need_input_grad: bool = True, relu_input: bool = False):
     """``(grad_output @ weight, grad_output.T @ input, grad_output.sum(0))`` of a linear layer with at most 16
-    outputs (policy-mean / value head) in one pass over the minibatch."""
+    outputs (policy-mean / value head) in one pass over the minibatch.  With ``relu_input`` (the layer's input is a
+    ReLU output) the returned grad_input is already masked by ``input > 0`` and a fourth value, its column sums
+    (the bias gradient of the layer in front of the ReLU), is returned; otherwise the fourth value is None."""
     grad_output, input, weight = _f32(grad_output, "grad_output"), _f32(input, "input"), _f32(weight, "weight")
     O, K = weight.shape
     rows = input.shape[0]
     lib = _native.lib()
     dev = input.device
     grad_input = torch.empty_like(input) if need_input_grad else None
-    width = O * K + _HEAD_PAD
+    width = (O + 1) * K + _HEAD_PAD
     partials = torch.empty((int(lib.cusrl_narrow_linear_num_partials(rows)), width), dtype=torch.float32, device=dev)
     packed = torch.empty(width, dtype=torch.float32, device=dev)
     check(
         lib.cusrl_narrow_linear_bwd(grad_output.data_ptr(), input.data_ptr(), weight.data_ptr(),
                                     None if grad_input is None else grad_input.data_ptr(), partials.data_ptr(),
-                                    packed.data_ptr(), rows, K, O, _stream()),
+                                    packed.data_ptr(), rows, K, O, int(relu_input), _stream()),
         "cusrl_narrow_linear_bwd",
     )
-    return grad_input, packed[: O * K].view(O, K), packed[O * K : O * K + O]
+    colsum = packed[O * K : (O + 1) * K] if relu_input else None
+    return grad_input, packed[: O * K].view(O, K), packed[(O + 1) * K : (O + 1) * K + O], colsum
 
 
 # ------------------------------------------------------------------------------------------------ gradient clipping

@@ -156,13 +156,15 @@ int64_t cusrl_colsum_num_partials(int64_t rows, int64_t H);
 /* ---- backward of a narrow linear layer (policy-mean / value heads; torch.nn.Linear backward with out_features <= 16)
  * One pass over the minibatch produces all three gradients of y = x W^T + b:
  *   grad_input [rows, K] = grad_out W   (skipped when NULL),   dW [O, K] = grad_out^T x,   db [O] = sum_rows grad_out.
- * grad_weight_bias: float[O*K + 16] = dW (row-major) followed by db (then zero padding);
- * partials: float[cusrl_narrow_linear_num_partials(rows)][O*K + 16] workspace.  Supported shapes
- * (cusrl_narrow_linear_supported): 1 <= O <= 16, K in {64, 128, ..., 1024} a power of two; all pointers 16-byte aligned.
- * Fixed summation order (deterministic). */
+ * relu_input != 0: x is the output of a ReLU (x > 0 <=> the ReLU passed); grad_input is then written already
+ * masked — the ReLU's backward — and its column sums, the producer layer's bias gradient, are returned too.
+ * packed: float[(O + 1) * K + 16] = dW (row-major) | column sums of the masked grad_input (zeros when
+ * relu_input == 0) | db, zero padded;  partials: float[cusrl_narrow_linear_num_partials(rows)][(O + 1) * K + 16].
+ * Supported shapes (cusrl_narrow_linear_supported): 1 <= O <= 16, K in {32, 64, ..., 1024} a power of two; all
+ * pointers 16-byte aligned.  Fixed summation order (deterministic). */
 int cusrl_narrow_linear_bwd(const float *grad_out, const float *input, const float *weight, float *grad_input,
-                            float *partials, float *grad_weight_bias, int64_t rows, int64_t in_features,
-                            int64_t out_features, void *stream);
+                            float *partials, float *packed, int64_t rows, int64_t in_features, int64_t out_features,
+                            int relu_input, void *stream);
 int64_t cusrl_narrow_linear_num_partials(int64_t rows);
 int cusrl_narrow_linear_supported(int64_t in_features, int64_t out_features);
 

@@ -387,15 +387,44 @@ def test_narrow_linear_backward_matches_matmul(ops, rows, K, O):
     torch.manual_seed(rows + K + O)
     grad, x, w = torch.randn(rows, O, device=DEV), torch.randn(rows, K, device=DEV), torch.randn(O, K, device=DEV)
     assert ops.narrow_linear_supported(K, O)
-    dx, dw, db = ops.narrow_linear_backward(grad, x, w)
+    dx, dw, db, none_colsum = ops.narrow_linear_backward(grad, x, w)
+    assert none_colsum is None
     g64, x64, w64 = grad.double(), x.double(), w.double()
     torch.testing.assert_close(dx.double(), g64 @ w64, rtol=1e-5, atol=1e-5 * float((g64.abs() @ w64.abs()).max()))
     # fp32 accumulation over `rows` products: 1e-5 relative to the absolute mass of each sum
     torch.testing.assert_close(dw.double(), g64.t() @ x64, rtol=1e-5, atol=1e-5 * float((g64.abs().t() @ x64.abs()).max()))
     torch.testing.assert_close(db.double(), g64.sum(0), rtol=1e-5, atol=1e-5 * float(g64.abs().sum(0).max()))
-    none, dw2, db2 = ops.narrow_linear_backward(grad, x, w, need_input_grad=False)
+    none, dw2, db2, _ = ops.narrow_linear_backward(grad, x, w, need_input_grad=False)
     assert none is None and torch.equal(dw2, dw) and torch.equal(db2, db)  # deterministic summation order
+    # input = a ReLU output: the same pass masks dX by (x > 0) and returns its column sums
+    relu_x = torch.relu(x)
+    mdx, mdw, mdb, colsum = ops.narrow_linear_backward(grad, relu_x, w, relu_input=True)
+    plain_dx, plain_dw, plain_db, _ = ops.narrow_linear_backward(grad, relu_x, w)
+    expect = plain_dx * (relu_x > 0)
+    assert torch.equal(mdx, expect) and torch.equal(mdw, plain_dw) and torch.equal(mdb, plain_db)
+    torch.testing.assert_close(colsum.double(), expect.double().sum(0), rtol=1e-5, atol=1e-5 * float(expect.abs().sum(0).max()) + 1e-12)
     assert not ops.narrow_linear_supported(48, 12) and not ops.narrow_linear_supported(128, 17)
+
+
+def test_head_behind_relu_backbone_matches_plain_autograd():
+    """Backbone (Linear-ReLU x2) + narrow heads: the head's backward also plays the last ReLU's backward; with two
+    heads on the same features autograd accumulates their gradients and the shortcut must void itself."""
+    from cusrl_amd.nn.module import Linear, Mlp
+
+    torch.manual_seed(5)
+    mlp = Mlp(48, (256, 128), ends_with_activation=True).to(DEV)
+    heads = [Linear(128, 12).to(DEV), Linear(128, 1).to(DEV)]
+    x = torch.randn(8192, 48, device=DEV)
+    for used in ([0], [1], [0, 1]):
+        params = list(mlp.parameters()) + [p for i in used for p in heads[i].parameters()]
+        feat = mlp(x)
+        loss = sum(heads[i](feat).square().sum() for i in used)
+        got = torch.autograd.grad(loss, params)
+        feat = mlp.layers(x)
+        loss = sum(torch.nn.functional.linear(feat, heads[i].weight, heads[i].bias).square().sum() for i in used)
+        want = torch.autograd.grad(loss, params)
+        for a, b in zip(got, want):
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-4 * float(b.abs().max()))
 
 
 def test_narrow_head_autograd_matches_plain_linear():
