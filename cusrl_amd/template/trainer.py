@@ -181,7 +181,7 @@ class Trainer:
                     if not env.spec.autoreset:
                         # index tensor (allowed by the contract).  A staged copy of the flags to pinned host memory
                         # + event wait + host scan was measured 4 % SLOWER per iteration than this blocking nonzero.
-                        done_indices = done.squeeze(-1).nonzero().reshape(-1)
+                        done_indices = self._done_indices(done)
                         if done_indices.numel():
                             init_observation, init_state, _ = env.reset(indices=done_indices)
                             next_observation, next_state = update_observation_and_state(
@@ -201,6 +201,18 @@ class Trainer:
         for hook in self.hooks:
             hook.post_update()
         return observation, state
+
+    @staticmethod
+    def _done_indices(done: torch.Tensor) -> torch.Tensor:
+        """``done.squeeze(-1).nonzero().squeeze(-1)`` (environment.py get_done_indices) on the device: ordered stream
+        compaction in two launches + one 4-byte read-back, instead of torch's four-kernel nonzero on the step's
+        critical path (the host waits for this result before it can issue the next act)."""
+        from cusrl_amd import ops
+
+        if done.dtype != torch.bool or not done.is_contiguous():
+            return done.reshape(-1).nonzero().reshape(-1)
+        indices, count = ops.compact_flags(done)
+        return indices[: int(count.item())]
 
     def _save_checkpoint(self):
         if self.logger is None or not distributed.is_main_process():
