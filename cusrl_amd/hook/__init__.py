@@ -2,6 +2,7 @@ from cusrl_amd.hook.control import ModuleInitialization
 from cusrl_amd.hook.auxiliary import AdversarialMotionPrior, RandomNetworkDistillation
 from cusrl_amd.hook.mdp import ObservationNormalization, RewardShaping
 from cusrl_amd.hook.on_policy import (
+    AdaptiveLRSchedule,
     AdvantageNormalization,
     AdvantageReduction,
     EntropyLoss,
@@ -10,11 +11,14 @@ from cusrl_amd.hook.on_policy import (
     OnPolicyPreparation,
     OnPolicyStatistics,
     PpoSurrogateLoss,
+    ThresholdLRSchedule,
     ValueComputation,
     ValueLoss,
 )
 
 __all__ = [
+    "AdaptiveLRSchedule",
+    "ThresholdLRSchedule",
     "AdversarialMotionPrior",
     "RandomNetworkDistillation",
     "RewardShaping",

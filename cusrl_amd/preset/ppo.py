@@ -46,8 +46,6 @@ def ppo_hook_suite(
     max_kl_divergence: float | None = None,
     empty_cuda_cache: bool = False,
 ) -> list[Hook]:
-    if desired_kl_divergence is not None:
-        raise NotImplementedError("AdaptiveLRSchedule is host-side scalar control, out of scope (SURVEY.md §2 row 3)")
     suite = [
         hooks.ModuleInitialization(init_actor=orthogonal_init, init_critic=orthogonal_init),
         hooks.ObservationNormalization() if normalize_observation else None,
@@ -60,6 +58,8 @@ def ppo_hook_suite(
         hooks.EntropyLoss(weight=entropy_loss_weight),
         hooks.GradientClipping(max_grad_norm, grad_clip_groups),
         hooks.OnPolicyStatistics(sampler=AutoMiniBatchSampler()),
+        (hooks.AdaptiveLRSchedule(desired_kl_divergence, max_kl_divergence=max_kl_divergence)
+         if desired_kl_divergence is not None else None),
     ]
     return [h for h in suite if h is not None]
 

@@ -30,11 +30,13 @@ _GROUP_KEYS = ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize", "dec
 class FlatAdam:
     @staticmethod
     def eligible(optimizer, flat_gradients: FlatGradients | None) -> bool:
-        """Exactly Adam / AdamW, one hyper-parameter set for all groups, plain (non-amsgrad, non-differentiable)
+        """Exactly Adam / AdamW with a single parameter group, plain (non-amsgrad, non-differentiable)
         fp32 parameters on the GPU whose gradients already live in ``flat_gradients``."""
         if type(optimizer) not in _SUPPORTED or flat_gradients is None:
             return False
         groups = optimizer.param_groups
+        if len(groups) != 1:  # schedules may move the groups' learning rates apart later on
+            return False
         first = groups[0]
         if any(group.get("amsgrad") or group.get("differentiable") for group in groups):
             return False

@@ -573,6 +573,67 @@ def make_aux_rewards(cusrl):
     print("aux_rewards.npz: RND + AMP")
 
 
+# ------------------------------------------------------------------------------------------------ lr schedules
+class ScheduleProbe:
+    """The slice of an agent the KL-driven LR schedules touch (shared by the generator and tests/test_host_logic.py)."""
+
+    def __init__(self):
+        self.optimizer = types.SimpleNamespace(param_groups=[
+            {"lr": 2e-4, "param_names": ["actor.backbone.0.weight", "actor.distribution.std"]},
+            {"lr": 1e-3, "param_names": ["critic.backbone.0.weight"]},
+        ])
+        self.metrics = {}
+        self.iteration = 0
+        self.recorded: list[dict] = []
+        self.loads = 0
+
+    def record(self, **kwargs):
+        self.recorded.append(kwargs)
+
+    def state_dict(self):
+        return {"marker": self.iteration}
+
+    def load_state_dict(self, state):
+        self.loads += 1
+
+    def run(self, hook, kls, schedule_first: bool):
+        hook.agent = self
+        hook.post_init()
+        rows = []
+        for i, kl in enumerate(kls):
+            self.iteration = i
+            if schedule_first:
+                hook.apply_schedule(i)
+            hook.pre_update(None)
+            self.metrics["kl_divergence"] = types.SimpleNamespace(mean=torch.tensor(kl, dtype=torch.float32))
+            self.recorded.clear()
+            hook.post_update()
+            merged = {k: v for item in self.recorded for k, v in item.items()}
+            rows.append([self.optimizer.param_groups[0]["lr"], self.optimizer.param_groups[1]["lr"],
+                         merged.get("lr_scale", np.nan), merged.get("update_rejected", np.nan), float(self.loads)])
+        return np.asarray(rows, dtype=np.float64)
+
+
+SCHEDULE_CASES = {
+    "adaptive": ("AdaptiveLRSchedule", dict(desired_kl_divergence=0.01), False),
+    "adaptive_all_maxkl": ("AdaptiveLRSchedule", dict(desired_kl_divergence=0.02, max_kl_divergence=0.05, scale_all_params=True,
+                                                      threshold=0.7, scale_factor=0.3), False),
+    "adaptive_warmup": ("AdaptiveLRSchedule", dict(desired_kl_divergence=0.01, warmup_iterations=4, initial_scale=0.25), True),
+    "threshold": ("ThresholdLRSchedule", dict(desired_kl_divergence=0.01), False),
+    "threshold_maxkl": ("ThresholdLRSchedule", dict(desired_kl_divergence=0.01, max_kl_divergence=0.03, threshold=1.5,
+                                                    scale_factor=1.25, scale_all_params=True), False),
+}
+SCHEDULE_KLS = [0.012, 0.031, 0.004, 0.0, 0.0105, 0.06, 0.02, 0.0007, 0.011, 0.25, 0.009, 0.0031, 0.018, 0.04]
+
+
+def make_lr_schedule(cusrl):
+    out = {"torch_version": np.array(torch.__version__), "kls": np.asarray(SCHEDULE_KLS)}
+    for tag, (cls_name, kwargs, schedule_first) in SCHEDULE_CASES.items():
+        out[tag] = ScheduleProbe().run(getattr(cusrl.hook, cls_name)(**kwargs), SCHEDULE_KLS, schedule_first)
+    np.savez_compressed(HERE / "lr_schedule.npz", **out)
+    print("lr_schedule.npz", {k: v.shape for k, v in out.items() if k not in ("torch_version",)})
+
+
 def main():
     cusrl = import_reference()
     cusrl.config.set_device("cpu")
@@ -585,6 +646,7 @@ def main():
     make_obs_norm(cusrl)
     make_recurrent(cusrl)
     make_aux_rewards(cusrl)
+    make_lr_schedule(cusrl)
     leaked = list(REFERENCE.rglob("__pycache__"))
     assert not leaked, f"bytecode leaked into the reference tree: {leaked[:3]}"
 

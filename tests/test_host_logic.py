@@ -271,3 +271,29 @@ def test_set_global_seed_is_rank_offset_and_reproducible():
     a = torch.randperm(8)
     cusrl.set_global_seed(42)
     assert torch.equal(a, torch.randperm(8)) and cusrl.config.seed == 42
+
+
+@pytest.mark.parametrize("tag", ["adaptive", "adaptive_all_maxkl", "adaptive_warmup", "threshold", "threshold_maxkl"])
+def test_kl_driven_lr_schedules_replay_reference_trajectories(tag):
+    """Learning rates, recorded lr_scale / update_rejected and roll-backs over a KL sequence, as recorded from the
+    reference's AdaptiveLRSchedule / ThresholdLRSchedule (tests/golden/lr_schedule.npz, make_golden.py)."""
+    import sys
+    from pathlib import Path
+
+    import cusrl_amd
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+    from make_golden import SCHEDULE_CASES, ScheduleProbe
+
+    golden = np.load(Path(__file__).resolve().parent / "golden" / "lr_schedule.npz")
+    cls_name, kwargs, schedule_first = SCHEDULE_CASES[tag]
+    got = ScheduleProbe().run(getattr(cusrl_amd.hook, cls_name)(**kwargs), list(golden["kls"]), schedule_first)
+    np.testing.assert_allclose(got, golden[tag], rtol=1e-12, atol=0, equal_nan=True)
+
+
+def test_ppo_preset_includes_the_adaptive_lr_schedule_when_asked():
+    import cusrl_amd
+
+    suite = cusrl_amd.preset.ppo_hook_suite(desired_kl_divergence=0.01, max_kl_divergence=0.05)
+    assert type(suite[-1]) is cusrl_amd.hook.AdaptiveLRSchedule and suite[-1].max_kl_divergence == 0.05
+    assert not any(isinstance(h, cusrl_amd.hook.AdaptiveLRSchedule) for h in cusrl_amd.preset.ppo_hook_suite())
