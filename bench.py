@@ -67,6 +67,10 @@ def summarize(observer):
     for name, records in observer.records.items():
         if not records:
             continue
+        # one entry point may be launched at several sizes (gather: the whole-buffer statistics pass and the few
+        # truncated rows of the value bootstrap): report the launches of the largest size, not a mixture
+        largest = max(b for _, _, b in records)
+        records = [r for r in records if r[2] == largest]
         total_ms = sum(s.elapsed_time(e) for s, e, _ in records)
         total_bytes = sum(b for _, _, b in records)
         gbs = total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
