@@ -77,12 +77,22 @@ __device__ __forceinline__ void value_terms(const float *__restrict__ ret, const
 
 constexpr int kLossSums = 5;  // value loss, surrogate, entropy, |logp ratio|, value
 
+// All five sums through ONE LDS exchange (one barrier instead of two per sum): wave-shuffle each, lane 0 of every
+// wave parks its five totals, the first five threads add the four waves up in fixed order.
 __device__ __forceinline__ void write_block_partials(const double (&acc)[kLossSums], double *__restrict__ partials) {
-    __shared__ double scratch[kWavesPerBlock];
+    __shared__ double scratch[kWavesPerBlock][kLossSums];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
     for (int k = 0; k < kLossSums; ++k) {
-        const double total = block_sum(acc[k], scratch);
-        if (threadIdx.x == 0) partials[int64_t(blockIdx.x) * kLossSums + k] = total;
+        const double total = wave_sum(acc[k]);
+        if (lane == 0) scratch[wave][k] = total;
+    }
+    __syncthreads();
+    if (threadIdx.x < kLossSums) {
+        double total = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) total += scratch[w][threadIdx.x];
+        partials[int64_t(blockIdx.x) * kLossSums + threadIdx.x] = total;
     }
 }
 
