@@ -57,6 +57,8 @@ _SIGNATURES = {
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
     "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
     "cusrl_episode_stats": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, _P]),
+    "cusrl_policy_stats": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P, _P, _P]),
+    "cusrl_policy_stats_num_partials": (c_int64, [c_int64]),
     "cusrl_relu_bwd_colsum": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
     "cusrl_colsum_num_partials": (c_int64, [c_int64, c_int64]),
     "cusrl_narrow_linear_bwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, c_int, _P]),

@@ -1,10 +1,17 @@
-"""Post-update policy statistics (counterpart of cusrl/hook/on_policy/stats.py:10-40): KL between the behaviour
-and the updated policy, importance-weighted advantage, action std — over batches from its own sampler."""
+"""Post-update policy statistics (counterpart of cusrl/hook/on_policy/stats.py:10-40).
+
+After every update the refreshed actor is evaluated on the batches of the hook's own sampler and three means are
+recorded: ``kl_divergence`` (behaviour policy stored in the buffer vs the updated policy),
+``importance_weighted_advantage`` and ``action_std``.  For a Gaussian policy on the GPU the three reductions come
+from ONE pass over the batch (``cusrl_policy_stats``: the actor's GEMMs are the only other device work of this
+hook); any other distribution family takes the op-by-op form through the actor's own ``compute_*`` methods.
+"""
 
 from __future__ import annotations
 
 import torch
 
+from cusrl_amd import ops
 from cusrl_amd.template.buffer import Sampler
 from cusrl_amd.template.hook import Hook
 
@@ -14,16 +21,42 @@ __all__ = ["OnPolicyStatistics"]
 class OnPolicyStatistics(Hook):
     def __init__(self, sampler: Sampler | None = None):
         super().__init__(training_only=True)
-        self.sampler = sampler if sampler is not None else Sampler()
+        self.sampler = Sampler() if sampler is None else sampler
 
     @torch.no_grad()
     def post_update(self):
-        actor = self.agent.actor
-        for _, batch in self.sampler(self.agent.buffer):
-            with self.agent.autocast():
-                action_dist, _ = actor(batch["observation"], memory=batch.get("actor_memory"), done=batch["done"])
-            self.agent.record(kl_divergence=actor.compute_kl_div(batch["action_dist"], action_dist))
-            logp_ratio = actor.compute_logp(action_dist, batch["action"]) - batch["action_logp"]
-            self.agent.record(importance_weighted_advantage=batch["advantage"] * logp_ratio.exp())
-            if "std" in action_dist:
-                self.agent.record(action_std=action_dist["std"])
+        agent = self.agent
+        for _, batch in self.sampler(agent.buffer):
+            with agent.autocast():
+                updated, _ = agent.actor(batch["observation"], memory=batch.get("actor_memory"), done=batch["done"])
+            if self._gaussian_on_device(batch["action_dist"], updated):
+                self._record_fused(batch, updated)
+            else:
+                self._record_generic(batch, updated)
+
+    # ------------------------------------------------------------------ Gaussian policy: one launch
+    def _gaussian_on_device(self, behaviour, updated) -> bool:
+        if not getattr(self.agent.actor.distribution, "is_normal", False):
+            return False
+        tensors = (behaviour.get("mean"), behaviour.get("std"), updated.get("mean"), updated.get("std"))
+        return all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+    def _record_fused(self, batch, updated):
+        behaviour, advantage = batch["action_dist"], batch["advantage"]
+        kl, weighted_advantage, std = ops.policy_stats(
+            behaviour["mean"], behaviour["std"], updated["mean"], updated["std"], batch["action"], batch["action_logp"],
+            advantage).unbind(0)
+        rows = batch["action_logp"].numel()
+        metrics = self.agent.metrics
+        metrics.record_reduced("kl_divergence", kl, rows)
+        metrics.record_reduced("importance_weighted_advantage", weighted_advantage, advantage.numel())
+        metrics.record_reduced("action_std", std, updated["std"].numel())
+
+    # ------------------------------------------------------------------ any other policy family
+    def _record_generic(self, batch, updated):
+        actor, record = self.agent.actor, self.agent.record
+        record(kl_divergence=actor.compute_kl_div(batch["action_dist"], updated))
+        log_ratio = actor.compute_logp(updated, batch["action"]) - batch["action_logp"]
+        record(importance_weighted_advantage=batch["advantage"] * log_ratio.exp())
+        if "std" in updated:
+            record(action_std=updated["std"])

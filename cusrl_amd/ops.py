@@ -455,6 +455,27 @@ def episode_stats(reward, done, episode_rew, episode_len, ring_rew, ring_len, nu
     )
 
 
+# ------------------------------------------------------------------------------------------------ policy statistics
+def policy_stats(old_mean: torch.Tensor, old_std: torch.Tensor, new_mean: torch.Tensor, new_std: torch.Tensor,
+                 action: torch.Tensor, old_logp: torch.Tensor, advantage: torch.Tensor) -> torch.Tensor:
+    """``[mean KL(old || new), mean advantage * exp(logp_new(action) - old_logp), mean new_std]`` of a Gaussian policy
+    over a batch (cusrl/hook/on_policy/stats.py:28-40) — a 3-element device tensor from one pass."""
+    tensors = [_f32(t, n) for t, n in ((old_mean, "old_mean"), (old_std, "old_std"), (new_mean, "new_mean"), (new_std, "new_std"),
+                                       (action, "action"), (old_logp, "old_logp"), (advantage, "advantage"))]
+    A = new_mean.shape[-1]
+    B = new_mean.numel() // A
+    D = advantage.numel() // B
+    if any(t.numel() != B * A for t in tensors[:5]) or tensors[5].numel() != B or tensors[6].numel() != B * D:
+        raise ValueError("policy_stats: inconsistent shapes")
+    lib = _native.lib()
+    dev = new_mean.device
+    partials = torch.empty((max(int(lib.cusrl_policy_stats_num_partials(B)), 1), 3), dtype=torch.float64, device=dev)
+    out = torch.empty(3, dtype=torch.float32, device=dev)
+    check(lib.cusrl_policy_stats(*(t.data_ptr() for t in tensors), B, A, D, partials.data_ptr(), out.data_ptr(), _stream()),
+          "cusrl_policy_stats")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ MLP backward epilogue
 def relu_backward_bias(grad_output: torch.Tensor, output: torch.Tensor | None) -> tuple[torch.Tensor, torch.Tensor]:
     """``(grad_output * (output > 0), masked.sum(0))`` in one pass; with ``output=None`` just the column sums

@@ -144,6 +144,16 @@ int cusrl_episode_stats(const float *reward, const uint8_t *done, float *episode
                         float *ring_rew, float *ring_len, uint64_t *num_episodes, double *step_reward_sum,
                         int64_t N, int64_t D, int64_t R, void *stream);
 
+/* ---- post-update policy statistics — cusrl/hook/on_policy/stats.py:28-40 for Normal policies ----
+ * out[0] = mean_b KL(N(old_mean, old_std) || N(new_mean, new_std)) summed over the A action dims (kl_divergence),
+ * out[1] = mean of advantage * exp(log N(action; new_mean, new_std) - old_logp)  (importance_weighted_advantage),
+ * out[2] = mean of new_std (action_std).  [B, A] matrices, old_logp [B], advantage [B, D];
+ * partials: double[cusrl_policy_stats_num_partials(B)][3] workspace.  Fixed summation order (deterministic). */
+int cusrl_policy_stats(const float *old_mean, const float *old_std, const float *new_mean, const float *new_std,
+                       const float *action, const float *old_logp, const float *advantage, int64_t B, int64_t A,
+                       int64_t D, double *partials, float *out, void *stream);
+int64_t cusrl_policy_stats_num_partials(int64_t B);
+
 /* ---- MLP backward epilogues (callers of the path: torch.nn.Linear / ReLU backward of the actor-critic) ----
  * Bias gradient = column sums of grad [rows, H]; with `output` != NULL the ReLU backward mask is applied first
  * (grad_in = grad * (output > 0), written to grad_in) and the column sums are taken of the masked gradient, i.e.

@@ -122,6 +122,19 @@ def merge_mean_var(means, vars_):
     return mean, var
 
 
+# ------------------------------------------------------------------------------------------ policy statistics
+def policy_stats(old_mean, old_std, new_mean, new_std, action, old_logp, advantage):
+    """cusrl/hook/on_policy/stats.py:28-40 for a Normal policy: (mean KL(old || new) summed over action dims,
+    mean advantage * exp(logp_new(action) - old_logp), mean new_std), computed in float64."""
+    mp, sp, mq, sq, x = (np.asarray(a, np.float64) for a in (old_mean, old_std, new_mean, new_std, action))
+    var_ratio = (sp / sq) ** 2  # torch.distributions.kl._kl_normal_normal
+    kl = (0.5 * (var_ratio + ((mp - mq) / sq) ** 2 - 1.0 - np.log(var_ratio))).sum(-1)
+    logp = (-((x - mq) ** 2) / (2.0 * sq**2) - np.log(sq) - 0.5 * np.log(2.0 * np.pi)).sum(-1)
+    weight = np.exp(logp - np.asarray(old_logp, np.float64).reshape(-1))
+    advantage = np.asarray(advantage, np.float64).reshape(weight.size, -1)
+    return float(kl.mean()), float((advantage * weight[:, None]).mean()), float(sq.mean())
+
+
 # ------------------------------------------------------------------------------------------ gradient clipping
 def clip_grad_norm(grad, max_norm):
     """cusrl/hook/on_policy/gradient_clipping.py:67-83 -> torch.nn.utils.clip_grad_norm_ (norm_type 2):

@@ -496,6 +496,23 @@ def test_assemble_gradients_sums_slabs_into_slots(ops):
     np.testing.assert_array_equal(got[:offset], expect[:offset])
 
 
+@pytest.mark.parametrize("B,A,D", [(98304, 12, 1), (1000, 7, 1), (3, 40, 2), (257, 4, 3)])
+def test_policy_stats_vs_oracle(ops, B, A, D):
+    rng = np.random.default_rng(B + A + D)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    mp, sp = f(B, A), (rng.random((B, A)) + 0.5).astype(np.float32)
+    mq, sq = mp + 0.05 * f(B, A), (sp * np.exp(0.05 * f(B, A))).astype(np.float32)  # an updated policy: close to the old
+    action = (mp + sp * f(B, A)).astype(np.float32)
+    old_logp, _ = oracle.normal_logp_entropy(action, mp, sp)
+    advantage = f(B, D)
+    got = host(ops.policy_stats(*(dev(x) for x in (mp, sp, mq, sq, action, old_logp, advantage))))
+    want = oracle.policy_stats(mp, sp, mq, sq, action, old_logp, advantage)
+    # the KL of two close Gaussians cancels to ~1e-3 of its terms: absolute fp32 error of the per-element terms
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-4, atol=2e-7 * A)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got[2], want[2], rtol=1e-6)
+
+
 def test_fused_linear_paths_match_plain_autograd():
     from cusrl_amd.nn.module import Mlp
 

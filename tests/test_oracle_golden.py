@@ -260,3 +260,22 @@ def test_adam_step_matches_torch_optimizer(cls_name, weight_decay):
     state = optimizer.state[reference]
     np.testing.assert_allclose(exp_avg, state["exp_avg"].numpy(), rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(exp_avg_sq, state["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-10)
+
+
+def test_policy_stats_matches_torch_distributions():
+    """OnPolicyStatistics (stats.py:28-40) goes through torch.distributions for Normal policies."""
+    import torch
+    from torch.distributions import Normal, kl_divergence
+
+    rng = np.random.default_rng(5)
+    B, A = 257, 6
+    mp, mq = rng.standard_normal((B, A)).astype(np.float32), rng.standard_normal((B, A)).astype(np.float32)
+    sp, sq = (rng.random((B, A)) + 0.5).astype(np.float32), (rng.random((B, A)) + 0.5).astype(np.float32)
+    action = (mp + sp * rng.standard_normal((B, A))).astype(np.float32)
+    advantage = rng.standard_normal((B, 1)).astype(np.float32)
+    p, q = Normal(torch.from_numpy(mp), torch.from_numpy(sp)), Normal(torch.from_numpy(mq), torch.from_numpy(sq))
+    old_logp = p.log_prob(torch.from_numpy(action)).sum(-1, keepdim=True)
+    kl = kl_divergence(p, q).sum(-1, keepdim=True).mean().item()
+    iw = (torch.from_numpy(advantage) * (q.log_prob(torch.from_numpy(action)).sum(-1, keepdim=True) - old_logp).exp()).mean().item()
+    got = oracle.policy_stats(mp, sp, mq, sq, action, old_logp.numpy(), advantage)
+    np.testing.assert_allclose(got, (kl, iw, float(sq.mean())), rtol=2e-5)
