@@ -268,7 +268,10 @@ __global__ __launch_bounds__(kBlock) void compact_flags_kernel(const uint8_t *__
         for (int j = 0; j < 16; ++j)
             if ((w[j >> 2] >> (8 * (j & 3))) & 1u) indices_out[pos++] = base + j;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count_out = block_offset + total;
+    // system-scope store: `count_out` may be pinned HOST memory that the caller polls instead of paying a device->host
+    // copy + stream synchronisation; consumers of indices_out are stream-ordered behind this kernel either way
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        __hip_atomic_store(count_out, block_offset + total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // --------------------------------------------------------------------------------------------- scatter
@@ -389,7 +392,7 @@ extern "C" int cusrl_compact_flags(const uint8_t *flags, int64_t n, int32_t *blo
     if (!flags || !block_counts || !indices_out) return CUSRL_E_INVALID;
     const int64_t blocks = cusrl_flag_blocks(n);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
-    if (recount) {
+    if (recount && blocks > 1) {  // a single block never reads the per-block counts (its offset is 0)
         hipLaunchKernelGGL(count_flags_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), flags, n,
                            block_counts);
         if (int rc = launch_status()) return rc;

@@ -147,6 +147,7 @@ class Trainer:
         self.trial_metadata = dict(trial_metadata or {})
         self.timer = Timer(self.agent.device)
         self.last_info: dict[str, float] = {}
+        self._done_counter = None
 
     def run_training_loop(self):
         try:
@@ -202,17 +203,19 @@ class Trainer:
             hook.post_update()
         return observation, state
 
-    @staticmethod
-    def _done_indices(done: torch.Tensor) -> torch.Tensor:
+    def _done_indices(self, done: torch.Tensor) -> torch.Tensor:
         """``done.squeeze(-1).nonzero().squeeze(-1)`` (environment.py get_done_indices) on the device: ordered stream
-        compaction in two launches + one 4-byte read-back, instead of torch's four-kernel nonzero on the step's
-        critical path (the host waits for this result before it can issue the next act)."""
+        compaction in two launches whose count lands in pinned host memory that the host polls — instead of torch's
+        four-kernel nonzero + copy + stream synchronisation on the step's critical path (the host needs this number
+        before it can issue the resets and the next act)."""
         from cusrl_amd import ops
 
         if done.dtype != torch.bool or not done.is_contiguous():
             return done.reshape(-1).nonzero().reshape(-1)
-        indices, count = ops.compact_flags(done)
-        return indices[: int(count.item())]
+        if self._done_counter is None:
+            self._done_counter = ops.HostCounter()
+        indices, _ = ops.compact_flags(done, count_out=self._done_counter.arm())
+        return indices[: self._done_counter.wait()]
 
     def _save_checkpoint(self):
         if self.logger is None or not distributed.is_main_process():

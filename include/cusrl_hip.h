@@ -63,7 +63,9 @@ int64_t cusrl_flag_blocks(int64_t n);
 /* Ordered stream compaction of a flag array (replaces `next_state[truncated]` boolean-mask indexing,
  * value.py:75): indices_out[0..count) = ascending flat slots with flags != 0, *count_out = count.
  * `block_counts` must have been filled by cusrl_next_value over the same flags, or pass recount != 0
- * to have this call count first. */
+ * to have this call count first.  `count_out` is written with a system-scope store and may point to pinned host
+ * memory (device-mapped): the host can then poll it instead of a device->host copy + stream synchronisation (the
+ * trainer's per-step read of the finished-env count, trainer.py:365-372). */
 int cusrl_compact_flags(const uint8_t *flags, int64_t n, int32_t *block_counts, int recount,
                         int64_t *indices_out, int32_t *count_out, void *stream);
 
