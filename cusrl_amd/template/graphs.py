@@ -97,6 +97,15 @@ class GraphedTrainStep:
         self.forward_backward = _Capture(agent)
         self.optimize = _Capture(agent)
         self.carry: dict[str, Any] = {}
+        # one process: nothing has to run between backward and the optimizer step, so the whole minibatch step is ONE
+        # graph; with several ranks the gradient all-reduce (RCCL, eager) sits between two graphs
+        from cusrl_amd.utils.distributed import configure_distributed
+
+        self.single_graph = not configure_distributed()
+
+    def _whole_step(self):
+        self._phase_a()
+        self._phase_b()
 
     # the two phases, written once and used for the eager warm-up, the capture and (implicitly) the replays
     def _phase_a(self):
@@ -138,8 +147,9 @@ class GraphedTrainStep:
             agent.flat_optimizer.refresh()  # learning-rate changes reach the captured step through device memory
         if self.state == 2:
             self.forward_backward.replay()
-            reduce_gradients(agent.optimizer, agent.flat_gradients)
-            self.optimize.replay()
+            if not self.single_graph:
+                reduce_gradients(agent.optimizer, agent.flat_gradients)
+                self.optimize.replay()
             return
         if self.state == 0:  # eager on the capture stream: warms rocBLAS / allocator and performs this real step
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -150,6 +160,11 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.carry = {}
             self.state = 1
+            return
+        if self.single_graph:
+            self.forward_backward.capture(self._whole_step, self.stream, pool=agent._graph_pool)
+            self.state = 2
+            self.forward_backward.replay()
             return
         self.forward_backward.capture(self._phase_a, self.stream, pool=agent._graph_pool)
         self.optimize.capture(self._phase_b, self.stream, pool=agent._graph_pool)
