@@ -98,7 +98,6 @@ def pmc_traffic(envs_per_gpu):
 def run_gpu(args, rank, world):
     import cusrl_amd as cusrl
     from cusrl_amd import ops
-    from cusrl_amd.utils import distributed
 
     device = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}")
     torch.cuda.set_device(device)

@@ -7,7 +7,7 @@ The library is the product: there is no CPU or eager fallback.  If it has not be
 from __future__ import annotations
 
 import ctypes
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "libcusrl_hip.so"

@@ -8,7 +8,6 @@ that buffer (``cusrl_clip_grad_norm``: norm and scale in two launches) instead o
 
 from __future__ import annotations
 
-import torch
 from torch import nn
 
 from cusrl_amd import ops

@@ -8,7 +8,6 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Any
 
-import torch
 from torch import Tensor, nn
 
 from cusrl_amd.nn import recurrent

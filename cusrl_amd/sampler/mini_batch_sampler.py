@@ -12,7 +12,6 @@ stream on a GPU buffer (indices are then uploaded, 8 B per sample).  The gather 
 from __future__ import annotations
 
 from collections.abc import Sequence
-from typing import Any
 
 import torch
 
