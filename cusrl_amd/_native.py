@@ -52,7 +52,7 @@ _SIGNATURES = {
     "cusrl_gather_rows": (c_int, [POINTER(Field), c_int, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_ppo_loss_fwd_bwd": (
         c_int,
-        [_P] * 8 + [c_int64] * 3 + [c_double] * 5 + [_P] * 8 + [_P, _P],
+        [_P] * 8 + [c_int64] * 3 + [c_double] * 5 + [_P] * 8 + [_P, c_int64, _P, _P],
     ),
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
     "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),

@@ -98,17 +98,25 @@ __device__ __forceinline__ void write_block_partials(const double (&acc)[kLossSu
 
 constexpr int kRowsPerBlock = kBlock;
 
-template <int LPR>
+// kStdVec: `std` is ONE row [A] shared by every sample (a state-independent std vector, distribution.py:228-247)
+// instead of a [B, A] matrix: it is read from L1 instead of streamed, and d_std leaves the kernel as per-block
+// column sums [A] (the gradient of the vector) instead of a [B, A] matrix that a sum(0) launch would have to reduce —
+// 96 of the 264 bytes per sample disappear.
+constexpr int kStdRowGroups = 16;
+
+template <int LPR, bool kStdVec>
 __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
     const float *__restrict__ advantage, const float *__restrict__ old_logp, const float *__restrict__ action,
     const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ ret,
     const float *__restrict__ curr_value, const float *__restrict__ old_value, int64_t B, int D, LossParams p,
     float *__restrict__ logp_out, float *__restrict__ entropy_out, float *__restrict__ lr_out,
     float *__restrict__ ratio_out, float *__restrict__ d_mean, float *__restrict__ d_std,
-    float *__restrict__ d_value, double *__restrict__ partials) {
+    float *__restrict__ d_value, double *__restrict__ partials, float *__restrict__ d_std_partials) {
     __shared__ float lp_part[kRowsPerBlock * LPR];
     __shared__ float en_part[kRowsPerBlock * LPR];
     __shared__ float dlp_row[kRowsPerBlock];
+    __shared__ float4 ds_stage[kStdVec ? kRowsPerBlock * LPR : 1];   // this block's d_std chunks, row-major
+    __shared__ float4 ds_group[kStdVec ? kStdRowGroups * LPR : 1];  // column sums of 16 row groups
     const int64_t row0 = int64_t(blockIdx.x) * kRowsPerBlock;
     const int64_t chunk0 = row0 * LPR;
     const int64_t total_chunks = B * LPR;
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
         if (q < total_chunks) {
             x[k] = x4[q];
             mu[k] = m4[q];
-            sg[k] = s4[q];
+            sg[k] = s4[kStdVec ? int64_t((k * kBlock + int(threadIdx.x)) % LPR) : q];  // chunk0 is a multiple of LPR
         }
     }
 #pragma unroll
@@ -176,6 +184,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
     for (int k = 0; k < LPR; ++k) {
         const int local = k * kBlock + threadIdx.x;
         const int64_t q = chunk0 + local;
+        if (kStdVec && q >= total_chunks) ds_stage[local] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < total_chunks) {
             const float dlp = dlp_row[local / LPR];
             const float xs[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
@@ -189,7 +198,32 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
                 gs[j] = dlp * ((diff * diff) / (var * ss[j]) - 1.0f / ss[j]) + p.g_ent / ss[j];  // + d entropy / d std
             }
             if (d_mean) dm4[q] = make_float4(gm[0], gm[1], gm[2], gm[3]);
-            if (d_std) ds4[q] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+            if (kStdVec)
+                ds_stage[local] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+            else if (d_std)
+                ds4[q] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+        }
+    }
+    if (kStdVec) {  // column sums of the block's [256, A] d_std tile, fixed order: 16 row groups, then the groups
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < kStdRowGroups * LPR) {
+            const int c = t % LPR, g = t / LPR;
+            float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = g; r < kRowsPerBlock; r += kStdRowGroups) {
+                const float4 v = ds_stage[r * LPR + c];
+                total.x += v.x, total.y += v.y, total.z += v.z, total.w += v.w;
+            }
+            ds_group[g * LPR + c] = total;
+        }
+        __syncthreads();
+        if (t < LPR && d_std_partials) {
+            float4 total = ds_group[t];
+            for (int g = 1; g < kStdRowGroups; ++g) {
+                const float4 v = ds_group[g * LPR + t];
+                total.x += v.x, total.y += v.y, total.z += v.z, total.w += v.w;
+            }
+            reinterpret_cast<float4 *>(d_std_partials)[int64_t(blockIdx.x) * LPR + t] = total;
         }
     }
     write_block_partials(acc, partials);
@@ -232,8 +266,15 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowwise_kernel(
 
 __global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double *__restrict__ partials, int64_t P,
                                                                    int64_t B, int D, LossParams p,
-                                                                   float *__restrict__ losses_out) {
+                                                                   float *__restrict__ losses_out,
+                                                                   const float *__restrict__ d_std_partials, int A,
+                                                                   float *__restrict__ d_std_vector) {
     __shared__ double scratch[kWavesPerBlock];
+    if (d_std_partials && int(threadIdx.x) < A) {  // std-vector mode: gradient of the vector = sum of the block sums
+        float total = 0.f;
+        for (int64_t i = 0; i < P; ++i) total += d_std_partials[i * A + threadIdx.x];
+        d_std_vector[threadIdx.x] = total;
+    }
     double sums[kLossSums];
 #pragma unroll
     for (int k = 0; k < kLossSums; ++k) {
@@ -259,18 +300,27 @@ using namespace cusrl;
 
 extern "C" int64_t cusrl_ppo_loss_num_partials(int64_t B) { return B <= 0 ? 0 : ceil_div(B, kRowsPerBlock); }
 
-#define CUSRL_LAUNCH_CHUNKED(LPR)                                                                                     \
-    hipLaunchKernelGGL(ppo_loss_chunked_kernel<LPR>, dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, old_logp, \
-                       action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out, entropy_out,            \
-                       logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials)
+#define CUSRL_LAUNCH_CHUNKED(LPR)                                                                                      \
+    if (std_vector)                                                                                                    \
+        hipLaunchKernelGGL((ppo_loss_chunked_kernel<LPR, true>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, \
+                           old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out,            \
+                           entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials);  \
+    else                                                                                                               \
+        hipLaunchKernelGGL((ppo_loss_chunked_kernel<LPR, false>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s,           \
+                           advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out, \
+                           entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials)
 
 extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action,
                                       const float *mean, const float *std, const float *ret, const float *curr_value,
                                       const float *old_value, int64_t B, int64_t A, int64_t D, double clip,
                                       double value_clip, double w_sur, double w_val, double w_ent, float *losses_out,
                                       float *logp_out, float *entropy_out, float *logp_ratio_out, float *ratio_out,
-                                      float *d_mean, float *d_std, float *d_value, double *partials, void *stream) {
+                                      float *d_mean, float *d_std, float *d_value, double *partials,
+                                      int64_t std_rows, float *d_std_partials, void *stream) {
     if (B <= 0 || A <= 0 || D <= 0) return CUSRL_E_INVALID;
+    if (std_rows != B && std_rows != 1) return CUSRL_E_INVALID;
+    const bool std_vector = std_rows == 1 && B != 1;
+    if (std_vector && d_std && !d_std_partials) return CUSRL_E_INVALID;
     if (!advantage || !old_logp || !action || !mean || !std || !ret || !curr_value || !losses_out || !partials)
         return CUSRL_E_INVALID;
     if (value_clip >= 0.0 && !old_value) return CUSRL_E_INVALID;
@@ -290,6 +340,7 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     const bool chunked = A % 4 == 0 && A / 4 <= 8 && aligned(action, 16) && aligned(mean, 16) && aligned(std, 16) &&
                          (!d_mean || aligned(d_mean, 16)) && (!d_std || aligned(d_std, 16));
+    if (std_vector && !chunked) return CUSRL_E_UNSUPPORTED;  // the row-vector form exists for the 16-byte-chunk layout
     if (chunked) {
         switch (A / 4) {
             case 1: CUSRL_LAUNCH_CHUNKED(1); break;
@@ -308,6 +359,6 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
     }
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, partials, blocks, B, int(D), p,
-                       losses_out);
+                       losses_out, (std_vector && d_std) ? d_std_partials : nullptr, int(A), d_std);
     return launch_status();
 }

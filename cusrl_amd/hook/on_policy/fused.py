@@ -152,8 +152,12 @@ class FusedPpoObjective:
         curr_value, old_value, ret, w_val, value_clip = self.value
         action_dist, action, old_logp = self.policy
         advantage, clip, w_sur = self.surrogate
+        std = action_dist["std"]
+        row_vector = getattr(std, "_cusrl_row_vector", None)
+        if row_vector is not None and std.dim() == 2 and std.stride(0) == 0 and ops.ppo_loss_accepts_std_vector(std.shape[-1]):
+            std = row_vector  # the [A] vector the batch view repeats: broadcast inside the kernel, d_std comes back as [A]
         total, losses, logp, entropy, logp_ratio, ratio = _FusedPpoFunction.apply(
-            action_dist["mean"], action_dist["std"], curr_value, advantage, old_logp, action, ret, old_value,
+            action_dist["mean"], std, curr_value, advantage, old_logp, action, ret, old_value,
             clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad,
         )
         batch["curr_action_logp"] = logp

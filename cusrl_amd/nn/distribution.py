@@ -179,6 +179,14 @@ class StddevVector(nn.Module):
 
     def forward(self, input: Tensor):
         with disable_autocast(input.device.type):
+            if torch.is_grad_enabled() and self.param.requires_grad and input.is_cuda:
+                # training: the bijector runs on the [A] vector and the batch sees a stride-0 view of it (no repeat
+                # launch, no [B, A] gradient for sum(0) to reduce); the fused PPO objective picks the vector up
+                # through `_cusrl_row_vector` and gets d_std as an [A] vector straight from its kernel
+                vector = self.bijector(self.param.float()).float()
+                expanded = vector.expand(*input.shape[:-1], -1)
+                expanded._cusrl_row_vector = vector
+                return expanded
             return self.bijector(self.param.float().repeat(*input.shape[:-1], 1)).float()
 
 

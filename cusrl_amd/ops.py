@@ -416,14 +416,21 @@ def ppo_loss_fwd_bwd(
     want_grads: bool = True,
 ) -> dict[str, torch.Tensor]:
     """One pass: losses[0:3] = (value, surrogate, entropy) weighted losses, losses[3:6] = means of |logp ratio|, entropy
-    and value (the metrics of common.py:45-49 / value.py:139-141), losses[6] = their sum, per-sample logp/entropy/ratios, and the gradients."""
+    and value (the metrics of common.py:45-49 / value.py:139-141), losses[6] = their sum, per-sample logp/entropy/ratios, and the gradients.
+
+    ``std`` is either the ``[B, A]`` matrix or the ``[A]`` vector it repeats (a state-independent std,
+    :func:`ppo_loss_accepts_std_vector`): then it is broadcast inside the kernel and ``d_std`` is the ``[A]`` gradient of
+    the vector."""
     advantage, old_logp = _f32(advantage, "advantage"), _f32(old_logp, "action_logp")
     action, mean, std = _f32(action, "action"), _f32(mean, "mean"), _f32(std, "std")
     ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
     A = mean.shape[-1]
     B = mean.numel() // A
     D = ret.shape[-1]
-    if advantage.numel() != B or old_logp.numel() != B or action.shape != mean.shape or std.shape != mean.shape:
+    std_vector = std.dim() == 1 and B != 1
+    if std_vector and not (std.numel() == A and ppo_loss_accepts_std_vector(A)):
+        raise ValueError("ppo_loss: a std vector must have one entry per action dim (and the action width a multiple of 4, <= 32)")
+    if advantage.numel() != B or old_logp.numel() != B or action.shape != mean.shape or (not std_vector and std.numel() != B * A):
         raise ValueError("ppo_loss: inconsistent batch shapes")
     if ret.numel() != B * D or curr_value.shape != ret.shape:
         raise ValueError("ppo_loss: return / value shapes differ")
@@ -442,23 +449,31 @@ def ppo_loss_fwd_bwd(
     }
     if want_grads:
         out["d_mean"], out["d_std"], out["d_value"] = torch.empty_like(mean), torch.empty_like(std), torch.empty_like(curr_value)
-    partials = torch.empty((int(lib.cusrl_ppo_loss_num_partials(B)), 5), dtype=torch.float64, device=dev)
+    num_partials = int(lib.cusrl_ppo_loss_num_partials(B))
+    partials = torch.empty((num_partials, 5), dtype=torch.float64, device=dev)
+    std_partials = torch.empty((num_partials, A), dtype=torch.float32, device=dev) if std_vector and want_grads else None
 
     def ptr(name):
         return out[name].data_ptr() if name in out else None
 
     _observed(
         "cusrl_ppo_loss_fwd_bwd",
-        lambda: B * (8 + 12 * A + 8 * D + (8 * A + 4 * D if want_grads else 0) + 16 + (4 * D if value_clip is not None else 0)),
+        lambda: B * (8 + (8 if std_vector else 12) * A + 8 * D + ((4 if std_vector else 8) * A + 4 * D if want_grads else 0) + 16
+                     + (4 * D if value_clip is not None else 0)),
         lambda: lib.cusrl_ppo_loss_fwd_bwd(
             advantage.data_ptr(), old_logp.data_ptr(), action.data_ptr(), mean.data_ptr(), std.data_ptr(),
             ret.data_ptr(), curr_value.data_ptr(), None if old_value is None or value_clip is None else old_value.data_ptr(),
             B, A, D, float(clip), -1.0 if value_clip is None else float(value_clip), float(w_sur), float(w_val), float(w_ent),
             ptr("losses"), ptr("logp"), ptr("entropy"), ptr("logp_ratio"), ptr("ratio"), ptr("d_mean"), ptr("d_std"), ptr("d_value"),
-            partials.data_ptr(), _stream(),
+            partials.data_ptr(), 1 if std_vector else B, None if std_partials is None else std_partials.data_ptr(), _stream(),
         ),
     )
     return out
+
+
+def ppo_loss_accepts_std_vector(action_dim: int) -> bool:
+    """The row-vector form of ``std`` exists for the 16-byte-chunk layout of the loss kernel."""
+    return action_dim % 4 == 0 and action_dim // 4 <= 8
 
 
 # ------------------------------------------------------------------------------------------------ rollout side

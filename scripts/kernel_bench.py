@@ -126,6 +126,9 @@ def bench_size(N, T=24, obs=48, act=12, mbs=4, only=None, iters=None):
     kw = dict(clip=0.2, value_clip=None, w_sur=1.0, w_val=0.5, w_ent=0.01)
     loss_bytes = B * (8 + 3 * 4 * act + 8 + 2 * 4 * act + 4 + 16)
     rows.measure(f"ppo loss fwd+bwd (B={B})", lambda: ops.ppo_loss_fwd_bwd(*a.values(), **kw), loss_bytes)
+    if ops.ppo_loss_accepts_std_vector(act):  # state-independent std handed over as its [A] vector (the ppo preset's case)
+        v = dict(a, std=torch.rand(act, device=DEV) + 0.5)
+        rows.measure(f"ppo loss fwd+bwd, std vector (B={B})", lambda: ops.ppo_loss_fwd_bwd(*v.values(), **kw), loss_bytes - B * 8 * act)
 
     # ---- MLP backward epilogues and the optimizer-side kernels of one minibatch step
     g256, y256 = f(B, 256), torch.relu(f(B, 256))

@@ -496,6 +496,31 @@ def test_assemble_gradients_sums_slabs_into_slots(ops):
     np.testing.assert_array_equal(got[:offset], expect[:offset])
 
 
+@pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 4, 2), (257, 32, 1), (2, 8, 1)])
+@pytest.mark.parametrize("vclip", [None, 0.2])
+def test_ppo_loss_std_vector_equals_repeated_matrix(ops, B, A, D, vclip):
+    """A state-independent std passed as its [A] vector: same forward numbers as the repeated [B, A] matrix, d_std =
+    the column sums of the matrix form's d_std."""
+    rng = np.random.default_rng(B * A)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    mean, adv, ret = f(B, A), f(B, 1), f(B, D)
+    vector = (rng.random(A) + 0.5).astype(np.float32)
+    matrix = np.repeat(vector[None], B, 0)
+    action = (mean + matrix * f(B, A)).astype(np.float32)
+    curr_value, old_value = ret + 0.3 * f(B, D), ret + 0.3 * f(B, D)
+    old_logp, _ = oracle.normal_logp_entropy(action, mean + 0.02 * f(B, A), matrix)
+    kw = dict(clip=0.2, value_clip=vclip, w_sur=1.0, w_val=0.5, w_ent=0.01)
+    args = lambda std: tuple(dev(x) for x in (adv, old_logp, action, mean, std, ret, curr_value, old_value))  # noqa: E731
+    full = ops.ppo_loss_fwd_bwd(*args(matrix), **kw)
+    vec = ops.ppo_loss_fwd_bwd(*args(vector), **kw)
+    assert ops.ppo_loss_accepts_std_vector(A) and vec["d_std"].shape == (A,)
+    for key in ("losses", "logp", "entropy", "ratio", "logp_ratio", "d_mean", "d_value"):
+        assert torch.equal(vec[key], full[key]), key  # same arithmetic per element and the same reduction order
+    want = full["d_std"].double().sum(0)
+    torch.testing.assert_close(vec["d_std"].double(), want, rtol=1e-5, atol=1e-5 * float(full["d_std"].abs().sum(0).max()))
+    assert not ops.ppo_loss_accepts_std_vector(7)
+
+
 @pytest.mark.parametrize("B,A,D", [(98304, 12, 1), (1000, 7, 1), (3, 40, 2), (257, 4, 3)])
 def test_policy_stats_vs_oracle(ops, B, A, D):
     rng = np.random.default_rng(B + A + D)
