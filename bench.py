@@ -45,6 +45,8 @@ def parse_args():
     parser.add_argument("--no-observer", action="store_true", help="do not bracket eager launches with HIP events")
     parser.add_argument("--autoreset", action="store_true",
                         help="env resets finished instances itself (no per-step index read-back in the trainer)")
+    parser.add_argument("--no-pin", action="store_true",
+                        help="leave the host thread unpinned (default: 8 CPUs of the GPU's NUMA node, cusrl_amd/utils/affinity.py)")
     return parser.parse_args()
 
 
@@ -99,8 +101,14 @@ def run_gpu(args, rank, world):
     import cusrl_amd as cusrl
     from cusrl_amd import ops
 
-    device = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}")
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
+    pinned = []
+    if not args.no_pin:
+        from cusrl_amd.utils.affinity import pin_host_thread
+
+        pinned = pin_host_thread(local_rank, cores=8, slot=local_rank)
     cusrl.config.set_device(device)
     if world > 1:
         cusrl.utils.configure_distributed()
@@ -198,6 +206,7 @@ def run_gpu(args, rank, world):
             "parallelism": f"dp{world}",
             "hipgraph": not args.eager,
             "autoreset": args.autoreset,
+            "host_thread_cpus": pinned,
         },
         "ppo_update_ms": round(update_ms, 3),
         "roofline": {
@@ -277,7 +286,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    all_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     result = run_gpu(args, rank, world)
+    if all_cpus is not None:
+        os.sched_setaffinity(0, all_cpus)  # the CPU baseline below gets every core back
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = run_cpu_baseline(args)

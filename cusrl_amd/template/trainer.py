@@ -122,7 +122,8 @@ class Trainer:
     def __init__(self, environment: Environment | Callable[[], Environment], agent_factory: AgentFactory,
                  logger_factory: Callable[[], Any] | None = None, num_iterations: int = 1000,
                  init_iteration: int | None = None, checkpoint_interval: int = 50, checkpoint_path: str | None = None,
-                 trial_metadata: Mapping[str, Any] | None = None, verbose: bool = True, hooks: Iterable[TrainerHook] = ()):
+                 trial_metadata: Mapping[str, Any] | None = None, verbose: bool = True, hooks: Iterable[TrainerHook] = (),
+                 pin_host_thread: bool = False):
         self.logger = None if logger_factory is None else logger_factory()
         self.environment = environment if isinstance(environment, Environment) else environment()
         self.agent: Agent = agent_factory.from_environment(self.environment)
@@ -147,6 +148,12 @@ class Trainer:
         self.trial_metadata = dict(trial_metadata or {})
         self.timer = Timer(self.agent.device)
         self.last_info: dict[str, float] = {}
+        self.host_thread_cpus: list[int] = []
+        if pin_host_thread and self.agent.device.type == "cuda":  # extension: NUMA-local placement of the driving thread
+            from cusrl_amd.utils.affinity import pin_host_thread as pin
+
+            index = self.agent.device.index if self.agent.device.index is not None else torch.cuda.current_device()
+            self.host_thread_cpus = pin(index, slot=distributed.local_rank())
         self._done_counter = None
 
     def run_training_loop(self):

@@ -2,6 +2,7 @@
 host-side validation mirrors the reference's error behaviour, the plugin surface composes like the reference's, and the
 hot path refuses to run anywhere but on the GPU."""
 
+import os
 import re
 from pathlib import Path
 from types import SimpleNamespace
@@ -297,3 +298,20 @@ def test_ppo_preset_includes_the_adaptive_lr_schedule_when_asked():
     suite = cusrl_amd.preset.ppo_hook_suite(desired_kl_divergence=0.01, max_kl_divergence=0.05)
     assert type(suite[-1]) is cusrl_amd.hook.AdaptiveLRSchedule and suite[-1].max_kl_divergence == 0.05
     assert not any(isinstance(h, cusrl_amd.hook.AdaptiveLRSchedule) for h in cusrl_amd.preset.ppo_hook_suite())
+
+
+def test_affinity_cpu_list_parsing_and_noop_without_topology(monkeypatch):
+    from cusrl_amd.utils import affinity
+
+    assert affinity._parse_cpu_list("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert affinity._parse_cpu_list("") == []
+    monkeypatch.setattr(affinity, "device_local_cpus", lambda index: [])
+    before = os.sched_getaffinity(0)
+    assert affinity.pin_host_thread(0) == [] and os.sched_getaffinity(0) == before  # unknown topology: left alone
+    cpus = sorted(before)
+    if len(cpus) >= 2:
+        monkeypatch.setattr(affinity, "device_local_cpus", lambda index: cpus)
+        try:
+            assert affinity.pin_host_thread(0, cores=1, slot=1) == [cpus[1]] and os.sched_getaffinity(0) == {cpus[1]}
+        finally:
+            os.sched_setaffinity(0, before)
