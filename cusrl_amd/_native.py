@@ -55,6 +55,7 @@ _SIGNATURES = {
         [_P] * 8 + [c_int64] * 3 + [c_double] * 5 + [_P] * 8 + [_P, c_int64, _P, _P],
     ),
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
+    "cusrl_ppo_loss_std_partial_rows": (c_int64, [c_int64]),
     "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
     "cusrl_episode_stats": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, _P]),
     "cusrl_policy_stats": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P, _P, _P]),

@@ -264,17 +264,53 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowwise_kernel(
     write_block_partials(acc, partials);
 }
 
+// Column sums of `rows` partial rows [rows][A] (A <= 32) by one block, fixed order: lane (a, g) walks rows g, g + 8, ...
+// four loads at a time, the 8 row groups are combined through LDS.  out[a] for a < A.
+constexpr int kStdSliceRows = 128;  // partial rows one block of the staged reduction takes
+
+__device__ __forceinline__ void reduce_std_rows(const float *__restrict__ in, int64_t rows, int A,
+                                                float *__restrict__ out) {
+    __shared__ float part[kBlock];
+    const int a = threadIdx.x & 31, g = threadIdx.x >> 5;
+    float total = 0.f;
+    if (a < A) {
+        int64_t r = g;
+        for (; r + 24 < rows; r += 32) {
+            const float v0 = in[r * A + a], v1 = in[(r + 8) * A + a], v2 = in[(r + 16) * A + a], v3 = in[(r + 24) * A + a];
+            total += (v0 + v1) + (v2 + v3);
+        }
+        for (; r < rows; r += 8) total += in[r * A + a];
+    }
+    part[threadIdx.x] = total;
+    __syncthreads();
+    if (g == 0 && a < A) {
+        float sum = part[a];
+#pragma unroll
+        for (int k = 1; k < kBlock / 32; ++k) sum += part[k * 32 + a];
+        out[a] = sum;
+    }
+    __syncthreads();
+}
+
+// Staged form for many partial rows: block b reduces rows [b * 128, b * 128 + 128) into stage[b][A].
+__global__ __launch_bounds__(kBlock) void std_rows_stage_kernel(const float *__restrict__ in, int64_t rows, int A,
+                                                                float *__restrict__ stage) {
+    const int64_t first = int64_t(blockIdx.x) * kStdSliceRows;
+    reduce_std_rows(in + first * A, min(int64_t(kStdSliceRows), rows - first), A, stage + int64_t(blockIdx.x) * A);
+}
+
+__global__ __launch_bounds__(kBlock) void std_rows_final_kernel(const float *__restrict__ stage, int64_t rows, int A,
+                                                                float *__restrict__ out) {
+    reduce_std_rows(stage, rows, A, out);
+}
+
 __global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double *__restrict__ partials, int64_t P,
                                                                    int64_t B, int D, LossParams p,
                                                                    float *__restrict__ losses_out,
                                                                    const float *__restrict__ d_std_partials, int A,
                                                                    float *__restrict__ d_std_vector) {
     __shared__ double scratch[kWavesPerBlock];
-    if (d_std_partials && int(threadIdx.x) < A) {  // std-vector mode: gradient of the vector = sum of the block sums
-        float total = 0.f;
-        for (int64_t i = 0; i < P; ++i) total += d_std_partials[i * A + threadIdx.x];
-        d_std_vector[threadIdx.x] = total;
-    }
+    if (d_std_partials) reduce_std_rows(d_std_partials, P, A, d_std_vector);  // std-vector mode, few blocks
     double sums[kLossSums];
 #pragma unroll
     for (int k = 0; k < kLossSums; ++k) {
@@ -299,6 +335,11 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double 
 using namespace cusrl;
 
 extern "C" int64_t cusrl_ppo_loss_num_partials(int64_t B) { return B <= 0 ? 0 : ceil_div(B, kRowsPerBlock); }
+
+extern "C" int64_t cusrl_ppo_loss_std_partial_rows(int64_t B) {
+    const int64_t blocks = cusrl_ppo_loss_num_partials(B);
+    return blocks + (blocks > kStdSliceRows ? ceil_div(blocks, kStdSliceRows) : 0);
+}
 
 #define CUSRL_LAUNCH_CHUNKED(LPR)                                                                                      \
     if (std_vector)                                                                                                    \
@@ -358,7 +399,20 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
                            logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials);
     }
     if (int rc = launch_status()) return rc;
+    // gradient of the std vector = column sums of the per-block sums: inside the finalize launch for up to 128 blocks
+    // (a 32 768-row minibatch), staged over 128-row slices beyond that
+    const bool reduce_std = std_vector && d_std;
+    const bool staged = reduce_std && blocks > kStdSliceRows;
     hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, partials, blocks, B, int(D), p,
-                       losses_out, (std_vector && d_std) ? d_std_partials : nullptr, int(A), d_std);
+                       losses_out, (reduce_std && !staged) ? d_std_partials : nullptr, int(A), d_std);
+    if (int rc = launch_status()) return rc;
+    if (staged) {
+        const int64_t slices = ceil_div(blocks, kStdSliceRows);
+        float *stage = d_std_partials + blocks * A;  // the workspace holds the slices' rows behind the blocks' rows
+        hipLaunchKernelGGL(std_rows_stage_kernel, dim3(uint32_t(slices)), dim3(kBlock), 0, s, d_std_partials, blocks,
+                           int(A), stage);
+        if (int rc = launch_status()) return rc;
+        hipLaunchKernelGGL(std_rows_final_kernel, dim3(1), dim3(kBlock), 0, s, stage, slices, int(A), d_std);
+    }
     return launch_status();
 }

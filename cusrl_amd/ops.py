@@ -451,7 +451,8 @@ def ppo_loss_fwd_bwd(
         out["d_mean"], out["d_std"], out["d_value"] = torch.empty_like(mean), torch.empty_like(std), torch.empty_like(curr_value)
     num_partials = int(lib.cusrl_ppo_loss_num_partials(B))
     partials = torch.empty((num_partials, 5), dtype=torch.float64, device=dev)
-    std_partials = torch.empty((num_partials, A), dtype=torch.float32, device=dev) if std_vector and want_grads else None
+    std_partials = (torch.empty((int(lib.cusrl_ppo_loss_std_partial_rows(B)), A), dtype=torch.float32, device=dev)
+                    if std_vector and want_grads else None)
 
     def ptr(name):
         return out[name].data_ptr() if name in out else None

@@ -123,7 +123,7 @@ int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, const int64_t *
  * std_rows = B: `std` is the [B,A] matrix of the reference's repeated std vector (distribution.py:228-247);
  * std_rows = 1: `std` is that vector itself, [A] — it is broadcast inside the kernel and d_std is the gradient of the
  * vector, [A] (= the column sums a sum(0) over [B,A] would give); needs A % 4 == 0, A <= 32 and the workspace
- * d_std_partials: float[cusrl_ppo_loss_num_partials(B)][A] (may be NULL otherwise). */
+ * d_std_partials: float[cusrl_ppo_loss_std_partial_rows(B)][A] (may be NULL otherwise). */
 int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action, const float *mean,
                            const float *std, const float *ret, const float *curr_value, const float *old_value,
                            int64_t B, int64_t A, int64_t D, double clip, double value_clip, double w_sur,
@@ -131,6 +131,7 @@ int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const 
                            float *logp_ratio_out, float *ratio_out, float *d_mean, float *d_std, float *d_value,
                            double *partials, int64_t std_rows, float *d_std_partials, void *stream);
 int64_t cusrl_ppo_loss_num_partials(int64_t B);
+int64_t cusrl_ppo_loss_std_partial_rows(int64_t B);
 
 /* ---- rollout-side: sampling and episode statistics ----
  * Normal sample + log-prob of the sample in one pass — cusrl/nn/module/distribution.py:198-205 (`rsample`, then

@@ -496,7 +496,7 @@ def test_assemble_gradients_sums_slabs_into_slots(ops):
     np.testing.assert_array_equal(got[:offset], expect[:offset])
 
 
-@pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 4, 2), (257, 32, 1), (2, 8, 1)])
+@pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 4, 2), (257, 32, 1), (2, 8, 1), (70001, 12, 1)])  # last: staged reduction
 @pytest.mark.parametrize("vclip", [None, 0.2])
 def test_ppo_loss_std_vector_equals_repeated_matrix(ops, B, A, D, vclip):
     """A state-independent std passed as its [A] vector: same forward numbers as the repeated [B, A] matrix, d_std =
