@@ -304,6 +304,17 @@ __global__ __launch_bounds__(kBlock) void std_rows_final_kernel(const float *__r
     reduce_std_rows(stage, rows, A, out);
 }
 
+// Many blocks (> 256, i.e. minibatches beyond 65 536 rows): one block cannot walk all partial rows at memory latency,
+// so slices of 256 rows are first reduced to one row each by as many blocks, and the finalize below reads those.
+__global__ __launch_bounds__(kBlock) void loss_partials_stage_kernel(const double *__restrict__ partials, int64_t P,
+                                                                     double *__restrict__ stage) {
+    const int64_t row = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    double acc[kLossSums];
+#pragma unroll
+    for (int k = 0; k < kLossSums; ++k) acc[k] = row < P ? partials[row * kLossSums + k] : 0.0;
+    write_block_partials(acc, stage);
+}
+
 __global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double *__restrict__ partials, int64_t P,
                                                                    int64_t B, int D, LossParams p,
                                                                    float *__restrict__ losses_out,
@@ -334,10 +345,16 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double 
 
 using namespace cusrl;
 
-extern "C" int64_t cusrl_ppo_loss_num_partials(int64_t B) { return B <= 0 ? 0 : ceil_div(B, kRowsPerBlock); }
+static int64_t loss_blocks(int64_t B) { return B <= 0 ? 0 : ceil_div(B, kRowsPerBlock); }
+
+// rows of the fp64 workspace: one per block, plus one per 256-block slice when the reduction is staged
+extern "C" int64_t cusrl_ppo_loss_num_partials(int64_t B) {
+    const int64_t blocks = loss_blocks(B);
+    return blocks + (blocks > kBlock ? ceil_div(blocks, kBlock) : 0);
+}
 
 extern "C" int64_t cusrl_ppo_loss_std_partial_rows(int64_t B) {
-    const int64_t blocks = cusrl_ppo_loss_num_partials(B);
+    const int64_t blocks = loss_blocks(B);
     return blocks + (blocks > kStdSliceRows ? ceil_div(blocks, kStdSliceRows) : 0);
 }
 
@@ -377,7 +394,7 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
     p.w_val = float(w_val);
     p.w_ent = float(w_ent);
     hipStream_t s = as_stream(stream);
-    const int64_t blocks = cusrl_ppo_loss_num_partials(B);
+    const int64_t blocks = loss_blocks(B);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     const bool chunked = A % 4 == 0 && A / 4 <= 8 && aligned(action, 16) && aligned(mean, 16) && aligned(std, 16) &&
                          (!d_mean || aligned(d_mean, 16)) && (!d_std || aligned(d_std, 16));
@@ -403,7 +420,17 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
     // (a 32 768-row minibatch), staged over 128-row slices beyond that
     const bool reduce_std = std_vector && d_std;
     const bool staged = reduce_std && blocks > kStdSliceRows;
-    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, partials, blocks, B, int(D), p,
+    const double *loss_rows = partials;
+    int64_t num_loss_rows = blocks;
+    if (blocks > kBlock) {
+        num_loss_rows = ceil_div(blocks, kBlock);
+        double *stage = partials + blocks * kLossSums;
+        hipLaunchKernelGGL(loss_partials_stage_kernel, dim3(uint32_t(num_loss_rows)), dim3(kBlock), 0, s, partials, blocks,
+                           stage);
+        if (int rc = launch_status()) return rc;
+        loss_rows = stage;
+    }
+    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, loss_rows, num_loss_rows, B, int(D), p,
                        losses_out, (reduce_std && !staged) ? d_std_partials : nullptr, int(A), d_std);
     if (int rc = launch_status()) return rc;
     if (staged) {

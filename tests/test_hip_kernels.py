@@ -244,7 +244,8 @@ def test_ppo_loss_vs_reference_goldens(ops, golden):
         np.testing.assert_allclose(host(out["d_value"]), g[p + "d_value"], rtol=1e-5, atol=1e-7 * scale)
 
 
-@pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 7, 1), (513, 32, 2), (3, 40, 1), (255, 4, 3)])
+@pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 7, 1), (513, 32, 2), (3, 40, 1), (255, 4, 3),
+                                   (70001, 12, 1)])  # last: > 256 blocks, staged reduction of the block partials
 @pytest.mark.parametrize("vclip", [None, 0.2])
 def test_ppo_loss_vs_oracle(ops, B, A, D, vclip):
     rng = np.random.default_rng(B + A)
