@@ -57,7 +57,10 @@ def main(out_dir: str):
     result["params_before"] = before
     result["params_after"] = torch.cat([p.detach().reshape(-1) for p in other.parameters()]).tolist()
 
-    result["averaged"] = distributed.average_dict({"shared": float(rank), f"only{rank}": 1.0})
+    result["averaged"] = distributed.average_dict({"shared": float(rank), f"only{rank}": 1.0})  # different keys: gather path
+    result["averaged_same_keys"] = distributed.average_dict({"b": float(rank), "a": 10.0 * rank, "c": 3})  # all-reduce path
+    result["fast_path_taken"] = distributed._average_same_keys({"x": float(rank)}) is not None
+    result["averaged_with_none"] = distributed.average_dict({"a": 1.0 + rank, "b": None if rank else 2.0})
     result["gathered"] = distributed.gather_obj(rank * 10)
     result["stack"] = distributed.gather_stack(torch.tensor([float(rank)])).tolist()
     distributed.barrier()

@@ -62,4 +62,6 @@ def test_parameter_broadcast_and_metric_averaging(ranks):
     assert ranks[0]["params_after"] == ranks[0]["params_before"] == ranks[1]["params_after"]
     for r in ranks:
         assert r["averaged"] == {"shared": 0.5, "only0": 1.0, "only1": 1.0}
+        assert r["averaged_same_keys"] == {"a": 5.0, "b": 0.5, "c": 3.0} and r["fast_path_taken"] is True
+        assert r["averaged_with_none"] == {"a": 1.5, "b": 2.0}
         assert r["gathered"] == [0, 10] and r["stack"] == [[0.0], [1.0]]
