@@ -147,6 +147,8 @@ class Trainer:
         self.checkpoint_interval = checkpoint_interval
         self.trial_metadata = dict(trial_metadata or {})
         self.timer = Timer(self.agent.device)
+        # Perf/*_time come from HIP events; on a GPU every 8th env step is bracketed and scaled (utils/timing.py)
+        self.timer_sampling = 8 if self.agent.device.type == "cuda" else 1
         self.last_info: dict[str, float] = {}
         self.host_thread_cpus: list[int] = []
         if pin_host_thread and self.agent.device.type == "cuda":  # extension: NUMA-local placement of the driving thread
@@ -170,16 +172,17 @@ class Trainer:
 
     def _rollout_and_update(self, observation, state):
         agent, env, timer, stats = self.agent, self.environment, self.timer, self.stats
+        every = self.timer_sampling  # the four sections of an env step are bracketed on every k-th step only
         while True:
-            with timer.record("agent"):
+            with timer.record("agent", every):
                 action = agent.act(observation, state)
-            with timer.record("environment"):
+            with timer.record("environment", every):
                 next_observation, next_state, reward, terminated, truncated, info = env.step(action)
                 if not stats.on_device:
                     stats.track_step(reward)
-            with timer.record("agent"):
+            with timer.record("agent", every):
                 ready = agent.step(next_observation, reward, terminated, truncated, next_state, **info)
-            with timer.record("environment"):
+            with timer.record("environment", every):
                 if stats.on_device:
                     # device-resident bookkeeping: one launch, and a host round trip only if the env needs indices
                     done = agent.transition.get("done")

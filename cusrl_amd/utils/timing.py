@@ -18,7 +18,9 @@ class Timer:
     (no synchronisation inside the loop).  Timing events are not free on this stack — each one is a barrier packet
     that costs the stream a bubble — so back-to-back sections SHARE their boundary event (the end of one section is
     the start of the next when it begins within 50 us of host time): the trainer's 4 sections per env step cost
-    4 events instead of 8."""
+    4 events instead of 8.  ``record(name, every=k)`` additionally SAMPLES a repetitive section: only every k-th
+    occurrence is bracketed and the accumulated time is scaled by occurrences / bracketed occurrences — the env-step
+    sections of the rollout loop cost ~0.6 ms per iteration (5 %) when every one of them is timed."""
 
     SHARE_WINDOW = 50e-6
 
@@ -30,6 +32,8 @@ class Timer:
         self._pending: dict[str, list] = defaultdict(list)
         self._boundary = None
         self._boundary_time = 0.0
+        self._seen: dict[tuple, int] = defaultdict(int)   # (name, every) -> occurrences
+        self._timed: dict[tuple, int] = defaultdict(int)  # (name, every) -> occurrences that were bracketed
 
     def _event(self):
         event = torch.cuda.Event(enable_timing=True)
@@ -64,16 +68,31 @@ class Timer:
 
     def __getitem__(self, name) -> float:
         self._resolve(name)
-        return self._total[name]
+        total = self._total[name]
+        for key, seen in self._seen.items():  # sampled sections of this name, scaled to all their occurrences
+            if key[0] == name and self._timed[key]:
+                self._resolve(key)
+                total += self._total[key] * (seen / self._timed[key])
+        return total
 
     def clear(self):
         self._pending.clear()
         self._boundary = None
         self._open.clear()
         self._total.clear()
+        self._seen.clear()
+        self._timed.clear()
 
     @contextmanager
-    def record(self, name):
+    def record(self, name, every: int = 1):
+        if every > 1:
+            key = (name, every)
+            self._seen[key] += 1
+            if (self._seen[key] - 1) % every:
+                yield
+                return
+            self._timed[key] += 1
+            name = key
         self.start(name)
         yield
         self.stop(name)

@@ -315,3 +315,20 @@ def test_affinity_cpu_list_parsing_and_noop_without_topology(monkeypatch):
             assert affinity.pin_host_thread(0, cores=1, slot=1) == [cpus[1]] and os.sched_getaffinity(0) == {cpus[1]}
         finally:
             os.sched_setaffinity(0, before)
+
+
+def test_timer_sampled_sections_scale_to_all_occurrences():
+    import time
+
+    import cusrl_amd as cusrl
+
+    timer = cusrl.utils.Timer("cpu")
+    for _ in range(16):
+        with timer.record("step", every=4):
+            time.sleep(0.002)
+    with timer.record("step"):  # an always-timed section under the same name adds on top
+        time.sleep(0.004)
+    assert timer._timed[("step", 4)] == 4 and timer._seen[("step", 4)] == 16
+    assert 0.032 * 0.8 + 0.004 <= timer["step"] <= 0.032 * 2.5 + 0.02
+    timer.clear()
+    assert timer["step"] == 0.0
