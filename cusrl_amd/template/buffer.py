@@ -188,17 +188,17 @@ class Buffer(MutableMapping):
                 if not isinstance(value, torch.Tensor):
                     return  # numpy / python inputs take the converting path
                 storage = self.storage[key]
-                paths.append((tuple(key.split(".")[1:]), storage, tuple(value.shape), value.dtype))
+                paths.append((tuple(key.split(".")[1:]), storage, value.shape, value.dtype))
             keys.append((name, get_schema(nested_value, name)))
             leaves.append((name, paths))
         table = ops.make_push_table([(storage, shape) for _, paths in leaves for _, storage, shape, _ in paths])
-        self._push_plan = (tuple(keys), leaves, table, {k: t.data_ptr() for k, t in self.storage.items()})
+        self._push_plan = (tuple(keys), leaves, table, tuple(self.storage.items()))
 
     def _fast_push(self, data: Mapping[str, Any]) -> bool:
         plan = getattr(self, "_push_plan", None)
         if plan is None:
             return False
-        keys, leaves, table, pointers = plan
+        keys, leaves, table, storage_refs = plan
         if len(data) != len(keys):
             return False
         for (name, schema), (got_name, got) in zip(keys, data.items()):
@@ -215,7 +215,7 @@ class Buffer(MutableMapping):
                         value = value[part] if isinstance(value, Mapping) else value[int(part)]
                 except (KeyError, IndexError, TypeError, ValueError):
                     return False
-                if (type(value) is not torch.Tensor or value.dtype != dtype or tuple(value.shape) != shape
+                if (type(value) is not torch.Tensor or value.shape != shape or value.dtype != dtype
                         or value.device != device or not value.is_contiguous()):
                     return False
                 table[index].src = value.data_ptr()
@@ -224,7 +224,8 @@ class Buffer(MutableMapping):
         for name, schema in keys:
             if isinstance(schema, dict) and len(data[name]) != len(schema):
                 return False
-        if any(self.storage[k].data_ptr() != p for k, p in pointers.items()) or len(pointers) != len(self.storage):
+        storage = self.storage
+        if len(storage_refs) != len(storage) or any(storage.get(k) is not t for k, t in storage_refs):
             return False  # a field was replaced / added behind our back
         for name, _ in keys:
             self._derived.pop(name, None)
