@@ -178,58 +178,58 @@ class Buffer(MutableMapping):
         self._push_plan = None
         if len(self.storage) > _native_max_fields():
             return
-        keys, leaves = [], []
+        names, absent, nested_sizes, specs, storages = [], [], [], [], []
         for name, nested_value in data.items():
+            names.append(name)
             if nested_value is None:
-                keys.append((name, None))
+                absent.append(name)
                 continue
-            paths = []
+            if isinstance(nested_value, (Mapping, tuple, list)):
+                nested_sizes.append((name, len(nested_value)))
             for key, value in iterate_nested(nested_value, name):
                 if not isinstance(value, torch.Tensor):
                     return  # numpy / python inputs take the converting path
-                storage = self.storage[key]
-                paths.append((tuple(key.split(".")[1:]), storage, value.shape, value.dtype))
-            keys.append((name, get_schema(nested_value, name)))
-            leaves.append((name, paths))
-        table = ops.make_push_table([(storage, shape) for _, paths in leaves for _, storage, shape, _ in paths])
-        self._push_plan = (tuple(keys), leaves, table, tuple(self.storage.items()))
+                path = tuple(int(part) if part.isdigit() else part for part in key.split(".")[1:])
+                specs.append((name, path, value.shape, value.dtype))
+                storages.append((self.storage[key], value.shape))
+        table = ops.make_push_table(storages)
+        fields = [table[i] for i in range(len(specs))]  # ctypes views of the array slots: `.src` writes go straight in
+        leaves = tuple((name, path, shape, dtype, field) for (name, path, shape, dtype), field in zip(specs, fields))
+        self._push_plan = (tuple(names), tuple(absent), tuple(nested_sizes), leaves, table, tuple(self.storage.items()))
 
     def _fast_push(self, data: Mapping[str, Any]) -> bool:
         plan = getattr(self, "_push_plan", None)
         if plan is None:
             return False
-        keys, leaves, table, storage_refs = plan
-        if len(data) != len(keys):
+        names, absent, nested_sizes, leaves, table, storage_refs = plan
+        if tuple(data) != names:
             return False
-        for (name, schema), (got_name, got) in zip(keys, data.items()):
-            if name != got_name or (schema is None) != (got is None):
+        for name in absent:
+            if data[name] is not None:
                 return False
-        index = 0
-        device = self.device
-        for name, paths in leaves:
-            nested_value = data[name]
-            for path, storage, shape, dtype in paths:
-                value = nested_value
-                try:
-                    for part in path:
-                        value = value[part] if isinstance(value, Mapping) else value[int(part)]
-                except (KeyError, IndexError, TypeError, ValueError):
-                    return False
-                if (type(value) is not torch.Tensor or value.shape != shape or value.dtype != dtype
+        device, tensor_type = self.device, torch.Tensor
+        try:
+            for name, path, shape, dtype, field in leaves:
+                value = data[name]
+                for part in path:
+                    value = value[part]
+                # a None / numpy / wrong-shape value fails here and takes the converting path
+                if (type(value) is not tensor_type or value.shape != shape or value.dtype != dtype
                         or value.device != device or not value.is_contiguous()):
                     return False
-                table[index].src = value.data_ptr()
-                index += 1
-        # nested containers may have gained leaves the plan does not know: compare schemas only when sizes differ
-        for name, schema in keys:
-            if isinstance(schema, dict) and len(data[name]) != len(schema):
+                field.src = value.data_ptr()
+        except (KeyError, IndexError, TypeError, ValueError):
+            return False
+        for name, size in nested_sizes:  # nested containers may have gained leaves the plan does not know
+            if len(data[name]) != size:
                 return False
         storage = self.storage
         if len(storage_refs) != len(storage) or any(storage.get(k) is not t for k, t in storage_refs):
             return False  # a field was replaced / added behind our back
-        for name, _ in keys:
-            self._derived.pop(name, None)
-        ops.push_table(table, index, self.cursor, self.parallelism)
+        if self._derived:
+            for name in names:
+                self._derived.pop(name, None)
+        ops.push_table(table, len(leaves), self.cursor, self.parallelism)
         self._advance()
         return True
 
