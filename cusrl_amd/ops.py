@@ -245,16 +245,25 @@ def next_value(
 
 
 def compact_flags(flags: torch.Tensor, block_counts: torch.Tensor | None = None,
-                  count_out: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+                  count_out: torch.Tensor | None = None, *, scratch: dict | None = None) -> tuple[torch.Tensor, torch.Tensor]:
     """Ascending flat slots whose flag is set + their number (int32[1]); no host synchronisation.  ``count_out``
-    may be a pinned host tensor (the kernel stores the count there with system scope; see :class:`HostCounter`)."""
+    may be a pinned host tensor (the kernel stores the count there with system scope; see :class:`HostCounter`).
+    ``scratch`` (a dict the caller keeps) lets a per-step caller reuse the counter and index buffers: the returned
+    indices are then only valid until the next call with the same scratch."""
     flags = _flag(flags, "flags")
     n = flags.numel()
     lib = _native.lib()
     recount = block_counts is None
-    if recount:
-        block_counts = torch.empty(max(int(lib.cusrl_flag_blocks(n)), 1), dtype=torch.int32, device=flags.device)
-    indices = torch.empty(n, dtype=torch.int64, device=flags.device)
+    if scratch is not None and scratch.get("n") == n and scratch.get("device") == flags.device:
+        indices = scratch["indices"]
+        if recount:
+            block_counts = scratch["counts"]
+    else:
+        if recount:
+            block_counts = torch.empty(max(int(lib.cusrl_flag_blocks(n)), 1), dtype=torch.int32, device=flags.device)
+        indices = torch.empty(n, dtype=torch.int64, device=flags.device)
+        if scratch is not None and recount:
+            scratch.update(n=n, device=flags.device, indices=indices, counts=block_counts)
     if count_out is not None:
         if count_out.dtype != torch.int32 or count_out.numel() != 1 or not (count_out.is_cuda or count_out.is_pinned()):
             raise TypeError("'count_out' must be a 1-element int32 tensor on the device or in pinned host memory")
@@ -266,6 +275,25 @@ def compact_flags(flags: torch.Tensor, block_counts: torch.Tensor | None = None,
         "cusrl_compact_flags",
     )
     return indices, count
+
+
+def assign_rows(dst: torch.Tensor, indices: torch.Tensor, src: torch.Tensor) -> None:
+    """``dst[indices] = src`` for a contiguous ``dst [N, ...]`` and ``src [K, ...]`` of the same dtype (the reset
+    observations spliced into the rollout's current observation, environment.py:365-379) — the 16-byte-lane row scatter
+    instead of torch's general ``index_put_``."""
+    require_device(src, "src"), require_device(dst, "dst"), require_device(indices, "indices")
+    if src.dtype != dst.dtype or indices.dtype != torch.int64 or not dst.is_contiguous() or src.shape[1:] != dst.shape[1:]:
+        raise TypeError("assign_rows: dtype/layout mismatch")
+    K = indices.numel()
+    if K == 0:
+        return
+    if src.shape[0] != K:
+        raise ValueError("assign_rows: one source row per index is required")
+    src, indices = src.contiguous(), indices.contiguous()
+    check(
+        _native.lib().cusrl_scatter_rows(src.data_ptr(), indices.data_ptr(), dst.data_ptr(), K, _row_bytes(src, 1), None, _stream()),
+        "cusrl_scatter_rows",
+    )
 
 
 class HostCounter:

@@ -157,6 +157,7 @@ class Trainer:
             index = self.agent.device.index if self.agent.device.index is not None else torch.cuda.current_device()
             self.host_thread_cpus = pin(index, slot=distributed.local_rank())
         self._done_counter = None
+        self._done_scratch: dict = {}
 
     def run_training_loop(self):
         try:
@@ -195,7 +196,7 @@ class Trainer:
                         done_indices = self._done_indices(done)
                         if done_indices.numel():
                             init_observation, init_state, _ = env.reset(indices=done_indices)
-                            next_observation, next_state = update_observation_and_state(
+                            next_observation, next_state = self._splice_resets(
                                 next_observation, next_state, done_indices, init_observation, init_state)
                 elif done_indices := get_done_indices(terminated, truncated):
                     if not env.spec.autoreset:
@@ -213,6 +214,25 @@ class Trainer:
             hook.post_update()
         return observation, state
 
+    @staticmethod
+    def _splice_resets(observation, state, indices, init_observation, init_state):
+        """``update_observation_and_state`` (environment.py:365-379) with the row scatter kernel when everything is a
+        matching device tensor; torch's ``index_put_`` otherwise."""
+        from cusrl_amd import ops
+
+        def spliceable(dst, src):
+            return (isinstance(dst, torch.Tensor) and isinstance(src, torch.Tensor) and dst.is_cuda and src.is_cuda
+                    and dst.dtype == src.dtype and dst.is_contiguous() and dst.dim() >= 2 and src.shape[1:] == dst.shape[1:]
+                    and src.shape[0] == indices.numel())
+
+        if (init_observation.shape != observation.shape and spliceable(observation, init_observation)
+                and (state is None or spliceable(state, init_state))):
+            ops.assign_rows(observation, indices, init_observation)
+            if state is not None:
+                ops.assign_rows(state, indices, init_state)
+            return observation, state
+        return update_observation_and_state(observation, state, indices, init_observation, init_state)
+
     def _done_indices(self, done: torch.Tensor) -> torch.Tensor:
         """``done.squeeze(-1).nonzero().squeeze(-1)`` (environment.py get_done_indices) on the device: ordered stream
         compaction in two launches whose count lands in pinned host memory that the host polls — instead of torch's
@@ -224,7 +244,9 @@ class Trainer:
             return done.reshape(-1).nonzero().reshape(-1)
         if self._done_counter is None:
             self._done_counter = ops.HostCounter()
-        indices, _ = ops.compact_flags(done, count_out=self._done_counter.arm())
+        # the index buffer is reused every step: its consumers (env.reset, the observation patch) are enqueued before
+        # the next step's compaction overwrites it
+        indices, _ = ops.compact_flags(done, count_out=self._done_counter.arm(), scratch=self._done_scratch)
         return indices[: self._done_counter.wait()]
 
     def _save_checkpoint(self):

@@ -539,6 +539,20 @@ def test_policy_stats_vs_oracle(ops, B, A, D):
     np.testing.assert_allclose(got[2], want[2], rtol=1e-6)
 
 
+def test_assign_rows_equals_index_put(ops):
+    torch.manual_seed(0)
+    for shape, dtype in (((4096, 48), torch.float32), ((100, 7), torch.float32), ((64, 3, 5), torch.float32), ((33, 1), torch.bool)):
+        dst = (torch.rand(shape, device=DEV) > 0.5) if dtype == torch.bool else torch.randn(shape, device=DEV)
+        indices = torch.randperm(shape[0], device=DEV)[: max(shape[0] // 7, 1)].sort().values
+        src = (torch.rand((indices.numel(),) + shape[1:], device=DEV) > 0.5) if dtype == torch.bool else torch.randn(
+            (indices.numel(),) + shape[1:], device=DEV)
+        want = dst.clone()
+        want[indices] = src
+        ops.assign_rows(dst, indices, src)
+        assert torch.equal(dst, want)
+    ops.assign_rows(dst, indices[:0], src[:0])  # empty: no launch
+
+
 def test_fused_linear_paths_match_plain_autograd():
     from cusrl_amd.nn.module import Mlp
 
