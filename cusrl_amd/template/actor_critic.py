@@ -159,8 +159,12 @@ class ActorCritic(Agent):
         """Store non-None fields as device tensors.  ``_clone`` keeps the reference's defensive copy
         (agent.py:257-261) for values that must survive an ``env.step`` before they are pushed (observation, state,
         recurrent memory); values pushed into the buffer right away are stored as they are."""
+        device, transition = self.device, self.transition
         for key, value in fields.items():
             if value is None:
+                continue
+            if not _clone and type(value) is torch.Tensor and value.device == device:
+                transition[key] = value  # the common case in the rollout loop: already a tensor where it belongs
                 continue
             try:
                 self.transition[key] = self.to_nested_tensor(value) if _clone else self._as_nested_tensor(value)

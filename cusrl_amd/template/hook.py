@@ -231,10 +231,10 @@ class HookComposite(Hook):
             yield from hook.named_parameters(prefix=lead + name)
 
     def active_hooks(self) -> Iterator[Hook]:
-        inference = self.agent.inference_mode
-        for hook in self._hooks:
-            if hook.active and not (inference and hook.training_only):
-                yield hook
+        # called for every lifecycle event of every env step: plain attribute reads instead of the two properties
+        if self.agent.inference_mode:
+            return iter([hook for hook in self._hooks if hook._active and not hook._training_only])
+        return iter([hook for hook in self._hooks if hook._active])
 
     def compile(self, **kwargs):
         for hook in self:
