@@ -239,6 +239,8 @@ class ActorCritic(Agent):
         return super().update()
 
     def _zero_grad(self):
+        if self.flat_optimizer is not None:
+            self.flat_optimizer.discard_pending_clip()  # a clip deferred for a step that never ran must not leak into this one
         if self.flat_gradients is None:
             self.optimizer.zero_grad()
         elif not self.flat_gradients.intact():

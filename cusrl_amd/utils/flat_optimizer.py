@@ -104,6 +104,9 @@ class FlatAdam:
         self._pending_clip = (ops.grad_sumsq(self.gradients.buffer), max_norm, norm)
         return norm[0]
 
+    def discard_pending_clip(self):
+        self._pending_clip = None
+
     def _sync_lr(self, group) -> None:
         lr = group["lr"]
         if isinstance(lr, torch.Tensor):
