@@ -24,7 +24,7 @@ class Field(Structure):
 class GradPiece(Structure):
     """``cusrl_grad_piece_t`` — one parameter's slot of the flat gradient buffer and what to sum into it."""
 
-    _fields_ = [("src", c_void_p), ("offset", c_int64), ("numel", c_int64), ("splits", c_int64)]
+    _fields_ = [("src", c_void_p), ("offset", c_int64), ("numel", c_int64), ("splits", c_int64), ("row_stride", c_int64)]
 
 
 class NativeError(RuntimeError):

@@ -199,8 +199,8 @@ namespace cusrl {
 
 struct GradPiece {
     const float *src;
-    int64_t offset, numel;
-    int32_t splits, pad;
+    int64_t offset, numel, row_stride;  // slab s, element e lives at src[s * row_stride + e]
+    int32_t splits, wide;               // wide: many slabs (block partials of a column-sum kernel), reduced cooperatively
 };
 
 struct GradTable {
@@ -209,7 +209,9 @@ struct GradTable {
     GradPiece piece[CUSRL_MAX_FIELDS];
 };
 
-constexpr int kAssemblePerBlock = kBlock * 4;  // elements of one piece per block
+constexpr int kAssemblePerBlock = kBlock * 4;  // elements of one piece per block (few slabs)
+constexpr int kAssembleWideCols = 16;          // elements per block of a WIDE piece: 16 columns x 16 slab groups
+constexpr int kAssembleWideSplits = 16;        // more slabs than this -> wide
 
 __global__ __launch_bounds__(kBlock) void assemble_gradients_kernel(const GradTable tab, float *__restrict__ flat) {
     const int blk = blockIdx.x;
@@ -219,6 +221,32 @@ __global__ __launch_bounds__(kBlock) void assemble_gradients_kernel(const GradTa
     const GradPiece piece = tab.piece[f];
     const float *__restrict__ src = piece.src;
     const int64_t n = piece.numel;
+    const int64_t stride = piece.row_stride;
+    if (piece.wide) {  // uniform per block: hundreds of partial rows (bias / head gradients), 16 slab groups in flight
+        __shared__ float red[kBlock];
+        const int c = threadIdx.x % kAssembleWideCols, g = threadIdx.x / kAssembleWideCols;
+        constexpr int kGroups = kBlock / kAssembleWideCols;
+        const int64_t e = int64_t(blk - tab.block_start[f]) * kAssembleWideCols + c;
+        float total = 0.f;
+        if (e < n) {
+            int s = g;
+            for (; s + 3 * kGroups < piece.splits; s += 4 * kGroups) {
+                const float a = src[int64_t(s) * stride + e], b = src[int64_t(s + kGroups) * stride + e],
+                            c2 = src[int64_t(s + 2 * kGroups) * stride + e], d = src[int64_t(s + 3 * kGroups) * stride + e];
+                total += (a + b) + (c2 + d);
+            }
+            for (; s < piece.splits; s += kGroups) total += src[int64_t(s) * stride + e];
+        }
+        red[threadIdx.x] = total;
+        __syncthreads();
+        if (g == 0 && e < n) {
+            float sum = red[c];
+#pragma unroll
+            for (int k = 1; k < kGroups; ++k) sum += red[k * kAssembleWideCols + c];
+            flat[piece.offset + e] = sum;
+        }
+        return;
+    }
     const int64_t base = int64_t(blk - tab.block_start[f]) * kAssemblePerBlock + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -227,11 +255,11 @@ __global__ __launch_bounds__(kBlock) void assemble_gradients_kernel(const GradTa
         float total = 0.f;
         int s = 0;
         for (; s + 4 <= piece.splits; s += 4) {  // fixed order, four independent loads in flight
-            const float a = src[int64_t(s) * n + e], b = src[int64_t(s + 1) * n + e], c = src[int64_t(s + 2) * n + e],
-                        d = src[int64_t(s + 3) * n + e];
+            const float a = src[int64_t(s) * stride + e], b = src[int64_t(s + 1) * stride + e],
+                        c = src[int64_t(s + 2) * stride + e], d = src[int64_t(s + 3) * stride + e];
             total += (a + b) + (c + d);
         }
-        for (; s < piece.splits; ++s) total += src[int64_t(s) * n + e];
+        for (; s < piece.splits; ++s) total += src[int64_t(s) * stride + e];
         flat[piece.offset + e] = total;
     }
 }
@@ -248,9 +276,12 @@ extern "C" int cusrl_assemble_gradients(const cusrl_grad_piece_t *pieces, int64_
         for (int i = 0; i < tab.n; ++i) {
             const cusrl_grad_piece_t &p = pieces[first + i];
             if (p.numel < 0 || p.offset < 0 || p.splits < 0 || (p.splits > 0 && !p.src)) return CUSRL_E_INVALID;
+            const int64_t row_stride = p.row_stride > 0 ? p.row_stride : p.numel;
+            if (row_stride < p.numel || p.splits > INT32_MAX) return CUSRL_E_INVALID;
+            const bool wide = p.splits > kAssembleWideSplits;
             tab.block_start[i] = int32_t(blocks);
-            tab.piece[i] = GradPiece{static_cast<const float *>(p.src), p.offset, p.numel, int32_t(p.splits), 0};
-            blocks += ceil_div(p.numel, kAssemblePerBlock);
+            tab.piece[i] = GradPiece{static_cast<const float *>(p.src), p.offset, p.numel, row_stride, int32_t(p.splits), wide};
+            blocks += ceil_div(p.numel, wide ? kAssembleWideCols : kAssemblePerBlock);
             if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
         }
         tab.block_start[tab.n] = int32_t(blocks);

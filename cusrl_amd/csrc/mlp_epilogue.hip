@@ -159,7 +159,7 @@ extern "C" int64_t cusrl_colsum_num_partials(int64_t rows, int64_t H) {
 extern "C" int cusrl_relu_bwd_colsum(const float *grad, const float *output, float *grad_in, float *partials,
                                      float *colsum, int64_t rows, int64_t H, void *stream) {
     if (rows <= 0 || H <= 0) return CUSRL_E_INVALID;
-    if (!grad || !partials || !colsum || (output && !grad_in)) return CUSRL_E_INVALID;
+    if (!grad || !partials || (output && !grad_in)) return CUSRL_E_INVALID;
     if (H > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     hipStream_t s = as_stream(stream);
     const int64_t P = cusrl_colsum_num_partials(rows, H);
@@ -174,6 +174,7 @@ extern "C" int cusrl_relu_bwd_colsum(const float *grad, const float *output, flo
             hipLaunchKernelGGL(colsum_chunked_kernel<false>, dim3(uint32_t(P)), dim3(kBlock), 0, s, grad, output, grad_in,
                                partials, rows, int(H));
     } else {
+        if (!colsum) return CUSRL_E_UNSUPPORTED;  // partials-only mode exists for the chunked layout
         // the partial count was sized for the layout chosen by H alone; recompute for the row-wise launch shape
         const int64_t Pr = ceil_div(rows, int64_t(kBlock) * 4);
         if (Pr > P) return CUSRL_E_UNSUPPORTED;
@@ -189,6 +190,7 @@ extern "C" int cusrl_relu_bwd_colsum(const float *grad, const float *output, flo
         return launch_status();
     }
     if (int rc = launch_status()) return rc;
+    if (!colsum) return 0;  // the caller reduces the P partial rows itself (cusrl_assemble_gradients)
     if (aligned(colsum, 16))
         hipLaunchKernelGGL(colsum_finalize_vec_kernel, dim3(uint32_t(ceil_div(H, 64))), dim3(kBlock), 0, s, partials, P,
                            int(H), colsum);

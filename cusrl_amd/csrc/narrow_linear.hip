@@ -189,10 +189,10 @@ extern "C" int cusrl_narrow_linear_bwd(const float *grad_out, const float *input
                                        float *grad_input, float *partials, float *packed, int64_t rows,
                                        int64_t in_features, int64_t out_features, int relu_input, void *stream) {
     using namespace cusrl;
-    if (!grad_out || !input || !weight || !partials || !packed || rows <= 0) return CUSRL_E_INVALID;
+    if (!grad_out || !input || !weight || !partials || rows <= 0) return CUSRL_E_INVALID;
     if (!narrow_shape_ok(in_features, out_features)) return CUSRL_E_UNSUPPORTED;
     if (out_features % 4 == 0 && !aligned(grad_out, 16)) return CUSRL_E_UNSUPPORTED;
-    if (!aligned(input, 16) || !aligned(weight, 16) || !aligned(partials, 16) || !aligned(packed, 16) ||
+    if (!aligned(input, 16) || !aligned(weight, 16) || !aligned(partials, 16) || (packed && !aligned(packed, 16)) ||
         (grad_input && !aligned(grad_input, 16)))
         return CUSRL_E_UNSUPPORTED;
     hipStream_t s = as_stream(stream);
@@ -211,6 +211,7 @@ extern "C" int cusrl_narrow_linear_bwd(const float *grad_out, const float *input
         default: return CUSRL_E_UNSUPPORTED;
     }
     if (rc) return rc;
+    if (!packed) return 0;  // the caller reduces the partial rows itself (cusrl_assemble_gradients)
     const int H = (int(out_features) + 1) * K + kHeadBiasPad;
     hipLaunchKernelGGL(narrow_linear_finalize_kernel, dim3(uint32_t(ceil_div(H, 64))), dim3(kBlock), 0, s, partials,
                        blocks, H, packed);

@@ -39,6 +39,20 @@ def collect_split_weight_grads():
         _split_grad_sink = previous
 
 
+def _hand_over(sink, key, gradient):
+    """A gradient whose column sums are still pending (``ops.DeferredColumns``) goes to the flat-gradient assembly
+    through the sink (and autograd gets no gradient for that parameter); without a sink, or when the parameter already
+    left something there (used twice in the graph), it is reduced right here."""
+    from cusrl_amd import ops
+
+    if not isinstance(gradient, ops.DeferredColumns):
+        return gradient
+    if sink is not None and key is not None and key not in sink:
+        sink[key] = gradient
+        return None
+    return gradient.materialize()
+
+
 class _WideBatchLinear(torch.autograd.Function):
     """``linear(x, w, b)`` (optionally + ReLU in the GEMM epilogue) with a backward shaped for 256 CUs.
 
@@ -66,6 +80,7 @@ class _WideBatchLinear(torch.autograd.Function):
             output = linear(input, weight, bias)
             ctx.save_for_backward(input, weight)
         ctx.splits, ctx.relu, ctx.has_bias = splits, relu, bias is not None
+        ctx.bias_key = bias.data_ptr() if bias is not None else None
         ctx.narrow = (not relu) and input.is_contiguous() and weight.is_contiguous() and _narrow_head(weight)
         ctx.input_is_relu_output = getattr(input, "_cusrl_relu_output", False)
         return output
@@ -76,17 +91,24 @@ class _WideBatchLinear(torch.autograd.Function):
 
         if ctx.relu:
             input, weight, output = ctx.saved_tensors
+            sink = _split_grad_sink
             premasked = getattr(grad_output, "_cusrl_premasked", None)
             if premasked is not None and premasked[1] == grad_output._version and ctx.has_bias:
                 grad_bias = premasked[0]  # the head behind this ReLU already masked its dX and summed its columns
             else:
-                grad_output, grad_bias = ops.relu_backward_bias(grad_output.contiguous(), output)
+                grad_output, grad_bias = ops.relu_backward_bias(
+                    grad_output.contiguous(), output, defer=sink is not None and ctx.has_bias and ctx.needs_input_grad[2])
+            grad_bias = _hand_over(sink, ctx.bias_key, grad_bias)
         else:
             input, weight = ctx.saved_tensors
             if ctx.narrow and ctx.needs_input_grad[1]:  # policy-mean / value head: dX, dW and db from one pass
                 fuse_relu = ctx.input_is_relu_output and ctx.needs_input_grad[0]
+                sink = _split_grad_sink
                 grad_input, grad_weight, grad_bias, masked_colsum = ops.narrow_linear_backward(
-                    grad_output.contiguous(), input, weight, need_input_grad=ctx.needs_input_grad[0], relu_input=fuse_relu)
+                    grad_output.contiguous(), input, weight, need_input_grad=ctx.needs_input_grad[0], relu_input=fuse_relu,
+                    defer=sink is not None)
+                grad_weight = _hand_over(sink, weight.data_ptr(), grad_weight)
+                grad_bias = _hand_over(sink, ctx.bias_key, grad_bias) if ctx.has_bias else None
                 if fuse_relu:
                     # The input is a ReLU output, so masking dX by (input > 0) here IS that ReLU's backward (it is
                     # idempotent, so the producer may safely repeat it).  Tell the producer — through the tensor it

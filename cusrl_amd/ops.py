@@ -569,16 +569,19 @@ def policy_stats(old_mean: torch.Tensor, old_std: torch.Tensor, new_mean: torch.
 
 
 # ------------------------------------------------------------------------------------------------ MLP backward epilogue
-def relu_backward_bias(grad_output: torch.Tensor, output: torch.Tensor | None) -> tuple[torch.Tensor, torch.Tensor]:
+def relu_backward_bias(grad_output: torch.Tensor, output: torch.Tensor | None, defer: bool = False):
     """``(grad_output * (output > 0), masked.sum(0))`` in one pass; with ``output=None`` just the column sums
-    (bias gradient of a linear layer, with or without the ReLU that follows it)."""
+    (bias gradient of a linear layer, with or without the ReLU that follows it).  ``defer``: return the column sums as
+    :class:`DeferredColumns` (no finalize launch) when the layout allows; the flat gradient assembly reduces them."""
     grad_output = _f32(grad_output, "grad_output")
     H = grad_output.shape[-1]
     rows = grad_output.numel() // H
     lib = _native.lib()
-    partials = torch.empty((max(int(lib.cusrl_colsum_num_partials(rows, H)), 1), H), dtype=torch.float32, device=grad_output.device)
-    colsum = torch.empty(H, dtype=torch.float32, device=grad_output.device)
+    num_partials = max(int(lib.cusrl_colsum_num_partials(rows, H)), 1)
+    partials = torch.empty((num_partials, H), dtype=torch.float32, device=grad_output.device)
     chunkable = H % 4 == 0 and H // 4 <= 256 and 256 % (H // 4) == 0
+    defer = defer and chunkable and grad_output.data_ptr() % 16 == 0 and (output is None or output.data_ptr() % 16 == 0)
+    colsum = None if defer else torch.empty(H, dtype=torch.float32, device=grad_output.device)
     if output is None and not chunkable and H > 1:
         return grad_output, grad_output.sum(0)  # narrow odd widths (e.g. a 12-wide policy head): torch's reduce is fine
     if output is None:
@@ -588,10 +591,11 @@ def relu_backward_bias(grad_output: torch.Tensor, output: torch.Tensor | None) -
         grad_in = torch.empty_like(grad_output)
         out_ptr, in_ptr = output.data_ptr(), grad_in.data_ptr()
     check(
-        lib.cusrl_relu_bwd_colsum(grad_output.data_ptr(), out_ptr, in_ptr, partials.data_ptr(), colsum.data_ptr(), rows, H, _stream()),
+        lib.cusrl_relu_bwd_colsum(grad_output.data_ptr(), out_ptr, in_ptr, partials.data_ptr(),
+                                  None if colsum is None else colsum.data_ptr(), rows, H, _stream()),
         "cusrl_relu_bwd_colsum",
     )
-    return grad_in, colsum
+    return grad_in, (DeferredColumns(partials, num_partials, H, 0, H) if colsum is None else colsum)
 
 
 # ------------------------------------------------------------------------------------------------ narrow heads
@@ -603,11 +607,12 @@ def narrow_linear_supported(in_features: int, out_features: int) -> bool:
 
 
 def narrow_linear_backward(grad_output: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
-                           need_input_grad: bool = True, relu_input: bool = False):
+                           need_input_grad: bool = True, relu_input: bool = False, defer: bool = False):
     """``(grad_output @ weight, grad_output.T @ input, grad_output.sum(0))`` of a linear layer with at most 16
     outputs (policy-mean / value head) in one pass over the minibatch.  With ``relu_input`` (the layer's input is a
     ReLU output) the returned grad_input is already masked by ``input > 0`` and a fourth value, its column sums
-    (the bias gradient of the layer in front of the ReLU), is returned; otherwise the fourth value is None."""
+    (the bias gradient of the layer in front of the ReLU), is returned; otherwise the fourth value is None.  ``defer``:
+    dW, db and the column sums come back as :class:`DeferredColumns` (no finalize launch)."""
     grad_output, input, weight = _f32(grad_output, "grad_output"), _f32(input, "input"), _f32(weight, "weight")
     O, K = weight.shape
     rows = input.shape[0]
@@ -615,14 +620,18 @@ def narrow_linear_backward(grad_output: torch.Tensor, input: torch.Tensor, weigh
     dev = input.device
     grad_input = torch.empty_like(input) if need_input_grad else None
     width = (O + 1) * K + _HEAD_PAD
-    partials = torch.empty((int(lib.cusrl_narrow_linear_num_partials(rows)), width), dtype=torch.float32, device=dev)
-    packed = torch.empty(width, dtype=torch.float32, device=dev)
+    num_partials = int(lib.cusrl_narrow_linear_num_partials(rows))
+    partials = torch.empty((num_partials, width), dtype=torch.float32, device=dev)
+    packed = None if defer else torch.empty(width, dtype=torch.float32, device=dev)
     check(
         lib.cusrl_narrow_linear_bwd(grad_output.data_ptr(), input.data_ptr(), weight.data_ptr(),
                                     None if grad_input is None else grad_input.data_ptr(), partials.data_ptr(),
-                                    packed.data_ptr(), rows, K, O, int(relu_input), _stream()),
+                                    None if packed is None else packed.data_ptr(), rows, K, O, int(relu_input), _stream()),
         "cusrl_narrow_linear_bwd",
     )
+    if defer:  # the three gradients stay as windows of the partial rows; cusrl_assemble_gradients sums them
+        window = lambda column, numel: DeferredColumns(partials, num_partials, width, column, numel)  # noqa: E731
+        return grad_input, window(0, O * K), window((O + 1) * K, O), (window(O * K, K) if relu_input else None)
     colsum = packed[O * K : (O + 1) * K] if relu_input else None
     return grad_input, packed[: O * K].view(O, K), packed[(O + 1) * K : (O + 1) * K + O], colsum
 
@@ -644,15 +653,38 @@ def clip_grad_norm_(flat_grad: torch.Tensor, max_norm: float | None) -> torch.Te
     return norm[0]
 
 
-def assemble_gradients(pieces: Sequence[tuple[torch.Tensor | None, int, int, int]], flat: torch.Tensor):
+class DeferredColumns:
+    """Column sums that have NOT been taken yet: ``splits`` partial rows of width ``row_stride`` floats, of which the
+    window ``[column, column + numel)`` sums to a gradient.  The column-sum kernels (ReLU-backward + bias gradient,
+    narrow-head backward) hand these out instead of running their finalize launch when the flat gradient assembly is
+    going to reduce them anyway (``assemble_gradients``)."""
+
+    __slots__ = ("partials", "splits", "row_stride", "column", "numel")
+
+    def __init__(self, partials: torch.Tensor, splits: int, row_stride: int, column: int, numel: int):
+        self.partials, self.splits, self.row_stride, self.column, self.numel = partials, splits, row_stride, column, numel
+
+    def materialize(self) -> torch.Tensor:
+        rows = self.partials.reshape(-1)[: self.splits * self.row_stride].view(self.splits, self.row_stride)
+        return rows[:, self.column : self.column + self.numel].sum(0)
+
+
+def assemble_gradients(pieces: Sequence[tuple], flat: torch.Tensor):
     """Fill the flat gradient buffer in one launch.  ``pieces`` = ``(src, offset, numel, splits)`` per parameter:
     ``src [splits, numel]`` slabs are summed into ``flat[offset : offset + numel]``; ``splits = 1`` copies a plain
-    gradient, ``src = None`` / ``splits = 0`` writes zeros."""
+    gradient, ``src = None`` / ``splits = 0`` writes zeros; a :class:`DeferredColumns` ``src`` is reduced over its
+    partial rows (``splits`` is taken from it)."""
     flat = _f32(flat, "flat")
     table = (_native.GradPiece * max(len(pieces), 1))()
     keep = []
     for slot, (src, offset, numel, splits) in zip(table, pieces):
-        if src is None or splits == 0:
+        slot.row_stride = 0
+        if isinstance(src, DeferredColumns):
+            if src.numel != numel or offset < 0 or offset + numel > flat.numel():
+                raise ValueError("deferred column sums do not match the parameter's slot")
+            keep.append(src.partials)
+            slot.src, slot.splits, slot.row_stride = src.partials.data_ptr() + 4 * src.column, src.splits, src.row_stride
+        elif src is None or splits == 0:
             slot.src, slot.splits = None, 0
         else:
             src = _f32(src, "gradient piece")

@@ -228,10 +228,11 @@ class FlatGradients:
         for p, grad in zip(self.params, grads):
             n = p.numel()
             slabs = split_slabs.pop(p.data_ptr(), None) if split_slabs else None
-            if slabs is not None and grad is not None:  # the weight was used more than once in the graph
-                grad, slabs = grad + slabs.sum(0), None
+            pending = isinstance(slabs, ops.DeferredColumns)  # partial rows of a column-sum kernel
+            if slabs is not None and grad is not None:  # the parameter was used more than once in the graph
+                grad, slabs = grad + (slabs.materialize() if pending else slabs.sum(0)).view_as(grad), None
             if slabs is not None:
-                pieces.append((slabs, offset, n, slabs.shape[0]))
+                pieces.append((slabs, offset, n, slabs.splits if pending else slabs.shape[0]))
             elif grad is not None:
                 pieces.append((grad, offset, n, 1))
             else:

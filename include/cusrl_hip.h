@@ -165,7 +165,8 @@ int64_t cusrl_policy_stats_num_partials(int64_t B);
  * Bias gradient = column sums of grad [rows, H]; with `output` != NULL the ReLU backward mask is applied first
  * (grad_in = grad * (output > 0), written to grad_in) and the column sums are taken of the masked gradient, i.e.
  * threshold_backward + sum(0) of autograd in one pass.  partials: float[cusrl_colsum_num_partials(rows, H)][H]
- * workspace; colsum: float[H] (fixed summation order: deterministic). */
+ * workspace; colsum: float[H] (fixed summation order: deterministic), or NULL to get the partial rows only (H % 4 == 0
+ * layouts): their column sums are then taken by cusrl_assemble_gradients. */
 int cusrl_relu_bwd_colsum(const float *grad, const float *output, float *grad_in, float *partials, float *colsum,
                           int64_t rows, int64_t H, void *stream);
 int64_t cusrl_colsum_num_partials(int64_t rows, int64_t H);
@@ -176,7 +177,8 @@ int64_t cusrl_colsum_num_partials(int64_t rows, int64_t H);
  * relu_input != 0: x is the output of a ReLU (x > 0 <=> the ReLU passed); grad_input is then written already
  * masked — the ReLU's backward — and its column sums, the producer layer's bias gradient, are returned too.
  * packed: float[(O + 1) * K + 16] = dW (row-major) | column sums of the masked grad_input (zeros when
- * relu_input == 0) | db, zero padded;  partials: float[cusrl_narrow_linear_num_partials(rows)][(O + 1) * K + 16].
+ * relu_input == 0) | db, zero padded (NULL: partial rows only, reduced later by cusrl_assemble_gradients);
+ * partials: float[cusrl_narrow_linear_num_partials(rows)][(O + 1) * K + 16].
  * Supported shapes (cusrl_narrow_linear_supported): 1 <= O <= 16, K in {32, 64, ..., 1024} a power of two; all
  * pointers 16-byte aligned.  Fixed summation order (deterministic). */
 int cusrl_narrow_linear_bwd(const float *grad_out, const float *input, const float *weight, float *grad_input,
@@ -195,12 +197,16 @@ int64_t cusrl_clip_grad_norm_num_partials(int64_t n);
 /* ---- flat gradient assembly (the buffer behind actor_critic.py:311-314: backward, all-reduce, clip, step) ----
  * flat[offset .. offset + numel) = sum over `splits` stacked slabs of src [splits][numel]; splits = 1 copies a
  * plain gradient, splits = 0 writes zeros (src ignored).  The split-batch weight-gradient GEMMs leave their
- * [S, out, in] partial products here instead of running one sum(0) each; one launch per 24 pieces.  Fixed order. */
+ * [S, out, in] partial products here instead of running one sum(0) each; the column-sum kernels (bias gradients,
+ * cusrl_relu_bwd_colsum / cusrl_narrow_linear_bwd called without their output pointer) leave their per-block partial
+ * rows here instead of running a finalize launch each (a column window of a wider partial row is addressed through
+ * `src` + `row_stride`).  One launch per 24 pieces.  Fixed order. */
 typedef struct {
     const void *src;
-    int64_t offset; /* element offset of the parameter's slot in `flat` */
+    int64_t offset;     /* element offset of the parameter's slot in `flat` */
     int64_t numel;
     int64_t splits;
+    int64_t row_stride; /* elements between consecutive slabs; 0 = numel (densely stacked slabs) */
 } cusrl_grad_piece_t;
 int cusrl_assemble_gradients(const cusrl_grad_piece_t *pieces, int64_t num_pieces, float *flat, void *stream);
 

@@ -553,6 +553,56 @@ def test_assign_rows_equals_index_put(ops):
     ops.assign_rows(dst, indices[:0], src[:0])  # empty: no launch
 
 
+def test_assemble_gradients_reduces_deferred_column_windows(ops):
+    """Partial rows of the column-sum kernels: a window [column, column + numel) of rows of width row_stride."""
+    rng = np.random.default_rng(9)
+    rows = rng.standard_normal((384, 1680)).astype(np.float32)
+    few = rng.standard_normal((5, 40)).astype(np.float32)
+    d_rows, d_few = dev(rows), dev(few)
+    flat = torch.full((1536 + 12 + 128 + 40 + 7,), float("nan"), device=DEV)
+    pieces = [(ops.DeferredColumns(d_rows, 384, 1680, 0, 1536), 0, 1536, 0),
+              (ops.DeferredColumns(d_rows, 384, 1680, 1664, 12), 1536, 12, 0),
+              (ops.DeferredColumns(d_rows, 384, 1680, 1536, 128), 1548, 128, 0),
+              (ops.DeferredColumns(d_few, 5, 40, 0, 40), 1676, 40, 0),   # few rows: the per-element path with a stride
+              (None, 1716, 7, 0)]
+    ops.assemble_gradients(pieces, flat)
+    got = host(flat).astype(np.float64)
+    want = np.concatenate([rows[:, :1536].sum(0, dtype=np.float64), rows[:, 1664:1676].sum(0, dtype=np.float64),
+                           rows[:, 1536:1664].sum(0, dtype=np.float64), few.sum(0, dtype=np.float64), np.zeros(7)])
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * np.abs(rows).sum(0).max())
+    torch.testing.assert_close(pieces[1][0].materialize().double(), torch.from_numpy(want[1536:1548]).to(DEV), rtol=1e-5, atol=1e-4)
+
+
+def test_flat_backward_with_deferred_sums_matches_plain_autograd():
+    """The agent's backward: split-GEMM slabs, deferred bias / head column sums, all summed by the assembly launch."""
+    from cusrl_amd.nn.module import Linear, Mlp, collect_split_weight_grads
+    from cusrl_amd.utils.distributed import FlatGradients
+
+    torch.manual_seed(11)
+    mlp = Mlp(48, (256, 128), ends_with_activation=True).to(DEV)
+    head = Linear(128, 12).to(DEV)
+    value_mlp = Mlp(48, (256, 128), ends_with_activation=True).to(DEV)
+    value_head = Linear(128, 1).to(DEV)
+    modules = torch.nn.ModuleList([mlp, head, value_mlp, value_head])
+    optimizer = torch.optim.SGD(modules.parameters(), lr=0.1)
+    flat = FlatGradients(optimizer)
+    x = torch.randn(8192, 48, device=DEV)
+
+    def loss_of(layers_only):
+        a = (mlp.layers(x) if layers_only else mlp(x))
+        b = (value_mlp.layers(x) if layers_only else value_mlp(x))
+        pa = torch.nn.functional.linear(a, head.weight, head.bias) if layers_only else head(a)
+        pb = torch.nn.functional.linear(b, value_head.weight, value_head.bias) if layers_only else value_head(b)
+        return pa.square().mean() + pb.square().mean()
+
+    with collect_split_weight_grads() as sink:
+        grads = torch.autograd.grad(loss_of(False), flat.params, allow_unused=True)
+    assert sum(g is None for g in grads) == len(flat.params)  # every gradient took the deferred route
+    flat.assemble(grads, sink)
+    want = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss_of(True), flat.params)])
+    torch.testing.assert_close(flat.buffer, want, rtol=2e-4, atol=1e-4 * float(want.abs().max()))
+
+
 def test_fused_linear_paths_match_plain_autograd():
     from cusrl_amd.nn.module import Mlp
 
