@@ -332,3 +332,45 @@ def test_timer_sampled_sections_scale_to_all_occurrences():
     assert 0.032 * 0.8 + 0.004 <= timer["step"] <= 0.032 * 2.5 + 0.02
     timer.clear()
     assert timer["step"] == 0.0
+
+
+def test_flat_gradient_assembly_builds_one_piece_per_parameter(monkeypatch):
+    """Host logic of FlatGradients.assemble: plain gradients, split-GEMM slabs, deferred column windows, unused
+    parameters and a parameter that got both a gradient and slabs (used twice) — checked against a numpy reduction."""
+    import torch
+
+    from cusrl_amd import ops
+    from cusrl_amd.utils.distributed import FlatGradients
+
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(4, 3)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 2)),
+              torch.nn.Parameter(torch.zeros(6)), torch.nn.Parameter(torch.zeros(3))]
+    flat = FlatGradients(torch.optim.SGD(params, lr=0.1))
+    captured = {}
+
+    def fake_assemble(pieces, buffer):  # numpy restatement of cusrl_assemble_gradients
+        captured["pieces"] = pieces
+        for src, offset, numel, splits in pieces:
+            if isinstance(src, ops.DeferredColumns):
+                buffer[offset : offset + numel] = src.materialize()
+            elif src is None or splits == 0:
+                buffer[offset : offset + numel] = 0
+            else:
+                buffer[offset : offset + numel] = src.reshape(splits, numel).sum(0)
+
+    monkeypatch.setattr(ops, "assemble_gradients", fake_assemble)
+    plain = torch.randn(4, 3)
+    slabs = torch.randn(7, 5)                      # [S, numel] slabs for params[1]
+    rows = torch.randn(9, 20)                      # partial rows; params[2] = window [4, 8), params[3] = window [10, 16)
+    twice_grad, twice_slabs = torch.randn(3), torch.randn(2, 3)
+    sink = {params[1].data_ptr(): slabs,
+            params[2].data_ptr(): ops.DeferredColumns(rows, 9, 20, 4, 4),
+            params[4].data_ptr(): twice_slabs}
+    flat.buffer.fill_(float("nan"))
+    flat.assemble([plain, None, None, None, twice_grad], sink)
+    assert not sink and len(captured["pieces"]) == 5
+    want = torch.cat([plain.reshape(-1), slabs.sum(0), rows[:, 4:8].sum(0), torch.zeros(6), twice_grad + twice_slabs.sum(0)])
+    torch.testing.assert_close(flat.buffer, want)
+    assert [piece[3] for piece in captured["pieces"]] == [1, 7, 9, 0, 1]
+    with pytest.raises(RuntimeError, match="not optimizer parameters"):
+        flat.assemble([plain, None, None, None, twice_grad], {12345: slabs})
