@@ -289,7 +289,10 @@ def main():
     all_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     result = run_gpu(args, rank, world)
     if all_cpus is not None:
-        os.sched_setaffinity(0, all_cpus)  # the CPU baseline below gets every core back
+        try:
+            os.sched_setaffinity(0, all_cpus)  # the CPU baseline below gets every core back
+        except OSError:
+            pass
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = run_cpu_baseline(args)

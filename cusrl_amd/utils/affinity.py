@@ -53,5 +53,8 @@ def pin_host_thread(device_index: int, cores: int = 8, slot: int = 0) -> list[in
         return []
     start = (slot * cores) % (len(local) - cores + 1)
     chosen = local[start : start + cores]
-    os.sched_setaffinity(0, chosen)
+    try:
+        os.sched_setaffinity(0, chosen)
+    except OSError:  # not permitted in this sandbox: leave the thread where it is
+        return []
     return chosen
