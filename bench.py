@@ -278,14 +278,40 @@ def run_cpu_baseline(args):
     }
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this same script under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1) — the process model of cusrl/utils/config.py:31-44,160-187."""
+    import subprocess
+
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {visible} GPU(s) visible; refusing to report a smaller job as n_gpus={args.gpus}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}: the line would misreport n_gpus")
     all_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     result = run_gpu(args, rank, world)
     if all_cpus is not None:

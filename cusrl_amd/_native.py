@@ -105,7 +105,14 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+# Launch census: how often each C-ABI entry point was called through ``check`` (every ``ops`` function reports its
+# launch here).  Tests use it to prove that a result came from the HIP kernel and not from a torch-op form
+# (``launch_counts["cusrl_rnd_reward"]`` must move when the RND hook runs on a GPU).
+launch_counts: dict[str, int] = {}
+
+
 def check(code: int, what: str) -> None:
+    launch_counts[what] = launch_counts.get(what, 0) + 1
     if code != 0:
         text = lib().cusrl_error_string(code).decode()
         raise NativeError(f"{what} failed with code {code}: {text}")

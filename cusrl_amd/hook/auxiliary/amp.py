@@ -100,8 +100,11 @@ class AdversarialMotionPrior(Hook):
             indices = torch.randint(agent_transition.size(0), (self.batch_size,), device=self.agent.device)
             agent_transition, expert_transition = agent_transition[indices], expert_transition[indices]
         expert_transition.requires_grad_(True)
+        from cusrl_amd.nn.module import double_differentiable
+
         agent_logit = self.discriminator(agent_transition)
-        expert_logit = self.discriminator(expert_transition)
+        with double_differentiable():  # the gradient penalty differentiates through this forward's backward
+            expert_logit = self.discriminator(expert_transition)
         discrimination = (self.criterion(agent_logit, torch.zeros_like(agent_logit))
                           + self.criterion(expert_logit, torch.ones_like(expert_logit))) / 2
         penalty = self.grad_penalty(expert_logit, expert_transition)

@@ -61,6 +61,10 @@ class ObservationNormalization(Hook):
         else:
             self.state_rms = None
 
+    def collective_phases(self):
+        # every statistics update all-gathers (mean, var, count) unless synchronisation is deferred to pre_update
+        return () if (self.defer_synchronization or self.frozen) else ("act",)
+
     # ---- rollout
     def pre_act(self, transition):
         observation, state = transition["observation"], transition.get("state")

@@ -56,6 +56,9 @@ class AdvantageNormalization(Hook):
         self.mini_batch_wise = mini_batch_wise
         self.synchronize = synchronize
 
+    def collective_phases(self):
+        return ("objective",) if (self.mini_batch_wise and self.synchronize) else ()
+
     def pre_update(self, buffer):
         if self.mini_batch_wise:
             return

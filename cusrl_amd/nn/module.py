@@ -15,7 +15,8 @@ from torch.nn.functional import linear
 
 from cusrl_amd.utils.nest import iterate_nested
 
-__all__ = ["Linear", "LinearFp32", "linear_act", "Mlp", "Module", "ModuleFactory", "disable_autocast", "resolve_activation_fn"]
+__all__ = ["Linear", "LinearFp32", "linear_act", "Mlp", "Module", "ModuleFactory", "disable_autocast", "double_differentiable",
+           "resolve_activation_fn"]
 
 
 def disable_autocast(device_type: str):
@@ -27,6 +28,24 @@ def disable_autocast(device_type: str):
 # no weight gradient: the flat-buffer assembly sums the slabs straight into the parameter's slot (one launch for all
 # parameters) instead of one sum(0) launch per layer followed by a concatenation.
 _split_grad_sink: dict[int, torch.Tensor] | None = None
+
+
+# The hand-written backward of ``_WideBatchLinear`` calls raw HIP kernels autograd cannot see, i.e. it is
+# once-differentiable.  Code that differentiates THROUGH a backward (``torch.autograd.grad(..., create_graph=True)``:
+# the AMP gradient penalty, cusrl/nn/layer/loss.py:10-56) wraps the forward in ``double_differentiable()`` so those
+# layers take torch's own differentiable ops whatever the batch size; outside the context a second differentiation
+# of the custom backward raises (``once_differentiable``) instead of silently treating it as a constant.
+_plain_linear_depth = 0
+
+
+@contextmanager
+def double_differentiable():
+    global _plain_linear_depth
+    _plain_linear_depth += 1
+    try:
+        yield
+    finally:
+        _plain_linear_depth -= 1
 
 
 @contextmanager
@@ -86,6 +105,7 @@ class _WideBatchLinear(torch.autograd.Function):
         return output
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_output):
         from cusrl_amd import ops
 
@@ -163,7 +183,8 @@ def linear_act(input: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | N
     if _device_fp32(input, weight) and (bias is not None or not relu):
         # the custom backward is once-differentiable: only take it where it pays (wide minibatches); small batches keep
         # torch's own double-differentiable ops (the AMP gradient penalty differentiates through the discriminator twice)
-        if torch.is_grad_enabled() and (weight.requires_grad or input.requires_grad) and input.shape[0] >= 4096:
+        if (torch.is_grad_enabled() and (weight.requires_grad or input.requires_grad) and input.shape[0] >= 4096
+                and not _plain_linear_depth):
             return _WideBatchLinear.apply(input, weight, bias, _batch_splits(input.shape[0]), relu)
         if torch.is_grad_enabled() and (weight.requires_grad or input.requires_grad):
             output = linear(input, weight, bias)

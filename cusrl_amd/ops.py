@@ -366,6 +366,10 @@ def gae(
     D = reward.numel() // max(T * N, 1)
     if done.numel() != T * N:
         raise ValueError(f"gae: 'done' must be [T, N, 1]; got {tuple(done.shape)}")
+    for out, name in ((advantage, "advantage"), (ret, "return")):
+        if out is not None and (not out.is_contiguous() or out.shape != reward.shape):
+            raise ValueError(f"gae: the '{name}' output must be a contiguous tensor of the reward's shape (results are "
+                             "written in place; a strided view would silently receive nothing)")
     advantage = torch.empty_like(reward) if advantage is None else _f32(advantage, "advantage")
     ret = torch.empty_like(reward) if ret is None else _f32(ret, "return")
     lib = _native.lib()

@@ -221,9 +221,12 @@ class ActorCritic(Agent):
         self.hook.pre_update(self.buffer)  # a3-a6: next_value, GAE, advantage normalisation
         with self._training_mode():
             recurrent = self.actor.is_recurrent or self.critic.is_recurrent  # dynamic sequence counts: not capturable
-            if self.compile and hasattr(self.sampler, "iter_indices") and not recurrent:
-                from cusrl_amd.template.graphs import GraphedTrainStep
+            graphed = self.compile and hasattr(self.sampler, "iter_indices") and not recurrent
+            if graphed:
+                from cusrl_amd.template.graphs import GraphedTrainStep, collective_phases
 
+                graphed = "objective" not in collective_phases(self)  # a hook's own collective stays out of capture
+            if graphed:
                 for metadata, indices in self.sampler.iter_indices(self.buffer):
                     key = (metadata["mini_batch_index"], metadata["temporal"], indices.numel())
                     if (step := self._graphed_steps.get(key)) is None:

@@ -26,7 +26,46 @@ import torch
 
 from cusrl_amd.utils.metrics import MetricTap
 
-__all__ = ["GraphedAct", "GraphedTrainStep"]
+__all__ = ["GraphedAct", "GraphedTrainStep", "capture_signature", "collective_phases"]
+
+
+def _freeze(value):
+    """Hashable snapshot of a mutable hook attribute (floats, tuples, None, small tensors by identity)."""
+    if isinstance(value, (list, tuple)):
+        return tuple(_freeze(v) for v in value)
+    if isinstance(value, dict):
+        return tuple(sorted((k, _freeze(v)) for k, v in value.items()))
+    try:
+        hash(value)
+        return value
+    except TypeError:
+        return id(value)
+
+
+def capture_signature(agent) -> tuple:
+    """Everything a captured region reads on the HOST while it is being captured and would therefore freeze:
+    every hook's registered mutable attributes and activity flag, ``agent.deterministic`` and the inference flag.
+    A graph is only replayed while the signature it was captured under still holds; a change (``update_attribute``
+    through a schedule, ``ObservationNormalization.freeze()``, ``set_inference_mode``) sends the graph back to its
+    eager warm-up + re-capture."""
+    parts = [agent.deterministic, agent.inference_mode]
+    for hook in agent.hook:
+        parts.append((hook.name, hook._active, tuple((name, _freeze(getattr(hook, name, None))) for name in sorted(hook._mutable))))
+    return tuple(parts)
+
+
+def collective_phases(agent) -> set[str]:
+    """Phases (``"act"`` / ``"objective"``) in which some active hook issues a cross-rank collective.  Collectives stay
+    outside captured regions (module docstring), so with several ranks such a phase runs eagerly."""
+    from cusrl_amd.utils import distributed
+
+    if not distributed.enabled():
+        return set()
+    phases: set[str] = set()
+    for hook in agent.hook:
+        if hook._active:
+            phases |= set(hook.collective_phases())
+    return phases
 
 
 class _Capture:
@@ -102,6 +141,12 @@ class GraphedTrainStep:
         from cusrl_amd.utils.distributed import configure_distributed
 
         self.single_graph = not configure_distributed()
+        self.signature: tuple | None = None
+
+    def eligible(self) -> bool:
+        """False when an objective-phase hook synchronises across ranks (e.g. minibatch-wise advantage normalisation
+        with ``synchronize``): that step runs eagerly instead of baking an RCCL call into a graph."""
+        return "objective" not in collective_phases(self.agent)
 
     def _whole_step(self):
         self._phase_a()
@@ -145,6 +190,11 @@ class GraphedTrainStep:
         self.metadata = dict(metadata)
         if agent.flat_optimizer is not None:
             agent.flat_optimizer.refresh()  # learning-rate changes reach the captured step through device memory
+        signature = capture_signature(agent)
+        if self.state == 2 and signature != self.signature:
+            self.flush_metrics()
+            self.state = 1  # a host-side value the capture froze has changed: capture again (the warm-up is still valid)
+        self.signature = signature
         if self.state == 2:
             self.forward_backward.replay()
             if not self.single_graph:
@@ -190,6 +240,7 @@ class GraphedAct:
         self.static_state: torch.Tensor | None = None
         self.capture = _Capture(agent)
         self.transition: dict[str, Any] = {}
+        self.signature: tuple | None = None
 
     def _body(self):
         agent = self.agent
@@ -210,7 +261,8 @@ class GraphedAct:
     def supported(self, observation, state) -> bool:
         agent = self.agent
         return (isinstance(observation, torch.Tensor) and observation.is_cuda and not agent.actor.is_recurrent
-                and not agent.critic.is_recurrent and not agent.inference_mode)
+                and not agent.critic.is_recurrent and not agent.inference_mode
+                and "act" not in collective_phases(agent))
 
     def run(self, observation: torch.Tensor, state: torch.Tensor | None) -> torch.Tensor:
         agent = self.agent
@@ -221,6 +273,11 @@ class GraphedAct:
         self.static_observation.copy_(observation)
         if state is not None:
             self.static_state.copy_(state)
+        signature = capture_signature(agent)
+        if self.state == 2 and signature != self.signature:
+            self.capture.flush_metrics()
+            self.state = 1
+        self.signature = signature
         if self.state == 2:
             self.capture.replay()
             agent.transition.clear()

@@ -181,6 +181,12 @@ class Hook(Generic[AgentT]):
 
     def apply_schedule(self, iteration: int): ...
 
+    def collective_phases(self) -> tuple[str, ...]:
+        """Extension: phases among ``"act"`` (pre_act .. post_act) and ``"objective"`` (pre_objective .. post_objective)
+        in which this hook calls a cross-rank collective when training is distributed.  ``compile=True`` keeps such
+        phases out of hipGraph capture (template/graphs.py)."""
+        return ()
+
     def pre_export(self, graph): ...
 
     def post_export(self, graph): ...

@@ -158,16 +158,22 @@ class Trainer:
             self.host_thread_cpus = pin(index, slot=distributed.local_rank())
         self._done_counter = None
         self._done_scratch: dict = {}
+        self._last_checkpoint_iteration: int | None = None
 
     def run_training_loop(self):
+        """Checkpoints as the reference does (trainer.py:280-294): once before the loop, every ``checkpoint_interval``
+        iterations, and once more after the loop when the last iteration was not saved."""
+        self._save_checkpoint()
         try:
             with self.timer.record("environment"):
                 observation, state, _ = self.environment.reset(randomize_episode_progress=True)
             while self.iteration < self.num_iterations:
                 observation, state = self._rollout_and_update(observation, state)
                 self.iteration += 1
-                if self.logger is not None and self.iteration % self.checkpoint_interval == 0:
+                if self.iteration % self.checkpoint_interval == 0:
                     self._save_checkpoint()
+            if self.iteration != self._last_checkpoint_iteration:
+                self._save_checkpoint()
         finally:
             self.environment.close()
 
@@ -255,6 +261,7 @@ class Trainer:
         self.logger.save_checkpoint(
             {"agent": self.agent.state_dict(), "environment": self.environment.state_dict(),
              "iteration": self.iteration, "stats": self.stats.state_dict()}, iteration=self.iteration)
+        self._last_checkpoint_iteration = self.iteration
 
     def _log_info(self, info: dict[str, float]):
         for key, value in self.environment.get_metrics().items():

@@ -197,6 +197,7 @@ class FlatGradients:
         total = sum(p.numel() for p in self.params)
         self.buffer = torch.zeros(total, dtype=torch.float32, device=device)
         self.views = []
+        self.absent: list[int] = []
         offset = 0
         for p in self.params:
             if p.dtype != torch.float32:
@@ -225,6 +226,10 @@ class FlatGradients:
         from cusrl_amd import ops
 
         pieces, offset = [], 0
+        # parameters autograd returned no gradient for (unused this step): torch's optimizers skip them; the flat Adam
+        # step reads this list and leaves their windows untouched (utils/flat_optimizer.py)
+        self.absent = [i for i, (p, grad) in enumerate(zip(self.params, grads))
+                       if grad is None and not (split_slabs and p.data_ptr() in split_slabs)]
         for p, grad in zip(self.params, grads):
             n = p.numel()
             slabs = split_slabs.pop(p.data_ptr(), None) if split_slabs else None

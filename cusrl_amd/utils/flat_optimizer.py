@@ -135,8 +135,16 @@ class FlatAdam:
         partials, max_norm, norm = self._pending_clip if self._pending_clip is not None else (None, None, None)
         self._pending_clip = None
         decoupled = bool(group.get("decoupled_weight_decay", False)) or isinstance(self.optimizer, torch.optim.AdamW)
+        # torch.optim skips parameters whose gradient is None (no momentum drift, no weight decay); the one-launch step
+        # covers the whole flat buffer, so the windows of such parameters are put back afterwards.  (Their step counter
+        # is the shared one: a parameter that is unused for a while and then used again sees a bias correction that is
+        # ahead of torch's per-parameter counter.)
+        kept = [(view, view.clone(), m, m.clone(), v, v.clone())
+                for view, m, v in (self._views[i] for i in self.gradients.absent)]
         ops.adam_step(self.param_buffer, self.gradients.buffer, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
                       self.ticket, betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"],
                       decoupled=decoupled, maximize=bool(group.get("maximize", False)), clip_partials=partials,
                       max_norm=max_norm, norm_out=norm)
+        for view, view0, m, m0, v, v0 in kept:
+            view.copy_(view0), m.copy_(m0), v.copy_(v0)
         return loss
