@@ -11,14 +11,21 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "libcusrl_hip.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_FIELDS = 24
+MAX_PACKED = 16
 
 
 class Field(Structure):
     """``cusrl_field_t`` — one buffer leaf of a multi-leaf launch."""
 
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("row_bytes", c_int64)]
+
+
+class PackedField(Structure):
+    """``cusrl_packed_field_t`` — one narrow leaf's place inside the per-slot record."""
+
+    _fields_ = [("ptr", c_void_p), ("offset", ctypes.c_int32), ("width", ctypes.c_int32)]
 
 
 class GradPiece(Structure):
@@ -50,9 +57,12 @@ _SIGNATURES = {
     "cusrl_normalize": (c_int, [_P, _P, _P, c_float, c_int64, c_int64, _P]),
     "cusrl_merge_mean_var": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
     "cusrl_gather_rows": (c_int, [POINTER(Field), c_int, _P, c_int64, c_int64, c_int64, c_int, _P]),
+    "cusrl_pack_rows": (c_int, [POINTER(PackedField), c_int, _P, c_int64, c_int64, _P]),
+    "cusrl_gather_rows_packed": (c_int, [POINTER(Field), c_int, _P, c_int64, POINTER(PackedField), c_int, _P, c_int64, c_int64,
+                                         c_int64, c_int, _P]),
     "cusrl_ppo_loss_fwd_bwd": (
         c_int,
-        [_P] * 8 + [c_int64] * 3 + [c_double] * 5 + [_P] * 8 + [_P, c_int64, _P, _P],
+        [_P] * 8 + [c_int64] * 3 + [c_double] * 5 + [_P] * 8 + [_P, c_int64, _P, _P, _P],
     ),
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
     "cusrl_ppo_loss_std_partial_rows": (c_int64, [c_int64]),
@@ -76,6 +86,15 @@ _SIGNATURES = {
     "cusrl_rms_normalize": (c_int, [_P, _P, _P, c_float, _P, c_int64, c_int64, _P]),
     "cusrl_rnd_reward": (c_int, [_P, _P, _P, _P, c_float, c_int64, c_int64, _P]),
     "cusrl_amp_style_reward": (c_int, [_P, _P, _P, c_float, c_int64, _P]),
+    "cusrl_comm_available": (c_int, []),
+    "cusrl_comm_last_error": (c_char_p, []),
+    "cusrl_comm_unique_id": (c_int, [_P]),
+    "cusrl_comm_create": (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
+    "cusrl_comm_destroy": (c_int, [_P]),
+    "cusrl_comm_world_size": (c_int, [_P]),
+    "cusrl_allreduce_mean": (c_int, [_P, c_int64, _P, _P]),
+    "cusrl_allgather": (c_int, [_P, _P, c_int64, _P, _P]),
+    "cusrl_broadcast": (c_int, [_P, c_int64, c_int, _P, _P]),
     "cusrl_sequence_count": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P]),
     "cusrl_sequence_blocks": (c_int64, [c_int64]),
     "cusrl_sequence_layout": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, _P, _P, _P, _P]),
@@ -115,4 +134,6 @@ def check(code: int, what: str) -> None:
     launch_counts[what] = launch_counts.get(what, 0) + 1
     if code != 0:
         text = lib().cusrl_error_string(code).decode()
+        if code == -4:  # CUSRL_E_COMM
+            text += ": " + lib().cusrl_comm_last_error().decode()
         raise NativeError(f"{what} failed with code {code}: {text}")

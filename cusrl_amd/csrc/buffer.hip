@@ -179,9 +179,136 @@ __device__ __forceinline__ void gather_bytes_packed(const char *__restrict__ src
     }
 }
 
-__global__ __launch_bounds__(kBlock) void gather_kernel(const GatherTable tab, const int64_t *__restrict__ idx,
-                                                        int64_t B, int64_t T, int64_t N, int temporal) {
+// ---- packed narrow leaves -----------------------------------------------------------------------------------------
+// A random row of a 1-4 byte leaf costs a whole memory sector, and the ppo buffer has nine such leaves (logp, value,
+// reward, next_value, advantage, return, three flags): ten sectors fetched for 27 useful bytes per sampled slot.
+// cusrl_pack_rows interleaves them ONCE per update into one record per slot (27 -> 32 B, one sector), and the gather
+// reads the record and fans the fields out to their separate, contiguous batch tensors (coalesced stores).
+// Descriptor table, by value in the kernarg segment, laid out for FEW WIDE independent scalar loads (kernarg misses
+// cost microseconds — see PushTable).  Entries are sorted by width on the host — [0, n4) move 4 bytes, [n4, n4 + n2)
+// 2 bytes, the rest 1 byte; an 8-byte leaf is two 4-byte entries with a row stride of 8 — so the kernels are three
+// straight-line, compile-time-indexed passes without any per-entry switch: every descriptor read is a load at a
+// static kernarg offset and no register image of the record has to be indexed at run time (that would live in scratch).
+struct RecordTable {
+    int32_t n4, n2, n1;
+    int32_t record_bytes;              // 16, 32 or 64
+    uint8_t offset[CUSRL_MAX_PACKED];  // byte offset inside the record
+    uint8_t stride[CUSRL_MAX_PACKED];  // bytes between consecutive rows of the leaf (its row size)
+    char *ptr[CUSRL_MAX_PACKED];       // pack: source leaf (+ byte offset);  gather: destination tensor (+ byte offset)
+};
+
+constexpr int kRecordRowsPerBlock = kBlock;  // one sampled slot per lane; parallelism inside a lane = the fields
+constexpr int kRecordTableDwords = sizeof(RecordTable) / 4;
+static_assert(sizeof(RecordTable) % 4 == 0 && kRecordTableDwords <= kWave, "one dword of the table per lane");
+
+// The table as seen by one wave: lane k holds dword k of the kernarg copy, fetched by ONE vector load (a single
+// round trip to kernarg memory; scalar loads sunk next to each use would be a chain of microsecond misses), and every
+// descriptor is then a v_readlane with a compile-time lane index, i.e. a scalar value again.
+struct WaveRecordTable {
+    uint32_t mine;
+    __device__ __forceinline__ explicit WaveRecordTable(size_t kernarg_offset) {
+        const uint32_t *karg = (const uint32_t *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + kernarg_offset);
+        const int lane = threadIdx.x & (kWave - 1);
+        mine = karg[lane < kRecordTableDwords ? lane : 0];
+    }
+    __device__ __forceinline__ uint32_t dword(int k) const { return __builtin_amdgcn_readlane(mine, k); }
+    __device__ __forceinline__ int n4() const { return int(dword(0)); }
+    __device__ __forceinline__ int n2() const { return int(dword(1)); }
+    __device__ __forceinline__ int n1() const { return int(dword(2)); }
+    __device__ __forceinline__ int record_bytes() const { return int(dword(3)); }
+    __device__ __forceinline__ int offset(int f) const { return (dword(4 + f / 4) >> (8 * (f % 4))) & 0xff; }
+    __device__ __forceinline__ int stride(int f) const {
+        return (dword(4 + CUSRL_MAX_PACKED / 4 + f / 4) >> (8 * (f % 4))) & 0xff;
+    }
+    __device__ __forceinline__ char *ptr(int f) const {
+        const int base = 4 + CUSRL_MAX_PACKED / 2 + 2 * f;
+        return reinterpret_cast<char *>(uint64_t(dword(base)) | (uint64_t(dword(base + 1)) << 32));
+    }
+};
+static_assert(offsetof(RecordTable, offset) == 16 && offsetof(RecordTable, stride) == 16 + CUSRL_MAX_PACKED &&
+                  offsetof(RecordTable, ptr) == 16 + 2 * CUSRL_MAX_PACKED,
+              "WaveRecordTable decodes this layout");
+
+// One lane = one sampled slot.  Every requested entry is loaded straight from the slot's record (the first load
+// misses, the others hit the same 32/64-byte line); all loads are issued before the first store.
+__device__ __forceinline__ void gather_record(const WaveRecordTable &rec, const char *__restrict__ src,
+                                              const int64_t *__restrict__ idx, int64_t rows, int64_t row0, int64_t B,
+                                              int64_t N, bool temporal) {
+    const int64_t out_row = min(row0, rows - 1);  // clamped, unpredicated (see gather_unit)
+    int64_t src_row;
+    if (temporal) {
+        const int64_t t = out_row / B, b = out_row - t * B;
+        src_row = t * N + idx[b];
+    } else {
+        src_row = idx[out_row];
+    }
+    const char *slot = src + src_row * rec.record_bytes();
+    const int n4 = rec.n4(), n42 = n4 + rec.n2(), n = n42 + rec.n1();
+    uint32_t word[CUSRL_MAX_PACKED];
+#pragma unroll
+    for (int f = 0; f < CUSRL_MAX_PACKED; ++f) {
+        word[f] = 0;
+        if (f < n) word[f] = *reinterpret_cast<const uint32_t *>(slot + (rec.offset(f) & ~3));
+    }
+#pragma unroll
+    for (int f = 0; f < CUSRL_MAX_PACKED; ++f) {
+        if (f < n) {  // wave-uniform class tests: entries are sorted 4-byte, 2-byte, 1-byte
+            char *dst = rec.ptr(f) + out_row * rec.stride(f);
+            const uint32_t v = word[f] >> ((rec.offset(f) & 3) * 8);
+            if (f < n4) *reinterpret_cast<uint32_t *>(dst) = v;
+            else if (f < n42) *reinterpret_cast<uint16_t *>(dst) = uint16_t(v);
+            else *reinterpret_cast<uint8_t *>(dst) = uint8_t(v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void pack_rows_kernel(const RecordTable rec_arg, char *__restrict__ record,
+                                                           int64_t rows) {
+    const WaveRecordTable rec(0);  // rec_arg is the first kernel argument: kernarg offset 0
+    const int64_t row = min(int64_t(blockIdx.x) * kBlock + threadIdx.x, rows - 1);  // clamped: duplicates rewrite equal bytes
+    char *out = record + row * rec.record_bytes();
+    const int n4 = rec.n4(), n42 = n4 + rec.n2(), n = n42 + rec.n1();
+    uint32_t word[CUSRL_MAX_PACKED];
+    // unit-stride across the wave for 1-channel leaves: coalesced reads, all issued before the stores
+#pragma unroll
+    for (int f = 0; f < CUSRL_MAX_PACKED; ++f) {
+        word[f] = 0;
+        if (f < n) {
+            const char *src = rec.ptr(f) + row * rec.stride(f);
+            if (f < n4) word[f] = *reinterpret_cast<const uint32_t *>(src);
+            else if (f < n42) word[f] = *reinterpret_cast<const uint16_t *>(src);
+            else word[f] = *reinterpret_cast<const uint8_t *>(src);
+        }
+    }
+    // narrow strided stores, merged in L2 (this runs once per update)
+#pragma unroll
+    for (int f = 0; f < CUSRL_MAX_PACKED; ++f) {
+        if (f < n) {
+            char *dst = out + rec.offset(f);
+            if (f < n4) *reinterpret_cast<uint32_t *>(dst) = word[f];
+            else if (f < n42) *reinterpret_cast<uint16_t *>(dst) = uint16_t(word[f]);
+            else *reinterpret_cast<uint8_t *>(dst) = uint8_t(word[f]);
+        }
+    }
+}
+
+struct GatherArgs {  // both tables in ONE kernel argument, so that the record table's kernarg offset is offsetof()
+    GatherTable tab;
+    RecordTable rec;
+};
+
+__global__ __launch_bounds__(kBlock) void gather_kernel(const GatherArgs args, const char *__restrict__ record,
+                                                        const int64_t *__restrict__ idx, int64_t B, int64_t T,
+                                                        int64_t N, int temporal) {
+    const GatherTable &tab = args.tab;
     const int blk = blockIdx.x;
+    if (blk >= tab.block_start[CUSRL_MAX_FIELDS]) {  // the blocks behind the last plain leaf unpack the record
+        const WaveRecordTable rec(offsetof(GatherArgs, rec));
+        const int64_t rows = temporal ? T * B : B;
+        const int64_t row0 = int64_t(blk - tab.block_start[CUSRL_MAX_FIELDS]) * kRecordRowsPerBlock + threadIdx.x;
+        gather_record(rec, record, idx, rows, row0, B, N, temporal != 0);
+        return;
+    }
     const int f = find_leaf(tab, blk);
     const GatherLeaf leaf = tab.leaf[f];
     const char *__restrict__ src = leaf.src;
@@ -341,13 +468,70 @@ extern "C" int cusrl_buffer_push(const cusrl_field_t *fields, int n_fields, int6
     return launch_status();
 }
 
-extern "C" int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, const int64_t *indices, int64_t B,
-                                 int64_t T, int64_t N, int temporal, void *stream) {
-    if (n_fields == 0 || B == 0) return 0;
-    if (!fields || !indices || n_fields < 0 || B < 0 || T < 1 || N < 1) return CUSRL_E_INVALID;
+static int fill_record_table(const cusrl_packed_field_t *packed, int n_packed, int64_t record_bytes,
+                             RecordTable &rec) {
+    rec.n4 = rec.n2 = rec.n1 = 0;
+    rec.record_bytes = int32_t(record_bytes);
+    for (int i = 0; i < CUSRL_MAX_PACKED; ++i) rec.offset[i] = 0, rec.stride[i] = 4, rec.ptr[i] = nullptr;
+    if (n_packed < 0 || n_packed > CUSRL_MAX_PACKED) return CUSRL_E_TOO_MANY;
+    if (n_packed == 0) return 0;
+    if (!packed || (record_bytes != 16 && record_bytes != 32 && record_bytes != 64)) return CUSRL_E_INVALID;
+    uint64_t used = 0;  // one bit per record byte: fields must not overlap
+    int entries = 0;
+    for (int i = 0; i < n_packed; ++i) {
+        const int32_t w = packed[i].width, off = packed[i].offset;
+        if (!packed[i].ptr || (w != 1 && w != 2 && w != 4 && w != 8) || off < 0 || off % w != 0 ||
+            off + w > record_bytes || !aligned(packed[i].ptr, uintptr_t(w)))
+            return CUSRL_E_INVALID;
+        const uint64_t bits = ((uint64_t(1) << w) - 1) << off;
+        if (used & bits) return CUSRL_E_INVALID;
+        used |= bits;
+        entries += w == 8 ? 2 : 1;
+    }
+    if (entries > CUSRL_MAX_PACKED) return CUSRL_E_TOO_MANY;
+    int at = 0;
+    for (int pass_width : {4, 2, 1}) {  // 4-byte entries first (an 8-byte leaf = two of them), then 2-byte, then 1-byte
+        for (int i = 0; i < n_packed; ++i) {
+            const int32_t w = packed[i].width, off = packed[i].offset;
+            if ((w == 8 ? 4 : w) != pass_width) continue;
+            for (int half = 0; half < (w == 8 ? 2 : 1); ++half) {
+                rec.offset[at] = uint8_t(off + 4 * half);
+                rec.stride[at] = uint8_t(w);
+                rec.ptr[at] = static_cast<char *>(packed[i].ptr) + 4 * half;
+                ++at;
+            }
+        }
+        (pass_width == 4 ? rec.n4 : pass_width == 2 ? rec.n2 : rec.n1) = at - (pass_width == 4 ? 0 : pass_width == 2 ? rec.n4 : rec.n4 + rec.n2);
+    }
+    return 0;
+}
+
+extern "C" int cusrl_pack_rows(const cusrl_packed_field_t *fields, int n_fields, void *record, int64_t record_bytes,
+                               int64_t rows, void *stream) {
+    if (n_fields == 0 || rows == 0) return 0;
+    if (!record || rows < 0 || !aligned(record, 16)) return CUSRL_E_INVALID;
+    RecordTable rec;
+    if (int rc = fill_record_table(fields, n_fields, record_bytes, rec)) return rc;
+    const int64_t blocks = ceil_div(rows, kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), rec,
+                       static_cast<char *>(record), rows);
+    return launch_status();
+}
+
+extern "C" int cusrl_gather_rows_packed(const cusrl_field_t *fields, int n_fields, const void *record,
+                                        int64_t record_bytes, const cusrl_packed_field_t *packed, int n_packed,
+                                        const int64_t *indices, int64_t B, int64_t T, int64_t N, int temporal,
+                                        void *stream) {
+    if ((n_fields == 0 && n_packed == 0) || B == 0) return 0;
+    if ((n_fields > 0 && !fields) || !indices || n_fields < 0 || B < 0 || T < 1 || N < 1) return CUSRL_E_INVALID;
     if (n_fields > CUSRL_MAX_FIELDS) return CUSRL_E_TOO_MANY;
+    if (n_packed > 0 && (!record || !aligned(record, 16))) return CUSRL_E_INVALID;
     const int64_t rows = temporal ? T * B : B;
-    GatherTable tab;
+    GatherArgs args;
+    GatherTable &tab = args.tab;
+    RecordTable &rec = args.rec;
+    if (int rc = fill_record_table(packed, n_packed, n_packed > 0 ? record_bytes : 16, rec)) return rc;
     int64_t blocks = 0;
     int n = 0;
     for (int i = 0; i < n_fields; ++i) {
@@ -375,12 +559,20 @@ extern "C" int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, cons
         if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
         ++n;
     }
-    if (n == 0) return 0;
     for (int i = n; i <= CUSRL_MAX_FIELDS; ++i) tab.block_start[i] = int32_t(blocks);
     tab.n = n;
-    hipLaunchKernelGGL(gather_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), tab, indices, B,
-                       T, N, temporal);
+    if (rec.n4 + rec.n2 + rec.n1 > 0) blocks += ceil_div(rows, kRecordRowsPerBlock);
+    if (blocks == 0) return 0;
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(gather_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), args,
+                       static_cast<const char *>(record), indices, B, T, N, temporal);
     return launch_status();
+}
+
+extern "C" int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, const int64_t *indices, int64_t B,
+                                 int64_t T, int64_t N, int temporal, void *stream) {
+    if (n_fields == 0 || B == 0) return 0;
+    return cusrl_gather_rows_packed(fields, n_fields, nullptr, 0, nullptr, 0, indices, B, T, N, temporal, stream);
 }
 
 extern "C" int64_t cusrl_flag_blocks(int64_t n) { return n <= 0 ? 0 : ceil_div(n, kFlagChunk); }

@@ -79,6 +79,7 @@ constexpr int kLossSums = 5;  // value loss, surrogate, entropy, |logp ratio|, v
 
 // All five sums through ONE LDS exchange (one barrier instead of two per sum): wave-shuffle each, lane 0 of every
 // wave parks its five totals, the first five threads add the four waves up in fixed order.
+template <bool kPublish = false>
 __device__ __forceinline__ void write_block_partials(const double (&acc)[kLossSums], double *__restrict__ partials) {
     __shared__ double scratch[kWavesPerBlock][kLossSums];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -92,11 +93,51 @@ __device__ __forceinline__ void write_block_partials(const double (&acc)[kLossSu
         double total = 0.0;
 #pragma unroll
         for (int w = 0; w < kWavesPerBlock; ++w) total += scratch[w][threadIdx.x];
-        partials[int64_t(blockIdx.x) * kLossSums + threadIdx.x] = total;
+        double *slot = partials + int64_t(blockIdx.x) * kLossSums + threadIdx.x;
+        if (kPublish)  // 8-byte agent-scope store: written through, visible to the finishing block without any fence
+            __hip_atomic_store(slot, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            *slot = total;
     }
 }
 
+// Hand-off of the per-block partial rows to whichever block finishes last, WITHOUT release / acquire fences: an
+// agent-scope release writes back every dirty line of the XCD's L2 — here the ~70 KB of gradients each block has just
+// stored — and measured slower than the separate finalize launch it was meant to save.  Instead the few partial values
+// are published with 8-byte agent-scope stores (write-through) and read back with agent-scope loads (L1 bypass), the
+// "8-byte agent atomics on both sides" form of the MI355X guide; the ticket is a relaxed agent-scope counter taken
+// after a barrier (which waits for the stores of every wave of the block).
+__device__ __forceinline__ double load_published(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_published(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr int kRowsPerBlock = kBlock;
+
+template <bool kPublished = false>
+__device__ __forceinline__ void reduce_std_rows(const float *in, int64_t rows, int A, float *__restrict__ out);
+template <bool kPublished = false>
+__device__ __forceinline__ void finalize_losses(const double *partials, int64_t P, int64_t B, int D,
+                                                const LossParams &p, float *__restrict__ losses_out,
+                                                const float *d_std_partials, int A, float *__restrict__ d_std_vector);
+
+// Last-block-done hand-off: every block publishes its partial rows, then takes a ticket; the block that draws the
+// last one reduces all rows in the same launch (no separate 1-block finalize launch).  The ticket re-arms itself, so
+// replayed hipGraphs need no memset.
+__device__ __forceinline__ bool last_block_done(unsigned int *__restrict__ ticket) {
+    __shared__ int is_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's published stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = drawn == gridDim.x - 1;
+        if (is_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return is_last != 0;
+}
 
 // kStdVec: `std` is ONE row [A] shared by every sample (a state-independent std vector, distribution.py:228-247)
 // instead of a [B, A] matrix: it is read from L1 instead of streamed, and d_std leaves the kernel as per-block
@@ -111,12 +152,12 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
     const float *__restrict__ curr_value, const float *__restrict__ old_value, int64_t B, int D, LossParams p,
     float *__restrict__ logp_out, float *__restrict__ entropy_out, float *__restrict__ lr_out,
     float *__restrict__ ratio_out, float *__restrict__ d_mean, float *__restrict__ d_std,
-    float *__restrict__ d_value, double *__restrict__ partials, float *__restrict__ d_std_partials) {
+    float *__restrict__ d_value, double *__restrict__ partials, float *__restrict__ d_std_partials,
+    unsigned int *__restrict__ ticket, float *__restrict__ losses_out) {
     __shared__ float lp_part[kRowsPerBlock * LPR];
     __shared__ float en_part[kRowsPerBlock * LPR];
     __shared__ float dlp_row[kRowsPerBlock];
-    __shared__ float4 ds_stage[kStdVec ? kRowsPerBlock * LPR : 1];   // this block's d_std chunks, row-major
-    __shared__ float4 ds_group[kStdVec ? kStdRowGroups * LPR : 1];  // column sums of 16 row groups
+    __shared__ float4 ds_wave[kStdVec ? kWavesPerBlock * LPR : 1];  // per-wave column sums of d_std
     const int64_t row0 = int64_t(blockIdx.x) * kRowsPerBlock;
     const int64_t chunk0 = row0 * LPR;
     const int64_t total_chunks = B * LPR;
@@ -180,11 +221,16 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
 
     float4 *__restrict__ dm4 = reinterpret_cast<float4 *>(d_mean);
     float4 *__restrict__ ds4 = reinterpret_cast<float4 *>(d_std);
+    // std-vector mode: a lane's k-th chunk belongs to column group (k * 256 + tid) % LPR; its d_std contribution is
+    // accumulated into that group's slot (compile-time slots, selected by comparison — a few v_cndmask, no scratch),
+    // so that afterwards plain wave-wide shuffle sums give the wave's [A] column sums: no [256, A] LDS tile, one barrier.
+    float4 ds_acc[kStdVec ? LPR : 1];
+#pragma unroll
+    for (int g = 0; g < (kStdVec ? LPR : 1); ++g) ds_acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < LPR; ++k) {
         const int local = k * kBlock + threadIdx.x;
         const int64_t q = chunk0 + local;
-        if (kStdVec && q >= total_chunks) ds_stage[local] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < total_chunks) {
             const float dlp = dlp_row[local / LPR];
             const float xs[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
@@ -198,35 +244,52 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
                 gs[j] = dlp * ((diff * diff) / (var * ss[j]) - 1.0f / ss[j]) + p.g_ent / ss[j];  // + d entropy / d std
             }
             if (d_mean) dm4[q] = make_float4(gm[0], gm[1], gm[2], gm[3]);
-            if (kStdVec)
-                ds_stage[local] = make_float4(gs[0], gs[1], gs[2], gs[3]);
-            else if (d_std)
+            if (kStdVec) {
+                const int group = local % LPR;
+#pragma unroll
+                for (int g = 0; g < LPR; ++g) {
+                    const bool hit = group == g;
+                    ds_acc[g].x += hit ? gs[0] : 0.f, ds_acc[g].y += hit ? gs[1] : 0.f;
+                    ds_acc[g].z += hit ? gs[2] : 0.f, ds_acc[g].w += hit ? gs[3] : 0.f;
+                }
+            } else if (d_std) {
                 ds4[q] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+            }
         }
     }
-    if (kStdVec) {  // column sums of the block's [256, A] d_std tile, fixed order: 16 row groups, then the groups
-        __syncthreads();
-        const int t = threadIdx.x;
-        if (t < kStdRowGroups * LPR) {
-            const int c = t % LPR, g = t / LPR;
-            float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int r = g; r < kRowsPerBlock; r += kStdRowGroups) {
-                const float4 v = ds_stage[r * LPR + c];
-                total.x += v.x, total.y += v.y, total.z += v.z, total.w += v.w;
-            }
-            ds_group[g * LPR + c] = total;
+    if (kStdVec) {  // column sums of the block's [256, A] d_std tile, fixed order: lanes of a wave, then the 4 waves
+        const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+#pragma unroll
+        for (int g = 0; g < LPR; ++g) {
+            const float4 total = make_float4(wave_sum(ds_acc[g].x), wave_sum(ds_acc[g].y), wave_sum(ds_acc[g].z),
+                                             wave_sum(ds_acc[g].w));
+            if (lane == 0) ds_wave[wave * LPR + g] = total;
         }
         __syncthreads();
         if (t < LPR && d_std_partials) {
-            float4 total = ds_group[t];
-            for (int g = 1; g < kStdRowGroups; ++g) {
-                const float4 v = ds_group[g * LPR + t];
+            float4 total = ds_wave[t];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) {
+                const float4 v = ds_wave[w * LPR + t];
                 total.x += v.x, total.y += v.y, total.z += v.z, total.w += v.w;
             }
-            reinterpret_cast<float4 *>(d_std_partials)[int64_t(blockIdx.x) * LPR + t] = total;
+            float4 *slot = reinterpret_cast<float4 *>(d_std_partials) + int64_t(blockIdx.x) * LPR + t;
+            if (ticket) {  // published as two 8-byte agent-scope stores (see load_published)
+                unsigned long long *q = reinterpret_cast<unsigned long long *>(slot);
+                __hip_atomic_store(q, (unsigned long long)__float_as_uint(total.x) | ((unsigned long long)__float_as_uint(total.y) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(total.z) | ((unsigned long long)__float_as_uint(total.w) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                *slot = total;
+            }
         }
     }
-    write_block_partials(acc, partials);
+    if (ticket) write_block_partials<true>(acc, partials);
+    else write_block_partials<false>(acc, partials);
+    if (ticket && last_block_done(ticket))  // uniform per block
+        finalize_losses<true>(partials, gridDim.x, B, D, p, losses_out, (kStdVec && d_std) ? d_std_partials : nullptr,
+                              LPR * 4, d_std);
 }
 
 // Any action width: one lane per row, scalar accesses.
@@ -236,7 +299,8 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowwise_kernel(
     const float *__restrict__ curr_value, const float *__restrict__ old_value, int64_t B, int A, int D, LossParams p,
     float *__restrict__ logp_out, float *__restrict__ entropy_out, float *__restrict__ lr_out,
     float *__restrict__ ratio_out, float *__restrict__ d_mean, float *__restrict__ d_std,
-    float *__restrict__ d_value, double *__restrict__ partials) {
+    float *__restrict__ d_value, double *__restrict__ partials, unsigned int *__restrict__ ticket,
+    float *__restrict__ losses_out) {
     double acc[kLossSums] = {0.0, 0.0, 0.0, 0.0, 0.0};
     const int64_t row = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (row < B) {
@@ -261,25 +325,29 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowwise_kernel(
         }
         value_terms(ret, curr_value, old_value, d_value, row, D, p, acc[0], acc[4]);
     }
-    write_block_partials(acc, partials);
+    if (ticket) write_block_partials<true>(acc, partials);
+    else write_block_partials<false>(acc, partials);
+    if (ticket && last_block_done(ticket))
+        finalize_losses<true>(partials, gridDim.x, B, D, p, losses_out, nullptr, A, nullptr);
 }
 
 // Column sums of `rows` partial rows [rows][A] (A <= 32) by one block, fixed order: lane (a, g) walks rows g, g + 8, ...
 // four loads at a time, the 8 row groups are combined through LDS.  out[a] for a < A.
 constexpr int kStdSliceRows = 128;  // partial rows one block of the staged reduction takes
 
-__device__ __forceinline__ void reduce_std_rows(const float *__restrict__ in, int64_t rows, int A,
-                                                float *__restrict__ out) {
+template <bool kPublished>
+__device__ __forceinline__ void reduce_std_rows(const float *in, int64_t rows, int A, float *__restrict__ out) {
     __shared__ float part[kBlock];
     const int a = threadIdx.x & 31, g = threadIdx.x >> 5;
+    auto at = [&](int64_t i) { return kPublished ? load_published(in + i) : in[i]; };
     float total = 0.f;
     if (a < A) {
         int64_t r = g;
         for (; r + 24 < rows; r += 32) {
-            const float v0 = in[r * A + a], v1 = in[(r + 8) * A + a], v2 = in[(r + 16) * A + a], v3 = in[(r + 24) * A + a];
+            const float v0 = at(r * A + a), v1 = at((r + 8) * A + a), v2 = at((r + 16) * A + a), v3 = at((r + 24) * A + a);
             total += (v0 + v1) + (v2 + v3);
         }
-        for (; r < rows; r += 8) total += in[r * A + a];
+        for (; r < rows; r += 8) total += at(r * A + a);
     }
     part[threadIdx.x] = total;
     __syncthreads();
@@ -296,12 +364,12 @@ __device__ __forceinline__ void reduce_std_rows(const float *__restrict__ in, in
 __global__ __launch_bounds__(kBlock) void std_rows_stage_kernel(const float *__restrict__ in, int64_t rows, int A,
                                                                 float *__restrict__ stage) {
     const int64_t first = int64_t(blockIdx.x) * kStdSliceRows;
-    reduce_std_rows(in + first * A, min(int64_t(kStdSliceRows), rows - first), A, stage + int64_t(blockIdx.x) * A);
+    reduce_std_rows<false>(in + first * A, min(int64_t(kStdSliceRows), rows - first), A, stage + int64_t(blockIdx.x) * A);
 }
 
 __global__ __launch_bounds__(kBlock) void std_rows_final_kernel(const float *__restrict__ stage, int64_t rows, int A,
                                                                 float *__restrict__ out) {
-    reduce_std_rows(stage, rows, A, out);
+    reduce_std_rows<false>(stage, rows, A, out);
 }
 
 // Many blocks (> 256, i.e. minibatches beyond 65 536 rows): one block cannot walk all partial rows at memory latency,
@@ -315,18 +383,18 @@ __global__ __launch_bounds__(kBlock) void loss_partials_stage_kernel(const doubl
     write_block_partials(acc, stage);
 }
 
-__global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double *__restrict__ partials, int64_t P,
-                                                                   int64_t B, int D, LossParams p,
-                                                                   float *__restrict__ losses_out,
-                                                                   const float *__restrict__ d_std_partials, int A,
-                                                                   float *__restrict__ d_std_vector) {
+template <bool kPublished>
+__device__ __forceinline__ void finalize_losses(const double *partials, int64_t P, int64_t B, int D,
+                                                const LossParams &p, float *__restrict__ losses_out,
+                                                const float *d_std_partials, int A, float *__restrict__ d_std_vector) {
     __shared__ double scratch[kWavesPerBlock];
-    if (d_std_partials) reduce_std_rows(d_std_partials, P, A, d_std_vector);  // std-vector mode, few blocks
+    if (d_std_partials) reduce_std_rows<kPublished>(d_std_partials, P, A, d_std_vector);  // std-vector mode, few blocks
     double sums[kLossSums];
 #pragma unroll
     for (int k = 0; k < kLossSums; ++k) {
         double s = 0.0;
-        for (int64_t i = threadIdx.x; i < P; i += kBlock) s += partials[i * kLossSums + k];
+        for (int64_t i = threadIdx.x; i < P; i += kBlock)
+            s += kPublished ? load_published(partials + i * kLossSums + k) : partials[i * kLossSums + k];
         sums[k] = block_sum(s, scratch);
     }
     if (threadIdx.x == 0) {
@@ -339,6 +407,14 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double 
         // sum(objectives.values()) in the hooks' insertion order            actor_critic.py:309
         losses_out[6] = (losses_out[0] + losses_out[1]) + losses_out[2];
     }
+}
+
+__global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double *__restrict__ partials, int64_t P,
+                                                                   int64_t B, int D, LossParams p,
+                                                                   float *__restrict__ losses_out,
+                                                                   const float *__restrict__ d_std_partials, int A,
+                                                                   float *__restrict__ d_std_vector) {
+    finalize_losses<false>(partials, P, B, D, p, losses_out, d_std_partials, A, d_std_vector);
 }
 
 }  // namespace cusrl
@@ -362,11 +438,13 @@ extern "C" int64_t cusrl_ppo_loss_std_partial_rows(int64_t B) {
     if (std_vector)                                                                                                    \
         hipLaunchKernelGGL((ppo_loss_chunked_kernel<LPR, true>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, \
                            old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out,            \
-                           entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials);  \
+                           entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,   \
+                           in_kernel, losses_out);                                                                     \
     else                                                                                                               \
         hipLaunchKernelGGL((ppo_loss_chunked_kernel<LPR, false>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s,           \
                            advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out, \
-                           entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials)
+                           entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,   \
+                           in_kernel, losses_out)
 
 extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action,
                                       const float *mean, const float *std, const float *ret, const float *curr_value,
@@ -374,7 +452,7 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
                                       double value_clip, double w_sur, double w_val, double w_ent, float *losses_out,
                                       float *logp_out, float *entropy_out, float *logp_ratio_out, float *ratio_out,
                                       float *d_mean, float *d_std, float *d_value, double *partials,
-                                      int64_t std_rows, float *d_std_partials, void *stream) {
+                                      int64_t std_rows, float *d_std_partials, uint32_t *ticket, void *stream) {
     if (B <= 0 || A <= 0 || D <= 0) return CUSRL_E_INVALID;
     if (std_rows != B && std_rows != 1) return CUSRL_E_INVALID;
     const bool std_vector = std_rows == 1 && B != 1;
@@ -399,6 +477,10 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
     const bool chunked = A % 4 == 0 && A / 4 <= 8 && aligned(action, 16) && aligned(mean, 16) && aligned(std, 16) &&
                          (!d_mean || aligned(d_mean, 16)) && (!d_std || aligned(d_std, 16));
     if (std_vector && !chunked) return CUSRL_E_UNSUPPORTED;  // the row-vector form exists for the 16-byte-chunk layout
+    // few enough blocks for ONE block to reduce every partial row at memory latency: the last block to finish does it
+    // inside the launch (ticket); larger minibatches keep the staged reduction launches below
+    const bool fused_finalize = ticket && blocks <= kBlock && (!(std_vector && d_std) || blocks <= kStdSliceRows);
+    unsigned int *in_kernel = fused_finalize ? ticket : nullptr;
     if (chunked) {
         switch (A / 4) {
             case 1: CUSRL_LAUNCH_CHUNKED(1); break;
@@ -413,9 +495,10 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
     } else {
         hipLaunchKernelGGL(ppo_loss_rowwise_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, old_logp,
                            action, mean, std, ret, curr_value, old_value, B, int(A), int(D), p, logp_out, entropy_out,
-                           logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials);
+                           logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, in_kernel, losses_out);
     }
     if (int rc = launch_status()) return rc;
+    if (fused_finalize) return 0;
     // gradient of the std vector = column sums of the per-block sums: inside the finalize launch for up to 128 blocks
     // (a 32 768-row minibatch), staged over 128-row slices beyond that
     const bool reduce_std = std_vector && d_std;

@@ -23,10 +23,30 @@ class OnPolicyStatistics(Hook):
         super().__init__(training_only=True)
         self.sampler = Sampler() if sampler is None else sampler
 
+    def _batches(self, buffer):
+        """The hook's sampler — except that ONE shuffled batch of the whole buffer (the preset's
+        ``AutoMiniBatchSampler()``: 1 epoch x 1 minibatch, stats.py:29-32) is not gathered at all: the three statistics
+        are means over all samples, i.e. invariant under the permutation, so the pass reads the buffer leaves in place
+        (flattened views) and the 110 MB whole-buffer gather disappears.  The permutation is still drawn: the reference
+        consumes one ``randperm`` from the global generator here, and the following iterations' index streams stay
+        bit-identical only if this one is consumed too."""
+        from cusrl_amd.sampler.mini_batch_sampler import AutoMiniBatchSampler, MiniBatchSampler
+
+        sampler = self.sampler
+        if (isinstance(sampler, (MiniBatchSampler, AutoMiniBatchSampler)) and sampler.num_epochs == 1
+                and sampler.num_mini_batches in (1, (1,)) and sampler.lazy):
+            for metadata, _indices in sampler.iter_indices(buffer):
+                if metadata["temporal"]:
+                    yield metadata, buffer.sample(lambda _name, tensor: tensor)
+                else:
+                    yield metadata, buffer.sample(lambda _name, tensor: tensor.flatten(0, 1))
+            return
+        yield from sampler(buffer)
+
     @torch.no_grad()
     def post_update(self):
         agent = self.agent
-        for _, batch in self.sampler(agent.buffer):
+        for _, batch in self._batches(agent.buffer):
             with agent.autocast():
                 updated, _ = agent.actor(batch["observation"], memory=batch.get("actor_memory"), done=batch["done"])
             if self._gaussian_on_device(batch["action_dist"], updated):

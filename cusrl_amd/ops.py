@@ -8,15 +8,17 @@ with torch's caching allocator.  PyTorch is plumbing here (memory, streams); the
 
 from __future__ import annotations
 
+import os
 from collections.abc import Sequence
 
 import torch
 
 from cusrl_amd import _native
-from cusrl_amd._native import Field, check
+from cusrl_amd._native import Field, PackedField, check
 
 __all__ = [
     "LaunchObserver",
+    "RecordPack",
     "adv_stats_finalize",
     "amp_style_reward_",
     "buffer_push",
@@ -25,6 +27,7 @@ __all__ = [
     "episode_stats",
     "gae",
     "gather_rows",
+    "gather_rows_packed",
     "merge_mean_var",
     "next_value",
     "normal_sample_logp",
@@ -211,6 +214,115 @@ def gather_rows(
             lambda: lib.cusrl_gather_rows(table, len(chunk), indices.data_ptr(), batch, capacity, parallelism, int(temporal), stream),
         )
     return outputs
+
+
+class RecordPack:
+    """The narrow leaves of a rollout buffer (1-8 bytes per slot: log-prob, value, reward, next_value, advantage,
+    return, flags) interleaved into ONE record per slot, so that a randomly sampled slot costs one memory sector instead
+    of one per leaf.  ``build()`` (re)writes the record from the leaves — once per update, after the ``pre_update`` hooks
+    have produced their fields; :func:`gather_rows_packed` then reads the record instead of the leaves."""
+
+    SIZES = (16, 32, 64)
+
+    @staticmethod
+    def eligible(storage: torch.Tensor) -> bool:
+        return storage.is_cuda and storage.is_contiguous() and storage.dim() >= 2 and _row_bytes(storage, 2) in (1, 2, 4, 8)
+
+    @classmethod
+    def plan(cls, storages: dict[str, torch.Tensor]) -> list[str]:
+        """Leaves to pack: narrow ones in storage order while they fit 64 bytes / ``MAX_PACKED`` fields; packing a
+        single leaf would only add a copy, so fewer than two means no record at all."""
+        chosen, total, entries = [], 0, 0
+        for name, storage in storages.items():
+            if not cls.eligible(storage):
+                continue
+            width = _row_bytes(storage, 2)
+            slots = 2 if width == 8 else 1  # the kernels move an 8-byte leaf as two 4-byte entries
+            if entries + slots > _native.MAX_PACKED or total + width > cls.SIZES[-1]:
+                break
+            chosen.append(name)
+            total += width
+            entries += slots
+        return chosen if len(chosen) >= 2 else []
+
+    def __init__(self, storages: dict[str, torch.Tensor]):
+        names = sorted(storages, key=lambda k: -_row_bytes(storages[k], 2))  # widest first: every offset is aligned
+        self.leaves = {name: storages[name] for name in names}
+        first = next(iter(self.leaves.values()))
+        self.rows = first.shape[0] * first.shape[1]
+        self.offsets: dict[str, int] = {}
+        offset = 0
+        for name, storage in self.leaves.items():
+            if not self.eligible(storage) or storage.shape[0] * storage.shape[1] != self.rows:
+                raise ValueError(f"leaf '{name}' cannot be packed")
+            self.offsets[name] = offset
+            offset += _row_bytes(storage, 2)
+        self.used_bytes = offset
+        self.record_bytes = next((size for size in self.SIZES if size >= offset), None)
+        entries = sum(2 if _row_bytes(t, 2) == 8 else 1 for t in self.leaves.values())
+        if self.record_bytes is None or entries > _native.MAX_PACKED:
+            raise ValueError("the packed leaves exceed one 64-byte record / 16 entries")
+        self.record = torch.empty((self.rows, self.record_bytes), dtype=torch.uint8, device=first.device)
+        self.key = tuple((name, t.data_ptr(), _row_bytes(t, 2)) for name, t in self.leaves.items())
+        self._table = (PackedField * len(self.leaves))()
+        for slot, (name, storage) in zip(self._table, self.leaves.items()):
+            slot.ptr, slot.offset, slot.width = storage.data_ptr(), self.offsets[name], _row_bytes(storage, 2)
+
+    def build(self) -> None:
+        _observed(
+            "cusrl_pack_rows",
+            lambda: self.rows * (self.used_bytes + self.record_bytes),
+            lambda: _native.lib().cusrl_pack_rows(self._table, len(self.leaves), self.record.data_ptr(), self.record_bytes,
+                                                  self.rows, _stream()),
+        )
+
+
+def gather_rows_packed(
+    storages: Sequence[torch.Tensor],
+    pack: RecordPack | None,
+    packed_names: Sequence[str],
+    indices: torch.Tensor,
+    capacity: int,
+    parallelism: int,
+    temporal: bool = False,
+) -> tuple[list[torch.Tensor], list[torch.Tensor]]:
+    """:func:`gather_rows` for ``storages`` plus, from the SAME launch, the leaves ``packed_names`` of ``pack`` read
+    through its per-slot record (one sector per sampled slot for all of them).  Results are identical to gathering
+    the leaves themselves as long as the record is current (``pack.build()`` after the last write to a packed leaf)."""
+    if not packed_names:
+        return gather_rows(storages, indices, capacity, parallelism, temporal), []
+    if len(storages) > _native.MAX_FIELDS:
+        raise ValueError("gather_rows_packed: too many plain leaves for one launch")
+    require_device(indices, "indices")
+    if indices.dtype != torch.int64:
+        raise TypeError(f"'indices' must be int64, got {indices.dtype}")
+    if not indices.is_contiguous():
+        indices = indices.contiguous()
+    batch = indices.numel()
+    lead = (capacity, batch) if temporal else (batch,)
+    outputs = [torch.empty(lead + tuple(s.shape[2:]), dtype=s.dtype, device=s.device) for s in storages]
+    sources = [pack.leaves[name] for name in packed_names]
+    packed_outputs = [torch.empty(lead + tuple(s.shape[2:]), dtype=s.dtype, device=s.device) for s in sources]
+    if batch == 0:
+        return outputs, packed_outputs
+    table = (Field * max(len(storages), 1))()
+    for i, src in enumerate(storages):
+        if not src.is_contiguous():
+            raise ValueError("buffer leaves must be contiguous [capacity, parallelism, ...] tensors")
+        table[i].src, table[i].dst, table[i].row_bytes = src.data_ptr(), outputs[i].data_ptr(), _row_bytes(src, 2)
+    packed_table = (PackedField * len(packed_names))()
+    for slot, name, out in zip(packed_table, packed_names, packed_outputs):
+        slot.ptr, slot.offset, slot.width = out.data_ptr(), pack.offsets[name], _row_bytes(pack.leaves[name], 2)
+    rows = batch * (capacity if temporal else 1)
+    lib = _native.lib()
+    stream = _stream()
+    _observed(
+        "cusrl_gather_rows_packed",
+        lambda: rows * (sum(2 * _row_bytes(s, 2) for s in storages) + sum(2 * _row_bytes(s, 2) for s in sources)) + batch * 8,
+        lambda: lib.cusrl_gather_rows_packed(table, len(storages), pack.record.data_ptr(), pack.record_bytes, packed_table,
+                                             len(packed_names), indices.data_ptr(), batch, capacity, parallelism, int(temporal), stream),
+    )
+    return outputs, packed_outputs
 
 
 # ------------------------------------------------------------------------------------------------ a3
@@ -506,10 +618,33 @@ def ppo_loss_fwd_bwd(
             ret.data_ptr(), curr_value.data_ptr(), None if old_value is None or value_clip is None else old_value.data_ptr(),
             B, A, D, float(clip), -1.0 if value_clip is None else float(value_clip), float(w_sur), float(w_val), float(w_ent),
             ptr("losses"), ptr("logp"), ptr("entropy"), ptr("logp_ratio"), ptr("ratio"), ptr("d_mean"), ptr("d_std"), ptr("d_value"),
-            partials.data_ptr(), 1 if std_vector else B, None if std_partials is None else std_partials.data_ptr(), _stream(),
+            partials.data_ptr(), 1 if std_vector else B, None if std_partials is None else std_partials.data_ptr(),
+            _ticket(dev).data_ptr() if _LOSS_TICKET else None, _stream(),
         ),
     )
     return out
+
+
+# Separate one-block finalize launch (default) vs last-block finalize inside the loss launch (CUSRL_LOSS_TICKET=1).
+# Measured on MI355X at a 24 576-row minibatch, graph-timed: two launches 9.85 us, one launch with the fence-free
+# ticket 10.4 us, one launch with release / acquire fences 11.1 us — the last block's extra dependent round trip costs
+# more than the 1.5 us kernel boundary it removes, so the ticket stays an opt-in (a test keeps both forms pinned).
+_LOSS_TICKET = os.environ.get("CUSRL_LOSS_TICKET", "0") != "0"
+
+
+_tickets: dict = {}
+
+
+def _ticket(device: torch.device) -> torch.Tensor:
+    """Zero-initialised uint32 a kernel's last-block-done hand-off counts on (self re-arming, so one per device and
+    stream serves every launch; allocated on first use, i.e. in an eager warm-up and never inside a capture)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    ticket = _tickets.get(key)
+    if ticket is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the first launch of a ticketed kernel on a stream must happen outside hipGraph capture")
+        ticket = _tickets[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return ticket
 
 
 def ppo_loss_accepts_std_vector(action_dim: int) -> bool:

@@ -30,6 +30,7 @@ class MiniBatchSampler(Sampler):
         shuffle: bool = True,
         *,
         permutation_device: str | torch.device | None = None,
+        lazy: bool = True,
     ):
         if num_epochs <= 0:
             raise ValueError("'num_epochs' must be positive")
@@ -49,6 +50,10 @@ class MiniBatchSampler(Sampler):
                 raise ValueError("'num_mini_batches' values must be positive")
         self.shuffle = shuffle
         self.permutation_device = None if permutation_device is None else torch.device(permutation_device)
+        # lazy (extension, default): batches are LazyBatch dicts — every field of the buffer is available, only the ones
+        # somebody reads are gathered (template/buffer.py); lazy=False gathers every leaf up front like the reference
+        self.lazy = lazy
+        self.hot_fields: set[str] = set()
 
     def iter_indices(self, buffer: Buffer):
         """Yield ``(metadata, device index slice)`` per minibatch — the permutation logic of ``__call__`` without
@@ -56,6 +61,7 @@ class MiniBatchSampler(Sampler):
         if not (buffer.full and buffer.cursor == 0):
             raise RuntimeError("MiniBatchSampler requires a full buffer with cursor reset to 0")
         num_samples = self._get_num_samples(buffer)
+        buffer.prepare_sampling()  # the packed narrow-leaf record, once per pass (a flag check when it is current)
         perm_device = self.permutation_device or buffer.device
         staged = perm_device != buffer.device
         epoch_indices = torch.randperm(num_samples, device=perm_device)
@@ -80,8 +86,17 @@ class MiniBatchSampler(Sampler):
                 yield metadata, device_indices[j * size : (j + 1) * size]
 
     def __call__(self, buffer: Buffer):
+        previous = None
         for metadata, indices in self.iter_indices(buffer):
-            yield metadata, buffer.gather(indices, temporal=self.temporal)
+            if previous is not None:
+                previous.expire()  # its index slice is about to be reused / redrawn
+            if self.lazy:
+                previous = batch = buffer.gather_lazy(indices, self.temporal, self.hot_fields)
+            else:
+                batch = buffer.gather(indices, temporal=self.temporal)
+            yield metadata, batch
+        if previous is not None:
+            previous.expire()
 
     def _get_num_samples(self, buffer: Buffer) -> int:
         return buffer.capacity * buffer.get_parallelism()
@@ -100,16 +115,21 @@ class AutoMiniBatchSampler(Sampler):
     """Temporal sampling iff some top-level field name ends with ``memory`` (``:136-140``)."""
 
     def __init__(self, num_epochs: int = 1, num_mini_batches: int | Sequence[int] = 1, shuffle: bool = True,
-                 *, permutation_device: str | torch.device | None = None):
+                 *, permutation_device: str | torch.device | None = None, lazy: bool = True):
         self.num_epochs = num_epochs
         self.num_mini_batches = num_mini_batches
         self.shuffle = shuffle
         self.permutation_device = permutation_device
+        self.lazy = lazy
+        self.hot_fields: set[str] = set()
 
     def _dispatch(self, buffer: Buffer) -> MiniBatchSampler:
         temporal = any(key.split(".")[0].endswith("memory") for key in buffer)
         cls = TemporalMiniBatchSampler if temporal else MiniBatchSampler
-        return cls(self.num_epochs, self.num_mini_batches, self.shuffle, permutation_device=self.permutation_device)
+        sampler = cls(self.num_epochs, self.num_mini_batches, self.shuffle, permutation_device=self.permutation_device,
+                      lazy=self.lazy)
+        sampler.hot_fields = self.hot_fields  # the per-call sampler objects share what earlier passes learned
+        return sampler
 
     def __call__(self, buffer: Buffer):
         return self._dispatch(buffer)(buffer)

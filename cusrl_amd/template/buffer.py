@@ -24,13 +24,143 @@ from cusrl_amd import ops
 from cusrl_amd.utils.config import device as resolve_device
 from cusrl_amd.utils.nest import get_schema, iterate_nested, reconstruct_nested
 
-__all__ = ["Buffer", "Sampler"]
+__all__ = ["Buffer", "LazyBatch", "Sampler"]
 
 
 def _native_max_fields() -> int:
     from cusrl_amd import _native
 
     return _native.MAX_FIELDS
+
+
+class LazyBatch(dict):
+    """A minibatch whose top-level fields are gathered on first access.
+
+    The reference gathers EVERY stored leaf for every minibatch (mini_batch_sampler.py:77,89 — 1118 B per sample for
+    the ``ppo`` buffer) although one PPO step reads about half of them (observation, action, old log-prob, advantage,
+    return, value, done: 520 B).  A ``LazyBatch`` still *exposes* every field — ``batch["reward"]``, ``"x" in batch``,
+    iteration, ``**batch`` all behave like the reference's dict — but a field's rows are only moved when somebody
+    reads it.  Fields read by earlier batches of the same consumer (``hot``: a set the sampler / captured step owns) are
+    fetched up front in ONE launch; anything else costs one extra launch on first access and joins ``hot``.  The
+    very first batch of a consumer (empty ``hot``) gathers everything at once, exactly like the reference.
+
+    Validity: pending fields read the buffer and the sampler's index slice *when accessed*; the sampler expires a batch
+    when it moves on (its index storage is redrawn in place for the next epoch, mini_batch_sampler.py:67-68), after which
+    reading a never-read field raises.  Fields already read stay valid forever, like the reference's fresh tensors.
+    """
+
+    __slots__ = ("_buffer", "_indices", "_temporal", "_pending", "_hot", "_expired", "_own")
+
+    def __init__(self, buffer: "Buffer", indices: torch.Tensor, temporal: bool, hot: set | None):
+        super().__init__()
+        self._buffer, self._indices, self._temporal = buffer, indices, temporal
+        self._hot = hot if hot is not None else set()
+        self._expired = False
+        self._own: set = set()  # keys the consumer wrote itself: reading them back says nothing about the buffer
+        names = list(buffer.schema)
+        first = not self._hot
+        eager = names if first else [name for name in names if name in self._hot]
+        self._pending = dict.fromkeys(name for name in names if name not in eager)
+        if eager:
+            dict.update(self, buffer.gather(indices, temporal, fields=eager))
+
+    # ---- materialisation
+    def _fetch(self, names):
+        if self._expired:
+            raise RuntimeError(
+                f"batch field(s) {sorted(names)} were never read while this minibatch was current and its sampler has "
+                "moved on; read them before advancing the sampler, or build the sampler with lazy=False")
+        dict.update(self, self._buffer.gather(self._indices, self._temporal, fields=list(names)))
+        for name in names:
+            self._pending.pop(name, None)
+
+    def _fetch_all(self):
+        if self._pending:
+            self._fetch(list(self._pending))
+
+    def expire(self):
+        """Called by the sampler when it advances: pending fields can no longer be produced."""
+        self._expired = True
+        self._buffer = self._indices = None
+
+    # ---- dict protocol
+    def __missing__(self, key):
+        if key in self._pending:
+            self._hot.add(key)
+            self._fetch([key])
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __getitem__(self, key):
+        try:
+            value = dict.__getitem__(self, key)
+        except KeyError:
+            return self.__missing__(key)
+        if key not in self._own:
+            self._hot.add(key)
+        return value
+
+    def get(self, key, default=None):
+        if dict.__contains__(self, key) or key in self._pending:
+            return self[key]
+        return default
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._pending
+
+    def __setitem__(self, key, value):
+        self._pending.pop(key, None)  # an overwritten field never needs its rows
+        self._own.add(key)
+        dict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        if key in self._pending:
+            del self._pending[key]
+            return
+        dict.__delitem__(self, key)
+
+    def pop(self, key, *default):
+        if key in self._pending:
+            self._fetch([key])
+        return dict.pop(self, key, *default)
+
+    def setdefault(self, key, default=None):
+        if key in self:
+            return self[key]
+        self[key] = default
+        return default
+
+    def __iter__(self):
+        self._fetch_all()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._pending)
+
+    def keys(self):
+        self._fetch_all()
+        return dict.keys(self)
+
+    def values(self):
+        self._fetch_all()
+        return dict.values(self)
+
+    def items(self):
+        self._fetch_all()
+        return dict.items(self)
+
+    def copy(self):
+        self._fetch_all()
+        return dict(self)
+
+    def __eq__(self, other):
+        self._fetch_all()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return f"LazyBatch({dict.__repr__(self)}, pending={list(self._pending)})"
 
 
 class Buffer(MutableMapping):
@@ -46,6 +176,14 @@ class Buffer(MutableMapping):
         # {sum, sumsq} partials the GAE kernel emits for the normalisation hook)
         self._derived: dict[str, Any] = {}
         self._push_plan = None
+        # narrow leaves interleaved into one record per slot for the minibatch gather (ops.RecordPack); rebuilt by
+        # prepare_sampling() after anything could have written to a packed leaf
+        self.pack_narrow_leaves = True
+        self._pack = None
+        self._pack_valid = False
+        # bumped whenever a storage tensor or the packed record is (re)allocated: captured hipGraphs bake those
+        # addresses in and compare this number before replaying (template/graphs.py)
+        self.layout_version = 0
 
     # ------------------------------------------------------------------ bookkeeping
     def get_parallelism(self) -> int:
@@ -58,6 +196,9 @@ class Buffer(MutableMapping):
         self.schema.clear()
         self._derived.clear()
         self._push_plan = None
+        self._pack = None
+        self._pack_valid = False
+        self.layout_version += 1
 
     def reset_cursor(self):
         self.cursor = 0
@@ -80,12 +221,14 @@ class Buffer(MutableMapping):
     def __getitem__(self, key):
         # hands out the storage tensors themselves: in-place edits by hooks are visible (advantage.py:102)
         self._derived.pop(key, None)
+        self._pack_valid = False
         return reconstruct_nested(self.storage, self.schema[key])
 
     def get(self, key, default=None):
         if (schema := self.schema.get(key)) is None:
             return default
         self._derived.pop(key, None)
+        self._pack_valid = False
         return reconstruct_nested(self.storage, schema)
 
     def __setitem__(self, name, data):
@@ -94,12 +237,14 @@ class Buffer(MutableMapping):
             return
         self._check_schema(name, data)
         self._derived.pop(name, None)
+        self._pack_valid = False
         for key, value in iterate_nested(data, name):
             value = self._as_tensor(value)
             self._validate_field_shape(key, value.shape)
             storage = self.storage.get(key)
             if storage is None:
                 storage = self.storage[key] = torch.zeros_like(value, device=self.device)
+                self.layout_version += 1
             if storage.data_ptr() != value.data_ptr():
                 storage.copy_(value)
 
@@ -110,6 +255,9 @@ class Buffer(MutableMapping):
             del self.storage[key]
         del self.schema[name]
         self._derived.pop(name, None)
+        self._pack = None
+        self._pack_valid = False
+        self.layout_version += 1
 
     # ------------------------------------------------------------------ extensions used by the HIP hooks
     def field(self, name: str, like: torch.Tensor) -> torch.Tensor:
@@ -120,7 +268,9 @@ class Buffer(MutableMapping):
             self._validate_field_shape(name, like.shape)
             storage = self.storage[name] = torch.empty_like(like, device=self.device)
             self.schema[name] = name
+            self.layout_version += 1
         self._derived.pop(name, None)
+        self._pack_valid = False
         return storage
 
     def set_derived(self, name: str, value: Any):
@@ -151,6 +301,7 @@ class Buffer(MutableMapping):
                 if storage is None:
                     self._validate_step_shape(key, value.shape)
                     storage = self.storage[key] = value.new_zeros(self.capacity, *value.shape)
+                    self.layout_version += 1
                 elif value.shape != storage.shape[1:]:
                     raise ValueError(
                         f"Shape mismatch for field '{key}': expected {tuple(storage.shape[1:])}, got {tuple(value.shape)}"
@@ -167,6 +318,7 @@ class Buffer(MutableMapping):
         self._build_push_plan(data)
 
     def _advance(self):
+        self._pack_valid = False
         self.cursor += 1
         if self.cursor == self.capacity:
             self.full = True
@@ -236,14 +388,54 @@ class Buffer(MutableMapping):
     # ------------------------------------------------------------------ a7/a8: sampling
     def sample(self, sampler: Callable[[str, torch.Tensor], torch.Tensor]) -> dict[str, Any]:
         """Generic per-leaf callback form of the reference (buffer.py:153-162)."""
+        self._pack_valid = False  # the callback sees (and may keep or edit) the storage tensors themselves
         batch = {key: sampler(key, tensor) for key, tensor in self.storage.items()}
         return reconstruct_nested(batch, self.schema)
 
-    def gather(self, indices: torch.Tensor, temporal: bool = False) -> dict[str, Any]:
-        """``flatten(0, 1)[indices]`` (or ``[:, indices]`` when ``temporal``) of EVERY leaf in one launch."""
-        keys = list(self.storage)
-        outputs = ops.gather_rows([self.storage[k] for k in keys], indices, self.capacity, self.parallelism, temporal)
-        return reconstruct_nested(dict(zip(keys, outputs)), self.schema)
+    def prepare_sampling(self) -> None:
+        """Refresh the packed record of the narrow leaves (one launch, ``cusrl_pack_rows``) if anything could have
+        written to them since it was built.  The samplers call this once per pass before the first minibatch; it is a
+        flag check when nothing changed.  Must run OUTSIDE hipGraph capture (captured steps only *read* the record)."""
+        if self._pack_valid:
+            return
+        if not self.pack_narrow_leaves or self.device.type != "cuda":
+            self._pack = None
+            return
+        names = ops.RecordPack.plan(self.storage)
+        if not names:
+            self._pack = None
+            return
+        key = tuple((name, self.storage[name].data_ptr(), ops._row_bytes(self.storage[name], 2)) for name in names)
+        if self._pack is None or set(self._pack.key) != set(key):
+            self._pack = ops.RecordPack({name: self.storage[name] for name in names})
+            self.layout_version += 1
+        self._pack.build()
+        self._pack_valid = True
+
+    def gather(self, indices: torch.Tensor, temporal: bool = False, fields: Sequence[str] | None = None) -> dict[str, Any]:
+        """``flatten(0, 1)[indices]`` (or ``[:, indices]`` when ``temporal``) of every leaf — or of the leaves of the
+        top-level ``fields`` only — in one launch; narrow leaves come through the packed record while it is current."""
+        if fields is None:
+            keys, schema = list(self.storage), self.schema
+        else:
+            schema = {name: self.schema[name] for name in fields}
+            keys = [key for name in fields for _, key in iterate_nested(self.schema[name])]
+        pack = self._pack if (self._pack_valid and self._pack is not None) else None
+        packed = [key for key in keys if pack is not None and key in pack.offsets]
+        plain = [key for key in keys if key not in packed] if packed else keys
+        if packed and len(plain) <= _native_max_fields():
+            outputs, packed_outputs = ops.gather_rows_packed(
+                [self.storage[k] for k in plain], pack, packed, indices, self.capacity, self.parallelism, temporal)
+            gathered = dict(zip(plain, outputs))
+            gathered.update(zip(packed, packed_outputs))
+        else:
+            outputs = ops.gather_rows([self.storage[k] for k in keys], indices, self.capacity, self.parallelism, temporal)
+            gathered = dict(zip(keys, outputs))
+        return reconstruct_nested(gathered, schema)
+
+    def gather_lazy(self, indices: torch.Tensor, temporal: bool = False, hot: set | None = None) -> LazyBatch:
+        """The minibatch as a :class:`LazyBatch`: the ``hot`` fields now (one launch), the rest on first access."""
+        return LazyBatch(self, indices, temporal, hot)
 
     # ------------------------------------------------------------------ validation (messages as in the reference)
     def _as_tensor(self, data) -> torch.Tensor:

@@ -138,10 +138,16 @@ class GraphedTrainStep:
         self.carry: dict[str, Any] = {}
         # one process: nothing has to run between backward and the optimizer step, so the whole minibatch step is ONE
         # graph; with several ranks the gradient all-reduce (RCCL, eager) sits between two graphs
-        from cusrl_amd.utils.distributed import configure_distributed
+        from cusrl_amd.utils.distributed import configure_distributed, native_comm
 
-        self.single_graph = not configure_distributed()
+        # ... unless the collectives go through the C ABI (RCCL kernels enqueued on the step's stream): then the
+        # all-reduce is captured as a node of the one graph
+        self.graph_collectives = configure_distributed() and native_comm() is not None
+        self.single_graph = not configure_distributed() or self.graph_collectives
         self.signature: tuple | None = None
+        # fields of the batch the step reads: learned by the eager warm-up (which gathers everything), so that the
+        # captured gather moves only those leaves (LazyBatch, template/buffer.py)
+        self.hot_fields: set[str] = set()
 
     def eligible(self) -> bool:
         """False when an objective-phase hook synchronises across ranks (e.g. minibatch-wise advantage normalisation
@@ -150,12 +156,16 @@ class GraphedTrainStep:
 
     def _whole_step(self):
         self._phase_a()
+        if self.graph_collectives:
+            from cusrl_amd.utils.distributed import reduce_gradients
+
+            reduce_gradients(self.agent.optimizer, self.agent.flat_gradients)  # a14, captured with the step
         self._phase_b()
 
     # the two phases, written once and used for the eager warm-up, the capture and (implicitly) the replays
     def _phase_a(self):
         agent = self.agent
-        batch = agent.buffer.gather(self.static_indices, temporal=self.temporal)
+        batch = agent.buffer.gather_lazy(self.static_indices, self.temporal, self.hot_fields)
         agent.actor.clear_intermediate_repr()
         agent.critic.clear_intermediate_repr()
         agent.hook.pre_objective(self.metadata, batch)
@@ -188,9 +198,10 @@ class GraphedTrainStep:
             self.state = 0
         self.static_indices.copy_(indices)
         self.metadata = dict(metadata)
+        agent.buffer.prepare_sampling()  # the captured gather reads the packed record: keep it current (flag check)
         if agent.flat_optimizer is not None:
             agent.flat_optimizer.refresh()  # learning-rate changes reach the captured step through device memory
-        signature = capture_signature(agent)
+        signature = (capture_signature(agent), agent.buffer.layout_version)
         if self.state == 2 and signature != self.signature:
             self.flush_metrics()
             self.state = 1  # a host-side value the capture froze has changed: capture again (the warm-up is still valid)

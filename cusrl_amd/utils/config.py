@@ -26,6 +26,12 @@ class _Config:
         self.world_size = int(env.get("WORLD_SIZE", 1)) if self.distributed else 1
         self.local_world_size = int(env.get("LOCAL_WORLD_SIZE", self.world_size)) if self.distributed else 1
         self._device = torch.device(f"cuda:{self.local_rank}" if self.cuda else "cpu")
+        # Collectives of the hot path through the C ABI (cusrl_allreduce_mean / cusrl_allgather / cusrl_broadcast on a
+        # communicator owned by libcusrl_hip.so) instead of torch.distributed: they are enqueued on the step's stream,
+        # so with compile=True the gradient all-reduce is captured INSIDE the minibatch step's hipGraph.  Opt-in
+        # (CUSRL_NATIVE_COLLECTIVES=1 or CONFIG.native_collectives = True before the agent is built): the default
+        # keeps torch.distributed's process group, whose multi-rank behaviour is exercised far more widely.
+        self.native_collectives = env.get("CUSRL_NATIVE_COLLECTIVES", "0") == "1"
 
     @property
     def device(self) -> torch.device:

@@ -23,6 +23,8 @@ from cusrl_amd.utils.config import CONFIG, configure_distributed
 
 __all__ = [
     "FlatGradients",
+    "RcclComm",
+    "native_comm",
     "average_dict",
     "barrier",
     "broadcast_parameters",
@@ -70,6 +72,105 @@ def print_rank0(*args, **kwargs):
 def barrier():
     if configure_distributed():
         torch.distributed.barrier()
+
+
+class RcclComm:
+    """A communicator created and used through the C ABI (``cusrl_comm_*`` in include/cusrl_hip.h, RCCL underneath).
+
+    Rank 0 draws the id, the other ranks receive it over the existing torch.distributed group (control plane only);
+    the collectives themselves are plain C calls that enqueue RCCL kernels on torch's current stream — capturable into
+    a hipGraph, no Python-side work objects, no extra stream hops."""
+
+    def __init__(self, world_size: int, rank: int, unique_id: bytes | None = None, device: torch.device | None = None):
+        import ctypes
+
+        from cusrl_amd import _native
+
+        self._lib = lib = _native.lib()
+        if not lib.cusrl_comm_available():
+            raise _native.NativeError("RCCL is not available to libcusrl_hip.so: " + lib.cusrl_comm_last_error().decode())
+        if unique_id is None:
+            if world_size != 1:
+                raise ValueError("a multi-rank communicator needs the id rank 0 drew (RcclComm.unique_id())")
+            unique_id = self.unique_id()
+        self.world_size, self.rank = world_size, rank
+        self.device = torch.device(CONFIG.device if device is None else device)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):  # ncclCommInitRank binds to the current device
+            _native.check(lib.cusrl_comm_create(unique_id, world_size, rank, ctypes.byref(handle)), "cusrl_comm_create")
+        self._handle = handle
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+
+        from cusrl_amd import _native
+
+        raw = ctypes.create_string_buffer(128)
+        _native.check(_native.lib().cusrl_comm_unique_id(raw), "cusrl_comm_unique_id")
+        return bytes(raw.raw)
+
+    @classmethod
+    def from_process_group(cls) -> "RcclComm":
+        payload = [cls.unique_id() if CONFIG.rank == 0 else None]
+        torch.distributed.broadcast_object_list(payload, src=0)
+        return cls(CONFIG.world_size, CONFIG.rank, payload[0])
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _check(self, tensor: torch.Tensor, name: str):
+        if not (tensor.is_cuda and tensor.is_contiguous() and tensor.device == self.device):
+            raise ValueError(f"{name}: expected a contiguous tensor on {self.device}")
+
+    def allreduce_mean_(self, tensor: torch.Tensor) -> torch.Tensor:
+        from cusrl_amd import _native
+
+        self._check(tensor, "allreduce_mean_")
+        if tensor.dtype != torch.float32:
+            raise TypeError("allreduce_mean_: float32 only (the flat gradient buffer)")
+        _native.check(self._lib.cusrl_allreduce_mean(tensor.data_ptr(), tensor.numel(), self._handle, self._stream()),
+                      "cusrl_allreduce_mean")
+        return tensor
+
+    def allgather(self, tensor: torch.Tensor) -> torch.Tensor:
+        from cusrl_amd import _native
+
+        self._check(tensor, "allgather")
+        out = tensor.new_empty((self.world_size,) + tuple(tensor.shape))
+        _native.check(self._lib.cusrl_allgather(tensor.data_ptr(), out.data_ptr(), tensor.numel() * tensor.element_size(),
+                                                self._handle, self._stream()), "cusrl_allgather")
+        return out
+
+    def broadcast_(self, tensor: torch.Tensor, root: int = 0) -> torch.Tensor:
+        from cusrl_amd import _native
+
+        self._check(tensor, "broadcast_")
+        _native.check(self._lib.cusrl_broadcast(tensor.data_ptr(), tensor.numel() * tensor.element_size(), root,
+                                                self._handle, self._stream()), "cusrl_broadcast")
+        return tensor
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.cusrl_comm_destroy(self._handle)
+            self._handle = None
+
+
+_native_comm: RcclComm | None = None
+
+
+def native_comm() -> RcclComm | None:
+    """The process-wide C-ABI communicator when ``CONFIG.native_collectives`` is on (created on first use; collective
+    over all ranks, so every rank must reach its first use together — it happens in ``broadcast_parameters`` at agent
+    construction).  ``None`` = collectives go through torch.distributed."""
+    global _native_comm
+    if not (CONFIG.native_collectives and CONFIG.device.type == "cuda" and configure_distributed()):
+        return None
+    if torch.distributed.get_backend() != torch.distributed.Backend.NCCL:
+        return None
+    if _native_comm is None:
+        _native_comm = RcclComm.from_process_group()
+    return _native_comm
 
 
 def gather_obj(obj: _T) -> list[_T]:
@@ -136,7 +237,10 @@ def broadcast_parameters(parameters: Iterable[torch.nn.Parameter]):
     if not params:
         return
     flat = torch.cat([p.data.reshape(-1) for p in params])
-    torch.distributed.broadcast(flat, src=0)
+    if (comm := native_comm()) is not None and flat.is_cuda:
+        comm.broadcast_(flat, 0)
+    else:
+        torch.distributed.broadcast(flat, src=0)
     offset = 0
     for p in params:
         n = p.numel()
@@ -148,6 +252,8 @@ def gather_stack(tensor: torch.Tensor) -> torch.Tensor:
     """``[W, *tensor.shape]`` with every rank's tensor."""
     if not configure_distributed():
         return tensor.unsqueeze(0)
+    if tensor.is_cuda and (comm := native_comm()) is not None:
+        return comm.allgather(tensor.contiguous())
     if torch.distributed.get_backend() == torch.distributed.Backend.GLOO:
         parts = [torch.empty_like(tensor) for _ in range(CONFIG.world_size)]
         torch.distributed.all_gather(parts, tensor)
@@ -161,6 +267,8 @@ def reduce_mean_(tensor: torch.Tensor) -> torch.Tensor:
     """In-place cross-rank average (RCCL ``AVG``; Gloo has no AVG, so SUM then divide)."""
     if not configure_distributed():
         return tensor
+    if tensor.is_cuda and tensor.dtype == torch.float32 and tensor.is_contiguous() and (comm := native_comm()) is not None:
+        return comm.allreduce_mean_(tensor)
     if torch.distributed.get_backend() == torch.distributed.Backend.GLOO:
         torch.distributed.all_reduce(tensor, op=torch.distributed.ReduceOp.SUM)
         return tensor.div_(CONFIG.world_size)

@@ -25,12 +25,14 @@
 extern "C" {
 #endif
 
-#define CUSRL_ABI_VERSION 1
+#define CUSRL_ABI_VERSION 2
 #define CUSRL_MAX_FIELDS 24 /* leaves per push / gather launch; larger tables are split by the host */
+#define CUSRL_MAX_PACKED 16 /* narrow leaves interleaved into one per-slot record (cusrl_pack_rows) */
 
 #define CUSRL_E_INVALID (-1)     /* NULL pointer, negative size, inconsistent arguments */
 #define CUSRL_E_TOO_MANY (-2)    /* n_fields > CUSRL_MAX_FIELDS */
 #define CUSRL_E_UNSUPPORTED (-3) /* shape outside what the kernels handle */
+#define CUSRL_E_COMM (-4)        /* RCCL unavailable or an RCCL call failed: see cusrl_comm_last_error() */
 
 /* One leaf of a multi-leaf copy.  `row_bytes` = bytes of one slot (C * element size). */
 typedef struct {
@@ -109,6 +111,25 @@ int cusrl_merge_mean_var(const float *gathered, int64_t W, int64_t D, float *mea
 int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, const int64_t *indices, int64_t B, int64_t T,
                       int64_t N, int temporal, void *stream);
 
+/* ---- a7/a8 with the narrow leaves packed — same reference lines, different byte traffic ----
+ * A minibatch row of a 1-8 byte leaf (action_logp, value, reward, next_value, advantage, return, the three flags of
+ * the `ppo` buffer) costs one memory sector per leaf when fetched from a random slot.  cusrl_pack_rows interleaves
+ * such leaves ONCE per update into one record per slot — record[s] = { field_0[s], field_1[s], ... } at the given
+ * byte offsets, record_bytes in {16, 32, 64}, `record` 16-byte aligned — and cusrl_gather_rows_packed gathers the
+ * wide leaves as cusrl_gather_rows does plus, for every sampled slot, ONE record read fanned out to the separate
+ * contiguous batch tensors (dst_k[b] = field_k of record[slot(b)]): identical results, one sector instead of ten.
+ * The host keeps the record valid (rebuilds it after any write to a packed leaf). */
+typedef struct {
+    void *ptr;      /* pack: source leaf base [rows, width] (read only); gather: destination base [B or T*B, width] */
+    int32_t offset; /* byte offset of the field inside the record; a multiple of width */
+    int32_t width;  /* 1, 2, 4 or 8 bytes */
+} cusrl_packed_field_t;
+int cusrl_pack_rows(const cusrl_packed_field_t *fields, int n_fields, void *record, int64_t record_bytes,
+                    int64_t rows, void *stream);
+int cusrl_gather_rows_packed(const cusrl_field_t *fields, int n_fields, const void *record, int64_t record_bytes,
+                             const cusrl_packed_field_t *packed, int n_packed, const int64_t *indices, int64_t B,
+                             int64_t T, int64_t N, int temporal, void *stream);
+
 /* ---- a9-a13  PPO objective, forward + backward ----
  * common.py:29-43 (Normal log-prob / entropy / ratio), ppo.py:10-18,50-55 (clipped surrogate),
  * value.py:85-89,121-137 (MSE or clipped value loss), ppo.py:82-84 (entropy bonus),
@@ -123,13 +144,16 @@ int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, const int64_t *
  * std_rows = B: `std` is the [B,A] matrix of the reference's repeated std vector (distribution.py:228-247);
  * std_rows = 1: `std` is that vector itself, [A] — it is broadcast inside the kernel and d_std is the gradient of the
  * vector, [A] (= the column sums a sum(0) over [B,A] would give); needs A % 4 == 0, A <= 32 and the workspace
- * d_std_partials: float[cusrl_ppo_loss_std_partial_rows(B)][A] (may be NULL otherwise). */
+ * d_std_partials: float[cusrl_ppo_loss_std_partial_rows(B)][A] (may be NULL otherwise).
+ * ticket: device uint32[1], zero-initialised once by the caller and owned by this entry point afterwards (it re-arms
+ * itself): with it, minibatches of up to 65 536 rows (32 768 with a std vector) are reduced to losses_out / d_std by
+ * the last block of the SAME launch instead of a second, one-block launch; NULL keeps the two-launch form. */
 int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action, const float *mean,
                            const float *std, const float *ret, const float *curr_value, const float *old_value,
                            int64_t B, int64_t A, int64_t D, double clip, double value_clip, double w_sur,
                            double w_val, double w_ent, float *losses_out, float *logp_out, float *entropy_out,
                            float *logp_ratio_out, float *ratio_out, float *d_mean, float *d_std, float *d_value,
-                           double *partials, int64_t std_rows, float *d_std_partials, void *stream);
+                           double *partials, int64_t std_rows, float *d_std_partials, uint32_t *ticket, void *stream);
 int64_t cusrl_ppo_loss_num_partials(int64_t B);
 int64_t cusrl_ppo_loss_std_partial_rows(int64_t B);
 
@@ -275,6 +299,31 @@ int cusrl_rnd_reward(const float *target, const float *prediction, float *reward
 /* AMP, cusrl/hook/auxiliary/amp.py:134-136: reward[i] += scale * -log(max(1 - 1/(1 + exp(-logit[i])), 1e-4));
  * bonus_out as above (`amp_reward`). */
 int cusrl_amp_style_reward(const float *logit, float *reward, float *bonus_out, float scale, int64_t rows, void *stream);
+
+/* ---- a6 / a14  data-parallel exchange over RCCL / xGMI — cusrl/utils/distributed.py:58-63, 101-110, 145-183 ----
+ * One process per GPU (cusrl/utils/config.py:31-44); a communicator spans all ranks of the job and binds to the
+ * device that is current when it is created.  Rank 0 draws the 128-byte id (cusrl_comm_unique_id), the host hands it
+ * to the other ranks by any means (the Python host uses its torch.distributed store), every rank calls
+ * cusrl_comm_create.  The three collectives only ENQUEUE work on `stream` (no host synchronisation, no allocation), so
+ * they may be issued during hipGraph capture and then replay as nodes of the captured minibatch step:
+ *   cusrl_allreduce_mean  buffer[i] = mean over ranks of buffer[i], in place, fp32 — `reduce_gradients` on the flat
+ *                         gradient buffer (distributed.py:145-172; caller template/actor_critic.py:314);
+ *   cusrl_allgather       output[r * bytes : (r + 1) * bytes] = rank r's input — `gather_stack` of cat(mean, var) for
+ *                         `reduce_mean_var_` (distributed.py:101-110, 175-183), merged by cusrl_merge_mean_var;
+ *   cusrl_broadcast       rank `root`'s buffer to every rank, in place — `broadcast_parameters` (distributed.py:58-63).
+ * RCCL is resolved at run time from the copy already loaded into the process (PyTorch-ROCm's), else the system one;
+ * cusrl_comm_available() == 0 when neither exists.  A failed RCCL call returns CUSRL_E_COMM and leaves its
+ * ncclResult_t text in cusrl_comm_last_error() (host string, valid until the thread's next cusrl_comm_* call). */
+typedef struct cusrl_comm cusrl_comm_t;
+int cusrl_comm_available(void);
+const char *cusrl_comm_last_error(void);
+int cusrl_comm_unique_id(void *id_out /* host, 128 bytes */);
+int cusrl_comm_create(const void *id /* host, 128 bytes */, int world_size, int rank, cusrl_comm_t **comm_out);
+int cusrl_comm_destroy(cusrl_comm_t *comm);
+int cusrl_comm_world_size(const cusrl_comm_t *comm);
+int cusrl_allreduce_mean(float *buffer, int64_t count, cusrl_comm_t *comm, void *stream);
+int cusrl_allgather(const void *input, void *output, int64_t bytes_per_rank, cusrl_comm_t *comm, void *stream);
+int cusrl_broadcast(void *buffer, int64_t bytes, int root, cusrl_comm_t *comm, void *stream);
 
 #ifdef __cplusplus
 }

@@ -119,6 +119,19 @@ def bench_size(N, T=24, obs=48, act=12, mbs=4, only=None, iters=None):
     small = [leaves[0], leaves[3], leaves[4], leaves[5], leaves[11], leaves[12]]
     row_small = sum(x[0, 0].numel() * x.element_size() for x in small)
     rows.measure("gather ppo-minimal leaves", lambda: ops.gather_rows(small, idx, T, N), B * (2 * row_small + 8))
+    # what a captured ppo minibatch step gathers now: observation, action (plain) + old log-prob, value, advantage,
+    # return, done read through the 32-byte record of the nine narrow leaves (LazyBatch + RecordPack)
+    names = ["logp", "value", "reward", "terminated", "truncated", "done", "next_value", "advantage", "return"]
+    narrow = dict(zip(names, [leaves[4], leaves[5], leaves[7], term, trunc, done, leaves[11], leaves[12], leaves[13]]))
+    pack = ops.RecordPack(narrow)
+    rows.measure("pack narrow leaves (once per update)", pack.build, S * (pack.used_bytes + pack.record_bytes))
+    hot = ["logp", "value", "advantage", "return", "done"]
+    hot_bytes = B * (2 * (4 * obs + 4 * act + 17) + 8)
+    rows.measure(f"gather hot leaves via record (B={B})",
+                 lambda: ops.gather_rows_packed([leaves[0], leaves[3]], pack, hot, idx, T, N), hot_bytes)
+    rows.measure(f"gather all leaves via record (B={B})",
+                 lambda: ops.gather_rows_packed([leaves[0], leaves[1], leaves[2], leaves[3], leaves[6]], pack, names, idx, T, N),
+                 B * (2 * row + 8))
 
     # ---- fused loss
     a = dict(advantage=f(B, 1), old_logp=f(B, 1) - 12, action=f(B, act), mean=f(B, act), std=torch.rand(B, act, device=DEV) + 0.5,

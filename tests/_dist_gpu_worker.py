@@ -1,5 +1,6 @@
 """One RCCL rank (torchrun, backend nccl == RCCL) running the ppo preset: exercises parameter broadcast, per-step flat
-gradient all-reduce between graph replays, advantage-statistics all-gather + HIP merge, metric all_gather_object."""
+gradient all-reduce (eager between graph replays, or captured inside the step's hipGraph when the collectives go through
+the C ABI), advantage-statistics all-gather + HIP merge, metric averaging.  ``argv``: out-dir, compile (0/1), native (0/1)."""
 
 import json
 import sys
@@ -11,25 +12,44 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 
 import cusrl_amd as cusrl  # noqa: E402
+from cusrl_amd import _native  # noqa: E402
 from cusrl_amd.utils import distributed  # noqa: E402
 
 
-def main(out_path: str, compile_: str):
+def main(out_dir: str, compile_: str, native: str):
     assert distributed.enabled()
+    cusrl.config.native_collectives = native == "1"
     cusrl.utils.configure_distributed()
     assert torch.distributed.get_backend() == "nccl"
+    rank, world = distributed.rank(), distributed.world_size()
     cusrl.set_global_seed(5)
     env = cusrl.testing.SyntheticEnvironment(256, 20, 6)
     factory = cusrl.preset.PpoAgentFactory(num_steps_per_update=8, sampler_epochs=3, sampler_mini_batches=2,
                                            compile=compile_ == "1")
     trainer = cusrl.Trainer(env, factory, num_iterations=3, verbose=False)
+    first_perm = torch.randperm(16, device="cuda").tolist()  # per-rank generator streams differ (seed + rank)
     trainer.run_training_loop()
-    mean, var = torch.tensor([1.0], device="cuda"), torch.tensor([4.0], device="cuda")
-    distributed.reduce_mean_var_(mean, var)  # world of one: unchanged, but through all_gather + the HIP merge kernel
+    params = torch.cat([p.detach().reshape(-1) for p in trainer.agent.parameters()])
+    # the advantage statistics every rank normalised with: local (mean, var) -> all_gather -> HIP merge
+    local_mean = torch.tensor([1.0 + rank, -2.0 * rank], device="cuda")
+    local_var = torch.tensor([0.5 + rank, 2.0], device="cuda")
+    mean, var = local_mean.clone(), local_var.clone()
+    distributed.reduce_mean_var_(mean, var)
+    flat = torch.full((1000,), float(rank + 1), device="cuda")
+    distributed.reduce_mean_(flat)
     info = {k: v for k, v in trainer.last_info.items() if k.startswith("Agent/")}
-    Path(out_path).write_text(json.dumps({"info": info, "mean": mean.item(), "var": var.item(),
-                                          "world": distributed.world_size()}))
+    graphs = [step.single_graph for step in getattr(trainer.agent, "_graphed_steps", {}).values()]
+    Path(out_dir, f"rank{rank}.json").write_text(json.dumps({
+        "info": info, "world": world, "rank": rank, "first_perm": first_perm,
+        "local_mean": local_mean.tolist(), "local_var": local_var.tolist(), "mean": mean.tolist(), "var": var.tolist(),
+        "flat_mean": flat[0].item(), "param_sum": params.double().sum().item(), "param_head": params[:64].tolist(),
+        "param_bytes": params.cpu().numpy().tobytes().hex()[:4096],
+        "native": distributed.native_comm() is not None, "single_graph": graphs,
+        "allreduce_calls": _native.launch_counts.get("cusrl_allreduce_mean", 0),
+        "allgather_calls": _native.launch_counts.get("cusrl_allgather", 0),
+    }))
+    distributed.barrier()
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3])

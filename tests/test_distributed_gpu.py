@@ -1,4 +1,6 @@
-"""The data-parallel path on RCCL (backend ``nccl``) with the single GPU a test box has: one torchrun rank."""
+"""The data-parallel path on RCCL (backend ``nccl``): one torchrun rank on the single GPU a test box has, two ranks when
+two GPUs are visible.  Both collective routes are exercised: torch.distributed's process group (eager all-reduce between
+two graphs) and the C-ABI communicator (``cusrl_allreduce_mean`` captured inside the minibatch step's hipGraph)."""
 
 import json
 import math
@@ -8,23 +10,96 @@ import subprocess
 import sys
 from pathlib import Path
 
+import numpy as np
 import pytest
+import torch
+
+import oracle
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-@pytest.mark.parametrize("compile_", ["0", "1"])
-def test_ppo_preset_over_rccl_single_rank(tmp_path, compile_):
+def _run(tmp_path, world: int, compile_: str, native: str):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    out = tmp_path / "result.json"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(ROOT / "tests" / "_dist_gpu_worker.py"), str(out), compile_]
-    done = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "_dist_gpu_worker.py"), str(tmp_path), compile_, native]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
-    result = json.loads(out.read_text())
-    assert result["world"] == 1 and result["mean"] == 1.0 and result["var"] == 4.0
+    return [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(world)]
+
+
+@pytest.mark.parametrize("compile_,native", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
+def test_ppo_preset_over_rccl_single_rank(tmp_path, compile_, native):
+    (result,) = _run(tmp_path, 1, compile_, native)
+    assert result["world"] == 1 and result["mean"] == result["local_mean"] and result["var"] == result["local_var"]
+    assert result["flat_mean"] == 1.0
     for key in ("Agent/value_loss", "Agent/surrogate_loss", "Agent/entropy_loss", "Agent/kl_divergence"):
         assert math.isfinite(result["info"][key]), key
+    assert result["native"] == (native == "1")
+    if native == "1":  # the C-ABI entry points really carried the collectives
+        assert result["allreduce_calls"] > 0 and result["allgather_calls"] > 0
+        if compile_ == "1":
+            assert result["single_graph"] and all(result["single_graph"])  # all-reduce captured inside the step graph
+    elif compile_ == "1":
+        assert result["single_graph"] and not any(result["single_graph"])  # eager all-reduce between two graphs
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("compile_,native", [("1", "0"), ("1", "1"), ("0", "1")])
+def test_two_rccl_ranks_stay_in_lockstep(tmp_path, compile_, native):
+    """Two ranks, 3 iterations of the preset: every rank ends with bit-identical parameters (same broadcast start, same
+    averaged gradients), drew different permutations, and merged the advantage statistics like the oracle."""
+    ranks = _run(tmp_path, 2, compile_, native)
+    assert ranks[0]["first_perm"] != ranks[1]["first_perm"]
+    assert ranks[0]["param_bytes"] == ranks[1]["param_bytes"] and ranks[0]["param_sum"] == ranks[1]["param_sum"]
+    means = np.array([r["local_mean"] for r in ranks], np.float32)
+    vars_ = np.array([r["local_var"] for r in ranks], np.float32)
+    mean, var = oracle.merge_mean_var(means, vars_)
+    for r in ranks:
+        np.testing.assert_allclose(r["mean"], mean, rtol=1e-6)
+        np.testing.assert_allclose(r["var"], var, rtol=1e-6)
+        assert r["flat_mean"] == 1.5
+        for key in ("Agent/value_loss", "Agent/surrogate_loss", "Agent/entropy_loss", "Agent/kl_divergence"):
+            assert math.isfinite(r["info"][key]) and r["info"][key] == ranks[0]["info"][key]  # rank-averaged logs
+
+
+def test_c_abi_communicator_of_one_rank_inside_a_hipgraph():
+    """cusrl_comm_* through ctypes in this process (world of one needs no launcher): the three collectives, their
+    argument errors, and an all-reduce captured into a hipGraph and replayed."""
+    from cusrl_amd import _native
+    from cusrl_amd.utils.distributed import RcclComm
+
+    lib = _native.lib()
+    assert lib.cusrl_comm_available() == 1
+    comm = RcclComm(1, 0, device=torch.device("cuda:0"))
+    assert lib.cusrl_comm_world_size(comm._handle) == 1
+    x = torch.arange(1000, dtype=torch.float32, device="cuda:0")
+    expect = x.clone()
+    comm.allreduce_mean_(x)
+    assert torch.equal(x, expect)                                    # the mean over one rank
+    stacked = comm.allgather(torch.tensor([1.0, 4.0], device="cuda:0"))
+    assert stacked.shape == (1, 2) and stacked.tolist() == [[1.0, 4.0]]
+    comm.broadcast_(x, 0)
+    assert torch.equal(x, expect)
+    stream, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+    y = torch.ones(4096, device="cuda:0")
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=stream):
+        y.mul_(2.0)
+        comm.allreduce_mean_(y)
+        y.add_(1.0)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, torch.full_like(y, 15.0))                  # ((1*2+1)*2+1)*2+1
+    with pytest.raises(TypeError):
+        comm.allreduce_mean_(torch.zeros(4, dtype=torch.float64, device="cuda:0"))
+    assert lib.cusrl_allreduce_mean(x.data_ptr(), -1, comm._handle, None) == -1      # CUSRL_E_INVALID
+    assert lib.cusrl_allreduce_mean(x.data_ptr(), 4, None, None) == -1
+    assert lib.cusrl_broadcast(x.data_ptr(), 4, 3, comm._handle, None) == -1         # root outside the world
+    assert lib.cusrl_comm_create(None, 1, 0, None) == -1
+    comm.close()

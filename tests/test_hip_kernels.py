@@ -116,6 +116,128 @@ def test_gather_more_than_max_fields(ops):
         assert torch.equal(out, x.flatten(0, 1)[idx])
 
 
+# ------------------------------------------------------------------------------------------------ a7/a8 packed record
+def _narrow_leaves(rng, T, N, kinds):
+    make = {
+        "f32": lambda: rng.standard_normal((T, N, 1)).astype(np.float32),
+        "bool": lambda: rng.random((T, N, 1)) < 0.4,
+        "i64": lambda: rng.integers(0, 1 << 40, (T, N, 1)).astype(np.int64),
+        "f16": lambda: rng.standard_normal((T, N, 1)).astype(np.float16),
+        "f32x2": lambda: rng.standard_normal((T, N, 2)).astype(np.float32),
+        "u8x2": lambda: rng.integers(0, 255, (T, N, 2)).astype(np.uint8),
+    }
+    return {f"{kind}_{i}": make[kind]() for i, kind in enumerate(kinds)}
+
+
+@pytest.mark.parametrize("T,N,B,kinds", [
+    (24, 64, 384, ["f32"] * 6 + ["bool"] * 3),                 # the ppo buffer's nine narrow leaves: 27 -> 32 B records
+    (3, 5, 15, ["f32", "bool"]),                                # 5 -> 16 B
+    (2, 4099, 1000, ["i64", "f32x2", "f32", "f16", "u8x2", "bool", "bool"] + ["f32"] * 7),   # 16 fields, 54 -> 64 B
+    (1, 1, 1, ["bool", "bool"]),
+])
+def test_packed_gather_bit_exact(ops, T, N, B, kinds):
+    """cusrl_pack_rows + cusrl_gather_rows_packed against the oracle's plain gather of the same leaves."""
+    rng = np.random.default_rng(T * N + len(kinds))
+    narrow = _narrow_leaves(rng, T, N, kinds)
+    wide = [rng.standard_normal((T, N, 48)).astype(np.float32), rng.standard_normal((T, N, 12)).astype(np.float32)]
+    storages = {k: dev(v) for k, v in narrow.items()}
+    assert ops.RecordPack.plan(storages) == list(storages)
+    pack = ops.RecordPack(storages)
+    assert pack.record_bytes in (16, 32, 64) and pack.used_bytes <= pack.record_bytes
+    pack.build()
+    idx = rng.permutation(T * N)[:B].astype(np.int64)
+    names = list(narrow)[::-1]  # any subset, in any order
+    outs, packed_outs = ops.gather_rows_packed([dev(x) for x in wide], pack, names, dev(idx), T, N)
+    for x, out in zip(wide, outs):
+        assert np.array_equal(host(out), oracle.gather_rows(x, idx))
+    for name, out in zip(names, packed_outs):
+        assert out.dtype == storages[name].dtype
+        assert np.array_equal(host(out), oracle.gather_rows(narrow[name], idx)), name
+    # temporal ([:, idx]) through the same record, and a record-only launch (no plain leaf at all)
+    env_idx = rng.permutation(N)[: max(N // 2, 1)].astype(np.int64)
+    outs, packed_outs = ops.gather_rows_packed([], pack, names[:3] or names, dev(env_idx), T, N, temporal=True)
+    assert outs == []
+    for name, out in zip(names[:3] or names, packed_outs):
+        assert np.array_equal(host(out), oracle.gather_rows(narrow[name], env_idx, temporal=True)), name
+    # the record follows the leaves only when rebuilt
+    first = next(iter(storages))
+    storages[first].copy_(dev(narrow[first][::-1].copy()))
+    pack.build()
+    (_, (again,)) = ops.gather_rows_packed([], pack, [first], dev(idx), T, N)
+    assert np.array_equal(host(again), oracle.gather_rows(narrow[first][::-1], idx))
+
+
+def test_packed_gather_argument_errors(ops):
+    """Negative return codes of the two entry points, straight through ctypes."""
+    from cusrl_amd import _native
+
+    lib = _native.lib()
+    leaf = torch.zeros(4, 2, 1, device=DEV)
+    record = torch.zeros(8, 16, dtype=torch.uint8, device=DEV)
+    out = torch.zeros(3, 1, device=DEV)
+    idx = torch.zeros(3, dtype=torch.int64, device=DEV)
+    table = (_native.PackedField * 2)()
+    table[0].ptr, table[0].offset, table[0].width = leaf.data_ptr(), 0, 4
+    table[1].ptr, table[1].offset, table[1].width = leaf.data_ptr(), 2, 4                      # misaligned, overlapping
+    assert lib.cusrl_pack_rows(table, 2, record.data_ptr(), 16, 8, None) == -1                # CUSRL_E_INVALID
+    table[1].offset = 4
+    assert lib.cusrl_pack_rows(table, 2, record.data_ptr(), 24, 8, None) == -1                # record size not 16/32/64
+    assert lib.cusrl_pack_rows(table, 17, record.data_ptr(), 16, 8, None) == -2               # CUSRL_E_TOO_MANY
+    table[1].width = 3
+    assert lib.cusrl_pack_rows(table, 2, record.data_ptr(), 16, 8, None) == -1                # unsupported width
+    table[1].width, table[0].ptr = 4, out.data_ptr()
+    assert lib.cusrl_gather_rows_packed(None, 0, None, 16, table, 1, idx.data_ptr(), 3, 4, 2, 0, None) == -1   # no record
+    assert lib.cusrl_gather_rows_packed(None, 25, record.data_ptr(), 16, table, 1, idx.data_ptr(), 3, 4, 2, 0, None) == -1
+    torch.cuda.synchronize()
+
+
+def test_buffer_gathers_through_the_record_and_lazily(ops):
+    """Buffer.prepare_sampling packs the narrow leaves; LazyBatch moves only what is read; results equal plain indexing."""
+    from cusrl_amd import _native
+    from cusrl_amd.sampler import MiniBatchSampler
+    from cusrl_amd.template.buffer import Buffer, LazyBatch
+
+    T, N = 6, 32
+    buffer = Buffer(T, N, device=DEV)
+    torch.manual_seed(3)
+    for _ in range(T):
+        buffer.push({"observation": torch.randn(N, 48, device=DEV), "action_dist": {"mean": torch.randn(N, 12, device=DEV),
+                     "std": torch.rand(N, 12, device=DEV)}, "reward": torch.randn(N, 1, device=DEV),
+                     "value": torch.randn(N, 1, device=DEV), "done": torch.rand(N, 1, device=DEV) < 0.2})
+    sampler = MiniBatchSampler(num_epochs=2, num_mini_batches=2)
+    counts = _native.launch_counts
+    packed_before, plain_before = counts.get("cusrl_gather_rows_packed", 0), counts.get("cusrl_gather_rows", 0)
+    seen = []
+    for metadata, batch in sampler(buffer):
+        assert isinstance(batch, LazyBatch) and set(dict.keys(batch)) | set(batch._pending) == set(buffer.schema)
+        first = not seen
+        if not first:
+            assert set(batch._pending) == {"action_dist", "value"}   # only what the first pass read is prefetched
+        reward, obs, done = batch["reward"], batch["observation"], batch["done"]
+        seen.append((reward, obs, done))
+        if metadata["epoch_index"] == 1 and metadata["mini_batch_index"] == 1:
+            value = batch["value"]                                    # a late reader: one extra launch, still correct
+            assert "value" in sampler.hot_fields
+        assert "next_observation" not in batch and batch.get("nope", 7) == 7
+    assert buffer._pack is not None and set(buffer._pack.leaves) == {"reward", "value", "done"}
+    assert counts.get("cusrl_gather_rows_packed", 0) - packed_before == 5 and counts.get("cusrl_gather_rows", 0) == plain_before
+    assert counts.get("cusrl_pack_rows", 0) >= 1
+    with pytest.raises(RuntimeError, match="never read"):
+        batch["action_dist"]                                          # the sampler has moved on
+    # values: the union of one epoch's minibatches is the whole buffer
+    for a, b in ((0, 1), (2, 3)):
+        rewards = torch.cat([seen[a][0], seen[b][0]]).flatten().sort().values
+        assert torch.equal(rewards, buffer["reward"].flatten().sort().values)
+    # eager form = the reference's: everything gathered at once, plain dict
+    eager = MiniBatchSampler(num_epochs=1, num_mini_batches=1, lazy=False)
+    torch.manual_seed(11)
+    (_, full), = list(eager(buffer))
+    torch.manual_seed(11)
+    perm = torch.randperm(T * N, device=DEV)
+    assert type(full) is dict and torch.equal(full["action_dist"]["std"], buffer["action_dist"]["std"].flatten(0, 1)[perm])
+    assert torch.equal(full["done"], buffer["done"].flatten(0, 1)[perm])
+
+
 # ------------------------------------------------------------------------------------------------ a3 next_value
 def test_next_value_vs_reference_goldens(ops, golden):
     g = golden("next_value")

@@ -374,3 +374,54 @@ def test_flat_gradient_assembly_builds_one_piece_per_parameter(monkeypatch):
     assert [piece[3] for piece in captured["pieces"]] == [1, 7, 9, 0, 1]
     with pytest.raises(RuntimeError, match="not optimizer parameters"):
         flat.assemble([plain, None, None, None, twice_grad], {12345: slabs})
+
+
+def test_lazy_batch_is_a_dict_that_gathers_on_first_access():
+    """LazyBatch (template/buffer.py) against a stand-in buffer: which fields are fetched when, dict protocol, expiry."""
+    from cusrl_amd.template.buffer import LazyBatch
+
+    class FakeBuffer:
+        schema = {"observation": "observation", "action_dist": {"mean": "action_dist.mean"}, "reward": "reward", "done": "done"}
+
+        def __init__(self):
+            self.calls = []
+
+        def gather(self, indices, temporal=False, fields=None):
+            self.calls.append(tuple(fields))
+            return {name: (name, len(self.calls)) for name in fields}
+
+    buffer, hot = FakeBuffer(), set()
+    first = LazyBatch(buffer, None, False, hot)                # empty hot set: everything at once, like the reference
+    assert buffer.calls == [("observation", "action_dist", "reward", "done")] and not first._pending
+    assert first["reward"] == ("reward", 1) and first.get("done") == ("done", 1) and hot == {"reward", "done"}
+    batch = LazyBatch(buffer, None, False, hot)                # now only the hot fields are prefetched
+    assert buffer.calls[-1] == ("reward", "done") and list(batch._pending) == ["observation", "action_dist"]
+    assert "observation" in batch and len(batch) == 4 and "next_observation" not in batch
+    assert batch.get("missing", 5) == 5 and len(buffer.calls) == 2
+    assert batch["observation"] == ("observation", 3) and "observation" in hot     # fetched alone, and learned
+    batch["curr_value"] = 1.0
+    batch["action_dist"] = "overwritten"                       # an overwritten field is never fetched
+    assert len(buffer.calls) == 3 and batch["action_dist"] == "overwritten"
+    assert set(batch) == {"reward", "done", "observation", "curr_value", "action_dist"}
+    assert dict(**batch)["curr_value"] == 1.0
+    third = LazyBatch(buffer, None, False, hot)
+    assert set(dict.keys(third)) == {"reward", "done", "observation"}
+    del third["action_dist"]
+    assert "action_dist" not in third and len(third) == 3
+    fourth = LazyBatch(buffer, None, False, hot)
+    assert fourth.pop("action_dist") == ("action_dist", len(buffer.calls)) and "action_dist" not in fourth
+    fifth = LazyBatch(buffer, None, False, hot)
+    fifth.expire()
+    assert fifth["reward"][0] == "reward"                      # fields already read stay valid
+    try:
+        fifth["action_dist"]
+    except RuntimeError as error:
+        assert "never read" in str(error)
+    else:
+        raise AssertionError("an expired batch must not fetch")
+    try:
+        fifth["nope"]
+    except KeyError:
+        pass
+    else:
+        raise AssertionError
