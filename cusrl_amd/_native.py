@@ -97,7 +97,8 @@ _SIGNATURES = {
     "cusrl_broadcast": (c_int, [_P, c_int64, c_int, _P, _P]),
     "cusrl_sequence_count": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P]),
     "cusrl_sequence_blocks": (c_int64, [c_int64]),
-    "cusrl_sequence_layout": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, _P, _P, _P, _P]),
+    "cusrl_sequence_layout": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
+    "cusrl_gather_memory": (c_int, [_P, _P, _P, _P, c_int64, c_int64, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

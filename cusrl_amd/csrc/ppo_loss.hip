@@ -49,29 +49,36 @@ __device__ __forceinline__ float row_terms(float logp, float entropy, float old_
     return p.g_sur * d_ratio * ratio;
 }
 
+// One value channel: (clipped) squared error, its gradient, the `value` metric.  `v` (the old value) is only read in
+// the clipped form.
+__device__ __forceinline__ void value_term(float cv, float R, float v, float *__restrict__ d_value_slot,
+                                           const LossParams &p, double &val_acc, double &value_sum_acc) {
+    value_sum_acc += double(cv);  // metric `value` = curr_value.sum(-1)        value.py:141
+    const float e1 = cv - R, l1 = e1 * e1, g1 = 2.0f * e1;
+    float g;
+    if (p.value_clip < 0.0f) {
+        val_acc += double(l1);  // mse_loss(return, curr_value)             value.py:132
+        g = g1;
+    } else {
+        const float c = p.value_clip;
+        const float dv = cv - v;
+        const float dvc = fminf(fmaxf(dv, -c), c);
+        const float e2 = (v + dvc) - R, l2 = e2 * e2;   // value.py:85-89
+        const float g2 = (dv >= -c && dv <= c) ? 2.0f * e2 : 0.0f;
+        val_acc += double(fmaxf(l1, l2));
+        g = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * (g1 + g2));
+    }
+    if (d_value_slot) *d_value_slot = p.g_val * g;
+}
+
 __device__ __forceinline__ void value_terms(const float *__restrict__ ret, const float *__restrict__ curr_value,
                                             const float *__restrict__ old_value, float *__restrict__ d_value,
                                             int64_t row, int D, const LossParams &p, double &val_acc,
                                             double &value_sum_acc) {
     for (int d = 0; d < D; ++d) {
         const int64_t i = row * D + d;
-        const float cv = curr_value[i], R = ret[i];
-        value_sum_acc += double(cv);  // metric `value` = curr_value.sum(-1)        value.py:141
-        const float e1 = cv - R, l1 = e1 * e1, g1 = 2.0f * e1;
-        float g;
-        if (p.value_clip < 0.0f) {
-            val_acc += double(l1);  // mse_loss(return, curr_value)             value.py:132
-            g = g1;
-        } else {
-            const float c = p.value_clip, v = old_value[i];
-            const float dv = cv - v;
-            const float dvc = fminf(fmaxf(dv, -c), c);
-            const float e2 = (v + dvc) - R, l2 = e2 * e2;   // value.py:85-89
-            const float g2 = (dv >= -c && dv <= c) ? 2.0f * e2 : 0.0f;
-            val_acc += double(fmaxf(l1, l2));
-            g = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * (g1 + g2));
-        }
-        if (d_value) d_value[i] = p.g_val * g;
+        value_term(curr_value[i], ret[i], p.value_clip < 0.0f ? 0.0f : old_value[i], d_value ? d_value + i : nullptr, p,
+                   val_acc, value_sum_acc);
     }
 }
 
@@ -165,6 +172,20 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
     const float4 *__restrict__ m4 = reinterpret_cast<const float4 *>(mean);
     const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(std);
 
+    // the per-row scalars of the second phase are requested together with the matrix chunks: one memory round trip
+    // per block instead of two dependent ones (the row phase used to start its own loads behind the first barrier)
+    const int64_t my_row = row0 + threadIdx.x;
+    const bool row_ok = my_row < B;
+    float pre_old_logp = 0.f, pre_adv = 0.f, pre_ret = 0.f, pre_cv = 0.f, pre_ov = 0.f;
+    if (row_ok) {
+        pre_old_logp = old_logp[my_row];
+        pre_adv = advantage[my_row];
+        if (D == 1) {
+            pre_ret = ret[my_row];
+            pre_cv = curr_value[my_row];
+            if (p.value_clip >= 0.0f) pre_ov = old_value[my_row];
+        }
+    }
     float4 x[LPR], mu[LPR], sg[LPR];
 #pragma unroll
     for (int k = 0; k < LPR; ++k) {
@@ -208,12 +229,15 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
                 entropy += en_part[threadIdx.x * LPR + j];
             }
             float ratio, lr;
-            dlp = row_terms(logp, entropy, old_logp[row], advantage[row], p, acc[1], acc[2], acc[3], ratio, lr);
+            dlp = row_terms(logp, entropy, pre_old_logp, pre_adv, p, acc[1], acc[2], acc[3], ratio, lr);
             if (logp_out) logp_out[row] = logp;
             if (entropy_out) entropy_out[row] = entropy;
             if (lr_out) lr_out[row] = lr;
             if (ratio_out) ratio_out[row] = ratio;
-            value_terms(ret, curr_value, old_value, d_value, row, D, p, acc[0], acc[4]);
+            if (D == 1)
+                value_term(pre_cv, pre_ret, pre_ov, d_value ? d_value + row : nullptr, p, acc[0], acc[4]);
+            else
+                value_terms(ret, curr_value, old_value, d_value, row, D, p, acc[0], acc[4]);
         }
         dlp_row[threadIdx.x] = dlp;
     }

@@ -26,9 +26,14 @@ from cusrl_amd.utils.nest import map_nested
 
 __all__ = [
     "SequenceLayout",
+    "compute_cumulative_sequence_lengths",
+    "compute_cumulative_timesteps",
+    "compute_reverse_cumulative_timesteps",
     "compute_sequence_indices",
     "compute_sequence_layout",
     "compute_sequence_lengths",
+    "cumulate_sequence_lengths",
+    "gather_memory",
     "scatter_memory",
     "select_initial_memory",
     "split_and_pad_sequences",
@@ -46,6 +51,9 @@ class SequenceLayout:
     dest: Tensor        # int64 [L * N]: pos * Ns + seq of slot t * N + n
     first_seq: Tensor   # int64 [N]: index of env n's first sequence
     mask: Tensor        # bool [L, Ns]
+    lengths: Tensor     # int64 [Ns]: valid steps of every sequence
+    last_seq: Tensor    # int64 [N]: index of the sequence still open at the end of env n's column
+    done_last: Tensor   # bool [N]: done[-1] (whether that sequence ended exactly at the last step)
 
 
 class _PackRows(torch.autograd.Function):
@@ -112,9 +120,12 @@ def compute_sequence_layout(done: Tensor) -> SequenceLayout:
     dest = torch.empty(L * N, dtype=torch.int64, device=dev)
     first_seq = torch.empty(N, dtype=torch.int64, device=dev)
     mask = torch.zeros(L, num_sequences, dtype=torch.bool, device=dev)
+    lengths = torch.empty(num_sequences, dtype=torch.int64, device=dev)
+    last_seq = torch.empty(N, dtype=torch.int64, device=dev)
     check(lib.cusrl_sequence_layout(done.data_ptr(), L, N, env_prefix.data_ptr(), block_totals.data_ptr(), num_sequences,
-                                    dest.data_ptr(), first_seq.data_ptr(), mask.data_ptr(), stream), "cusrl_sequence_layout")
-    return SequenceLayout(L, N, num_sequences, dest, first_seq, mask)
+                                    dest.data_ptr(), first_seq.data_ptr(), mask.data_ptr(), lengths.data_ptr(),
+                                    last_seq.data_ptr(), stream), "cusrl_sequence_layout")
+    return SequenceLayout(L, N, num_sequences, dest, first_seq, mask, lengths, last_seq, done[-1].reshape(N))
 
 
 def split_and_pad_sequences(compact_sequences: Tensor, done: Tensor, layout: SequenceLayout | None = None) -> tuple[Tensor, Tensor]:
@@ -166,9 +177,55 @@ def select_initial_memory(memory: Any, expected_shape) -> Any:
 
 
 def compute_sequence_lengths(done: Tensor) -> Tensor:
-    """Length of every sequence, env-major order (recurrent.py:63-92)."""
-    layout = compute_sequence_layout(done)
-    return layout.mask.sum(dim=0)
+    """Length of every sequence, env-major order (recurrent.py:63-92) — written by the layout kernel."""
+    return compute_sequence_layout(done).lengths
+
+
+def cumulate_sequence_lengths(sequence_lens: Tensor) -> Tensor:
+    out = sequence_lens.new_zeros(sequence_lens.size(0) + 1)
+    out[1:] = sequence_lens.cumsum(dim=0)
+    return out
+
+
+def compute_cumulative_sequence_lengths(done: Tensor) -> Tensor:
+    return cumulate_sequence_lengths(compute_sequence_lengths(done))
+
+
+def compute_cumulative_timesteps(done: Tensor, layout: SequenceLayout | None = None) -> Tensor:
+    """``[L, N, 1]`` int64: position of every slot inside its own sequence, counted from the sequence's first step
+    (recurrent.py:28-32) — the ``pos`` part of the layout kernel's padded-row index, no scan."""
+    layout = layout or compute_sequence_layout(done)
+    return (layout.dest // layout.num_sequences).view(layout.length, layout.num_envs, 1)
+
+
+def compute_reverse_cumulative_timesteps(done: Tensor, layout: SequenceLayout | None = None) -> Tensor:
+    """``[L, N, 1]`` int64: steps left until the slot's sequence ends (recurrent.py:95-99)."""
+    layout = layout or compute_sequence_layout(done)
+    position, sequence = layout.dest // layout.num_sequences, layout.dest % layout.num_sequences
+    return (layout.lengths[sequence] - 1 - position).view(layout.length, layout.num_envs, 1)
+
+
+def gather_memory(memory: Any, done: Tensor, layout: SequenceLayout | None = None) -> Any:
+    """Inverse of :func:`scatter_memory` (recurrent.py:124-157): ``[Ns, ...]`` per-sequence states -> ``[N, ...]``, each env
+    getting the state of the sequence still open at the end of its column, cleared where it ended exactly at the last
+    step.  One HIP launch per tensor (``cusrl_gather_memory``)."""
+    if memory is None:
+        return None
+    layout = layout or compute_sequence_layout(done)
+
+    def gather(mem: Tensor) -> Tensor:
+        ops.require_device(mem, "memory")
+        mem = mem.contiguous()
+        if mem.shape[0] != layout.num_sequences:
+            raise ValueError(f"gather_memory: expected {layout.num_sequences} sequences, got {mem.shape[0]}")
+        result = mem.new_empty((layout.num_envs,) + tuple(mem.shape[1:]))
+        row_bytes = mem.element_size() * (mem.numel() // max(mem.shape[0], 1))
+        check(_native.lib().cusrl_gather_memory(mem.data_ptr(), layout.last_seq.data_ptr(), layout.done_last.data_ptr(),
+                                                result.data_ptr(), layout.num_envs, row_bytes,
+                                                torch.cuda.current_stream().cuda_stream), "cusrl_gather_memory")
+        return result
+
+    return map_nested(gather, memory)
 
 
 def compute_sequence_indices(done: Tensor) -> Tensor:

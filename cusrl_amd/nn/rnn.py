@@ -97,9 +97,7 @@ class Rnn(Module):
         if done is not None:
             if not sequential:
                 raise ValueError("'done' can be provided only when 'sequential' is True")
-            if pack_sequence:
-                raise NotImplementedError("packed sequences (final-state recovery) are not built; PPO does not use them")
-            latent, memory = self._forward_sequence(input, memory, done)
+            latent, memory = self._forward_sequence(input, memory, done, pack_sequence=pack_sequence)
         else:
             latent, memory = self._forward_tensor(input, memory, sequential=sequential)
         return self.output_proj(latent), memory
@@ -121,13 +119,25 @@ class Rnn(Module):
             out_memory = map_nested(lambda m: m.reshape(*batch_dims, m.size(-1)), out_memory)
         return latent, out_memory
 
-    def _forward_sequence(self, input: Tensor, memory: Any, done: Tensor):
+    def _forward_sequence(self, input: Tensor, memory: Any, done: Tensor, pack_sequence: bool = False):
         layout = recurrent.compute_sequence_layout(done)
         padded_input, _ = recurrent.split_and_pad_sequences(input, done, layout)
         scattered = recurrent.scatter_memory(memory, done, layout)
-        padded_latent, _ = self._forward_tensor(padded_input, scattered)
-        # the RNN also consumed padded steps, so its final state is not the state at each episode's last valid step
-        return recurrent.unpad_and_merge_sequences(padded_latent, layout), None
+        if pack_sequence:
+            # rnn.py:273-291: the padded batch goes through the RNN as a PackedSequence, so every sequence stops at ITS
+            # last valid step and the returned state is the true final state; gather_memory maps it back to envs.
+            # (The PackedSequence API wants the lengths on the host: one read-back, as in the reference.)
+            if input.dim() != 3:
+                raise ValueError(f"Packed RNN input must be 3D, but got {input.dim()} dimensions")
+            packed = nn.utils.rnn.pack_padded_sequence(padded_input, lengths=layout.lengths.cpu(), enforce_sorted=False)
+            packed_latent, scattered_output = self.rnn(packed, scattered)
+            padded_latent, _ = nn.utils.rnn.pad_packed_sequence(packed_latent, total_length=padded_input.size(0))
+            output_memory = recurrent.gather_memory(scattered_output, done, layout)
+        else:
+            padded_latent, _ = self._forward_tensor(padded_input, scattered)
+            # the RNN also consumed padded steps, so its final state is not the state at each episode's last valid step
+            output_memory = None
+        return recurrent.unpad_and_merge_sequences(padded_latent, layout), output_memory
 
     def step_memory(self, input: Tensor, memory: Any = None, sequential: bool = True, **kwargs):
         if sequential and input.dim() >= 3:

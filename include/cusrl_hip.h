@@ -282,14 +282,21 @@ int cusrl_rms_normalize(const float *x, const float *mean, const float *std, flo
  *           of sequences Ns (num_sequences, device int32[1]) — the host reads Ns to size the padded tensors;
  *  phase 2  cusrl_sequence_layout: dest[t*N + n] = pos * Ns + seq (int64: row of slot (t, n) inside the padded
  *           [L, Ns] layout), first_seq[n] = index of env n's first sequence, and mask[pos * Ns + seq] = 1 for valid
- *           padded positions (mask [L, Ns] bytes must be zeroed by the caller).
- * Packing / unpacking any [L, N, ...] tensor is then cusrl_scatter_rows / cusrl_gather_rows with `dest`. */
+ *           padded positions (mask [L, Ns] bytes must be zeroed by the caller); optionally (NULL to skip)
+ *           seq_lengths[seq] = number of valid steps of every sequence (int64[Ns], `compute_sequence_lengths`) and
+ *           last_seq[n] = index of the sequence still running at the end of env n's column (int64[N]).
+ * Packing / unpacking any [L, N, ...] tensor is then cusrl_scatter_rows / cusrl_gather_rows with `dest`.
+ * cusrl_gather_memory — cusrl/nn/utils/recurrent.py:124-157 (`gather_memory`, the inverse of scatter_memory used by
+ * the packed-sequence forward, cusrl/nn/module/rnn.py:273-291): out[n] = memory[last_seq[n]], zeroed where
+ * done_last[n] (the env finished exactly at the last step); rows of row_bytes bytes. */
 int cusrl_sequence_count(const uint8_t *done, int64_t L, int64_t N, int32_t *env_prefix, int32_t *block_totals,
                          int32_t *num_sequences, void *stream);
 int64_t cusrl_sequence_blocks(int64_t N);
 int cusrl_sequence_layout(const uint8_t *done, int64_t L, int64_t N, const int32_t *env_prefix,
                           const int32_t *block_totals, int64_t Ns, int64_t *dest, int64_t *first_seq, uint8_t *mask,
-                          void *stream);
+                          int64_t *seq_lengths, int64_t *last_seq, void *stream);
+int cusrl_gather_memory(const void *memory, const int64_t *last_seq, const uint8_t *done_last, void *out, int64_t N,
+                        int64_t row_bytes, void *stream);
 
 /* ---- intrinsic-reward epilogues ----
  * RND, cusrl/hook/auxiliary/rnd.py:71-74: reward[i] += scale * mean_k (target[i,k] - prediction[i,k])^2 for i < rows

@@ -510,6 +510,56 @@ def make_recurrent(cusrl):
     print("recurrent.npz:", idx, "cases + GRU/LSTM wrappers")
 
 
+def make_recurrent_packed(cusrl):
+    """SURVEY.md §8f rank 1, second half: ``gather_memory`` (nn/utils/recurrent.py:124-157), the per-slot time indices
+    (``compute_cumulative_timesteps`` / ``compute_reverse_cumulative_timesteps`` ``:28-32,95-99``) and the
+    ``pack_sequence=True`` path of the ``Rnn`` wrapper that recovers every env's final recurrent state
+    (nn/module/rnn.py:273-291), as in cusrl_test/nn/module/test_rnn.py:88-128."""
+    from cusrl.nn.utils import recurrent as R  # noqa: PLC0415
+
+    out = dict(META)
+    gen = torch.Generator().manual_seed(405)
+    idx = 0
+    for L, N, H, p_done in [(6, 5, 4, 0.3), (24, 16, 6, 0.05), (3, 1, 2, 0.5), (8, 7, 4, 0.0), (5, 4, 3, 1.0), (16, 33, 8, 0.25)]:
+        done = torch.rand(L, N, 1, generator=gen) < p_done
+        num_sequences = int(R.compute_sequence_lengths(done).numel())
+        scattered = torch.randn(num_sequences, H, generator=gen)
+        p = f"c{idx}_"
+        out[p + "done"], out[p + "scattered"] = np_(done), np_(scattered)
+        out[p + "gathered"] = np_(R.gather_memory(scattered, done))
+        nested = {"hidden": scattered, "cell": scattered * 2.0}
+        out[p + "gathered_cell"] = np_(R.gather_memory(nested, done)["cell"])
+        out[p + "cumulative_timesteps"] = np_(R.compute_cumulative_timesteps(done))
+        out[p + "reverse_cumulative_timesteps"] = np_(R.compute_reverse_cumulative_timesteps(done))
+        out[p + "cumulative_sequence_lengths"] = np_(R.compute_cumulative_sequence_lengths(done))
+        idx += 1
+    out["num_cases"] = np.array(idx)
+    for kind in ("RNN", "GRU", "LSTM"):
+        torch.manual_seed(19)
+        rnn = cusrl.Rnn.Factory(kind, hidden_size=8, num_layers=2)(5)
+        L, N = 12, 9
+        warmup = torch.randn(4, N, 5, generator=gen)
+        x = torch.randn(L, N, 5, generator=gen)
+        done = torch.rand(L, N, 1, generator=gen) > 0.75
+        p = kind.lower() + "_"
+        for k, v in rnn.state_dict().items():
+            out[p + "param/" + k] = np_(v)
+        out[p + "param_names"] = np.array(list(rnn.state_dict().keys()))
+        out[p + "warmup"], out[p + "x"], out[p + "done"] = np_(warmup), np_(x), np_(done)
+        flat = (lambda m: np_(torch.cat([m["hidden"], m["cell"]], -1))) if kind == "LSTM" else np_
+        with torch.no_grad():
+            _, initial = rnn(warmup)
+            out[p + "initial_memory"] = flat(initial)
+            clone = (lambda m: {k: v.clone() for k, v in m.items()}) if kind == "LSTM" else torch.clone
+            y, memory = rnn(x, memory=clone(initial), done=done, pack_sequence=True)
+            out[p + "packed_output"], out[p + "packed_memory"] = np_(y), flat(memory)
+            y_unpacked, none = rnn(x, memory=clone(initial), done=done)
+            assert none is None
+            out[p + "unpacked_output"] = np_(y_unpacked)
+    np.savez_compressed(HERE / "recurrent_packed.npz", **out)
+    print("recurrent_packed.npz:", idx, "cases + RNN/GRU/LSTM packed forward")
+
+
 # ------------------------------------------------------------------------------------------------ RND / AMP
 def make_aux_rewards(cusrl):
     """RandomNetworkDistillation.pre_update / objective (hook/auxiliary/rnd.py:55-81) and
@@ -634,19 +684,19 @@ def make_lr_schedule(cusrl):
     print("lr_schedule.npz", {k: v.shape for k, v in out.items() if k not in ("torch_version",)})
 
 
+MAKERS = ("gae", "next_value", "randperm", "losses", "merge", "update_trace", "obs_norm", "recurrent", "aux_rewards",
+          "lr_schedule", "recurrent_packed")
+
+
 def main():
+    """``make_golden.py`` regenerates every fixture; ``make_golden.py NAME...`` only the named ones (see MAKERS)."""
     cusrl = import_reference()
     cusrl.config.set_device("cpu")
-    make_gae(cusrl)
-    make_next_value(cusrl)
-    make_randperm(cusrl)
-    make_losses(cusrl)
-    make_merge(cusrl)
-    make_update_trace(cusrl)
-    make_obs_norm(cusrl)
-    make_recurrent(cusrl)
-    make_aux_rewards(cusrl)
-    make_lr_schedule(cusrl)
+    selected = sys.argv[1:] or MAKERS
+    unknown = [name for name in selected if name not in MAKERS]
+    assert not unknown, f"unknown fixtures {unknown}; choose from {MAKERS}"
+    for name in selected:
+        globals()[f"make_{name}"](cusrl)
     leaked = list(REFERENCE.rglob("__pycache__"))
     assert not leaked, f"bytecode leaked into the reference tree: {leaked[:3]}"
 

@@ -129,3 +129,75 @@ def test_recurrent_ppo_preset_trains(rnn_type):
     keys = set(trainer.agent.buffer.storage)
     assert {"actor_memory", "critic_memory", "next_critic_memory"} <= {k.split(".")[0] for k in keys}
     assert np.isfinite(trainer.last_info["Agent/value_loss"]) and np.isfinite(trainer.last_info["Agent/kl_divergence"])
+
+
+@pytest.mark.gpu
+def test_gather_memory_and_time_indices_bit_exact_vs_reference(golden):
+    """cusrl_gather_memory + the layout kernel's per-sequence outputs against the reference's recurrent.py:28-157."""
+    from cusrl_amd import _native
+    from cusrl_amd.nn import recurrent as R
+
+    g = golden("recurrent_packed")
+    before = _native.launch_counts.get("cusrl_gather_memory", 0)
+    for i in range(int(g["num_cases"])):
+        p = f"c{i}_"
+        done = torch.from_numpy(g[p + "done"].copy()).to(DEV)
+        scattered = torch.from_numpy(g[p + "scattered"].copy()).to(DEV)
+        layout = R.compute_sequence_layout(done)
+        assert np.array_equal(R.gather_memory(scattered, done, layout).cpu().numpy(), g[p + "gathered"]), f"case {i}"
+        nested = R.gather_memory({"hidden": scattered, "cell": scattered * 2.0}, done)
+        assert np.array_equal(nested["cell"].cpu().numpy(), g[p + "gathered_cell"])
+        assert np.array_equal(R.compute_cumulative_timesteps(done).cpu().numpy(), g[p + "cumulative_timesteps"])
+        assert np.array_equal(R.compute_reverse_cumulative_timesteps(done).cpu().numpy(), g[p + "reverse_cumulative_timesteps"])
+        assert np.array_equal(R.compute_cumulative_sequence_lengths(done).cpu().numpy(), g[p + "cumulative_sequence_lengths"])
+        # scatter followed by gather returns the stored memory of every env that did not finish at the last step
+        memory = torch.randn(done.shape[1], 7, device=DEV)
+        roundtrip = R.gather_memory(R.scatter_memory(memory, done, layout), done, layout)
+        single = (layout.lengths.numel() == done.shape[1])  # no boundary inside the batch: first == last sequence
+        if single:
+            assert torch.equal(roundtrip, memory * (~done[-1]).float())
+    assert _native.launch_counts.get("cusrl_gather_memory", 0) - before >= 3 * int(g["num_cases"])
+    # config-4 row width: [Ns, 512] states of 16 384 envs
+    done = torch.rand(24, 16384, 1, device=DEV) < 0.02
+    layout = R.compute_sequence_layout(done)
+    states = torch.randn(layout.num_sequences, 512, device=DEV)
+    out = R.gather_memory(states, done, layout)
+    expect = states[layout.last_seq] * (~done[-1]).float()
+    assert torch.equal(out, expect)
+    assert int(layout.lengths.sum()) == 24 * 16384 and int(layout.lengths.max()) <= 24
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RNN", "GRU", "LSTM"])
+def test_packed_sequences_recover_the_final_memory(golden, kind):
+    """``pack_sequence=True`` (rnn.py:273-291): outputs and the per-env final state vs the reference's own run."""
+    g = golden("recurrent_packed")
+    p = kind.lower() + "_"
+    rnn = cusrl.Rnn.Factory(kind, hidden_size=8, num_layers=2)(5)
+    names = [str(n) for n in g[p + "param_names"]]
+    assert list(rnn.state_dict().keys()) == names
+    rnn.load_state_dict({n: torch.from_numpy(g[p + "param/" + n].copy()) for n in names})
+    rnn = rnn.to(DEV)
+    x, done = torch.from_numpy(g[p + "x"].copy()).to(DEV), torch.from_numpy(g[p + "done"].copy()).to(DEV)
+    warmup = torch.from_numpy(g[p + "warmup"].copy()).to(DEV)
+
+    def flat(memory):
+        return torch.cat([memory["hidden"], memory["cell"]], -1) if kind == "LSTM" else memory
+
+    with torch.no_grad():
+        _, initial = rnn(warmup)
+        np.testing.assert_allclose(flat(initial).cpu().numpy(), g[p + "initial_memory"], rtol=1e-5, atol=2e-6)
+        clone = {k: v.clone() for k, v in initial.items()} if kind == "LSTM" else initial.clone()
+        y, memory = rnn(x, memory=clone, done=done, pack_sequence=True)
+    np.testing.assert_allclose(y.cpu().numpy(), g[p + "packed_output"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(flat(memory).cpu().numpy(), g[p + "packed_memory"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(y.cpu().numpy(), g[p + "unpacked_output"], rtol=1e-5, atol=2e-6)
+    # the step-by-step rollout ends in the same state (cusrl_test/nn/module/test_rnn.py:88-128)
+    with torch.no_grad():
+        step_memory = {k: v.clone() for k, v in initial.items()} if kind == "LSTM" else initial.clone()
+        for t in range(x.size(0)):
+            _, step_memory = rnn(x[t], memory=step_memory, sequential=False)
+            rnn.reset_memory(step_memory, done[t])
+    torch.testing.assert_close(flat(memory), flat(step_memory), rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError, match="Packed RNN input must be 3D"):
+        rnn(torch.randn(4, 3, 2, 5, device=DEV), done=torch.zeros(4, 3, 1, dtype=torch.bool, device=DEV), pack_sequence=True)
