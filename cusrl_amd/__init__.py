@@ -10,7 +10,9 @@ from cusrl_amd.nn import (
     Actor, AdaptiveNormalDist, Distribution, Gru, LinearFp32, Lstm, Mlp, Module, ModuleFactory, NormalDist,
     OneHotCategoricalDist, Rnn, RunningMeanStd, Value,
 )
-from cusrl_amd.sampler import AutoMiniBatchSampler, MiniBatchSampler, TemporalMiniBatchSampler
+from cusrl_amd.sampler import (
+    AutoMiniBatchSampler, AutoRandomSampler, MiniBatchSampler, RandomSampler, TemporalMiniBatchSampler, TemporalRandomSampler,
+)
 from cusrl_amd.template import (
     ActorCritic,
     Agent,
@@ -34,6 +36,7 @@ __all__ = [
     "AdaptiveNormalDist",
     "Agent",
     "AutoMiniBatchSampler",
+    "AutoRandomSampler",
     "Buffer",
     "Distribution",
     "Environment",
@@ -49,10 +52,12 @@ __all__ = [
     "NormalDist",
     "OneHotCategoricalDist",
     "OptimizerFactory",
+    "RandomSampler",
     "Rnn",
     "RunningMeanStd",
     "Sampler",
     "TemporalMiniBatchSampler",
+    "TemporalRandomSampler",
     "Trainer",
     "TrainerHook",
     "Value",

@@ -60,16 +60,19 @@ _SIGNATURES = {
     "cusrl_pack_rows": (c_int, [POINTER(PackedField), c_int, _P, c_int64, c_int64, _P]),
     "cusrl_gather_rows_packed": (c_int, [POINTER(Field), c_int, _P, c_int64, POINTER(PackedField), c_int, _P, c_int64, c_int64,
                                          c_int64, c_int, _P]),
+    "cusrl_window_indices": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int64, _P]),
     "cusrl_ppo_loss_fwd_bwd": (
         c_int,
         [_P] * 8 + [c_int64] * 3 + [c_double] * 5 + [_P] * 8 + [_P, c_int64, _P, _P, _P],
     ),
+    "cusrl_ppo_loss_categorical_fwd_bwd": (c_int, [_P] * 7 + [c_int64] * 3 + [c_double] * 5 + [_P] * 7 + [_P, _P]),
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
     "cusrl_ppo_loss_std_partial_rows": (c_int64, [c_int64]),
     "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
     "cusrl_episode_stats": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, _P]),
     "cusrl_policy_stats": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P, _P, _P]),
     "cusrl_policy_stats_num_partials": (c_int64, [c_int64]),
+    "cusrl_categorical_policy_stats": (c_int, [_P] * 5 + [c_int64, c_int64, c_int64, _P, _P, _P]),
     "cusrl_relu_bwd_colsum": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
     "cusrl_colsum_num_partials": (c_int64, [c_int64, c_int64]),
     "cusrl_narrow_linear_bwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, c_int, _P]),

@@ -431,6 +431,19 @@ __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(const char *__rest
         *reinterpret_cast<V *>(dst + dst_row[it] * row_bytes + col[it] * int64_t(sizeof(V))) = regs[it];
 }
 
+// Flat slot list of random temporal windows (cusrl/sampler/random_sampler.py:95-109): window b covers `L` consecutive
+// steps of env[b] from logical step start[b]; logical time 0 is physical row `cursor` once the ring is full.
+// out[t * B + b] = ((cursor + start[b] + t) % T) * N + env[b].
+__global__ __launch_bounds__(kBlock) void window_indices_kernel(const int64_t *__restrict__ start,
+                                                                const int64_t *__restrict__ env,
+                                                                int64_t *__restrict__ out, int64_t B, int64_t L,
+                                                                int64_t T, int64_t N, int64_t cursor) {
+    const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= B * L) return;
+    const int64_t t = i / B, b = i - t * B;
+    out[i] = ((cursor + start[b] + t) % T) * N + env[b];
+}
+
 static int pick_unit(const void *a, const void *b, int64_t row_bytes) {
     for (int unit : {16, 8, 4, 2})
         if (row_bytes % unit == 0 && aligned(a, unit) && aligned(b, unit)) return unit;
@@ -573,6 +586,17 @@ extern "C" int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, cons
                                  int64_t T, int64_t N, int temporal, void *stream) {
     if (n_fields == 0 || B == 0) return 0;
     return cusrl_gather_rows_packed(fields, n_fields, nullptr, 0, nullptr, 0, indices, B, T, N, temporal, stream);
+}
+
+extern "C" int cusrl_window_indices(const int64_t *start, const int64_t *env, int64_t *out, int64_t B, int64_t L,
+                                    int64_t T, int64_t N, int64_t cursor, void *stream) {
+    if (B == 0 || L == 0) return 0;
+    if (!start || !env || !out || B < 0 || L < 0 || T < 1 || N < 1 || cursor < 0 || cursor >= T) return CUSRL_E_INVALID;
+    const int64_t blocks = ceil_div(B * L, kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(window_indices_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), start, env, out,
+                       B, L, T, N, cursor);
+    return launch_status();
 }
 
 extern "C" int64_t cusrl_flag_blocks(int64_t n) { return n <= 0 ? 0 : ceil_div(n, kFlagChunk); }

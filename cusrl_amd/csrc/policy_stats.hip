@@ -55,6 +55,58 @@ __global__ __launch_bounds__(kBlock) void policy_stats_kernel(const float *__res
     }
 }
 
+// One-hot categorical policies (torch.distributions.kl._kl_categorical_categorical, OneHotCategorical.log_prob):
+//   kl = sum_j p_j (log p_j - log q_j)  [inf where q_j = 0 < p_j, 0 where p_j = 0],  logp_q(action) = log q_taken.
+// The third sum stays zero (no `action_std` for this family).
+__global__ __launch_bounds__(kBlock) void categorical_policy_stats_kernel(const float *__restrict__ old_logits,
+                                                                          const float *__restrict__ new_logits,
+                                                                          const float *__restrict__ action,
+                                                                          const float *__restrict__ old_logp,
+                                                                          const float *__restrict__ advantage,
+                                                                          int64_t B, int A, int D,
+                                                                          double *__restrict__ partials) {
+    __shared__ double scratch[kWavesPerBlock][kStatSums];
+    double acc[kStatSums] = {0.0, 0.0, 0.0};
+    const int64_t row = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (row < B) {
+        const float *zp = old_logits + row * A, *zq = new_logits + row * A, *a = action + row * A;
+        float mp = zp[0], mq = zq[0];
+        for (int j = 1; j < A; ++j) mp = fmaxf(mp, zp[j]), mq = fmaxf(mq, zq[j]);
+        float sp = 0.f, sq = 0.f, best = a[0];
+        int taken = 0;
+        for (int j = 0; j < A; ++j) {
+            sp += expf(zp[j] - mp), sq += expf(zq[j] - mq);
+            if (a[j] > best) best = a[j], taken = j;
+        }
+        const float np = mp + logf(sp), nq = mq + logf(sq);
+        float kl = 0.f;
+        for (int j = 0; j < A; ++j) {
+            const float lp = zp[j] - np, lq = zq[j] - nq, pj = expf(lp);
+            float t = pj * (lp - lq);
+            if (expf(lq) == 0.0f) t = INFINITY;  // t[(q.probs == 0)] = inf
+            if (pj == 0.0f) t = 0.0f;            // t[(p.probs == 0)] = 0
+            kl += t;
+        }
+        const float weight = expf((zq[taken] - nq) - old_logp[row]);
+        float iw = 0.f;
+        for (int d = 0; d < D; ++d) iw += advantage[row * D + d] * weight;
+        acc[0] = double(kl), acc[1] = double(iw);
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < kStatSums; ++k) {
+        const double total = wave_sum(acc[k]);
+        if (lane == 0) scratch[wave][k] = total;
+    }
+    __syncthreads();
+    if (threadIdx.x < kStatSums) {
+        double total = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) total += scratch[w][threadIdx.x];
+        partials[int64_t(blockIdx.x) * kStatSums + threadIdx.x] = total;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void policy_stats_finalize_kernel(const double *__restrict__ partials, int64_t P,
                                                                        int64_t B, int A, int D,
                                                                        float *__restrict__ out) {
@@ -89,6 +141,21 @@ extern "C" int cusrl_policy_stats(const float *old_mean, const float *old_std, c
     hipStream_t s = as_stream(stream);
     policy_stats_kernel<<<uint32_t(blocks), kBlock, 0, s>>>(old_mean, old_std, new_mean, new_std, action, old_logp,
                                                              advantage, B, int(A), int(D), partials);
+    if (int rc = launch_status()) return rc;
+    policy_stats_finalize_kernel<<<1, kBlock, 0, s>>>(partials, blocks, B, int(A), int(D), out);
+    return launch_status();
+}
+
+extern "C" int cusrl_categorical_policy_stats(const float *old_logits, const float *new_logits, const float *action,
+                                              const float *old_logp, const float *advantage, int64_t B, int64_t A,
+                                              int64_t D, double *partials, float *out, void *stream) {
+    using namespace cusrl;
+    if (!old_logits || !new_logits || !action || !old_logp || !advantage || !partials || !out) return CUSRL_E_INVALID;
+    if (B <= 0 || A <= 0 || D <= 0 || A > INT32_MAX || D > INT32_MAX) return CUSRL_E_INVALID;
+    const int64_t blocks = ceil_div(B, kBlock);
+    hipStream_t s = as_stream(stream);
+    categorical_policy_stats_kernel<<<uint32_t(blocks), kBlock, 0, s>>>(old_logits, new_logits, action, old_logp,
+                                                                         advantage, B, int(A), int(D), partials);
     if (int rc = launch_status()) return rc;
     policy_stats_finalize_kernel<<<1, kBlock, 0, s>>>(partials, blocks, B, int(A), int(D), out);
     return launch_status();

@@ -355,6 +355,52 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowwise_kernel(
         finalize_losses<true>(partials, gridDim.x, B, D, p, losses_out, nullptr, A, nullptr);
 }
 
+// One-hot categorical policies (discrete action spaces, cusrl/nn/module/distribution.py:332-366 on top of
+// torch.distributions.OneHotCategorical): log-prob = log-softmax(logits)[argmax(action)], entropy = -sum p log p,
+// d logp / d logits = onehot - p, d entropy / d logits_j = -p_j (log p_j + entropy).  One lane per row; the row is
+// walked three times (max, normaliser + the taken action, gradients) — the second and third walk hit L1.
+__global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
+    const float *__restrict__ advantage, const float *__restrict__ old_logp, const float *__restrict__ action,
+    const float *__restrict__ logits, const float *__restrict__ ret, const float *__restrict__ curr_value,
+    const float *__restrict__ old_value, int64_t B, int A, int D, LossParams p, float *__restrict__ logp_out,
+    float *__restrict__ entropy_out, float *__restrict__ lr_out, float *__restrict__ ratio_out,
+    float *__restrict__ d_logits, float *__restrict__ d_value, double *__restrict__ partials) {
+    double acc[kLossSums] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    const int64_t row = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (row < B) {
+        const float *z = logits + row * A, *a = action + row * A;
+        float zmax = z[0];
+        for (int j = 1; j < A; ++j) zmax = fmaxf(zmax, z[j]);
+        float sum = 0.0f, best = a[0];
+        int taken = 0;  // value.max(-1)[1]: first index of the largest entry of the (one-hot) action
+        for (int j = 0; j < A; ++j) {
+            sum += expf(z[j] - zmax);
+            if (a[j] > best) best = a[j], taken = j;
+        }
+        const float log_norm = zmax + logf(sum);  // logsumexp
+        float entropy = 0.0f;
+        for (int j = 0; j < A; ++j) {
+            const float lp = z[j] - log_norm;
+            entropy -= expf(lp) * lp;  // -(probs * logits).sum(-1)
+        }
+        const float logp = z[taken] - log_norm;
+        float ratio, lr;
+        const float dlp = row_terms(logp, entropy, old_logp[row], advantage[row], p, acc[1], acc[2], acc[3], ratio, lr);
+        if (logp_out) logp_out[row] = logp;
+        if (entropy_out) entropy_out[row] = entropy;
+        if (lr_out) lr_out[row] = lr;
+        if (ratio_out) ratio_out[row] = ratio;
+        if (d_logits) {
+            for (int j = 0; j < A; ++j) {
+                const float lp = z[j] - log_norm, pj = expf(lp);
+                d_logits[row * A + j] = dlp * ((j == taken ? 1.0f : 0.0f) - pj) - p.g_ent * (pj * (lp + entropy));
+            }
+        }
+        value_terms(ret, curr_value, old_value, d_value, row, D, p, acc[0], acc[4]);
+    }
+    write_block_partials<false>(acc, partials);
+}
+
 // Column sums of `rows` partial rows [rows][A] (A <= 32) by one block, fixed order: lane (a, g) walks rows g, g + 8, ...
 // four loads at a time, the 8 row groups are combined through LDS.  out[a] for a < A.
 constexpr int kStdSliceRows = 128;  // partial rows one block of the staged reduction takes
@@ -456,6 +502,50 @@ extern "C" int64_t cusrl_ppo_loss_num_partials(int64_t B) {
 extern "C" int64_t cusrl_ppo_loss_std_partial_rows(int64_t B) {
     const int64_t blocks = loss_blocks(B);
     return blocks + (blocks > kStdSliceRows ? ceil_div(blocks, kStdSliceRows) : 0);
+}
+
+extern "C" int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const float *old_logp, const float *action,
+                                                  const float *logits, const float *ret, const float *curr_value,
+                                                  const float *old_value, int64_t B, int64_t A, int64_t D, double clip,
+                                                  double value_clip, double w_sur, double w_val, double w_ent,
+                                                  float *losses_out, float *logp_out, float *entropy_out,
+                                                  float *logp_ratio_out, float *ratio_out, float *d_logits,
+                                                  float *d_value, double *partials, void *stream) {
+    if (B <= 0 || A <= 0 || D <= 0) return CUSRL_E_INVALID;
+    if (!advantage || !old_logp || !action || !logits || !ret || !curr_value || !losses_out || !partials)
+        return CUSRL_E_INVALID;
+    if (value_clip >= 0.0 && !old_value) return CUSRL_E_INVALID;
+    if (A > INT32_MAX || D > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    LossParams p;
+    p.lo = float(1.0 - clip);
+    p.hi = float(1.0 + clip);
+    p.value_clip = value_clip < 0.0 ? -1.0f : float(value_clip);
+    p.g_sur = float(-w_sur / double(B));
+    p.g_ent = float(-w_ent / double(B));
+    p.g_val = float(w_val / double(B * D));
+    p.w_sur = float(w_sur);
+    p.w_val = float(w_val);
+    p.w_ent = float(w_ent);
+    hipStream_t s = as_stream(stream);
+    const int64_t blocks = loss_blocks(B);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(ppo_loss_categorical_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, old_logp,
+                       action, logits, ret, curr_value, old_value, B, int(A), int(D), p, logp_out, entropy_out,
+                       logp_ratio_out, ratio_out, d_logits, d_value, partials);
+    if (int rc = launch_status()) return rc;
+    const double *loss_rows = partials;
+    int64_t num_loss_rows = blocks;
+    if (blocks > kBlock) {
+        num_loss_rows = ceil_div(blocks, kBlock);
+        double *stage = partials + blocks * kLossSums;
+        hipLaunchKernelGGL(loss_partials_stage_kernel, dim3(uint32_t(num_loss_rows)), dim3(kBlock), 0, s, partials, blocks,
+                           stage);
+        if (int rc = launch_status()) return rc;
+        loss_rows = stage;
+    }
+    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, loss_rows, num_loss_rows, B, int(D), p,
+                       losses_out, nullptr, int(A), nullptr);
+    return launch_status();
 }
 
 #define CUSRL_LAUNCH_CHUNKED(LPR)                                                                                      \

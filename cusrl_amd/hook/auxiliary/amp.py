@@ -84,11 +84,17 @@ class AdversarialMotionPrior(Hook):
         transition["expert_transition"] = self.transition_rms.normalize(expert_transition)
         logit = self.discriminator(agent_transition)
         reward = transition["reward"]
-        if reward.is_cuda and reward.is_contiguous() and reward.shape == logit.shape and reward.dtype == torch.float32:
+        if reward.is_cuda:
+            # on the GPU the style-reward epilogue is ALWAYS the HIP kernel; a reward it cannot update in place (strided,
+            # several channels) gets the kernel's bonus added instead of a silent torch-op evaluation
             from cusrl_amd import ops
 
-            style_reward = ops.amp_style_reward_(reward, logit, self.reward_scale)
-        else:
+            if reward.is_contiguous() and reward.shape == logit.shape and reward.dtype == torch.float32:
+                style_reward = ops.amp_style_reward_(reward, logit, self.reward_scale)
+            else:
+                style_reward = ops.amp_style_reward_(torch.zeros_like(logit, dtype=torch.float32), logit.float(), self.reward_scale)
+                reward.add_(style_reward.to(reward.dtype))
+        else:  # CPU agents (host-logic tests, no GPU in the process): the reference's torch ops
             style_reward = self.reward_scale * -torch.log(torch.clamp(1 - 1 / (1 + torch.exp(-logit)), min=1e-4))
             reward.add_(style_reward)
         self.agent.record(amp_reward=style_reward)

@@ -43,11 +43,18 @@ class RandomNetworkDistillation(Hook):
         flat = next_state.reshape(-1, next_state.shape[-1])
         target, prediction = self.target(flat), self.predictor(flat)
         reward = buffer["reward"]
-        if reward.is_cuda and reward.shape[-1] == 1 and reward.is_contiguous():
+        if reward.is_cuda:
+            # on the GPU the epilogue is ALWAYS the HIP kernel: a layout it cannot take is brought into shape (one
+            # reward channel at a time, contiguous staging) rather than silently computed by torch ops
             from cusrl_amd import ops
 
-            bonus = ops.rnd_reward_(reward, target, prediction, self.reward_scale)
-        else:  # multi-channel rewards broadcast the bonus over channels like the reference; host tensors: torch ops
+            if reward.shape[-1] == 1 and reward.is_contiguous():
+                bonus = ops.rnd_reward_(reward, target, prediction, self.reward_scale)
+            else:  # multi-channel / strided rewards: the same bonus is added to every channel (broadcast, rnd.py:71-74)
+                staged = reward.new_zeros(reward.shape[:-1] + (1,)).contiguous()
+                bonus = ops.rnd_reward_(staged, target, prediction, self.reward_scale)
+                reward.add_(bonus)
+        else:  # CPU agents (host-logic tests, no GPU in the process): the reference's torch ops
             bonus = self.reward_scale * (target - prediction).square().mean(dim=-1, keepdim=True).view(*reward.shape[:-1], 1)
             reward.add_(bonus)
         self.agent.record(rnd_reward=bonus)

@@ -57,6 +57,35 @@ class _FusedPpoFunction(torch.autograd.Function):
         return (d_mean.view(shapes[0]), d_std.view(shapes[1]), d_value.view(shapes[2]), *([None] * 11))
 
 
+class _FusedCategoricalPpoFunction(torch.autograd.Function):
+    """The same objective for a one-hot categorical policy: gradients wrt ``logits`` and ``curr_value``."""
+
+    @staticmethod
+    def forward(ctx, logits, curr_value, advantage, old_logp, action, ret, old_value, clip, value_clip, w_sur, w_val, w_ent,
+                unit_grad):
+        out = ops.ppo_loss_categorical_fwd_bwd(
+            advantage, old_logp, action, logits, ret, curr_value, old_value,
+            clip=clip, value_clip=value_clip, w_sur=w_sur, w_val=w_val, w_ent=w_ent, want_grads=True,
+        )
+        ctx.save_for_backward(out["d_logits"], out["d_value"])
+        ctx.set_materialize_grads(False)
+        ctx.unit_grad = unit_grad
+        ctx.shapes = (logits.shape, curr_value.shape)
+        losses = out["losses"]
+        side = (losses, out["logp"], out["entropy"], out["logp_ratio"], out["ratio"])
+        ctx.mark_non_differentiable(*side)
+        return (losses[6], *side)
+
+    @staticmethod
+    def backward(ctx, grad_total, *_unused):
+        if grad_total is None:
+            return (None,) * 13
+        d_logits, d_value = ctx.saved_tensors
+        if not ctx.unit_grad:
+            d_logits, d_value = d_logits * grad_total, d_value * grad_total
+        return (d_logits.view(ctx.shapes[0]), d_value.view(ctx.shapes[1]), *([None] * 11))
+
+
 def _overrides(hook, method: str) -> bool:
     from cusrl_amd.template.hook import Hook
 
@@ -88,7 +117,8 @@ class FusedPpoObjective:
 
         agent = composite.agent
         distribution = getattr(getattr(agent, "actor", None), "distribution", None)
-        if not getattr(distribution, "is_normal", False) or agent.device.type != "cuda":
+        supported = getattr(distribution, "is_normal", False) or getattr(distribution, "is_categorical", False)
+        if not supported or agent.device.type != "cuda":
             return False
         terms = (ValueLoss, OnPolicyPreparation, PpoSurrogateLoss, EntropyLoss)
         # hooks whose objective neither reads nor differentiates the policy terms: they keep fusion available
@@ -152,6 +182,13 @@ class FusedPpoObjective:
         curr_value, old_value, ret, w_val, value_clip = self.value
         action_dist, action, old_logp = self.policy
         advantage, clip, w_sur = self.surrogate
+        if "logits" in action_dist:  # one-hot categorical policy (discrete action space)
+            total, losses, logp, entropy, logp_ratio, ratio = _FusedCategoricalPpoFunction.apply(
+                action_dist["logits"].float(), curr_value, advantage, old_logp, action, ret, old_value,
+                clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad,
+            )
+            self._publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio)
+            return
         std = action_dist["std"]
         row_vector = getattr(std, "_cusrl_row_vector", None)
         if row_vector is not None and std.dim() == 2 and std.stride(0) == 0 and ops.ppo_loss_accepts_std_vector(std.shape[-1]):
@@ -160,6 +197,10 @@ class FusedPpoObjective:
             action_dist["mean"], std, curr_value, advantage, old_logp, action, ret, old_value,
             clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad,
         )
+        self._publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio)
+
+    @staticmethod
+    def _publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio):
         batch["curr_action_logp"] = logp
         batch["curr_entropy"] = entropy
         batch["action_logp_ratio"] = logp_ratio

@@ -51,7 +51,9 @@ class OnPolicyStatistics(Hook):
                 updated, _ = agent.actor(batch["observation"], memory=batch.get("actor_memory"), done=batch["done"])
             if self._gaussian_on_device(batch["action_dist"], updated):
                 self._record_fused(batch, updated)
-            else:
+            elif self._categorical_on_device(batch["action_dist"], updated):
+                self._record_fused_categorical(batch, updated)
+            else:  # other policy families, CPU agents, autocast dtypes: the actor's own compute_* methods
                 self._record_generic(batch, updated)
 
     # ------------------------------------------------------------------ Gaussian policy: one launch
@@ -71,6 +73,21 @@ class OnPolicyStatistics(Hook):
         metrics.record_reduced("kl_divergence", kl, rows)
         metrics.record_reduced("importance_weighted_advantage", weighted_advantage, advantage.numel())
         metrics.record_reduced("action_std", std, updated["std"].numel())
+
+    # ------------------------------------------------------------------ one-hot categorical policy: one launch
+    def _categorical_on_device(self, behaviour, updated) -> bool:
+        if not getattr(self.agent.actor.distribution, "is_categorical", False):
+            return False
+        tensors = (behaviour.get("logits"), updated.get("logits"))
+        return all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+    def _record_fused_categorical(self, batch, updated):
+        advantage = batch["advantage"]
+        kl, weighted_advantage, _ = ops.categorical_policy_stats(
+            batch["action_dist"]["logits"], updated["logits"], batch["action"], batch["action_logp"], advantage).unbind(0)
+        metrics = self.agent.metrics
+        metrics.record_reduced("kl_divergence", kl, batch["action_logp"].numel())
+        metrics.record_reduced("importance_weighted_advantage", weighted_advantage, advantage.numel())
 
     # ------------------------------------------------------------------ any other policy family
     def _record_generic(self, batch, updated):

@@ -251,6 +251,7 @@ class OneHotCategoricalDistFactory(DistributionFactory):
 class OneHotCategoricalDist(Distribution):
     Factory = OneHotCategoricalDistFactory
     is_normal = False
+    is_categorical = True  # the fused PPO objective has a one-hot categorical form (cusrl_ppo_loss_categorical_fwd_bwd)
 
     @staticmethod
     def _dist(dist_params):

@@ -153,10 +153,11 @@ class RunningMeanStd(nn.Module):
         return self.normalize(input)
 
     def normalize(self, input: Tensor) -> Tensor:
-        if input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled():
+        if input.is_cuda and input.dtype == torch.float32 and not input.requires_grad:
             from cusrl_amd import ops
 
             return ops.rms_normalize(input, self.mean, self.std, self.clamp)
+        # differentiable inputs (autograd has to see the ops), other dtypes (autocast), CPU module state
         output = (input - self.mean) / self.std
         if self.clamp is not None:
             output = output.clamp(-self.clamp, self.clamp)

@@ -32,6 +32,7 @@ __all__ = [
     "next_value",
     "normal_sample_logp",
     "normalize_",
+    "ppo_loss_categorical_fwd_bwd",
     "ppo_loss_fwd_bwd",
     "masked_col_stats",
     "relu_backward_bias",
@@ -41,6 +42,7 @@ __all__ = [
     "rms_normalize",
     "scatter_rows",
     "set_launch_observer",
+    "window_indices",
 ]
 
 
@@ -214,6 +216,21 @@ def gather_rows(
             lambda: lib.cusrl_gather_rows(table, len(chunk), indices.data_ptr(), batch, capacity, parallelism, int(temporal), stream),
         )
     return outputs
+
+
+def window_indices(start: torch.Tensor, env: torch.Tensor, length: int, capacity: int, parallelism: int,
+                   cursor: int | None) -> torch.Tensor:
+    """Flat slots ``[length * B]`` of ``B`` temporal windows (``data[time_indices, env_indices]`` of
+    cusrl/sampler/random_sampler.py:101-113 as one index list); ``cursor`` = oldest row of a FULL ring, else None."""
+    require_device(start, "start_indices"), require_device(env, "env_indices")
+    if start.dtype != torch.int64 or env.dtype != torch.int64 or start.shape != env.shape:
+        raise TypeError("window_indices: int64 index vectors of equal length are required")
+    start, env = start.contiguous(), env.contiguous()
+    out = torch.empty(length * start.numel(), dtype=torch.int64, device=start.device)
+    check(_native.lib().cusrl_window_indices(start.data_ptr(), env.data_ptr(), out.data_ptr(), start.numel(), length,
+                                             capacity, parallelism, 0 if cursor is None else cursor, _stream()),
+          "cusrl_window_indices")
+    return out
 
 
 class RecordPack:
@@ -632,6 +649,62 @@ def ppo_loss_fwd_bwd(
 _LOSS_TICKET = os.environ.get("CUSRL_LOSS_TICKET", "0") != "0"
 
 
+def ppo_loss_categorical_fwd_bwd(
+    advantage: torch.Tensor,
+    old_logp: torch.Tensor,
+    action: torch.Tensor,
+    logits: torch.Tensor,
+    ret: torch.Tensor,
+    curr_value: torch.Tensor,
+    old_value: torch.Tensor | None,
+    *,
+    clip: float,
+    value_clip: float | None,
+    w_sur: float,
+    w_val: float,
+    w_ent: float,
+    want_grads: bool = True,
+) -> dict[str, torch.Tensor]:
+    """:func:`ppo_loss_fwd_bwd` for one-hot categorical policies (``action`` one-hot ``[B, A]``, ``logits [B, A]``):
+    same ``losses`` layout and per-sample outputs, gradients ``d_logits`` / ``d_value``."""
+    advantage, old_logp = _f32(advantage, "advantage"), _f32(old_logp, "action_logp")
+    action, logits = _f32(action, "action"), _f32(logits, "logits")
+    ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
+    A = logits.shape[-1]
+    B = logits.numel() // A
+    D = ret.shape[-1]
+    if advantage.numel() != B or old_logp.numel() != B or action.shape != logits.shape:
+        raise ValueError("ppo_loss_categorical: inconsistent batch shapes")
+    if ret.numel() != B * D or curr_value.shape != ret.shape:
+        raise ValueError("ppo_loss_categorical: return / value shapes differ")
+    if value_clip is not None:
+        if old_value is None:
+            raise ValueError("ppo_loss_categorical: the clipped value loss needs the old value")
+        old_value = _f32(old_value, "value")
+    dev = logits.device
+    lib = _native.lib()
+    out = {name: torch.empty(advantage.shape, dtype=torch.float32, device=dev) for name in ("logp", "entropy", "logp_ratio", "ratio")}
+    out["losses"] = torch.empty(7, dtype=torch.float32, device=dev)
+    if want_grads:
+        out["d_logits"], out["d_value"] = torch.empty_like(logits), torch.empty_like(curr_value)
+    partials = torch.empty((int(lib.cusrl_ppo_loss_num_partials(B)), 5), dtype=torch.float64, device=dev)
+
+    def ptr(name):
+        return out[name].data_ptr() if name in out else None
+
+    _observed(
+        "cusrl_ppo_loss_categorical_fwd_bwd",
+        lambda: B * (8 + 8 * A + 8 * D + ((4 * A + 4 * D) if want_grads else 0) + 16 + (4 * D if value_clip is not None else 0)),
+        lambda: lib.cusrl_ppo_loss_categorical_fwd_bwd(
+            advantage.data_ptr(), old_logp.data_ptr(), action.data_ptr(), logits.data_ptr(), ret.data_ptr(), curr_value.data_ptr(),
+            None if old_value is None or value_clip is None else old_value.data_ptr(), B, A, D, float(clip),
+            -1.0 if value_clip is None else float(value_clip), float(w_sur), float(w_val), float(w_ent), ptr("losses"), ptr("logp"),
+            ptr("entropy"), ptr("logp_ratio"), ptr("ratio"), ptr("d_logits"), ptr("d_value"), partials.data_ptr(), _stream(),
+        ),
+    )
+    return out
+
+
 _tickets: dict = {}
 
 
@@ -704,6 +777,26 @@ def policy_stats(old_mean: torch.Tensor, old_std: torch.Tensor, new_mean: torch.
     out = torch.empty(3, dtype=torch.float32, device=dev)
     check(lib.cusrl_policy_stats(*(t.data_ptr() for t in tensors), B, A, D, partials.data_ptr(), out.data_ptr(), _stream()),
           "cusrl_policy_stats")
+    return out
+
+
+def categorical_policy_stats(old_logits: torch.Tensor, new_logits: torch.Tensor, action: torch.Tensor, old_logp: torch.Tensor,
+                             advantage: torch.Tensor) -> torch.Tensor:
+    """``[mean KL(old || new), mean advantage * exp(logp_new(action) - old_logp), 0]`` of a one-hot categorical policy over
+    a batch — the discrete-action form of :func:`policy_stats`."""
+    tensors = [_f32(t, n) for t, n in ((old_logits, "old_logits"), (new_logits, "new_logits"), (action, "action"),
+                                       (old_logp, "old_logp"), (advantage, "advantage"))]
+    A = new_logits.shape[-1]
+    B = new_logits.numel() // A
+    D = advantage.numel() // B
+    if any(t.numel() != B * A for t in tensors[:3]) or tensors[3].numel() != B or tensors[4].numel() != B * D:
+        raise ValueError("categorical_policy_stats: inconsistent shapes")
+    lib = _native.lib()
+    dev = new_logits.device
+    partials = torch.empty((max(int(lib.cusrl_policy_stats_num_partials(B)), 1), 3), dtype=torch.float64, device=dev)
+    out = torch.empty(3, dtype=torch.float32, device=dev)
+    check(lib.cusrl_categorical_policy_stats(*(t.data_ptr() for t in tensors), B, A, D, partials.data_ptr(), out.data_ptr(), _stream()),
+          "cusrl_categorical_policy_stats")
     return out
 
 

@@ -49,11 +49,13 @@ class LazyBatch(dict):
     reading a never-read field raises.  Fields already read stay valid forever, like the reference's fresh tensors.
     """
 
-    __slots__ = ("_buffer", "_indices", "_temporal", "_pending", "_hot", "_expired", "_own")
+    __slots__ = ("_buffer", "_indices", "_temporal", "_pending", "_hot", "_expired", "_own", "_lead_shape")
 
-    def __init__(self, buffer: "Buffer", indices: torch.Tensor, temporal: bool, hot: set | None):
+    def __init__(self, buffer: "Buffer", indices: torch.Tensor, temporal: bool, hot: set | None,
+                 lead_shape: tuple[int, ...] | None = None):
         super().__init__()
         self._buffer, self._indices, self._temporal = buffer, indices, temporal
+        self._lead_shape = lead_shape
         self._hot = hot if hot is not None else set()
         self._expired = False
         self._own: set = set()  # keys the consumer wrote itself: reading them back says nothing about the buffer
@@ -62,15 +64,20 @@ class LazyBatch(dict):
         eager = names if first else [name for name in names if name in self._hot]
         self._pending = dict.fromkeys(name for name in names if name not in eager)
         if eager:
-            dict.update(self, buffer.gather(indices, temporal, fields=eager))
+            dict.update(self, self._gather(eager))
 
     # ---- materialisation
+    def _gather(self, names):
+        if self._lead_shape is None:  # (stand-in buffers of the host-logic tests only know the three-argument form)
+            return self._buffer.gather(self._indices, self._temporal, fields=names)
+        return self._buffer.gather(self._indices, self._temporal, fields=names, lead_shape=self._lead_shape)
+
     def _fetch(self, names):
         if self._expired:
             raise RuntimeError(
                 f"batch field(s) {sorted(names)} were never read while this minibatch was current and its sampler has "
                 "moved on; read them before advancing the sampler, or build the sampler with lazy=False")
-        dict.update(self, self._buffer.gather(self._indices, self._temporal, fields=list(names)))
+        dict.update(self, self._gather(list(names)))
         for name in names:
             self._pending.pop(name, None)
 
@@ -412,9 +419,12 @@ class Buffer(MutableMapping):
         self._pack.build()
         self._pack_valid = True
 
-    def gather(self, indices: torch.Tensor, temporal: bool = False, fields: Sequence[str] | None = None) -> dict[str, Any]:
+    def gather(self, indices: torch.Tensor, temporal: bool = False, fields: Sequence[str] | None = None,
+               lead_shape: tuple[int, ...] | None = None) -> dict[str, Any]:
         """``flatten(0, 1)[indices]`` (or ``[:, indices]`` when ``temporal``) of every leaf — or of the leaves of the
-        top-level ``fields`` only — in one launch; narrow leaves come through the packed record while it is current."""
+        top-level ``fields`` only — in one launch; narrow leaves come through the packed record while it is current.
+        ``lead_shape``: view the gathered rows as ``[*lead_shape, ...]`` (the ``[sequence_len, batch]`` windows of the
+        temporal random sampler, whose flat slot list is ``sequence_len * batch`` long)."""
         if fields is None:
             keys, schema = list(self.storage), self.schema
         else:
@@ -431,11 +441,14 @@ class Buffer(MutableMapping):
         else:
             outputs = ops.gather_rows([self.storage[k] for k in keys], indices, self.capacity, self.parallelism, temporal)
             gathered = dict(zip(keys, outputs))
+        if lead_shape is not None:
+            gathered = {key: rows.view(tuple(lead_shape) + tuple(rows.shape[1:])) for key, rows in gathered.items()}
         return reconstruct_nested(gathered, schema)
 
-    def gather_lazy(self, indices: torch.Tensor, temporal: bool = False, hot: set | None = None) -> LazyBatch:
+    def gather_lazy(self, indices: torch.Tensor, temporal: bool = False, hot: set | None = None,
+                    lead_shape: tuple[int, ...] | None = None) -> LazyBatch:
         """The minibatch as a :class:`LazyBatch`: the ``hot`` fields now (one launch), the rest on first access."""
-        return LazyBatch(self, indices, temporal, hot)
+        return LazyBatch(self, indices, temporal, hot, lead_shape)
 
     # ------------------------------------------------------------------ validation (messages as in the reference)
     def _as_tensor(self, data) -> torch.Tensor:

@@ -130,6 +130,14 @@ int cusrl_gather_rows_packed(const cusrl_field_t *fields, int n_fields, const vo
                              const cusrl_packed_field_t *packed, int n_packed, const int64_t *indices, int64_t B,
                              int64_t T, int64_t N, int temporal, void *stream);
 
+/* ---- random temporal windows — cusrl/sampler/random_sampler.py:95-113 (`TemporalRandomSampler`) ----
+ * out[t * B + b] = ((cursor + start[b] + t) % T) * N + env[b] for t < L, b < B: the flat slots of B windows of L
+ * consecutive steps, window b belonging to env[b] and starting at LOGICAL step start[b] (physical row `cursor` is
+ * logical step 0 of a full ring; pass cursor = 0 while the ring is still filling).  The list feeds cusrl_gather_rows
+ * (temporal = 0, B' = L * B) — `data[time_indices, env_indices]` of the reference for every leaf in one launch. */
+int cusrl_window_indices(const int64_t *start, const int64_t *env, int64_t *out, int64_t B, int64_t L, int64_t T,
+                         int64_t N, int64_t cursor, void *stream);
+
 /* ---- a9-a13  PPO objective, forward + backward ----
  * common.py:29-43 (Normal log-prob / entropy / ratio), ppo.py:10-18,50-55 (clipped surrogate),
  * value.py:85-89,121-137 (MSE or clipped value loss), ppo.py:82-84 (entropy bonus),
@@ -156,6 +164,18 @@ int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const 
                            double *partials, int64_t std_rows, float *d_std_partials, uint32_t *ticket, void *stream);
 int64_t cusrl_ppo_loss_num_partials(int64_t B);
 int64_t cusrl_ppo_loss_std_partial_rows(int64_t B);
+
+/* The same objective for one-hot categorical policies (discrete action spaces) —
+ * cusrl/nn/module/distribution.py:332-366 over torch.distributions.OneHotCategorical: action [B,A] one-hot (the taken
+ * action is its first arg-max), logits [B,A] unnormalised; logp = log_softmax(logits)[taken],
+ * entropy = -sum_j p_j log p_j, ratio / surrogate / value / entropy terms and losses_out[7] exactly as above;
+ * d_logits [B,A], d_value [B,D] = d(total loss)/d(.).  partials: double[cusrl_ppo_loss_num_partials(B)][5]. */
+int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const float *old_logp, const float *action,
+                                       const float *logits, const float *ret, const float *curr_value,
+                                       const float *old_value, int64_t B, int64_t A, int64_t D, double clip,
+                                       double value_clip, double w_sur, double w_val, double w_ent, float *losses_out,
+                                       float *logp_out, float *entropy_out, float *logp_ratio_out, float *ratio_out,
+                                       float *d_logits, float *d_value, double *partials, void *stream);
 
 /* ---- rollout-side: sampling and episode statistics ----
  * Normal sample + log-prob of the sample in one pass — cusrl/nn/module/distribution.py:198-205 (`rsample`, then
@@ -184,6 +204,12 @@ int cusrl_policy_stats(const float *old_mean, const float *old_std, const float 
                        const float *action, const float *old_logp, const float *advantage, int64_t B, int64_t A,
                        int64_t D, double *partials, float *out, void *stream);
 int64_t cusrl_policy_stats_num_partials(int64_t B);
+/* The same hook for one-hot categorical policies (cusrl/nn/module/distribution.py:332-366; torch's
+ * _kl_categorical_categorical): out[0] = mean_b KL(softmax(old_logits) || softmax(new_logits)),
+ * out[1] = mean of advantage * exp(log_softmax(new_logits)[taken] - old_logp), out[2] = 0 (no action std). */
+int cusrl_categorical_policy_stats(const float *old_logits, const float *new_logits, const float *action,
+                                   const float *old_logp, const float *advantage, int64_t B, int64_t A, int64_t D,
+                                   double *partials, float *out, void *stream);
 
 /* ---- MLP backward epilogues (callers of the path: torch.nn.Linear / ReLU backward of the actor-critic) ----
  * Bias gradient = column sums of grad [rows, H]; with `output` != NULL the ReLU backward mask is applied first

@@ -186,6 +186,50 @@ def gather_rows(storage: np.ndarray, indices, temporal: bool = False) -> np.ndar
     return out
 
 
+def window_slots(start, env, sequence_len: int, capacity: int, parallelism: int, cursor: int | None) -> np.ndarray:
+    """cusrl/sampler/random_sampler.py:101-113 restated: physical flat slots ``[sequence_len, B]`` of windows that start at
+    logical step ``start[b]`` in env ``env[b]``; ``cursor`` = oldest row of a full ring (None while it is filling)."""
+    start, env = np.asarray(start, np.int64), np.asarray(env, np.int64)
+    time = start[None, :] + np.arange(sequence_len, dtype=np.int64)[:, None]
+    if cursor is not None:
+        time = (cursor + time) % capacity
+    return time * parallelism + env[None, :]
+
+
+def sequence_lengths(done: np.ndarray) -> np.ndarray:
+    """cusrl/nn/utils/recurrent.py:63-92 restated: lengths of the done-split sequences, env-major order."""
+    close = np.array(done).reshape(done.shape[0], -1).astype(bool)
+    close[-1] = True  # the last step always closes a sequence
+    ends = np.nonzero(close.T.reshape(-1))[0]
+    return np.diff(np.concatenate(([-1], ends))).astype(np.int64)
+
+
+def sequence_layout(done: np.ndarray) -> tuple[np.ndarray, int]:
+    """Where ``split_and_pad_sequences`` (recurrent.py:215-252) puts every slot: ``dest[t * N + n] = pos * Ns + seq`` with
+    ``seq`` the env-major index of the slot's sequence and ``pos`` its step inside that sequence; also returns ``Ns``."""
+    close = np.array(done).reshape(done.shape[0], -1).astype(bool)
+    L, N = close.shape
+    close[-1] = True
+    counts = close.sum(axis=0)
+    first = np.concatenate(([0], np.cumsum(counts)[:-1]))
+    before = np.cumsum(close, axis=0) - close                     # sequences of this env closed before step t
+    restart = np.where(close, np.arange(1, L + 1)[:, None], 0)    # a close at t makes t + 1 the next sequence's start
+    start = np.maximum.accumulate(np.vstack((np.zeros((1, N), np.int64), restart[:-1])), axis=0)
+    pos = np.arange(L)[:, None] - start
+    num_sequences = int(counts.sum())
+    return ((pos * num_sequences) + first[None, :] + before).reshape(-1).astype(np.int64), num_sequences
+
+
+def gather_memory(memory: np.ndarray, done: np.ndarray) -> np.ndarray:
+    """cusrl/nn/utils/recurrent.py:124-157 restated: the state of the sequence still open at the end of each env's
+    column (sequences are numbered env-major, a done before the last step opens a new one), cleared where done[-1]."""
+    done = np.asarray(done).reshape(done.shape[0], -1).astype(bool)
+    last = np.cumsum(done[:-1].sum(axis=0)) + np.arange(done.shape[1])
+    out = np.array(memory[last], copy=True)
+    out[done[-1]] = 0
+    return out
+
+
 class Mt19937:
     """torch's CPU generator stream as consumed by ``torch.randperm`` (see the C source)."""
 
@@ -252,3 +296,49 @@ def ppo_loss(advantage, old_logp, action, mean, std, ret, curr_value, old_value=
         _p(out["d_mean"], c_f), _p(out["d_std"], c_f), _p(out["d_value"], c_f),
     )
     return out
+
+
+def categorical_ppo_loss(advantage, old_logp, action, logits, ret, curr_value, old_value=None, *, clip=0.2,
+                         value_clip=None, w_sur=1.0, w_val=0.5, w_ent=0.01):
+    """The objective of :func:`ppo_loss` for a one-hot categorical policy, restated in numpy (float64 arithmetic, results
+    rounded to float32): cusrl/nn/module/distribution.py:332-366 (``OneHotCategorical``: log-prob of the first arg-max
+    of the one-hot action under log-softmax(logits), entropy ``-sum p log p``), hook/on_policy/ppo.py:10-18,82-84,
+    hook/on_policy/value.py:85-89,121-137.  Returns losses[3], logp, entropy, ratio, d_logits, d_value."""
+    adv = np.asarray(advantage, np.float64).reshape(-1)
+    old_logp = np.asarray(old_logp, np.float64).reshape(-1)
+    z = np.asarray(logits, np.float64)
+    B, A = z.shape
+    ret, cv = np.asarray(ret, np.float64), np.asarray(curr_value, np.float64)
+    D = ret.shape[-1]
+    taken = np.asarray(action).argmax(-1)  # first maximum, like value.max(-1)[1]
+    log_p = z - (z.max(-1, keepdims=True) + np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1, keepdims=True)))
+    prob = np.exp(log_p)
+    logp = log_p[np.arange(B), taken]
+    entropy = -(prob * log_p).sum(-1)
+    ratio = np.exp(logp - old_logp)
+    lo, hi = np.float64(np.float32(1.0 - clip)), np.float64(np.float32(1.0 + clip))
+    s1, s2 = adv * ratio, adv * np.clip(ratio, lo, hi)
+    surrogate = -np.minimum(s1, s2).mean() * w_sur
+    inside = (ratio >= lo) & (ratio <= hi)
+    d_ratio = np.where(s1 < s2, adv, np.where(s1 > s2, np.where(inside, adv, 0.0), 0.5 * adv + np.where(inside, 0.5 * adv, 0.0)))
+    dlp = (-w_sur / B) * d_ratio * ratio
+    onehot = np.zeros_like(z)
+    onehot[np.arange(B), taken] = 1.0
+    d_logits = dlp[:, None] * (onehot - prob) - (-w_ent / B) * prob * (log_p + entropy[:, None])
+    e1 = cv - ret
+    if value_clip is None:
+        value_loss, g = (e1 * e1).mean() * w_val, 2.0 * e1
+    else:
+        ov = np.asarray(old_value, np.float64)
+        dv = cv - ov
+        e2 = (ov + np.clip(dv, -value_clip, value_clip)) - ret
+        l1, l2 = e1 * e1, e2 * e2
+        value_loss = np.maximum(l1, l2).mean() * w_val
+        g2 = np.where((dv >= -value_clip) & (dv <= value_clip), 2.0 * e2, 0.0)
+        g = np.where(l1 > l2, 2.0 * e1, np.where(l1 < l2, g2, e1 + 0.5 * g2))
+    d_value = (w_val / (B * D)) * g
+    entropy_loss = -entropy.mean() * w_ent
+    f = np.float32
+    return dict(losses=np.array([value_loss, surrogate, entropy_loss], f), logp=logp.astype(f)[:, None],
+                entropy=entropy.astype(f)[:, None], ratio=ratio.astype(f)[:, None], d_logits=d_logits.astype(f),
+                d_value=d_value.astype(f))

@@ -269,6 +269,62 @@ def make_losses(cusrl):
     print("losses.npz:", idx, "cases")
 
 
+def make_categorical_losses(cusrl):
+    """Rows a9-a12 for discrete action spaces (BASELINE config 1): ``OneHotCategoricalDist`` log-prob / entropy / KL
+    (nn/module/distribution.py:332-366) under the same surrogate / value / entropy losses, with gradients wrt logits."""
+    from cusrl.hook.on_policy.ppo import _ppo_surrogate_loss  # noqa: PLC0415
+    from cusrl.hook.on_policy.value import _clipped_value_loss  # noqa: PLC0415
+
+    out = dict(META)
+    gen = torch.Generator().manual_seed(2025)
+    idx = 0
+    dist = cusrl.OneHotCategoricalDist(4, 3)  # only its stateless compute_* methods are used
+    for B, A, D, clip, vclip, w in [
+        (64, 3, 1, 0.2, None, (1.0, 0.5, 0.0)),       # MountainCar-v0: 3 actions, 4 x 4 minibatches of 8 envs x 16 steps... x2
+        (257, 6, 1, 0.2, None, (1.0, 0.5, 0.01)),
+        (1000, 18, 2, 0.3, 0.5, (2.0, 0.25, 0.05)),
+        (1, 2, 1, 0.2, None, (1.0, 0.5, 0.01)),
+        (300, 40, 1, 0.1, 0.2, (1.0, 1.0, 0.02)),
+    ]:
+        w_sur, w_val, w_ent = w
+        logits = (2.0 * torch.randn(B, A, generator=gen)).requires_grad_()
+        old_logits = logits.detach() + 0.2 * torch.randn(B, A, generator=gen)
+        taken = torch.multinomial(torch.softmax(old_logits, -1), 1, generator=gen).squeeze(-1)
+        action = torch.nn.functional.one_hot(taken, A).float()
+        old_logp = dist.compute_logp({"logits": old_logits}, action)
+        advantage = torch.randn(B, 1, generator=gen)
+        ret = torch.randn(B, D, generator=gen)
+        old_value = ret + 0.3 * torch.randn(B, D, generator=gen)
+        curr_value = (old_value + 0.3 * torch.randn(B, D, generator=gen)).requires_grad_()
+        params = {"logits": logits}
+        logp = dist.compute_logp(params, action)
+        entropy = dist.compute_entropy(params)
+        kl = dist.compute_kl_div({"logits": old_logits}, params)
+        logp_ratio = logp - old_logp
+        ratio = logp_ratio.exp()
+        surrogate = _ppo_surrogate_loss(advantage, ratio, clip) * w_sur
+        if vclip is None:
+            value_loss = torch.nn.functional.mse_loss(ret, curr_value) * w_val
+        else:
+            value_loss = _clipped_value_loss(old_value, curr_value, ret, vclip) * w_val
+        entropy_loss = -entropy.mean() * w_ent
+        loss = sum({"value_loss": value_loss, "surrogate_loss": surrogate, "entropy_loss": entropy_loss}.values())
+        loss.backward()
+        p = f"c{idx}_"
+        for k, v in dict(
+            logits=logits, old_logits=old_logits, action=action, old_logp=old_logp, advantage=advantage, ret=ret,
+            old_value=old_value, curr_value=curr_value, logp=logp, entropy=entropy, kl=kl, logp_ratio=logp_ratio, ratio=ratio,
+            surrogate=surrogate, value_loss=value_loss, entropy_loss=entropy_loss, loss=loss, d_logits=logits.grad,
+            d_value=curr_value.grad,
+        ).items():
+            out[p + k] = np_(v)
+        out[p + "params"] = np.array([clip, -1.0 if vclip is None else vclip, w_sur, w_val, w_ent], dtype=np.float64)
+        idx += 1
+    out["num_cases"] = np.array(idx)
+    np.savez_compressed(HERE / "categorical_losses.npz", **out)
+    print("categorical_losses.npz:", idx, "cases")
+
+
 # -------------------------------------------------------------- merge mean/var
 def make_merge(cusrl):
     """Row a6: distributed.reduce_mean_var_ (distributed.py:175-183) with gather_stack replaced by given stacks."""
@@ -391,6 +447,93 @@ def make_update_trace(cusrl):
         out[p + "metric_vals"] = np.array(list(metrics.values()), dtype=np.float64)
         print(f"update trace {tag}: {len(trace['objectives'])} train steps, buffer leaves {list(buffer_in)}")
     np.savez_compressed(HERE / "update_trace.npz", **out)
+
+
+MOUNTAIN_CAR_KWARGS = dict(  # cusrl/zoo/gym/classic_control.py:65-80 (the `ppo` registration of MountainCar-v0)
+    num_steps_per_update=16, actor_hidden_dims=(64, 64), critic_hidden_dims=(64, 64), activation_fn="Tanh",
+    action_space_type="discrete", lr=3e-4, sampler_epochs=4, sampler_mini_batches=4, orthogonal_init=False,
+    normalize_observation=True, gae_gamma=0.99, gae_lamda=0.98, entropy_loss_weight=0.0, max_grad_norm=0.5,
+)
+
+
+def make_update_trace_config1(cusrl):
+    """BASELINE config 1 (MountainCar-v0 `ppo` preset, 8 vectorised envs): one rollout + one full ``agent.update()`` with
+    exactly the zoo's agent kwargs — discrete 3-way policy, Tanh (64, 64), observation normalisation, T = 16, 4 x 4
+    minibatches — on a random-tensor env of MountainCar's shapes (observation 2, 3 one-hot actions; gymnasium and with
+    it the car dynamics are absent from the image, and the update path never sees the dynamics anyway)."""
+    from cusrl.testing.environment import DummyTorchEnvironment  # noqa: PLC0415
+
+    cusrl.config.set_device("cpu")
+    out = dict(META)
+    torch.manual_seed(21)
+    env = DummyTorchEnvironment(num_instances=8, observation_dim=2, action_dim=3, reward_dim=1)
+    underlying = cusrl.preset.PpoAgentFactory(**MOUNTAIN_CAR_KWARGS).to_underlying()
+    trace = {"objectives": [], "indices": [], "grads_unclipped": [], "grads": [], "params_after": []}
+
+    class Capture(cusrl.Hook):
+        def __init__(self, where):
+            super().__init__()
+            self.where = where
+            self.name_(f"capture_{where}")
+
+        def pre_optim(self, optimizer):
+            flat = torch.cat([p.grad.reshape(-1) for g in optimizer.param_groups for p in g["params"]])
+            trace["grads_unclipped" if self.where == "pre" else "grads"].append(np_(flat))
+
+        def post_optim(self):
+            if self.where == "post":
+                trace["params_after"].append(np_(torch.cat([p.detach().reshape(-1) for _, p in self.agent.named_parameters()])))
+
+        def objective(self, metadata, batch):
+            if self.where == "post":
+                trace["indices"].append(np_(batch["flat_index"].squeeze(-1)))
+
+    underlying.register_hook(Capture("pre"), before="gradient_clipping")
+    underlying.register_hook(Capture("post"), after="gradient_clipping")
+    agent = underlying(env.spec)
+    state0 = {n: np_(p) for n, p in agent.named_parameters()}
+    orig_objective = agent.hook.objective
+
+    def wrapped(metadata, batch, _o=orig_objective):
+        res = _o(metadata, batch)
+        trace["objectives"].append(np.array([res["value_loss"].item(), res["surrogate_loss"].item(),
+                                             res["entropy_loss"].item()], dtype=np.float32))
+        return res
+
+    agent.hook.objective = wrapped
+    observation, state, _ = env.reset()
+    step = 0
+    while True:
+        action = agent.act(observation, state)
+        observation, state, reward, terminated, truncated, _ = env.step(action)
+        flat_index = (torch.arange(8) + step * 8).reshape(8, 1)
+        ready = agent.step(observation, reward, terminated, truncated, state, flat_index=flat_index)
+        step += 1
+        if ready:
+            break
+    buffer_in = {k: np_(v) for k, v in agent.buffer.storage.items()}
+    torch.manual_seed(99)
+    metrics = agent.update()
+    for k, v in state0.items():
+        out["param0/" + k] = v
+    out["param_names"] = np.array(list(state0.keys()))
+    for k, v in buffer_in.items():
+        out["buffer_in/" + k] = v
+    out["buffer_keys"] = np.array(list(buffer_in.keys()))
+    for k in ("next_value", "advantage", "return"):
+        out["buffer_out/" + k] = np_(agent.buffer.storage[k])
+    for k in ("objectives", "indices"):
+        out[k] = np.stack(trace[k])
+    kept = [0, 5, len(trace["grads"]) - 1]  # the wide per-step vectors: first, one in the middle, last train step
+    out["kept_steps"] = np.array(kept)
+    for k in ("grads_unclipped", "grads", "params_after"):
+        out[k] = np.stack([trace[k][i] for i in kept])
+    out["metric_keys"] = np.array(list(metrics.keys()))
+    out["metric_vals"] = np.array(list(metrics.values()), dtype=np.float64)
+    rms = agent.hook["observation_normalization"].observation_rms
+    out["rms_mean"], out["rms_var"], out["rms_count"] = np_(rms.mean), np_(rms.var), np.array(rms.count)
+    np.savez_compressed(HERE / "update_trace_config1.npz", **out)
+    print(f"update trace config 1: {len(trace['objectives'])} train steps, buffer leaves {list(buffer_in)}")
 
 
 # ------------------------------------------------------------------------------- observation normalisation
@@ -560,6 +703,45 @@ def make_recurrent_packed(cusrl):
     print("recurrent_packed.npz:", idx, "cases + RNN/GRU/LSTM packed forward")
 
 
+def make_random_sampler(cusrl):
+    """SURVEY.md §8f rank 4 (sampler part): ``RandomSampler`` / ``TemporalRandomSampler`` / ``AutoRandomSampler``
+    (sampler/random_sampler.py:18-138) on partially filled and wrapped ring buffers; the CPU generator stream
+    (``torch.randint``) is part of what is pinned."""
+    from cusrl.sampler.random_sampler import AutoRandomSampler, RandomSampler, TemporalRandomSampler  # noqa: PLC0415
+
+    out = dict(META)
+    idx = 0
+    for capacity, parallelism, pushes, memory in [(4, 1, 3, True), (4, 2, 6, True), (8, 5, 8, False), (6, 3, 15, True), (5, 7, 2, False)]:
+        buffer = cusrl.Buffer(capacity=capacity, parallelism=parallelism, device="cpu")
+        steps = []
+        for step in range(pushes):
+            base = torch.arange(parallelism, dtype=torch.float32).unsqueeze(-1) * 100.0 + step
+            data = {"observation": torch.cat([base, -base, base * 0.5], dim=-1), "flag": (base.long() % 3 == 0)}
+            if memory:
+                data["actor_memory"] = base + 1000.0
+            buffer.push(data)
+            steps.append(data)
+        p = f"c{idx}_"
+        out[p + "shape"] = np.array([capacity, parallelism, pushes, int(memory)])
+        for key in steps[0]:
+            out[p + "push/" + key] = np.stack([np_(s[key]) for s in steps])
+        cases = [("random", RandomSampler(num_batches=2, batch_size=11)),
+                 ("temporal_full", TemporalRandomSampler(num_batches=2, batch_size=4)),
+                 ("temporal_2", TemporalRandomSampler(num_batches=3, batch_size=5, sequence_len=2)),
+                 ("auto", AutoRandomSampler(num_batches=2, batch_size=6, sequence_len=3))]
+        for tag, sampler in cases:
+            torch.manual_seed(1000 + idx)
+            for j, (metadata, batch) in enumerate(sampler(buffer)):
+                q = f"{p}{tag}_{j}_"
+                out[q + "temporal"] = np.array(metadata["temporal"])
+                for key, value in batch.items():
+                    out[q + key] = np_(value)
+        idx += 1
+    out["num_cases"] = np.array(idx)
+    np.savez_compressed(HERE / "random_sampler.npz", **out)
+    print("random_sampler.npz:", idx, "buffers x 4 samplers")
+
+
 # ------------------------------------------------------------------------------------------------ RND / AMP
 def make_aux_rewards(cusrl):
     """RandomNetworkDistillation.pre_update / objective (hook/auxiliary/rnd.py:55-81) and
@@ -685,7 +867,7 @@ def make_lr_schedule(cusrl):
 
 
 MAKERS = ("gae", "next_value", "randperm", "losses", "merge", "update_trace", "obs_norm", "recurrent", "aux_rewards",
-          "lr_schedule", "recurrent_packed")
+          "lr_schedule", "recurrent_packed", "random_sampler", "categorical_losses", "update_trace_config1")
 
 
 def main():

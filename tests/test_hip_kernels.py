@@ -366,6 +366,54 @@ def test_ppo_loss_vs_reference_goldens(ops, golden):
         np.testing.assert_allclose(host(out["d_value"]), g[p + "d_value"], rtol=1e-5, atol=1e-7 * scale)
 
 
+def test_categorical_ppo_loss_vs_reference_goldens(ops, golden):
+    """cusrl_ppo_loss_categorical_fwd_bwd vs the reference's OneHotCategoricalDist + PPO hooks (losses, autograd grads)."""
+    g = golden("categorical_losses")
+    for i in cases(g):
+        p = f"c{i}_"
+        clip, vclip, w_sur, w_val, w_ent = g[p + "params"]
+        out = ops.ppo_loss_categorical_fwd_bwd(
+            dev(g[p + "advantage"]), dev(g[p + "old_logp"]), dev(g[p + "action"]), dev(g[p + "logits"]), dev(g[p + "ret"]),
+            dev(g[p + "curr_value"]), dev(g[p + "old_value"]), clip=clip, value_clip=None if vclip < 0 else vclip,
+            w_sur=w_sur, w_val=w_val, w_ent=w_ent)
+        B = g[p + "logits"].shape[0]
+        np.testing.assert_allclose(host(out["logp"]), g[p + "logp"], rtol=1e-5, atol=1e-6)      # 1e-5 rel fp32
+        np.testing.assert_allclose(host(out["entropy"]), g[p + "entropy"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(host(out["ratio"]), g[p + "ratio"], rtol=2e-5)
+        losses = host(out["losses"])
+        np.testing.assert_allclose(losses[0], g[p + "value_loss"], rtol=1e-5)
+        np.testing.assert_allclose(losses[1], g[p + "surrogate"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(losses[2], g[p + "entropy_loss"], rtol=1e-5, atol=1e-8)
+        assert losses[6] == np.float32(np.float32(losses[0] + losses[1]) + losses[2])
+        np.testing.assert_allclose(host(out["d_logits"]), g[p + "d_logits"], rtol=1e-4, atol=1e-6 / B)
+        np.testing.assert_allclose(host(out["d_value"]), g[p + "d_value"], rtol=1e-5, atol=1e-7 / B)
+
+
+@pytest.mark.parametrize("B,A,D", [(64, 3, 1), (24576, 3, 1), (70001, 18, 2), (5, 64, 1)])
+@pytest.mark.parametrize("vclip", [None, 0.2])
+def test_categorical_ppo_loss_vs_oracle(ops, B, A, D, vclip):
+    rng = np.random.default_rng(B * A)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    logits, adv, ret = 2.0 * f(B, A), f(B, 1), f(B, D)
+    taken = rng.integers(0, A, B)
+    action = np.eye(A, dtype=np.float32)[taken]
+    curr_value, old_value = ret + 0.3 * f(B, D), ret + 0.3 * f(B, D)
+    behaviour = oracle.categorical_ppo_loss(adv, np.zeros((B, 1), np.float32), action, logits + 0.05 * f(B, A), ret, curr_value)
+    old_logp = behaviour["logp"]
+    kw = dict(clip=0.2, value_clip=vclip, w_sur=1.0, w_val=0.5, w_ent=0.01)
+    out = ops.ppo_loss_categorical_fwd_bwd(*(dev(x) for x in (adv, old_logp, action, logits, ret, curr_value, old_value)), **kw)
+    ref = oracle.categorical_ppo_loss(adv, old_logp, action, logits, ret, curr_value, old_value, **kw)
+    losses = host(out["losses"])
+    np.testing.assert_allclose(losses[:3], ref["losses"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(losses[4], ref["entropy"].mean(dtype=np.float64), rtol=1e-5)
+    np.testing.assert_allclose(host(out["logp"]), ref["logp"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(out["entropy"]), ref["entropy"], rtol=1e-5, atol=1e-6)
+    ratio = ref["ratio"].ravel()
+    safe = (np.abs(ratio - 0.8) > 1e-4) & (np.abs(ratio - 1.2) > 1e-4)
+    np.testing.assert_allclose(host(out["d_logits"])[safe], ref["d_logits"][safe], rtol=1e-3, atol=1e-6 / B)
+    np.testing.assert_allclose(host(out["d_value"]), ref["d_value"], rtol=1e-4, atol=1e-7 / B)
+
+
 @pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 7, 1), (513, 32, 2), (3, 40, 1), (255, 4, 3),
                                    (70001, 12, 1)])  # last: > 256 blocks, staged reduction of the block partials
 @pytest.mark.parametrize("vclip", [None, 0.2])

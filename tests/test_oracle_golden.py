@@ -279,3 +279,45 @@ def test_policy_stats_matches_torch_distributions():
     iw = (torch.from_numpy(advantage) * (q.log_prob(torch.from_numpy(action)).sum(-1, keepdim=True) - old_logp).exp()).mean().item()
     got = oracle.policy_stats(mp, sp, mq, sq, action, old_logp.numpy(), advantage)
     np.testing.assert_allclose(got, (kl, iw, float(sq.mean())), rtol=2e-5)
+
+
+def test_gather_memory_restatement_vs_reference(golden):
+    """oracle.gather_memory (numpy restatement of nn/utils/recurrent.py:124-157) against the reference's outputs."""
+    g = golden("recurrent_packed")
+    for i in range(int(g["num_cases"])):
+        p = f"c{i}_"
+        assert np.array_equal(oracle.gather_memory(g[p + "scattered"], g[p + "done"]), g[p + "gathered"]), i
+
+
+def test_categorical_objective_restatement_vs_reference(golden):
+    """oracle.categorical_ppo_loss against losses and autograd gradients recorded from the reference's
+    OneHotCategoricalDist + PPO hooks (golden ``categorical_losses.npz``); 1e-5 relative fp32."""
+    g = golden("categorical_losses")
+    for i in range(int(g["num_cases"])):
+        p = f"c{i}_"
+        clip, vclip, w_sur, w_val, w_ent = g[p + "params"]
+        ref = oracle.categorical_ppo_loss(g[p + "advantage"], g[p + "old_logp"], g[p + "action"], g[p + "logits"], g[p + "ret"],
+                                          g[p + "curr_value"], g[p + "old_value"], clip=clip, value_clip=None if vclip < 0 else vclip,
+                                          w_sur=w_sur, w_val=w_val, w_ent=w_ent)
+        B = g[p + "logits"].shape[0]
+        np.testing.assert_allclose(ref["logp"], g[p + "logp"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ref["entropy"], g[p + "entropy"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ref["ratio"], g[p + "ratio"], rtol=2e-5)
+        np.testing.assert_allclose(ref["losses"], [g[p + "value_loss"], g[p + "surrogate"], g[p + "entropy_loss"]], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(ref["d_logits"], g[p + "d_logits"], rtol=1e-4, atol=2e-7 / B)
+        np.testing.assert_allclose(ref["d_value"], g[p + "d_value"], rtol=1e-5, atol=1e-7 / B)
+
+
+def test_sequence_layout_restatement_vs_reference(golden):
+    """oracle.sequence_lengths / sequence_layout against the reference's split_and_pad_sequences outputs."""
+    g = golden("recurrent")
+    for i in range(int(g["num_cases"])):
+        p = f"c{i}_"
+        x, done, padded, mask = g[p + "x"], g[p + "done"], g[p + "padded"], g[p + "mask"]
+        assert np.array_equal(oracle.sequence_lengths(done), g[p + "sequence_lengths"])
+        dest, num_sequences = oracle.sequence_layout(done)
+        assert num_sequences == padded.shape[1]
+        assert np.array_equal(padded.reshape(-1, x.shape[-1])[dest], x.reshape(-1, x.shape[-1]))
+        valid = np.zeros(mask.size, bool)
+        valid[dest] = True
+        assert np.array_equal(valid.reshape(mask.shape), mask)
