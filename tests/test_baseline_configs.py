@@ -116,16 +116,24 @@ def test_config1_mountain_car_update_replays_the_reference(cusrl, golden, mode):
     torch.manual_seed(99)
     with Launches() as launched:
         metrics = agent.update()
-    assert np.array_equal(host(torch.stack(trace["indices"])), g["indices"]), "minibatch permutations differ"
+    # which reference train steps the Python-side trace holds: all 16 when eager; under compile=True only epoch 0 (eager
+    # warm-up) and epoch 1 (capture) execute Python, and the tensors taken during the capture live in the graph's pool, so
+    # after the replays of epochs 2-3 they show the LAST epoch's values — i.e. reference steps 0-3 and 12-15
+    steps = list(range(16)) if mode != "hipgraph" else [0, 1, 2, 3, 12, 13, 14, 15]
+    assert len(trace["indices"]) == len(steps)
+    assert np.array_equal(host(torch.stack(trace["indices"])), g["indices"][steps]), "minibatch permutations differ"
     for key in ("next_value", "advantage", "return"):
         np.testing.assert_allclose(host(agent.buffer[key]), g[f"buffer_out/{key}"], rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(host(torch.stack(trace["objectives"])), g["objectives"], rtol=2e-5, atol=1e-6)
-    kept = [int(i) for i in g["kept_steps"]]
-    pick = lambda name: host(torch.stack([trace[name][i] for i in kept]))  # noqa: E731
-    np.testing.assert_allclose(pick("grads_unclipped"), g["grads_unclipped"], rtol=1e-3, atol=2e-6)
-    clipped = g["grads_unclipped" if agent.flat_optimizer is not None else "grads"]
+    np.testing.assert_allclose(host(torch.stack(trace["objectives"])), g["objectives"][steps], rtol=2e-5, atol=1e-6)
+    kept = [(row, steps.index(int(step))) for row, step in enumerate(g["kept_steps"]) if int(step) in steps]
+    rows = [row for row, _ in kept]
+    pick = lambda name: host(torch.stack([trace[name][i] for _, i in kept]))  # noqa: E731
+    np.testing.assert_allclose(pick("grads_unclipped"), g["grads_unclipped"][rows], rtol=1e-3, atol=2e-6)
+    clipped = g["grads_unclipped" if agent.flat_optimizer is not None else "grads"][rows]
     np.testing.assert_allclose(pick("grads"), clipped, rtol=1e-3, atol=2e-6)
-    np.testing.assert_allclose(pick("params_after"), g["params_after"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(pick("params_after"), g["params_after"][rows], rtol=1e-4, atol=2e-6)
+    final = torch.cat([p.detach().reshape(-1) for _, p in agent.named_parameters()])
+    np.testing.assert_allclose(host(final), g["params_after"][-1], rtol=1e-4, atol=2e-6)  # end state of all 16 steps
     ref = dict(zip((str(k) for k in g["metric_keys"]), g["metric_vals"]))
     for key in ("Agent/value_loss", "Agent/surrogate_loss", "Agent/entropy_loss", "Agent/entropy", "Agent/value",
                 "Agent/grad_norm/default", "Agent/ratio", "Agent/kl_divergence", "Agent/importance_weighted_advantage"):
