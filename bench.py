@@ -8,9 +8,14 @@ on the GPU; weights are random-init.  Multi-GPU (launched by torchrun, one rank 
 per rank (weak scaling), gradients and advantage statistics are all-reduced over RCCL/xGMI.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     — dominant hot-path kernel (minibatch gather): algorithmic bytes / HIP-event time vs 8 TB/s HBM
-  kernels      — same accounting for every HIP kernel of the path (separate short instrumented pass)
-  cpu_baseline — oracle/torch_ppo.py (reference-equivalent torch CPU path) timed on this box's host cores
+  roofline       — dominant hot-path kernel = the minibatch gather that replays inside every captured train step (20 per
+                   iteration): algorithmic bytes of exactly that launch / its graph-timed duration vs 8 TB/s HBM
+  roofline_scale — GAE, the PPO objective (std-vector form the preset runs) and the gather at 1 048 576 envs, where a
+                   bandwidth roofline can physically be approached (config 2 moves 1-13 MB per launch out of L2 / MALL)
+  kernels        — the same accounting for every HIP kernel of the path at this workload's sizes
+  cpu_baseline   — oracle/torch_ppo.py (reference-equivalent torch CPU path) timed on this box's host cores
+
+`python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run, one process per GPU).
 """
 
 from __future__ import annotations
@@ -39,10 +44,12 @@ def parse_args():
     parser.add_argument("--envs-per-gpu", type=int, default=NUM_ENVS)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-kernel-pass", action="store_true")
+    parser.add_argument("--no-scale-pass", action="store_true", help="skip the 1 048 576-env roofline-scale kernel pass")
+    parser.add_argument("--native-collectives", action="store_true",
+                        help="collectives through the C ABI (cusrl_allreduce_mean ...): all-reduce captured inside the step graph")
     parser.add_argument("--cpu-seconds", type=float, default=15.0)
     parser.add_argument("--eager", action="store_true", help="disable hipGraph replay (compile=False)")
     parser.add_argument("--no-timer", action="store_true", help="replace the trainer's section timer by a no-op (diagnostic)")
-    parser.add_argument("--no-observer", action="store_true", help="do not bracket eager launches with HIP events")
     parser.add_argument("--autoreset", action="store_true",
                         help="env resets finished instances itself (no per-step index read-back in the trainer)")
     parser.add_argument("--no-pin", action="store_true",
@@ -50,51 +57,71 @@ def parse_args():
     return parser.parse_args()
 
 
-KERNEL_NAMES = {
-    "cusrl_gather_rows": "cusrl::gather_kernel",
-    "cusrl_buffer_push": "cusrl::push_kernel",
-    "cusrl_gae": "cusrl::gae_kernel",
-    "cusrl_next_value": "cusrl::next_value_kernel",
-    "cusrl_normalize": "cusrl::normalize_kernel",
-    "cusrl_ppo_loss_fwd_bwd": "cusrl::ppo_loss_chunked_kernel<3> (+ finalize)",
-    "cusrl_normal_sample_logp": "cusrl::normal_sample_logp_kernel",
-    "cusrl_episode_stats": "cusrl::episode_stats_kernel",
-}
-
-
-def summarize(observer):
-    """Per C-ABI entry: launches, average HIP-event time, algorithmic bytes and achieved GB/s."""
-    torch.cuda.synchronize()
-    out = {}
-    for name, records in observer.records.items():
-        if not records:
-            continue
-        # one entry point may be launched at several sizes (gather: the whole-buffer statistics pass and the few
-        # truncated rows of the value bootstrap): report the launches of the largest size, not a mixture
-        largest = max(b for _, _, b in records)
-        records = [r for r in records if r[2] == largest]
-        total_ms = sum(s.elapsed_time(e) for s, e, _ in records)
-        total_bytes = sum(b for _, _, b in records)
-        gbs = total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
-        out[name] = {
-            "kernel": KERNEL_NAMES.get(name, name),
-            "launches": len(records),
-            "avg_us": round(total_ms * 1e3 / len(records), 3),
-            "bytes_per_launch": int(total_bytes / len(records)),
-            "achieved_GBps": round(gbs, 1),
-            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
-        }
-    return out
-
-
 def pmc_traffic(envs_per_gpu):
-    """HBM bytes of the timed launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
-    passes, FETCH_SIZE doubled per the gfx950 correction — profiles/r01/pmc_summary.json, scripts/gpu_pmc.sh).
-    Counters cannot be read from inside this process, so the committed measurement of the same launch is quoted."""
-    path = ROOT / "profiles" / "r01" / "pmc_summary.json"
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
+    passes, scripts/gpu_pmc.sh).  Hardware counters cannot be read from inside this process, so the committed
+    measurement is QUOTED — and only while the kernel source it was taken from is the one in this tree (sha256 of
+    cusrl_amd/csrc/buffer.hip recorded next to the numbers); otherwise null."""
+    import hashlib
+
+    path = ROOT / "profiles" / "r02" / "pmc_summary.json"
     if envs_per_gpu != NUM_ENVS or not path.exists():
-        return None
-    return json.loads(path.read_text())["gather_whole_buffer"]["hbm_traffic_bytes_corrected"]
+        return None, None
+    summary = json.loads(path.read_text())
+    source = hashlib.sha256((ROOT / "cusrl_amd" / "csrc" / "buffer.hip").read_bytes()).hexdigest()[:16]
+    entry = summary.get("gather_minibatch_hot_leaves")
+    if not entry or summary.get("buffer_hip_sha256_16") != source:
+        return None, None
+    return entry["hbm_traffic_bytes"], f"quoted: rocprofv3 PMC passes of this kernel source ({summary.get('commit', '?')}), profiles/r02/pmc_summary.json"
+
+
+def graph_time(fn, launches=10, replays=20):
+    """Average device time of ``fn`` (one launch) from a hipGraph of `launches` back-to-back calls replayed `replays`
+    times between ONE HIP-event pair on the stream the graph runs on — the kernel's duration as it is inside the
+    captured train step, without host launch overhead or per-launch event bubbles."""
+    stream, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        fn()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=stream):
+        for _ in range(launches):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        start.record()
+        for _ in range(replays):
+            graph.replay()
+        end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) * 1e3 / (launches * replays)  # us
+
+
+def dominant_kernel(agent):
+    """The minibatch gather exactly as the captured train step issues it: same buffer, same leaves (the fields the
+    step's hooks read, LazyBatch), same packed record, a real permutation slice as indices."""
+    from cusrl_amd import ops
+
+    buffer = agent.buffer
+    steps = list(getattr(agent, "_graphed_steps", {}).values())
+    hot = sorted(steps[0].hot_fields & set(buffer.schema)) if steps else sorted(buffer.schema)
+    batch = buffer.capacity * buffer.parallelism // max(len(steps), 1) if steps else buffer.capacity * buffer.parallelism // 4
+    indices = torch.randperm(buffer.capacity * buffer.parallelism, device=buffer.device)[:batch].contiguous()
+    buffer.prepare_sampling()
+    leaves = [key for name in hot for _, key in cusrl_iterate(buffer.schema[name])]
+    row_bytes = sum(ops._row_bytes(buffer.storage[key], 2) for key in leaves)
+    packed = [key for key in leaves if buffer._pack is not None and key in buffer._pack.offsets]
+    us = graph_time(lambda: buffer.gather(indices, fields=hot))
+    nbytes = batch * (2 * row_bytes + 8)
+    return {"fields": hot, "leaves": len(leaves), "packed_leaves": len(packed), "rows": batch, "row_bytes": row_bytes,
+            "bytes_per_launch": nbytes, "avg_us": round(us, 3), "achieved_GBps": round(nbytes / us / 1e3, 1)}
+
+
+def cusrl_iterate(schema):
+    from cusrl_amd.utils.nest import iterate_nested
+
+    return iterate_nested(schema)
 
 
 def run_gpu(args, rank, world):
@@ -110,6 +137,7 @@ def run_gpu(args, rank, world):
 
         pinned = pin_host_thread(local_rank, cores=8, slot=local_rank)
     cusrl.config.set_device(device)
+    cusrl.config.native_collectives = bool(args.native_collectives)
     if world > 1:
         cusrl.utils.configure_distributed()
     cusrl.set_global_seed(42)
@@ -148,12 +176,7 @@ def run_gpu(args, rank, world):
         observation, state = trainer._rollout_and_update(observation, state)
         trainer.iteration += 1
 
-    # ---- timed region: exactly `steps` iterations.  The dominant kernel (minibatch gather) is bracketed by HIP
-    # events live: 20 of its 21 launches per iteration replay inside hipGraphs (not observable from the host); the
-    # 21st — the statistics pass over the whole buffer, same kernel, 2x the rows — is launched eagerly and timed.
-    observer = ops.LaunchObserver(only={"cusrl_gather_rows"})
-    if not args.no_observer:
-        ops.set_launch_observer(observer)
+    # ---- timed region: exactly `steps` iterations, bracketed by barrier + synchronize on both sides
     update_events.clear()
     barrier()
     t0 = time.perf_counter()
@@ -162,10 +185,10 @@ def run_gpu(args, rank, world):
         trainer.iteration += 1
     barrier()
     elapsed = time.perf_counter() - t0
-    ops.set_launch_observer(None)
-    live = summarize(observer)
-    dominant = live.get("cusrl_gather_rows", {"achieved_GBps": 0.0, "bytes_per_launch": 0, "avg_us": 0.0, "launches": 0})
     update_ms = sum(s.elapsed_time(e) for s, e in update_events) / max(len(update_events), 1)
+    # the dominant kernel replays inside hipGraphs (20 launches per iteration) where it cannot be bracketed from the
+    # host: time the identical launch stand-alone from a graph right after the timed region
+    dominant = dominant_kernel(agent) if rank == 0 else None
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -184,7 +207,28 @@ def run_gpu(args, rank, world):
             kernels[name] = {"avg_us": round(us, 2), "bytes_per_launch": int(nbytes),
                              "achieved_GBps": round(nbytes / us / 1e3, 1), "frac_of_hbm_peak": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
 
+    scale = {}
+    if not args.no_scale_pass and rank == 0 and world == 1:
+        # the north-star bar "GAE + loss kernels >= 40 % of the HBM roofline" needs sizes where a launch outlives its
+        # latency: the same kernels at 1 048 576 envs (24 M slots), graph-timed by scripts/kernel_bench.py
+        sys.path.insert(0, str(ROOT / "scripts"))
+        import kernel_bench
+
+        wanted = {"gae + return + stats": "gae", "ppo loss fwd+bwd, std vector": "ppo_loss_std_vector",
+                  "ppo loss fwd+bwd (": "ppo_loss_std_matrix", "gather hot leaves via record": "gather_hot_leaves"}
+        for name, (us, nbytes) in kernel_bench.bench_size(1 << 20, only=("gae + return", "ppo loss", "gather hot"), iters=10).items():
+            for prefix, key in wanted.items():
+                if name.startswith(prefix):
+                    scale[key] = {"avg_us": round(us, 1), "bytes_per_launch": int(nbytes),
+                                  "achieved_GBps": round(nbytes / us / 1e3, 1),
+                                  "frac_of_hbm_peak": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+        torch.cuda.empty_cache()
+
     steps_per_iteration = args.envs_per_gpu * HORIZON * world
+    traffic, traffic_source = pmc_traffic(args.envs_per_gpu)
+    dominant = dominant or {"achieved_GBps": 0.0, "bytes_per_launch": 0, "avg_us": 0.0, "rows": 0, "fields": [], "leaves": 0,
+                            "packed_leaves": 0, "row_bytes": 0}
+    backend = torch.distributed.get_backend() if world > 1 else None
     result = {
         "metric": "env_steps_per_sec",
         "value": round(steps_per_iteration * args.steps / elapsed, 1),
@@ -204,6 +248,10 @@ def run_gpu(args, rank, world):
             "envs_per_gpu": args.envs_per_gpu,
             "env_steps_per_iteration": steps_per_iteration,
             "parallelism": f"dp{world}",
+            "backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend,
+            "rccl_ranks": world if backend == "nccl" else 0,
+            "collectives": ("c-abi (cusrl_allreduce_mean captured in the step graph)" if args.native_collectives and world > 1
+                            else "torch.distributed (eager all-reduce between two graphs per step)" if world > 1 else "none"),
             "hipgraph": not args.eager,
             "autoreset": args.autoreset,
             "host_thread_cpus": pinned,
@@ -211,17 +259,26 @@ def run_gpu(args, rank, world):
         "ppo_update_ms": round(update_ms, 3),
         "roofline": {
             "bound": "hbm",
-            "kernel": "cusrl::gather_kernel (all 14 buffer leaves in one launch; timed: the eager whole-buffer launch "
-                      "of the statistics pass, 98304 rows; the 20 in-graph minibatch launches move 24576 rows each)",
+            "kernel": f"cusrl::gather_kernel — the minibatch gather of a captured train step (20 launches per iteration): "
+                      f"{dominant['rows']} sampled slots x {dominant['leaves']} leaves the step reads ({', '.join(dominant['fields'])}; "
+                      f"{dominant['packed_leaves']} narrow ones through the packed per-slot record), {dominant['row_bytes']} B/slot "
+                      "read + written + 8 B index",
+            "timing": "graph-timed: hipGraph of 10 identical launches x 20 replays between one HIP-event pair, right after "
+                      "the timed region, on the graph's stream (the in-step launch cannot be bracketed from the host); "
+                      "rocprofv3 per-grid averages of the same command: profiles/r02/",
             "achieved": dominant["achieved_GBps"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(dominant["achieved_GBps"] / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(args.envs_per_gpu),
+            "traffic": traffic,
+            "traffic_source": traffic_source,
             "bytes_per_launch": dominant["bytes_per_launch"],
             "avg_us": dominant["avg_us"],
-            "launches": dominant["launches"],
+            "launches_per_iteration": 20,
+            "note": "GAE stages its (reward, value, next_value, done) tuple in registers, not LDS: every element is used "
+                    "once by the lane that loaded it (DESIGN.md section 3)",
         },
+        "roofline_scale": {"envs": 1 << 20, "timing": "graph-timed (scripts/kernel_bench.py)", **scale},
         "kernels": kernels,
     }
     trainer.environment.close()

@@ -1,21 +1,21 @@
 #!/bin/bash
-# HBM traffic of one kernel from PMC counters, as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE and WRITE_SIZE in
-# SEPARATE rocprofv3 passes (TCC slot limit), --kernel-trace only.  Usage: scripts/gpu_pmc.sh <tag> <kernel substring> [kernel_bench args]
+# HBM traffic of the gather / pack launches from PMC counters, as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE and
+# WRITE_SIZE in SEPARATE rocprofv3 passes (TCC slot limit), --kernel-trace only.  Usage: scripts/gpu_pmc.sh [tag]
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=$1; KERNEL=$2; shift 2
+TAG=${1:-pmc}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p "$R/gpurun_out/$TAG"
 for C in FETCH_SIZE WRITE_SIZE; do
   OUT=/tmp/pmc_${TAG}_$C; rm -rf "$OUT"
-  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT" -o pmc -- \
-      python "$R/scripts/kernel_bench.py" "$@" > /tmp/pmc_${TAG}_$C.log 2>&1 < /dev/null
+  timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT" -o pmc -- \
+      python "$R/scripts/pmc_cases.py" "$R/gpurun_out/$TAG" > /tmp/pmc_${TAG}_$C.log 2>&1 < /dev/null
   echo "$C pass rc=$?"
   F=$(find "$OUT" -name "*counter_collection.csv" < /dev/null | head -1)
   if [ -n "$F" ]; then
     head -1 "$F" > "$R/gpurun_out/$TAG/${C}_counters.csv"
-    grep "$KERNEL" "$F" | head -400 >> "$R/gpurun_out/$TAG/${C}_counters.csv"
+    grep -E "cusrl::(gather_kernel|push_kernel|pack_rows_kernel)" "$F" >> "$R/gpurun_out/$TAG/${C}_counters.csv"
     wc -l "$R/gpurun_out/$TAG/${C}_counters.csv"
   else echo "no counter csv"; find "$OUT" -type f < /dev/null | head; tail -5 /tmp/pmc_${TAG}_$C.log; fi
 done
-head -3 "$R/gpurun_out/$TAG/FETCH_SIZE_counters.csv" | cut -c1-400
+python "$R/scripts/pmc_summarize.py" "$R/gpurun_out/$TAG" "$R/gpurun_out/$TAG/pmc_summary.json" | tail -60

@@ -8,7 +8,7 @@ OUT=/tmp/prof_$TAG
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$OUT"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o bench -- \
-    python "$R/bench.py" --no-cpu-baseline --no-kernel-pass "$@" > /tmp/prof_$TAG.log 2>&1 < /dev/null
+    python "$R/bench.py" --no-cpu-baseline --no-kernel-pass --no-scale-pass "$@" > /tmp/prof_$TAG.log 2>&1 < /dev/null
 echo "rocprofv3 rc=$?"
 grep "^{" /tmp/prof_$TAG.log | cut -c1-400
 mkdir -p "$R/gpurun_out/$TAG"

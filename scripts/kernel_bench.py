@@ -68,7 +68,8 @@ class _Rows(dict):
         self.only, self.iters = only, iters
 
     def measure(self, name, fn, nbytes):
-        if self.only is None or self.only in name:
+        only = (self.only,) if isinstance(self.only, str) else self.only
+        if only is None or any(tag in name for tag in only):
             self[name] = (timeit(fn, self.iters), nbytes)
 
 

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 PMC passes of scripts/pmc_cases.py into profiles/r02/pmc_summary.json.
+
+    python scripts/pmc_summarize.py <dir with cases.json, FETCH_SIZE_counters.csv, WRITE_SIZE_counters.csv> <out.json>
+
+Rows are matched to cases by kernel name + grid size.  FETCH_SIZE / WRITE_SIZE come in KB (rocprofv3 derived metrics);
+the gfx950 correction of the read counter is CALIBRATED here instead of assumed: ``stream_16B`` moves a known 1 GiB each
+way, the three ``random_rows_*`` cases read a known number of distinct rows far beyond the caches.
+"""
+import csv
+import hashlib
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def per_launch(path, cases):
+    sums = {name: [] for name in cases}
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            kernel, grid = row["Kernel_Name"], int(row["Grid_Size"])
+            for name, case in cases.items():
+                if case["kernel"] in kernel and grid == case["grid_threads"]:
+                    sums[name].append(float(row["Counter_Value"]))
+    return {name: (sum(v) / len(v) if v else None) for name, v in sums.items()}, {name: len(v) for name, v in sums.items()}
+
+
+def main(directory, out_path):
+    directory = Path(directory)
+    cases = json.loads((directory / "cases.json").read_text())
+    fetch_kb, fetch_n = per_launch(directory / "FETCH_SIZE_counters.csv", cases)
+    write_kb, write_n = per_launch(directory / "WRITE_SIZE_counters.csv", cases)
+    out = {"unit": "bytes per launch", "counter_unit": "KB (x1024)", "cases": {}}
+    stream = fetch_kb.get("stream_16B")
+    factor_stream = (1 << 30) / (stream * 1024) if stream else None
+    for name, case in cases.items():
+        fetch = None if fetch_kb[name] is None else fetch_kb[name] * 1024
+        write = None if write_kb[name] is None else write_kb[name] * 1024
+        out["cases"][name] = {"algorithmic_bytes": case["algorithmic_bytes"], "fetch_raw": fetch, "write_raw": write,
+                              "rows_matched": [fetch_n[name], write_n[name]]}
+    calibration = {"stream_16B_read_factor": factor_stream}
+    for name, rows, row_bytes in (("random_rows_4B", 1 << 23, 4), ("random_rows_32B", 1 << 23, 32), ("random_rows_192B", 1 << 21, 192)):
+        raw = out["cases"][name]["fetch_raw"]
+        if raw:
+            index_bytes = rows * 8  # the int64 index vector is a streaming read counted at the streaming factor
+            row_raw = raw - index_bytes / (factor_stream or 2.0)
+            calibration[name] = {"raw_fetch_bytes_per_row": row_raw / rows, "row_bytes": row_bytes}
+    out["calibration"] = calibration
+    # the read counter tallies each memory-side request at 64 B: a streaming 128-byte request counts half (factor 2);
+    # a random row shorter than a request is ONE request (raw ~64 B per 4- or 32-byte row), so for the row part of a
+    # gather raw x 2 is an UPPER bound (request = 128 B) and raw x 1 a LOWER bound (request = 64 B)
+    for name in ("gather_minibatch_hot_leaves", "gather_minibatch_all_leaves", "gather_minibatch_all_plain", "pack_rows"):
+        entry = out["cases"].get(name)
+        if entry and entry["fetch_raw"] is not None and entry["write_raw"] is not None:
+            lo, hi = entry["fetch_raw"] + entry["write_raw"], 2 * entry["fetch_raw"] + entry["write_raw"]
+            entry["hbm_traffic_bytes_bracket"] = [lo, hi]
+            entry["hbm_traffic_bytes"] = hi
+            entry["traffic_over_algorithmic_bracket"] = [round(lo / entry["algorithmic_bytes"], 3), round(hi / entry["algorithmic_bytes"], 3)]
+            out[name] = entry
+    out["buffer_hip_sha256_16"] = hashlib.sha256((ROOT / "cusrl_amd" / "csrc" / "buffer.hip").read_bytes()).hexdigest()[:16]
+    try:
+        out["commit"] = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "worktree"
+    except OSError:
+        out["commit"] = "worktree"
+    Path(out_path).write_text(json.dumps(out, indent=1))
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
