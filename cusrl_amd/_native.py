@@ -55,6 +55,7 @@ _SIGNATURES = {
     "cusrl_col_stats_num_partials": (c_int64, [c_int64, c_int64]),
     "cusrl_stats_finalize": (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P]),
     "cusrl_normalize": (c_int, [_P, _P, _P, c_float, c_int64, c_int64, _P]),
+    "cusrl_normalize_from_partials": (c_int, [_P, _P, c_int64, c_int64, c_float, c_int64, c_int64, _P, _P, _P]),
     "cusrl_merge_mean_var": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
     "cusrl_gather_rows": (c_int, [POINTER(Field), c_int, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_pack_rows": (c_int, [POINTER(PackedField), c_int, _P, c_int64, c_int64, _P]),
@@ -69,7 +70,7 @@ _SIGNATURES = {
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
     "cusrl_ppo_loss_std_partial_rows": (c_int64, [c_int64]),
     "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
-    "cusrl_episode_stats": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, _P]),
+    "cusrl_episode_stats": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_policy_stats": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P, _P, _P]),
     "cusrl_policy_stats_num_partials": (c_int64, [c_int64]),
     "cusrl_categorical_policy_stats": (c_int, [_P] * 5 + [c_int64, c_int64, c_int64, _P, _P, _P]),

@@ -103,15 +103,17 @@ __device__ __forceinline__ typename Vec<VEC>::type pack(const float (&in)[VEC]) 
     }
 }
 
-template <int VEC, int TC, bool kTwoLambdas>
-__global__ __launch_bounds__(kBlock) void gae_kernel(const float *__restrict__ reward, const float *__restrict__ value,
+// BLK = threads per block: 256 at scale; 64 (one wave) for small rollouts, where the launch is pure latency and spreading
+// the few columns over 4x more CUs — with the whole horizon requested in ONE load round (TC >= T) — is what counts.
+template <int VEC, int TC, bool kTwoLambdas, int BLK = kBlock>
+__global__ __launch_bounds__(BLK) void gae_kernel(const float *__restrict__ reward, const float *__restrict__ value,
                                                      const float *__restrict__ next_value,
                                                      const uint8_t *__restrict__ done, float *__restrict__ advantage,
                                                      float *__restrict__ ret, double *__restrict__ partials, int T,
                                                      int64_t N, int D, float gamma, float c_adv, float c_val) {
     using V = typename Vec<VEC>::type;
     const int64_t C = N * D;
-    const int64_t col = (int64_t(blockIdx.x) * kBlock + threadIdx.x) * VEC;
+    const int64_t col = (int64_t(blockIdx.x) * BLK + threadIdx.x) * VEC;
     const bool active = col < C;
     // VEC == 4 is only launched with D == 1 (done index == column); otherwise the flag of column j is env j / D.
     const int64_t env = (VEC == 4 || D == 1) ? col : col / D;
@@ -179,14 +181,18 @@ __global__ __launch_bounds__(kBlock) void gae_kernel(const float *__restrict__ r
 
     if (partials) {
         // per-block {sum, sumsq} per value channel, written to partials[blockIdx][d][2]
-        __shared__ double red[kBlock][2];
+        __shared__ double red[BLK][2];
         if (D == 1) {
-            __shared__ double scratch[kWavesPerBlock];
-            const double s = block_sum(sum, scratch);
-            const double q = block_sum(sumsq, scratch);
+            __shared__ double scratch[BLK / kWave][2];
+            const double s = wave_sum(sum), q = wave_sum(sumsq);
+            if ((threadIdx.x & (kWave - 1)) == 0) scratch[threadIdx.x / kWave][0] = s, scratch[threadIdx.x / kWave][1] = q;
+            __syncthreads();
             if (threadIdx.x == 0) {
-                partials[int64_t(blockIdx.x) * 2 + 0] = s;
-                partials[int64_t(blockIdx.x) * 2 + 1] = q;
+                double ts = 0.0, tq = 0.0;
+#pragma unroll
+                for (int w = 0; w < BLK / kWave; ++w) ts += scratch[w][0], tq += scratch[w][1];
+                partials[int64_t(blockIdx.x) * 2 + 0] = ts;
+                partials[int64_t(blockIdx.x) * 2 + 1] = tq;
             }
         } else {
             red[threadIdx.x][0] = active ? sum : 0.0;
@@ -194,10 +200,10 @@ __global__ __launch_bounds__(kBlock) void gae_kernel(const float *__restrict__ r
             __syncthreads();
             if (threadIdx.x < D) {
                 // thread k of this block owns column base + k, channel (base + k) % D
-                const int64_t base = int64_t(blockIdx.x) * kBlock;
+                const int64_t base = int64_t(blockIdx.x) * BLK;
                 int first = int((int64_t(threadIdx.x) - base % D + D) % D);
                 double s = 0.0, q = 0.0;
-                for (int k = first; k < kBlock; k += D) {
+                for (int k = first; k < BLK; k += D) {
                     s += red[k][0];
                     q += red[k][1];
                 }
@@ -322,6 +328,62 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(float *__restrict__ x
     }
 }
 
+// Normalisation straight from the block partials (single-process case: no cross-rank merge sits between the statistics
+// and their use): every block re-reduces the few partial rows itself (P x D x 16 bytes, L2-resident) in the same fixed
+// order as stats_finalize_kernel, so the separate one-block finalize launch disappears; block 0 also publishes mean / var.
+__global__ __launch_bounds__(kBlock) void normalize_from_partials_kernel(float *__restrict__ x,
+                                                                         const double *__restrict__ partials, int64_t P,
+                                                                         int64_t count, float eps, int64_t E, int D,
+                                                                         int vec4, float *__restrict__ mean_out,
+                                                                         float *__restrict__ var_out) {
+    __shared__ double scratch[kWavesPerBlock];
+    __shared__ float s_mean[kBlock], s_sd[kBlock];
+    for (int d = 0; d < D; ++d) {
+        double s = 0.0, q = 0.0;
+        for (int64_t p = threadIdx.x; p < P; p += kBlock) {
+            s += partials[(p * D + d) * 2 + 0];
+            q += partials[(p * D + d) * 2 + 1];
+        }
+        s = block_sum(s, scratch);
+        q = block_sum(q, scratch);
+        if (threadIdx.x == 0) {
+            const double n = double(count);
+            const double m = s / n;
+            const double v = (q - s * m) / (n - 1.0);
+            const float mean = float(m), var = float(v < 0.0 ? 0.0 : v);
+            s_mean[d] = mean;
+            s_sd[d] = sqrtf(__fadd_rn(var, eps));
+            if (blockIdx.x == 0) mean_out[d] = mean, var_out[d] = var;
+        }
+    }
+    __syncthreads();
+    const int64_t tid = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    if (D == 1) {
+        const float m = s_mean[0], sd = s_sd[0];
+        if (vec4) {
+            const int64_t n4 = E / 4;
+            for (int64_t i = tid; i < n4; i += stride) {
+                float4 v = reinterpret_cast<float4 *>(x)[i];
+                v.x = __fdiv_rn(__fsub_rn(v.x, m), sd);
+                v.y = __fdiv_rn(__fsub_rn(v.y, m), sd);
+                v.z = __fdiv_rn(__fsub_rn(v.z, m), sd);
+                v.w = __fdiv_rn(__fsub_rn(v.w, m), sd);
+                reinterpret_cast<float4 *>(x)[i] = v;
+            }
+            if (tid == 0)
+                for (int64_t i = n4 * 4; i < E; ++i) x[i] = __fdiv_rn(__fsub_rn(x[i], m), sd);
+        } else {
+            for (int64_t i = tid; i < E; i += stride) x[i] = __fdiv_rn(__fsub_rn(x[i], m), sd);
+        }
+    } else {
+        for (int64_t i = tid; i < E; i += stride) {
+            const int d = int(i % D);
+            x[i] = __fdiv_rn(__fsub_rn(x[i], s_mean[d]), s_sd[d]);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------------- merge
 __global__ void merge_mean_var_kernel(const float *__restrict__ gathered, int W, int D, float *__restrict__ mean,
                                       float *__restrict__ var) {
@@ -376,8 +438,8 @@ static bool gae_vec4(const float *reward, const float *value, const float *next_
 extern "C" int64_t cusrl_gae_num_partials(int64_t T, int64_t N, int64_t D) {
     (void)T;
     if (N <= 0 || D <= 0) return 0;
-    // upper bound valid for both the 4-columns-per-lane and the 1-column-per-lane launch shapes
-    return ceil_div(N * D, kBlock);
+    // upper bound valid for every launch shape (one-wave blocks of the small-rollout path included)
+    return ceil_div(N * D, kWave);
 }
 
 extern "C" int cusrl_gae(const float *reward, const float *value, const float *next_value, const uint8_t *done,
@@ -411,9 +473,33 @@ extern "C" int cusrl_gae(const float *reward, const float *value, const float *n
         else
             hipLaunchKernelGGL((gae_kernel<4, 6, false>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, reward, value,
                                next_value, done, advantage, ret, stat_partials, int(T), N, int(D), g, c_adv, c_val);
+    } else if (C <= 65536 && T <= 32) {
+        // small rollouts (config 2: 4096 columns x 24 steps): one-wave blocks on 4x more CUs, the whole horizon in ONE
+        // load round (32 steps x 4 streams in flight per lane) — the launch is one memory latency + the scan
+        const int64_t blocks = ceil_div(C, kWave);
+        if (stat_partials) {
+            const int64_t rows = cusrl_gae_num_partials(T, N, D);
+            if (rows > blocks)
+                if (hipError_t e = hipMemsetAsync(stat_partials + blocks * D * 2, 0,
+                                                  sizeof(double) * size_t((rows - blocks) * D * 2), s))
+                    return int(e);
+        }
+        if (two)
+            hipLaunchKernelGGL((gae_kernel<1, 32, true, kWave>), dim3(uint32_t(blocks)), dim3(kWave), 0, s, reward, value,
+                               next_value, done, advantage, ret, stat_partials, int(T), N, int(D), g, c_adv, c_val);
+        else
+            hipLaunchKernelGGL((gae_kernel<1, 32, false, kWave>), dim3(uint32_t(blocks)), dim3(kWave), 0, s, reward, value,
+                               next_value, done, advantage, ret, stat_partials, int(T), N, int(D), g, c_adv, c_val);
     } else {
         const int64_t blocks = ceil_div(C, kBlock);
         if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+        if (stat_partials) {
+            const int64_t rows = cusrl_gae_num_partials(T, N, D);
+            if (rows > blocks)
+                if (hipError_t e = hipMemsetAsync(stat_partials + blocks * D * 2, 0,
+                                                  sizeof(double) * size_t((rows - blocks) * D * 2), s))
+                    return int(e);
+        }
         if (two)
             hipLaunchKernelGGL((gae_kernel<1, 8, true>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, reward, value,
                                next_value, done, advantage, ret, stat_partials, int(T), N, int(D), g, c_adv, c_val);
@@ -462,6 +548,22 @@ extern "C" int cusrl_normalize(float *x, const float *mean, const float *var, fl
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(normalize_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), x, mean, var, eps,
                        E, int(D), vec4);
+    return launch_status();
+}
+
+extern "C" int cusrl_normalize_from_partials(float *x, const double *stat_partials, int64_t num_partials, int64_t count,
+                                             float eps, int64_t rows, int64_t D, float *mean_out, float *var_out,
+                                             void *stream) {
+    if (rows < 0 || D < 0 || num_partials < 0 || count < 0) return CUSRL_E_INVALID;
+    if (rows == 0 || D == 0) return 0;
+    if (!x || !stat_partials || !mean_out || !var_out) return CUSRL_E_INVALID;
+    if (D > kBlock) return CUSRL_E_UNSUPPORTED;
+    const int64_t E = rows * D;
+    const int vec4 = D == 1 && aligned(x, 16);
+    int64_t blocks = ceil_div(vec4 ? E / 4 + 1 : E, kBlock);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(normalize_from_partials_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), x,
+                       stat_partials, num_partials, count, eps, E, int(D), vec4, mean_out, var_out);
     return launch_status();
 }
 

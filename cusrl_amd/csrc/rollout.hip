@@ -46,6 +46,13 @@ __global__ __launch_bounds__(kBlock) void normal_sample_logp_kernel(const float 
     logp[row] = lp;
 }
 
+// Ring slots are handed out in ascending env order, like the reference's `(arange(count) + num_episodes) % R`
+// (trainer.py:63-70): a block's first slot = episodes so far + finished envs in all EARLIER blocks, which every block
+// counts for itself from the flag bytes (b x 256 bytes, 16 per lane-load, L2-resident; no count launch, no ticket).
+// The running episode counter is double-buffered — every block reads counter[parity], the last block writes
+// counter[parity ^ 1] — so no block can observe this step's update.  kOrdered = false (N > 262 144, where the
+// quadratic flag re-read would matter) falls back to an atomic ticket: same slots, unspecified order within the step.
+template <bool kOrdered>
 __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const float *__restrict__ reward,
                                                                const uint8_t *__restrict__ done,
                                                                float *__restrict__ episode_rew,
@@ -54,18 +61,47 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const float *__re
                                                                float *__restrict__ ring_len,
                                                                unsigned long long *__restrict__ num_episodes,
                                                                double *__restrict__ step_reward_sum, int64_t N, int D,
-                                                               int64_t R) {
+                                                               int64_t R, int parity) {
     __shared__ double scratch[kWavesPerBlock];
+    __shared__ int iscratch[kWavesPerBlock];
     const int64_t n = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     const bool active = n < N;
     const bool finished = active && done[n] != 0;
     unsigned long long slot = 0;
     float len = 0.0f;
     if (active) len = episode_len[n] + 1.0f;
-    if (finished) {
-        slot = atomicAdd(num_episodes, 1ull) % (unsigned long long)R;  // ticket = position in the ring
-        ring_len[slot] = len;
+    if constexpr (kOrdered) {
+        int earlier = 0;
+        const int64_t chunks = int64_t(blockIdx.x) * (kBlock / 16);  // 16-flag chunks in front of this block
+        const bool vec = (reinterpret_cast<uintptr_t>(done) & 15) == 0;
+        for (int64_t c = threadIdx.x; c < chunks; c += kBlock) {
+            if (vec) {
+                const uint4 v = reinterpret_cast<const uint4 *>(done)[c];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t x = w[k];
+                    x |= x >> 4, x |= x >> 2, x |= x >> 1;  // any bit of a byte -> its bit 0
+                    earlier += __popc(x & 0x01010101u);
+                }
+            } else {
+                for (int j = 0; j < 16; ++j) earlier += done[c * 16 + j] != 0;
+            }
+        }
+        int own_total;
+        const int own_prefix = block_exclusive_scan(finished ? 1 : 0, iscratch, own_total);
+        const int before = block_sum(earlier, iscratch);
+        __shared__ int s_before;
+        if (threadIdx.x == 0) s_before = before;
+        __syncthreads();
+        const unsigned long long base = num_episodes[parity];
+        if (finished) slot = (base + (unsigned long long)(s_before + own_prefix)) % (unsigned long long)R;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+            num_episodes[parity ^ 1] = base + (unsigned long long)(s_before + own_total);
+    } else {
+        if (finished) slot = atomicAdd(num_episodes + parity, 1ull) % (unsigned long long)R;
     }
+    if (finished) ring_len[slot] = len;
     for (int d = 0; d < D; ++d) {
         float r = 0.0f;
         if (active) {
@@ -156,16 +192,25 @@ extern "C" int cusrl_normal_sample_logp(const float *mean, const float *std, con
 
 extern "C" int cusrl_episode_stats(const float *reward, const uint8_t *done, float *episode_rew, float *episode_len,
                                    float *ring_rew, float *ring_len, uint64_t *num_episodes, double *step_reward_sum,
-                                   int64_t N, int64_t D, int64_t R, void *stream) {
-    if (N < 0 || D <= 0 || R <= 0) return CUSRL_E_INVALID;
+                                   int64_t N, int64_t D, int64_t R, int parity, void *stream) {
+    if (N < 0 || D <= 0 || R <= 0 || (parity != 0 && parity != 1)) return CUSRL_E_INVALID;
     if (N == 0) return 0;
     if (!reward || !done || !episode_rew || !episode_len || !ring_rew || !ring_len || !num_episodes || !step_reward_sum)
         return CUSRL_E_INVALID;
     if (D > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     const int64_t blocks = ceil_div(N, kBlock);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
-    hipLaunchKernelGGL(episode_stats_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), reward, done,
-                       episode_rew, episode_len, ring_rew, ring_len,
-                       reinterpret_cast<unsigned long long *>(num_episodes), step_reward_sum, N, int(D), R);
+    unsigned long long *counter = reinterpret_cast<unsigned long long *>(num_episodes);
+    if (N <= 262144) {
+        hipLaunchKernelGGL(episode_stats_kernel<true>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), reward,
+                           done, episode_rew, episode_len, ring_rew, ring_len, counter, step_reward_sum, N, int(D), R, parity);
+    } else {  // ticket form: the counter of this step is first copied over, then bumped atomically
+        if (hipError_t e = hipMemcpyAsync(counter + (parity ^ 1), counter + parity, sizeof(unsigned long long),
+                                          hipMemcpyDeviceToDevice, as_stream(stream)))
+            return int(e);
+        hipLaunchKernelGGL(episode_stats_kernel<false>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), reward,
+                           done, episode_rew, episode_len, ring_rew, ring_len, counter, step_reward_sum, N, int(D), R,
+                           parity ^ 1);
+    }
     return launch_status();
 }

@@ -77,6 +77,10 @@ class AdvantageNormalization(Hook):
             partials = derived[1]  # emitted by the GAE launch for exactly this tensor
         else:
             partials = ops.col_stats(advantage)
+        if not (self.synchronize and distributed.enabled()) and advantage.is_contiguous():
+            # nothing sits between the statistics and their use: finalize + normalise in one launch
+            ops.normalize_from_partials_(advantage, partials, count, 1e-8)
+            return
         var, mean = ops.adv_stats_finalize(partials, count)
         if self.synchronize:
             distributed.reduce_mean_var_(mean, var)

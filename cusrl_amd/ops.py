@@ -32,6 +32,7 @@ __all__ = [
     "next_value",
     "normal_sample_logp",
     "normalize_",
+    "normalize_from_partials_",
     "ppo_loss_categorical_fwd_bwd",
     "ppo_loss_fwd_bwd",
     "masked_col_stats",
@@ -556,6 +557,25 @@ def normalize_(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, eps: floa
     return x
 
 
+def normalize_from_partials_(x: torch.Tensor, partials: torch.Tensor, count: int, eps: float = 1e-8) -> tuple[torch.Tensor, torch.Tensor]:
+    """:func:`adv_stats_finalize` + :func:`normalize_` as ONE launch (single-process case); returns ``(var, mean)``."""
+    require_device(x, "x")
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise TypeError("normalize_from_partials_: expected a contiguous float32 tensor")
+    P, D, _ = partials.shape
+    if x.shape[-1] != D:
+        raise ValueError("normalize_from_partials_: the partials belong to another tensor")
+    mean = torch.empty(D, dtype=torch.float32, device=x.device)
+    var = torch.empty(D, dtype=torch.float32, device=x.device)
+    _observed(
+        "cusrl_normalize_from_partials",
+        lambda: x.numel() * 8,
+        lambda: _native.lib().cusrl_normalize_from_partials(x.data_ptr(), partials.data_ptr(), P, count, eps, x.numel() // max(D, 1), D,
+                                                            mean.data_ptr(), var.data_ptr(), _stream()),
+    )
+    return var, mean
+
+
 def merge_mean_var(gathered: torch.Tensor, mean: torch.Tensor, var: torch.Tensor) -> None:
     """Equal-weight cross-rank merge of distributed.py:175-183 from the all-gathered ``[W, 2D]`` rows."""
     gathered = _f32(gathered, "gathered")
@@ -744,8 +764,11 @@ def normal_sample_logp(mean: torch.Tensor, std: torch.Tensor, eps: torch.Tensor)
     return action, logp
 
 
-def episode_stats(reward, done, episode_rew, episode_len, ring_rew, ring_len, num_episodes, step_reward_sum) -> None:
-    """One-launch ``EnvironmentStats.track_step`` + ``track_episode`` (cusrl/template/trainer.py:54-76), no host sync."""
+def episode_stats(reward, done, episode_rew, episode_len, ring_rew, ring_len, num_episodes, step_reward_sum, parity: int) -> None:
+    """One-launch ``EnvironmentStats.track_step`` + ``track_episode`` (cusrl/template/trainer.py:54-76), no host sync.
+    ``num_episodes`` is the double-buffered int64[2] counter: read at ``parity``, written at ``parity ^ 1``."""
+    if num_episodes.numel() != 2 or num_episodes.dtype != torch.int64:
+        raise TypeError("episode_stats: 'num_episodes' must be the int64[2] double-buffered counter")
     reward = _f32(reward, "reward")
     done = _flag(done, "done")
     N, D = reward.shape
@@ -754,7 +777,7 @@ def episode_stats(reward, done, episode_rew, episode_len, ring_rew, ring_len, nu
         lambda: N * (12 * D + 9),
         lambda: _native.lib().cusrl_episode_stats(
             reward.data_ptr(), done.data_ptr(), episode_rew.data_ptr(), episode_len.data_ptr(), ring_rew.data_ptr(),
-            ring_len.data_ptr(), num_episodes.data_ptr(), step_reward_sum.data_ptr(), N, D, ring_len.numel(), _stream(),
+            ring_len.data_ptr(), num_episodes.data_ptr(), step_reward_sum.data_ptr(), N, D, ring_len.numel(), int(parity), _stream(),
         ),
     )
 

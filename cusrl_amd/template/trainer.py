@@ -35,7 +35,8 @@ class EnvironmentStats:
         self.total_steps = self.num_steps = 0
         self._num_episodes = 0
         if self.on_device:
-            self._episodes_dev = zeros(1, dtype=torch.int64)
+            self._episodes_dev = zeros(2, dtype=torch.int64)  # double-buffered: see cusrl_episode_stats
+            self._parity = 0
             self._reward_sum = zeros(reward_dim, dtype=torch.float64)
 
     # ---- device path: one launch per env step
@@ -45,11 +46,12 @@ class EnvironmentStats:
         self.total_steps += self.num_envs
         self.num_steps += 1
         ops.episode_stats(reward, done, self.episode_rew, self.episode_len, self.rew_buffer, self.len_buffer,
-                          self._episodes_dev, self._reward_sum)
+                          self._episodes_dev, self._reward_sum, self._parity)
+        self._parity ^= 1
 
     @property
     def num_episodes(self) -> int:
-        return int(self._episodes_dev.item()) if self.on_device else self._num_episodes
+        return int(self._episodes_dev[self._parity].item()) if self.on_device else self._num_episodes
 
     # ---- host path (reference form)
     def track_step(self, reward):

@@ -99,6 +99,12 @@ int cusrl_stats_finalize(const double *stat_partials, int64_t num_partials, int6
 int cusrl_normalize(float *x, const float *mean, const float *var, float eps, int64_t rows, int64_t D,
                     void *stream);
 
+/* The two steps above in ONE launch for the single-process case (no cross-rank merge between statistics and their
+ * use): every block reduces the partial rows itself (same fixed order), then normalises its share of x; mean_out /
+ * var_out [D] receive the statistics (block 0).  Bit-identical to cusrl_stats_finalize + cusrl_normalize. */
+int cusrl_normalize_from_partials(float *x, const double *stat_partials, int64_t num_partials, int64_t count, float eps,
+                                  int64_t rows, int64_t D, float *mean_out, float *var_out, void *stream);
+
 /* ---- a6  reduce_mean_var_ merge — cusrl/utils/distributed.py:175-183 ----
  * gathered = [W, 2*D] rows of cat(mean_r, var_r) (the all_gather result); writes the equal-weight merge
  * mean = avg_r mean_r, var = avg_r (var_r + (mean_r - mean)^2) into mean[D], var[D]. */
@@ -187,13 +193,15 @@ int cusrl_normal_sample_logp(const float *mean, const float *std, const float *e
 /* EnvironmentStats.track_step + track_episode — cusrl/template/trainer.py:54-76, in one launch and without the
  * host round trip of `get_done_indices(...).tolist()` (environment.py:356-362):
  *   episode_rew[n] += reward[n]; episode_len[n] += 1; step_reward_sum[d] += sum_n reward[n,d];
- *   for done[n]: slot = (num_episodes++) % R; ring_rew[slot] = episode_rew[n]; ring_len[slot] = episode_len[n];
- *                episode_rew[n] = 0; episode_len[n] = 0.
+ *   for done[n], in ASCENDING n: slot = (num_episodes++) % R; ring_rew[slot] = episode_rew[n];
+ *                ring_len[slot] = episode_len[n]; episode_rew[n] = 0; episode_len[n] = 0.
  * reward, episode_rew [N,D]; done [N] bytes; episode_len [N]; ring_rew [R,D]; ring_len [R];
- * num_episodes: device uint64[1]; step_reward_sum: device double[D]. */
+ * num_episodes: device uint64[2], double-buffered — the launch reads num_episodes[parity] and leaves the updated count
+ * in num_episodes[parity ^ 1]; the caller flips `parity` (0 / 1) every call; step_reward_sum: device double[D].
+ * (Beyond 262 144 envs slots are drawn by atomic ticket: same set of slots, unspecified order within the step.) */
 int cusrl_episode_stats(const float *reward, const uint8_t *done, float *episode_rew, float *episode_len,
                         float *ring_rew, float *ring_len, uint64_t *num_episodes, double *step_reward_sum,
-                        int64_t N, int64_t D, int64_t R, void *stream);
+                        int64_t N, int64_t D, int64_t R, int parity, void *stream);
 
 /* ---- post-update policy statistics — cusrl/hook/on_policy/stats.py:28-40 for Normal policies ----
  * out[0] = mean_b KL(N(old_mean, old_std) || N(new_mean, new_std)) summed over the A action dims (kl_divergence),

@@ -139,7 +139,7 @@ def test_config1_mountain_car_update_replays_the_reference(cusrl, golden, mode):
                 "Agent/grad_norm/default", "Agent/ratio", "Agent/kl_divergence", "Agent/importance_weighted_advantage"):
         np.testing.assert_allclose(metrics[key], ref[key], rtol=1e-3, atol=1e-5, err_msg=key)
     # the HIP entry points carried it
-    assert launched["cusrl_next_value"] == 1 and launched["cusrl_gae"] == 1 and launched["cusrl_normalize"] == 1
+    assert launched["cusrl_next_value"] == 1 and launched["cusrl_gae"] == 1 and launched["cusrl_normalize_from_partials"] == 1
     assert launched["cusrl_categorical_policy_stats"] == 1
     gathers = launched["cusrl_gather_rows"] + launched["cusrl_gather_rows_packed"]
     if mode == "fused":

@@ -33,7 +33,7 @@ def test_library_exports_every_symbol_declared_in_the_header():
 def test_size_helpers_and_argument_validation_without_a_gpu():
     lib = _native.lib()
     assert lib.cusrl_flag_blocks(0) == 0 and lib.cusrl_flag_blocks(1) == 1 and lib.cusrl_flag_blocks(4097) == 2
-    assert lib.cusrl_gae_num_partials(24, 4096, 1) == 16
+    assert lib.cusrl_gae_num_partials(24, 4096, 1) == 64  # one row per 64-column wave block (small-rollout shape)
     assert lib.cusrl_ppo_loss_num_partials(24576) == 96
     assert lib.cusrl_col_stats_num_partials(98304, 1) == 24
     # invalid arguments are rejected on the host before any launch
