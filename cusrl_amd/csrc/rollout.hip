@@ -52,31 +52,48 @@ __global__ __launch_bounds__(kBlock) void normal_sample_logp_kernel(const float 
 // The running episode counter is double-buffered — every block reads counter[parity], the last block writes
 // counter[parity ^ 1] — so no block can observe this step's update.  kOrdered = false (N > 262 144, where the
 // quadratic flag re-read would matter) falls back to an atomic ticket: same slots, unspecified order within the step.
+constexpr int64_t kOrderedStatsMaxEnvs = 262144;
+
 template <bool kOrdered>
 __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const float *__restrict__ reward,
                                                                const uint8_t *__restrict__ done,
+                                                               const uint8_t *__restrict__ done_b,
+                                                               uint8_t *__restrict__ done_out,
                                                                float *__restrict__ episode_rew,
                                                                float *__restrict__ episode_len,
                                                                float *__restrict__ ring_rew,
                                                                float *__restrict__ ring_len,
                                                                unsigned long long *__restrict__ num_episodes,
-                                                               double *__restrict__ step_reward_sum, int64_t N, int D,
+                                                               double *__restrict__ step_reward_sum,
+                                                               int64_t *__restrict__ indices_out,
+                                                               int32_t *__restrict__ count_out, int64_t N, int D,
                                                                int64_t R, int parity) {
+    // `done_b` != NULL: the flag of env n is done[n] | done_b[n] (terminated | truncated, actor_critic.py:277), written
+    // to done_out; indices_out / count_out != NULL: the finished envs in ascending order + their number
+    // (environment.py:356-362 `get_done_indices`), the count with a system-scope store (may be pinned host memory).
     __shared__ double scratch[kWavesPerBlock];
     __shared__ int iscratch[kWavesPerBlock];
     const int64_t n = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     const bool active = n < N;
-    const bool finished = active && done[n] != 0;
+    bool finished = false;
+    if (active) {
+        finished = done[n] != 0 || (done_b && done_b[n] != 0);
+        if (done_out) done_out[n] = finished ? 1 : 0;
+    }
     unsigned long long slot = 0;
     float len = 0.0f;
     if (active) len = episode_len[n] + 1.0f;
     if constexpr (kOrdered) {
         int earlier = 0;
         const int64_t chunks = int64_t(blockIdx.x) * (kBlock / 16);  // 16-flag chunks in front of this block
-        const bool vec = (reinterpret_cast<uintptr_t>(done) & 15) == 0;
+        const bool vec = ((reinterpret_cast<uintptr_t>(done) | reinterpret_cast<uintptr_t>(done_b)) & 15) == 0;
         for (int64_t c = threadIdx.x; c < chunks; c += kBlock) {
             if (vec) {
-                const uint4 v = reinterpret_cast<const uint4 *>(done)[c];
+                uint4 v = reinterpret_cast<const uint4 *>(done)[c];
+                if (done_b) {
+                    const uint4 u = reinterpret_cast<const uint4 *>(done_b)[c];
+                    v.x |= u.x, v.y |= u.y, v.z |= u.z, v.w |= u.w;
+                }
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -85,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const float *__re
                     earlier += __popc(x & 0x01010101u);
                 }
             } else {
-                for (int j = 0; j < 16; ++j) earlier += done[c * 16 + j] != 0;
+                for (int j = 0; j < 16; ++j) earlier += (done[c * 16 + j] != 0 || (done_b && done_b[c * 16 + j] != 0));
             }
         }
         int own_total;
@@ -95,9 +112,14 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const float *__re
         if (threadIdx.x == 0) s_before = before;
         __syncthreads();
         const unsigned long long base = num_episodes[parity];
-        if (finished) slot = (base + (unsigned long long)(s_before + own_prefix)) % (unsigned long long)R;
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        if (finished) {
+            slot = (base + (unsigned long long)(s_before + own_prefix)) % (unsigned long long)R;
+            if (indices_out) indices_out[s_before + own_prefix] = n;
+        }
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
             num_episodes[parity ^ 1] = base + (unsigned long long)(s_before + own_total);
+            if (count_out) __hip_atomic_store(count_out, s_before + own_total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     } else {
         if (finished) slot = atomicAdd(num_episodes + parity, 1ull) % (unsigned long long)R;
     }
@@ -201,16 +223,37 @@ extern "C" int cusrl_episode_stats(const float *reward, const uint8_t *done, flo
     const int64_t blocks = ceil_div(N, kBlock);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     unsigned long long *counter = reinterpret_cast<unsigned long long *>(num_episodes);
-    if (N <= 262144) {
+    if (N <= kOrderedStatsMaxEnvs) {
         hipLaunchKernelGGL(episode_stats_kernel<true>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), reward,
-                           done, episode_rew, episode_len, ring_rew, ring_len, counter, step_reward_sum, N, int(D), R, parity);
+                           done, nullptr, nullptr, episode_rew, episode_len, ring_rew, ring_len, counter, step_reward_sum,
+                           nullptr, nullptr, N, int(D), R, parity);
     } else {  // ticket form: the counter of this step is first copied over, then bumped atomically
         if (hipError_t e = hipMemcpyAsync(counter + (parity ^ 1), counter + parity, sizeof(unsigned long long),
                                           hipMemcpyDeviceToDevice, as_stream(stream)))
             return int(e);
         hipLaunchKernelGGL(episode_stats_kernel<false>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), reward,
-                           done, episode_rew, episode_len, ring_rew, ring_len, counter, step_reward_sum, N, int(D), R,
-                           parity ^ 1);
+                           done, nullptr, nullptr, episode_rew, episode_len, ring_rew, ring_len, counter, step_reward_sum,
+                           nullptr, nullptr, N, int(D), R, parity ^ 1);
     }
+    return launch_status();
+}
+
+extern "C" int64_t cusrl_step_epilogue_max_envs(void) { return kOrderedStatsMaxEnvs; }
+
+extern "C" int cusrl_step_epilogue(const float *reward, const uint8_t *terminated, const uint8_t *truncated,
+                                   uint8_t *done_out, float *episode_rew, float *episode_len, float *ring_rew,
+                                   float *ring_len, uint64_t *num_episodes, double *step_reward_sum,
+                                   int64_t *indices_out, int32_t *count_out, int64_t N, int64_t D, int64_t R, int parity,
+                                   void *stream) {
+    if (N <= 0 || D <= 0 || R <= 0 || (parity != 0 && parity != 1)) return CUSRL_E_INVALID;
+    if (!reward || !terminated || !truncated || !done_out || !episode_rew || !episode_len || !ring_rew || !ring_len ||
+        !num_episodes || !step_reward_sum || !indices_out || !count_out)
+        return CUSRL_E_INVALID;
+    if (D > INT32_MAX || N > kOrderedStatsMaxEnvs) return CUSRL_E_UNSUPPORTED;
+    const int64_t blocks = ceil_div(N, kBlock);
+    hipLaunchKernelGGL(episode_stats_kernel<true>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), reward,
+                       terminated, truncated, done_out, episode_rew, episode_len, ring_rew, ring_len,
+                       reinterpret_cast<unsigned long long *>(num_episodes), step_reward_sum, indices_out, count_out, N,
+                       int(D), R, parity);
     return launch_status();
 }

@@ -43,6 +43,7 @@ __all__ = [
     "rms_normalize",
     "scatter_rows",
     "set_launch_observer",
+    "step_epilogue",
     "window_indices",
 ]
 
@@ -778,6 +779,26 @@ def episode_stats(reward, done, episode_rew, episode_len, ring_rew, ring_len, nu
         lambda: _native.lib().cusrl_episode_stats(
             reward.data_ptr(), done.data_ptr(), episode_rew.data_ptr(), episode_len.data_ptr(), ring_rew.data_ptr(),
             ring_len.data_ptr(), num_episodes.data_ptr(), step_reward_sum.data_ptr(), N, D, ring_len.numel(), int(parity), _stream(),
+        ),
+    )
+
+
+def step_epilogue(reward, terminated, truncated, done_out, episode_rew, episode_len, ring_rew, ring_len, num_episodes,
+                  step_reward_sum, indices_out, count_out, parity: int) -> None:
+    """``done = terminated | truncated`` + episode statistics + ordered finished-env indices and their count in ONE launch
+    (``cusrl_step_epilogue``); ``count_out`` may be pinned host memory (:class:`HostCounter`)."""
+    reward = _f32(reward, "reward")
+    terminated, truncated = _flag(terminated, "terminated"), _flag(truncated, "truncated")
+    N, D = reward.shape
+    if terminated.numel() != N or truncated.numel() != N or done_out.numel() != N or indices_out.numel() < N:
+        raise ValueError("step_epilogue: inconsistent sizes")
+    _observed(
+        "cusrl_step_epilogue",
+        lambda: N * (12 * D + 11),
+        lambda: _native.lib().cusrl_step_epilogue(
+            reward.data_ptr(), terminated.data_ptr(), truncated.data_ptr(), done_out.data_ptr(), episode_rew.data_ptr(),
+            episode_len.data_ptr(), ring_rew.data_ptr(), ring_len.data_ptr(), num_episodes.data_ptr(), step_reward_sum.data_ptr(),
+            indices_out.data_ptr(), count_out.data_ptr(), N, D, ring_len.numel(), int(parity), _stream(),
         ),
     )
 

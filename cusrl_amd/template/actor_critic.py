@@ -209,7 +209,10 @@ class ActorCritic(Agent):
             raise TypeError("'terminated' must have dtype bool")
         if transition["truncated"].dtype != torch.bool:
             raise TypeError("'truncated' must have dtype bool")
-        transition["done"] = transition["terminated"] | transition["truncated"]
+        supplied = kwargs.get("done")  # extension: the trainer's fused step epilogue already formed terminated | truncated
+        if not (type(supplied) is torch.Tensor and supplied.dtype == torch.bool and supplied.shape == transition["terminated"].shape
+                and supplied.device == transition["terminated"].device):
+            transition["done"] = transition["terminated"] | transition["truncated"]
         self.hook.post_step(transition)
         if not self.inference_mode:
             self.buffer.push(transition)  # a1: every leaf of the transition in one HIP launch

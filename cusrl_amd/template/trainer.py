@@ -49,6 +49,18 @@ class EnvironmentStats:
                           self._episodes_dev, self._reward_sum, self._parity)
         self._parity ^= 1
 
+    def track_fused(self, reward, terminated, truncated, done_out, indices_out, count_out):
+        """``cusrl_step_epilogue``: ``done = terminated | truncated``, the statistics of :meth:`track` and the ordered
+        finished-env indices + count — one launch for what the reference does in ``ActorCritic.step`` (the OR),
+        ``track_step`` / ``track_episode`` and ``get_done_indices``."""
+        from cusrl_amd import ops
+
+        self.total_steps += self.num_envs
+        self.num_steps += 1
+        ops.step_epilogue(reward, terminated, truncated, done_out, self.episode_rew, self.episode_len, self.rew_buffer,
+                          self.len_buffer, self._episodes_dev, self._reward_sum, indices_out, count_out, self._parity)
+        self._parity ^= 1
+
     @property
     def num_episodes(self) -> int:
         return int(self._episodes_dev[self._parity].item()) if self.on_device else self._num_episodes
@@ -185,14 +197,38 @@ class Trainer:
         while True:
             with timer.record("agent", every):
                 action = agent.act(observation, state)
+            fused = False
             with timer.record("environment", every):
                 next_observation, next_state, reward, terminated, truncated, info = env.step(action)
                 if not stats.on_device:
                     stats.track_step(reward)
+                elif self._epilogue_applies(reward, terminated, truncated, info):
+                    # ONE launch right behind env.step: done flag, episode statistics, ordered finished-env indices and
+                    # their count (into pinned host memory).  agent.step's host work (hooks, push) runs while it
+                    # executes, so the count is already there when the resets need it — no blocking read-back.
+                    fused = True
+                    if self._done_counter is None:
+                        from cusrl_amd import ops
+
+                        self._done_counter = ops.HostCounter()
+                    done = torch.empty_like(terminated)
+                    indices = self._done_scratch.get("epilogue")
+                    if indices is None or indices.numel() != terminated.numel() or indices.device != terminated.device:
+                        indices = self._done_scratch["epilogue"] = torch.empty(terminated.numel(), dtype=torch.int64,
+                                                                               device=terminated.device)
+                    stats.track_fused(reward, terminated, truncated, done, indices, self._done_counter.arm())
+                    info = {**info, "done": done}
             with timer.record("agent", every):
                 ready = agent.step(next_observation, reward, terminated, truncated, next_state, **info)
             with timer.record("environment", every):
-                if stats.on_device:
+                if fused:
+                    if not env.spec.autoreset:
+                        done_indices = indices[: self._done_counter.wait()]
+                        if done_indices.numel():
+                            init_observation, init_state, _ = env.reset(indices=done_indices)
+                            next_observation, next_state = self._splice_resets(
+                                next_observation, next_state, done_indices, init_observation, init_state)
+                elif stats.on_device:
                     # device-resident bookkeeping: one launch, and a host round trip only if the env needs indices
                     done = agent.transition.get("done")
                     if not isinstance(done, torch.Tensor) or done.device != stats.device:
@@ -221,6 +257,21 @@ class Trainer:
         for hook in self.hooks:
             hook.post_update()
         return observation, state
+
+    def _epilogue_applies(self, reward, terminated, truncated, info) -> bool:
+        """Device tensors of the shapes the fused step epilogue takes ([N, D] fp32 reward, [N, 1] bool flags)."""
+        stats = self.stats
+        limit = getattr(self, "_epilogue_limit", None)
+        if limit is None:
+            from cusrl_amd import _native
+
+            limit = self._epilogue_limit = int(_native.lib().cusrl_step_epilogue_max_envs())
+        return (isinstance(reward, torch.Tensor) and isinstance(terminated, torch.Tensor) and isinstance(truncated, torch.Tensor)
+                and reward.device == stats.device and terminated.device == stats.device and truncated.device == stats.device
+                and reward.dtype == torch.float32 and terminated.dtype == torch.bool and truncated.dtype == torch.bool
+                and reward.dim() == 2 and terminated.shape == (stats.num_envs, 1) and truncated.shape == terminated.shape
+                and reward.is_contiguous() and terminated.is_contiguous() and truncated.is_contiguous()
+                and stats.num_envs <= limit and "done" not in info)
 
     @staticmethod
     def _splice_resets(observation, state, indices, init_observation, init_state):

@@ -203,6 +203,19 @@ int cusrl_episode_stats(const float *reward, const uint8_t *done, float *episode
                         float *ring_rew, float *ring_len, uint64_t *num_episodes, double *step_reward_sum,
                         int64_t N, int64_t D, int64_t R, int parity, void *stream);
 
+/* The whole per-env-step epilogue of the rollout loop in ONE launch (cusrl/template/actor_critic.py:277,
+ * cusrl/template/trainer.py:300-313, cusrl/template/environment.py:356-362):
+ *   done_out[n] = terminated[n] | truncated[n];   episode statistics exactly as cusrl_episode_stats with that flag;
+ *   indices_out[0 .. count) = the finished envs in ascending order (`get_done_indices`), *count_out = their number.
+ * count_out is written with a system-scope store and may be pinned host memory: the host launches this right after
+ * env.step, runs agent.step (hooks, buffer push) meanwhile, and finds the count waiting instead of blocking on a
+ * device->host copy.  Needs N <= cusrl_step_epilogue_max_envs(). */
+int cusrl_step_epilogue(const float *reward, const uint8_t *terminated, const uint8_t *truncated, uint8_t *done_out,
+                        float *episode_rew, float *episode_len, float *ring_rew, float *ring_len, uint64_t *num_episodes,
+                        double *step_reward_sum, int64_t *indices_out, int32_t *count_out, int64_t N, int64_t D, int64_t R,
+                        int parity, void *stream);
+int64_t cusrl_step_epilogue_max_envs(void);
+
 /* ---- post-update policy statistics — cusrl/hook/on_policy/stats.py:28-40 for Normal policies ----
  * out[0] = mean_b KL(N(old_mean, old_std) || N(new_mean, new_std)) summed over the A action dims (kl_divergence),
  * out[1] = mean of advantage * exp(log N(action; new_mean, new_std) - old_logp)  (importance_weighted_advantage),

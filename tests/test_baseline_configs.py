@@ -179,6 +179,7 @@ def test_config2_and_3_full_size_iteration(cusrl, num_envs):
     with Launches() as launched:
         trainer.run_training_loop()
     assert launched["cusrl_buffer_push"] == 24 and launched["cusrl_gae"] == 1 and launched["cusrl_ppo_loss_fwd_bwd"] == 20
+    assert launched["cusrl_step_epilogue"] == 24 and launched["cusrl_episode_stats"] == 0  # one launch per env step
     assert launched["cusrl_gather_rows_packed"] >= 20 and launched["cusrl_pack_rows"] >= 1 and launched["cusrl_policy_stats"] == 1
     buffer = trainer.agent.buffer
     S = 24 * num_envs

@@ -517,6 +517,54 @@ def test_episode_stats_one_launch_matches_reference_bookkeeping(ops, N, D, R):
         assert np.array_equal(host(ring_rew), h_ring_rew) and np.array_equal(host(ring_len), h_ring_len)
 
 
+@pytest.mark.parametrize("N,D", [(4096, 1), (777, 2), (65536, 1)])
+def test_step_epilogue_is_done_flag_statistics_and_ordered_indices_in_one_launch(ops, N, D):
+    """cusrl_step_epilogue vs the three things it replaces: terminated | truncated (actor_critic.py:277), the episode
+    bookkeeping (trainer.py:54-76) and get_done_indices (environment.py:356-362) — indices bit-exact and ascending."""
+    rng = np.random.default_rng(N)
+    R = 100
+    episode_rew, episode_len = torch.zeros(N, D, device=DEV), torch.zeros(N, 1, device=DEV)
+    ring_rew, ring_len = torch.zeros(R, D, device=DEV), torch.zeros(R, 1, device=DEV)
+    count = torch.zeros(2, dtype=torch.int64, device=DEV)
+    reward_sum = torch.zeros(D, dtype=torch.float64, device=DEV)
+    indices = torch.full((N,), -1, dtype=torch.int64, device=DEV)
+    counter = ops.HostCounter()
+    h_rew, h_len, total, parity = np.zeros((N, D), np.float32), np.zeros((N, 1), np.float32), 0, 0
+    h_ring_rew, h_ring_len = np.zeros((R, D), np.float32), np.zeros((R, 1), np.float32)
+    for step in range(5):
+        reward = rng.standard_normal((N, D)).astype(np.float32)
+        terminated, truncated = rng.random((N, 1)) < 0.004, rng.random((N, 1)) < 0.002
+        done = torch.empty(N, 1, dtype=torch.bool, device=DEV)
+        ops.step_epilogue(dev(reward), dev(terminated), dev(truncated), done, episode_rew, episode_len, ring_rew, ring_len, count,
+                          reward_sum, indices, counter.arm(), parity)
+        parity ^= 1
+        k = counter.wait(timeout=1.0)
+        expect = terminated | truncated
+        assert np.array_equal(host(done), expect)
+        want = np.flatnonzero(expect)
+        assert k == want.size and np.array_equal(host(indices[:k]), want)
+        h_rew += reward
+        h_len += 1
+        slots = (np.arange(want.size) + total) % R
+        if want.size <= R:
+            h_ring_rew[slots], h_ring_len[slots] = h_rew[want], h_len[want]
+        h_rew[want] = 0
+        h_len[want] = 0
+        total += want.size
+        assert int(count[parity].item()) == total
+    assert np.array_equal(host(episode_rew), h_rew) and np.array_equal(host(episode_len), h_len)
+    if N * 0.006 * 3 < R:
+        assert np.array_equal(host(ring_rew), h_ring_rew) and np.array_equal(host(ring_len), h_ring_len)
+    lib = __import__("cusrl_amd")._native.lib()
+    assert lib.cusrl_step_epilogue_max_envs() == 262144
+    args = [None] * 12
+    assert lib.cusrl_step_epilogue(*args, 4, 1, 100, 0, None) == -1                      # CUSRL_E_INVALID: null pointers
+    ptrs = [t.data_ptr() for t in (episode_rew, done, done, done, episode_rew, episode_len, ring_rew, ring_len, count, reward_sum,
+                                   indices, count)]
+    assert lib.cusrl_step_epilogue(*ptrs, 4, 1, 100, 2, None) == -1                      # parity must be 0 / 1
+    assert lib.cusrl_step_epilogue(*ptrs, 262145, 1, 100, 0, None) == -3                 # CUSRL_E_UNSUPPORTED: too many envs
+
+
 # ------------------------------------------------------------------------------------------------ MLP backward epilogue
 @pytest.mark.parametrize("rows,H", [(24576, 256), (24576, 128), (24576, 12), (24576, 1), (100, 32), (7, 5), (1, 4), (4097, 64)])
 @pytest.mark.parametrize("mask", [True, False])
