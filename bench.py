@@ -69,7 +69,7 @@ def pmc_traffic(envs_per_gpu):
         return None, None
     summary = json.loads(path.read_text())
     source = hashlib.sha256((ROOT / "cusrl_amd" / "csrc" / "buffer.hip").read_bytes()).hexdigest()[:16]
-    entry = summary.get("gather_minibatch_hot_leaves")
+    entry = summary.get("gather_minibatch_hot_record")
     if not entry or summary.get("buffer_hip_sha256_16") != source:
         return None, None
     return entry["hbm_traffic_bytes"], f"quoted: rocprofv3 PMC passes of this kernel source ({summary.get('commit', '?')}), profiles/r02/pmc_summary.json"

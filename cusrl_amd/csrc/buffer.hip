@@ -68,10 +68,11 @@ constexpr int kGatherOpsPerBlock = kBlock * kGatherItems;
 struct GatherLeaf {
     const char *src;
     char *dst;
-    int32_t row_bytes;
+    int32_t src_pitch;      // bytes between consecutive source rows: the row size, or the record size for a leaf that
+                            // is read out of (dst_pitch: written into) the per-slot record
     int32_t unit;           // bytes per lane-op: 16 / 8 / 4 / 2 / 1;  0 = "four 1-byte rows packed"
-    int32_t lanes_per_row;  // row_bytes / unit
-    int32_t pad;
+    int32_t lanes_per_row;  // row bytes / unit
+    int32_t dst_pitch;
 };
 
 struct GatherTable {  // same two-round-trip kernarg layout as PushTable
@@ -115,7 +116,7 @@ __device__ __forceinline__ void pin_loaded(uint8_t (&r)[kGatherItems]) {
 template <typename V>
 __device__ __forceinline__ void gather_unit(const char *__restrict__ src, char *__restrict__ dst,
                                             const int64_t *__restrict__ idx, int64_t ops, int64_t op0, int lpr,
-                                            int64_t row_bytes, int64_t B, int64_t N, bool temporal) {
+                                            int64_t src_pitch, int64_t dst_pitch, int64_t B, int64_t N, bool temporal) {
     int64_t row[kGatherItems], col[kGatherItems], src_row[kGatherItems];
 #pragma unroll
     for (int it = 0; it < kGatherItems; ++it) {
@@ -128,7 +129,10 @@ __device__ __forceinline__ void gather_unit(const char *__restrict__ src, char *
             col[it] = op - row[it] * lpr;
         }
     }
-    if (temporal) {
+    if (idx == nullptr) {  // identity: a strided row copy (building the per-slot record from the leaves)
+#pragma unroll
+        for (int it = 0; it < kGatherItems; ++it) src_row[it] = row[it];
+    } else if (temporal) {
 #pragma unroll
         for (int it = 0; it < kGatherItems; ++it) {
             const int64_t t = row[it] / B, b = row[it] - t * B;
@@ -141,14 +145,14 @@ __device__ __forceinline__ void gather_unit(const char *__restrict__ src, char *
     V regs[kGatherItems];
 #pragma unroll
     for (int it = 0; it < kGatherItems; ++it)
-        regs[it] = *reinterpret_cast<const V *>(src + src_row[it] * row_bytes + col[it] * int64_t(sizeof(V)));
+        regs[it] = *reinterpret_cast<const V *>(src + src_row[it] * src_pitch + col[it] * int64_t(sizeof(V)));
     pin_loaded(regs);  // all row loads are in flight before the first store (hipcc otherwise re-interleaves
                        // load / wait / store per item, i.e. one exposed memory latency per item)
     // stores are unconditional as well: a clamped lane-op rewrites the last element with the identical bytes, which
     // keeps the whole body branch-free (with masked stores LLVM sinks each load into its store's block again)
 #pragma unroll
     for (int it = 0; it < kGatherItems; ++it)
-        *reinterpret_cast<V *>(dst + row[it] * row_bytes + col[it] * int64_t(sizeof(V))) = regs[it];
+        *reinterpret_cast<V *>(dst + row[it] * dst_pitch + col[it] * int64_t(sizeof(V))) = regs[it];
 }
 
 // 1-byte leaves (terminated / truncated / done): one lane gathers 4 consecutive output rows (4 index loads, then 4
@@ -191,10 +195,10 @@ __device__ __forceinline__ void gather_bytes_packed(const char *__restrict__ src
 // static kernarg offset and no register image of the record has to be indexed at run time (that would live in scratch).
 struct RecordTable {
     int32_t n4, n2, n1;
-    int32_t record_bytes;              // 16, 32 or 64
-    uint8_t offset[CUSRL_MAX_PACKED];  // byte offset inside the record
-    uint8_t stride[CUSRL_MAX_PACKED];  // bytes between consecutive rows of the leaf (its row size)
-    char *ptr[CUSRL_MAX_PACKED];       // pack: source leaf (+ byte offset);  gather: destination tensor (+ byte offset)
+    int32_t record_bytes;               // a multiple of 16, at most CUSRL_MAX_RECORD_BYTES
+    uint16_t offset[CUSRL_MAX_PACKED];  // byte offset inside the record
+    uint8_t stride[CUSRL_MAX_PACKED];   // bytes between consecutive rows of the leaf (its row size)
+    char *ptr[CUSRL_MAX_PACKED];        // pack: source leaf (+ byte offset);  gather: destination tensor (+ byte offset)
 };
 
 constexpr int kRecordRowsPerBlock = kBlock;  // one sampled slot per lane; parallelism inside a lane = the fields
@@ -216,17 +220,17 @@ struct WaveRecordTable {
     __device__ __forceinline__ int n2() const { return int(dword(1)); }
     __device__ __forceinline__ int n1() const { return int(dword(2)); }
     __device__ __forceinline__ int record_bytes() const { return int(dword(3)); }
-    __device__ __forceinline__ int offset(int f) const { return (dword(4 + f / 4) >> (8 * (f % 4))) & 0xff; }
+    __device__ __forceinline__ int offset(int f) const { return (dword(4 + f / 2) >> (16 * (f % 2))) & 0xffff; }
     __device__ __forceinline__ int stride(int f) const {
-        return (dword(4 + CUSRL_MAX_PACKED / 4 + f / 4) >> (8 * (f % 4))) & 0xff;
+        return (dword(4 + CUSRL_MAX_PACKED / 2 + f / 4) >> (8 * (f % 4))) & 0xff;
     }
     __device__ __forceinline__ char *ptr(int f) const {
-        const int base = 4 + CUSRL_MAX_PACKED / 2 + 2 * f;
+        const int base = 4 + CUSRL_MAX_PACKED / 2 + CUSRL_MAX_PACKED / 4 + 2 * f;
         return reinterpret_cast<char *>(uint64_t(dword(base)) | (uint64_t(dword(base + 1)) << 32));
     }
 };
-static_assert(offsetof(RecordTable, offset) == 16 && offsetof(RecordTable, stride) == 16 + CUSRL_MAX_PACKED &&
-                  offsetof(RecordTable, ptr) == 16 + 2 * CUSRL_MAX_PACKED,
+static_assert(offsetof(RecordTable, offset) == 16 && offsetof(RecordTable, stride) == 16 + 2 * CUSRL_MAX_PACKED &&
+                  offsetof(RecordTable, ptr) == 16 + 3 * CUSRL_MAX_PACKED,
               "WaveRecordTable decodes this layout");
 
 // One lane = one sampled slot.  Every requested entry is loaded straight from the slot's record (the first load
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const GatherArgs args, c
     char *__restrict__ dst = leaf.dst;
     const int unit = leaf.unit;
     const int lpr = leaf.lanes_per_row;
-    const int64_t row_bytes = leaf.row_bytes;
+    const int64_t src_pitch = leaf.src_pitch, dst_pitch = leaf.dst_pitch;
     const int64_t rows = temporal ? T * B : B;
     const bool temp = temporal != 0;
     if (unit == 0) {  // one packed lane-op per lane: kBlock ops per block
@@ -325,11 +329,11 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const GatherArgs args, c
     const int64_t op0 = int64_t(blk - tab.block_start[f]) * kGatherOpsPerBlock + threadIdx.x;
     const int64_t ops = rows * lpr;
     switch (unit) {
-        case 16: gather_unit<uint4>(src, dst, idx, ops, op0, lpr, row_bytes, B, N, temp); break;
-        case 8: gather_unit<uint2>(src, dst, idx, ops, op0, lpr, row_bytes, B, N, temp); break;
-        case 4: gather_unit<uint32_t>(src, dst, idx, ops, op0, lpr, row_bytes, B, N, temp); break;
-        case 2: gather_unit<uint16_t>(src, dst, idx, ops, op0, lpr, row_bytes, B, N, temp); break;
-        default: gather_unit<uint8_t>(src, dst, idx, ops, op0, lpr, row_bytes, B, N, temp); break;
+        case 16: gather_unit<uint4>(src, dst, idx, ops, op0, lpr, src_pitch, dst_pitch, B, N, temp); break;
+        case 8: gather_unit<uint2>(src, dst, idx, ops, op0, lpr, src_pitch, dst_pitch, B, N, temp); break;
+        case 4: gather_unit<uint32_t>(src, dst, idx, ops, op0, lpr, src_pitch, dst_pitch, B, N, temp); break;
+        case 2: gather_unit<uint16_t>(src, dst, idx, ops, op0, lpr, src_pitch, dst_pitch, B, N, temp); break;
+        default: gather_unit<uint8_t>(src, dst, idx, ops, op0, lpr, src_pitch, dst_pitch, B, N, temp); break;
     }
 }
 
@@ -481,34 +485,52 @@ extern "C" int cusrl_buffer_push(const cusrl_field_t *fields, int n_fields, int6
     return launch_status();
 }
 
+// Splits the packed-field list into (a) narrow entries (1 / 2 / 4 / 8 bytes) for the record kernels' RecordTable and
+// (b) wide fields (a multiple of 16 bytes at a 16-byte-aligned offset: observation, action rows), which are moved as
+// ordinary 16-byte-lane leaves whose source (gather) or destination (pack) pitch is the record size.
+struct WideField {
+    char *ptr;
+    int32_t offset, width;
+};
+
 static int fill_record_table(const cusrl_packed_field_t *packed, int n_packed, int64_t record_bytes,
-                             RecordTable &rec) {
+                             RecordTable &rec, WideField *wide, int &n_wide) {
     rec.n4 = rec.n2 = rec.n1 = 0;
     rec.record_bytes = int32_t(record_bytes);
+    n_wide = 0;
     for (int i = 0; i < CUSRL_MAX_PACKED; ++i) rec.offset[i] = 0, rec.stride[i] = 4, rec.ptr[i] = nullptr;
-    if (n_packed < 0 || n_packed > CUSRL_MAX_PACKED) return CUSRL_E_TOO_MANY;
+    if (n_packed < 0 || n_packed > CUSRL_MAX_PACKED + CUSRL_MAX_FIELDS) return CUSRL_E_TOO_MANY;
     if (n_packed == 0) return 0;
-    if (!packed || (record_bytes != 16 && record_bytes != 32 && record_bytes != 64)) return CUSRL_E_INVALID;
-    uint64_t used = 0;  // one bit per record byte: fields must not overlap
+    if (!packed || record_bytes < 16 || record_bytes % 16 != 0 || record_bytes > CUSRL_MAX_RECORD_BYTES)
+        return CUSRL_E_INVALID;
+    uint8_t used[CUSRL_MAX_RECORD_BYTES] = {0};  // fields must not overlap
     int entries = 0;
     for (int i = 0; i < n_packed; ++i) {
         const int32_t w = packed[i].width, off = packed[i].offset;
-        if (!packed[i].ptr || (w != 1 && w != 2 && w != 4 && w != 8) || off < 0 || off % w != 0 ||
-            off + w > record_bytes || !aligned(packed[i].ptr, uintptr_t(w)))
-            return CUSRL_E_INVALID;
-        const uint64_t bits = ((uint64_t(1) << w) - 1) << off;
-        if (used & bits) return CUSRL_E_INVALID;
-        used |= bits;
-        entries += w == 8 ? 2 : 1;
+        const bool narrow = w == 1 || w == 2 || w == 4 || w == 8;
+        const bool is_wide = w >= 16 && w % 16 == 0;
+        if (!packed[i].ptr || (!narrow && !is_wide) || off < 0 || off + w > record_bytes) return CUSRL_E_INVALID;
+        if (narrow && (off % w != 0 || !aligned(packed[i].ptr, uintptr_t(w)))) return CUSRL_E_INVALID;
+        if (is_wide && (off % 16 != 0 || !aligned(packed[i].ptr, 16))) return CUSRL_E_INVALID;
+        for (int b = off; b < off + w; ++b) {
+            if (used[b]) return CUSRL_E_INVALID;
+            used[b] = 1;
+        }
+        if (is_wide) {
+            if (n_wide == CUSRL_MAX_FIELDS) return CUSRL_E_TOO_MANY;
+            wide[n_wide++] = WideField{static_cast<char *>(packed[i].ptr), off, w};
+        } else {
+            entries += w == 8 ? 2 : 1;
+        }
     }
     if (entries > CUSRL_MAX_PACKED) return CUSRL_E_TOO_MANY;
     int at = 0;
     for (int pass_width : {4, 2, 1}) {  // 4-byte entries first (an 8-byte leaf = two of them), then 2-byte, then 1-byte
         for (int i = 0; i < n_packed; ++i) {
             const int32_t w = packed[i].width, off = packed[i].offset;
-            if ((w == 8 ? 4 : w) != pass_width) continue;
+            if (w >= 16 || (w == 8 ? 4 : w) != pass_width) continue;
             for (int half = 0; half < (w == 8 ? 2 : 1); ++half) {
-                rec.offset[at] = uint8_t(off + 4 * half);
+                rec.offset[at] = uint16_t(off + 4 * half);
                 rec.stride[at] = uint8_t(w);
                 rec.ptr[at] = static_cast<char *>(packed[i].ptr) + 4 * half;
                 ++at;
@@ -519,16 +541,52 @@ static int fill_record_table(const cusrl_packed_field_t *packed, int n_packed, i
     return 0;
 }
 
+static void set_block_tail(GatherTable &tab, int n, int64_t blocks) {
+    for (int i = n; i <= CUSRL_MAX_FIELDS; ++i) tab.block_start[i] = int32_t(blocks);
+    tab.n = n;
+}
+
 extern "C" int cusrl_pack_rows(const cusrl_packed_field_t *fields, int n_fields, void *record, int64_t record_bytes,
                                int64_t rows, void *stream) {
     if (n_fields == 0 || rows == 0) return 0;
     if (!record || rows < 0 || !aligned(record, 16)) return CUSRL_E_INVALID;
-    RecordTable rec;
-    if (int rc = fill_record_table(fields, n_fields, record_bytes, rec)) return rc;
-    const int64_t blocks = ceil_div(rows, kBlock);
-    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), rec,
-                       static_cast<char *>(record), rows);
+    GatherArgs args;
+    RecordTable &rec = args.rec;
+    WideField wide[CUSRL_MAX_FIELDS];
+    int n_wide = 0;
+    if (int rc = fill_record_table(fields, n_fields, record_bytes, rec, wide, n_wide)) return rc;
+    if (n_wide > 0) {  // wide leaves: a strided row copy leaf -> record (the gather kernel without an index vector)
+        GatherTable &tab = args.tab;
+        int64_t blocks = 0;
+        for (int i = 0; i < n_wide; ++i) {
+            GatherLeaf &leaf = tab.leaf[i];
+            leaf.src = wide[i].ptr;
+            leaf.dst = static_cast<char *>(record) + wide[i].offset;
+            leaf.src_pitch = wide[i].width;
+            leaf.dst_pitch = int32_t(record_bytes);
+            leaf.unit = 16;
+            leaf.lanes_per_row = wide[i].width / 16;
+            tab.block_start[i] = int32_t(blocks);
+            blocks += ceil_div(rows * leaf.lanes_per_row, kGatherOpsPerBlock);
+            if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+        }
+        set_block_tail(tab, n_wide, blocks);
+        RecordTable none = rec;
+        none.n4 = none.n2 = none.n1 = 0;
+        GatherArgs copy_args;
+        copy_args.tab = tab;
+        copy_args.rec = none;
+        hipLaunchKernelGGL(gather_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), copy_args,
+                           static_cast<const char *>(nullptr), static_cast<const int64_t *>(nullptr), rows, int64_t(1),
+                           rows, 0);
+        if (int rc = launch_status()) return rc;
+    }
+    if (rec.n4 + rec.n2 + rec.n1 > 0) {
+        const int64_t blocks = ceil_div(rows, kBlock);
+        if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), rec,
+                           static_cast<char *>(record), rows);
+    }
     return launch_status();
 }
 
@@ -544,7 +602,9 @@ extern "C" int cusrl_gather_rows_packed(const cusrl_field_t *fields, int n_field
     GatherArgs args;
     GatherTable &tab = args.tab;
     RecordTable &rec = args.rec;
-    if (int rc = fill_record_table(packed, n_packed, n_packed > 0 ? record_bytes : 16, rec)) return rc;
+    WideField wide[CUSRL_MAX_FIELDS];
+    int n_wide = 0;
+    if (int rc = fill_record_table(packed, n_packed, n_packed > 0 ? record_bytes : 16, rec, wide, n_wide)) return rc;
     int64_t blocks = 0;
     int n = 0;
     for (int i = 0; i < n_fields; ++i) {
@@ -554,8 +614,7 @@ extern "C" int cusrl_gather_rows_packed(const cusrl_field_t *fields, int n_field
         GatherLeaf &leaf = tab.leaf[n];
         leaf.src = static_cast<const char *>(fields[i].src);
         leaf.dst = static_cast<char *>(fields[i].dst);
-        leaf.row_bytes = int32_t(rb);
-        leaf.pad = 0;
+        leaf.src_pitch = leaf.dst_pitch = int32_t(rb);
         int64_t ops;
         if (rb == 1 && aligned(leaf.dst, 4)) {
             leaf.unit = 0;
@@ -572,8 +631,21 @@ extern "C" int cusrl_gather_rows_packed(const cusrl_field_t *fields, int n_field
         if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
         ++n;
     }
-    for (int i = n; i <= CUSRL_MAX_FIELDS; ++i) tab.block_start[i] = int32_t(blocks);
-    tab.n = n;
+    for (int i = 0; i < n_wide; ++i) {  // wide leaves that live in the record: same lanes, source pitch = record size
+        if (n == CUSRL_MAX_FIELDS) return CUSRL_E_TOO_MANY;
+        GatherLeaf &leaf = tab.leaf[n];
+        leaf.src = static_cast<const char *>(record) + wide[i].offset;
+        leaf.dst = wide[i].ptr;
+        leaf.src_pitch = int32_t(record_bytes);
+        leaf.dst_pitch = wide[i].width;
+        leaf.unit = 16;
+        leaf.lanes_per_row = wide[i].width / 16;
+        tab.block_start[n] = int32_t(blocks);
+        blocks += ceil_div(rows * leaf.lanes_per_row, kGatherOpsPerBlock);
+        if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+        ++n;
+    }
+    set_block_tail(tab, n, blocks);
     if (rec.n4 + rec.n2 + rec.n1 > 0) blocks += ceil_div(rows, kRecordRowsPerBlock);
     if (blocks == 0) return 0;
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;

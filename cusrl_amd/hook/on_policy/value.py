@@ -134,7 +134,10 @@ class ValueLoss(Hook):
         curr_value = self.agent.critic.evaluate(state, memory=batch.get("critic_memory"), done=batch["done"])
         batch["curr_value"] = curr_value
         if (fused := FusedPpoObjective.current(self)) is not None:
-            return fused.add_value(curr_value, batch["value"], batch["return"], self.weight, self.loss_clip)
+            # the behaviour-policy value is only read by the clipped form: not touching it keeps the leaf out of the
+            # lazy minibatch (and of the per-slot record, which then fits 256 bytes for the `ppo` buffer)
+            old_value = batch["value"] if self.loss_clip is not None else None
+            return fused.add_value(curr_value, old_value, batch["return"], self.weight, self.loss_clip)
         if self.loss_clip is None:
             loss = nn.functional.mse_loss(batch["return"], curr_value)
         else:

@@ -236,28 +236,57 @@ def window_indices(start: torch.Tensor, env: torch.Tensor, length: int, capacity
 
 
 class RecordPack:
-    """The narrow leaves of a rollout buffer (1-8 bytes per slot: log-prob, value, reward, next_value, advantage,
-    return, flags) interleaved into ONE record per slot, so that a randomly sampled slot costs one memory sector instead
-    of one per leaf.  ``build()`` (re)writes the record from the leaves — once per update, after the ``pre_update`` hooks
-    have produced their fields; :func:`gather_rows_packed` then reads the record instead of the leaves."""
+    """Leaves of a rollout buffer interleaved into ONE record per slot, so that a randomly sampled slot costs as few
+    128-byte memory lines as possible (MI355X fetches a whole line for a random row of any size <= 128 B, measured:
+    profiles/r02/pmc_summary.json).  Two uses:
 
-    SIZES = (16, 32, 64)
+    * the narrow leaves (1-8 bytes per slot: log-prob, value, reward, next_value, advantage, return, flags): 27 B of the
+      ``ppo`` buffer -> one 32-byte record instead of nine separate line fetches;
+    * the HOT set — every leaf one training step reads, wide ones included (observation 192 B + action 48 B + log-prob,
+      advantage, return 12 B + done 1 B = 253 B -> a 256-byte record = exactly two lines per sampled slot).
+
+    ``build()`` (re)writes the record from the leaves — once per update, after the ``pre_update`` hooks have produced
+    their fields; :func:`gather_rows_packed` then reads the record instead of the leaves.  Layout: wide leaves (a
+    multiple of 16 bytes) first at 16-byte offsets, then 8/4-byte, 2-byte and 1-byte entries; the record size is the next
+    of 16 / 32 / 64 / a multiple of 128 bytes."""
+
+    NARROW = (1, 2, 4, 8)
+    MAX_BYTES = 1024
 
     @staticmethod
-    def eligible(storage: torch.Tensor) -> bool:
-        return storage.is_cuda and storage.is_contiguous() and storage.dim() >= 2 and _row_bytes(storage, 2) in (1, 2, 4, 8)
+    def eligible(storage: torch.Tensor, wide: bool = False) -> bool:
+        if not (storage.is_cuda and storage.is_contiguous() and storage.dim() >= 2):
+            return False
+        width = _row_bytes(storage, 2)
+        return width in RecordPack.NARROW or (wide and width % 16 == 0 and 0 < width <= 512 and storage.data_ptr() % 16 == 0)
+
+    @staticmethod
+    def _entries(width: int) -> int:
+        return 0 if width >= 16 else (2 if width == 8 else 1)
+
+    @staticmethod
+    def _size(total: int) -> int:
+        return next((size for size in (16, 32, 64) if size >= total), -(-total // 128) * 128)
 
     @classmethod
-    def plan(cls, storages: dict[str, torch.Tensor]) -> list[str]:
-        """Leaves to pack: narrow ones in storage order while they fit 64 bytes / ``MAX_PACKED`` fields; packing a
-        single leaf would only add a copy, so fewer than two means no record at all."""
+    def plan(cls, storages: dict[str, torch.Tensor], hot: Sequence[str] | None = None) -> list[str]:
+        """Leaves to pack.  ``hot`` (leaf names) given: exactly those, wide ones included, when they are all eligible and
+        fit; otherwise the narrow leaves in storage order while they fit 64 bytes / ``MAX_PACKED`` entries (packing a
+        single leaf would only add a copy, so fewer than two means no record at all)."""
+        if hot:
+            chosen = [name for name in storages if name in hot]
+            widths = [_row_bytes(storages[name], 2) for name in chosen]
+            if (len(chosen) >= 2 and all(cls.eligible(storages[name], wide=True) for name in chosen)
+                    and sum(cls._entries(w) for w in widths) <= _native.MAX_PACKED
+                    and sum(1 for w in widths if w >= 16) <= _native.MAX_FIELDS and cls._size(sum(widths)) <= cls.MAX_BYTES):
+                return chosen
         chosen, total, entries = [], 0, 0
         for name, storage in storages.items():
             if not cls.eligible(storage):
                 continue
             width = _row_bytes(storage, 2)
-            slots = 2 if width == 8 else 1  # the kernels move an 8-byte leaf as two 4-byte entries
-            if entries + slots > _native.MAX_PACKED or total + width > cls.SIZES[-1]:
+            slots = cls._entries(width)
+            if entries + slots > _native.MAX_PACKED or total + width > 64:
                 break
             chosen.append(name)
             total += width
@@ -265,22 +294,23 @@ class RecordPack:
         return chosen if len(chosen) >= 2 else []
 
     def __init__(self, storages: dict[str, torch.Tensor]):
-        names = sorted(storages, key=lambda k: -_row_bytes(storages[k], 2))  # widest first: every offset is aligned
+        # widest first: wide leaves land on 16-byte offsets, every narrow entry on a multiple of its width
+        names = sorted(storages, key=lambda k: -_row_bytes(storages[k], 2))
         self.leaves = {name: storages[name] for name in names}
         first = next(iter(self.leaves.values()))
         self.rows = first.shape[0] * first.shape[1]
         self.offsets: dict[str, int] = {}
         offset = 0
         for name, storage in self.leaves.items():
-            if not self.eligible(storage) or storage.shape[0] * storage.shape[1] != self.rows:
+            if not self.eligible(storage, wide=True) or storage.shape[0] * storage.shape[1] != self.rows:
                 raise ValueError(f"leaf '{name}' cannot be packed")
             self.offsets[name] = offset
             offset += _row_bytes(storage, 2)
         self.used_bytes = offset
-        self.record_bytes = next((size for size in self.SIZES if size >= offset), None)
-        entries = sum(2 if _row_bytes(t, 2) == 8 else 1 for t in self.leaves.values())
-        if self.record_bytes is None or entries > _native.MAX_PACKED:
-            raise ValueError("the packed leaves exceed one 64-byte record / 16 entries")
+        self.record_bytes = self._size(offset)
+        widths = [_row_bytes(t, 2) for t in self.leaves.values()]
+        if self.record_bytes > self.MAX_BYTES or sum(self._entries(w) for w in widths) > _native.MAX_PACKED:
+            raise ValueError("the packed leaves exceed one record (1024 bytes / 16 narrow entries)")
         self.record = torch.empty((self.rows, self.record_bytes), dtype=torch.uint8, device=first.device)
         self.key = tuple((name, t.data_ptr(), _row_bytes(t, 2)) for name, t in self.leaves.items())
         self._table = (PackedField * len(self.leaves))()

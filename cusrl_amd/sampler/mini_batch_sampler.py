@@ -61,7 +61,8 @@ class MiniBatchSampler(Sampler):
         if not (buffer.full and buffer.cursor == 0):
             raise RuntimeError("MiniBatchSampler requires a full buffer with cursor reset to 0")
         num_samples = self._get_num_samples(buffer)
-        buffer.prepare_sampling()  # the packed narrow-leaf record, once per pass (a flag check when it is current)
+        # the per-slot record, once per pass (a flag check when it is current): the fields earlier passes read, if known
+        buffer.prepare_sampling(self.hot_fields if self.lazy else None)
         perm_device = self.permutation_device or buffer.device
         staged = perm_device != buffer.device
         epoch_indices = torch.randperm(num_samples, device=perm_device)

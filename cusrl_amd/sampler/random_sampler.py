@@ -48,7 +48,7 @@ class RandomSampler(_RandomBase):
 
     def __call__(self, buffer: Buffer):
         num_samples = (buffer.capacity if buffer.full else buffer.cursor) * buffer.get_parallelism()
-        buffer.prepare_sampling()
+        buffer.prepare_sampling(self.hot_fields if self.lazy else None)
         previous = None
         for batch_index in range(self.num_batches):
             metadata = {"batch_index": batch_index, "total_batches": self.num_batches, "temporal": False}
@@ -81,7 +81,7 @@ class TemporalRandomSampler(_RandomBase):
         if sequence_len == 0:
             raise RuntimeError("TemporalRandomSampler can sample only from a non-empty buffer")
         num_starts = valid_sequence_len - sequence_len + 1  # starts live in logical time (oldest valid step = 0)
-        buffer.prepare_sampling()
+        buffer.prepare_sampling(self.hot_fields if self.lazy else None)
         previous = None
         for batch_index in range(self.num_batches):
             metadata = {"batch_index": batch_index, "total_batches": self.num_batches, "temporal": True}

@@ -186,7 +186,11 @@ class Buffer(MutableMapping):
         # narrow leaves interleaved into one record per slot for the minibatch gather (ops.RecordPack); rebuilt by
         # prepare_sampling() after anything could have written to a packed leaf
         self.pack_narrow_leaves = True
+        self.pack_hot_fields = True
         self._pack = None
+        self._pack_hot = None
+        self._hot_fields: set[str] = set()
+        self._hot_dirty = False
         self._pack_valid = False
         # bumped whenever a storage tensor or the packed record is (re)allocated: captured hipGraphs bake those
         # addresses in and compare this number before replaying (template/graphs.py)
@@ -205,6 +209,7 @@ class Buffer(MutableMapping):
         self._push_plan = None
         self._pack = None
         self._pack_valid = False
+        self._hot_dirty = bool(self._hot_fields)  # the field names stay known; their leaves are re-resolved
         self.layout_version += 1
 
     def reset_cursor(self):
@@ -399,16 +404,33 @@ class Buffer(MutableMapping):
         batch = {key: sampler(key, tensor) for key, tensor in self.storage.items()}
         return reconstruct_nested(batch, self.schema)
 
-    def prepare_sampling(self) -> None:
-        """Refresh the packed record of the narrow leaves (one launch, ``cusrl_pack_rows``) if anything could have
-        written to them since it was built.  The samplers call this once per pass before the first minibatch; it is a
-        flag check when nothing changed.  Must run OUTSIDE hipGraph capture (captured steps only *read* the record)."""
+    def prepare_sampling(self, hot_fields=None) -> None:
+        """Refresh the per-slot record (``cusrl_pack_rows``) if anything could have written to its leaves since it was
+        built.  The samplers call this once per pass before the first minibatch; it is a flag check when nothing changed.
+        ``hot_fields``: the top-level fields the consumer is known to read (a sampler's ``hot_fields``); once known, the
+        record holds exactly their leaves — wide ones included — so a sampled slot is two memory lines; before that
+        (first pass) it holds the narrow leaves.  Must run OUTSIDE hipGraph capture (captured steps only *read* it)."""
+        if hot_fields and self.pack_hot_fields:
+            # the union over all consumers, so that two samplers with different appetites do not re-plan the record in turns
+            known, schema = self._hot_fields, self.schema
+            fresh = [name for name in hot_fields if name not in known and name in schema]
+            if fresh:
+                known.update(fresh)
+                self._hot_dirty = True
+        if self._hot_dirty:
+            self._hot_dirty = False
+            hot = None
+            if self._hot_fields and self.pack_hot_fields:
+                hot = tuple(key for name in self.schema if name in self._hot_fields for _, key in iterate_nested(self.schema[name]))
+            if hot != self._pack_hot:
+                self._pack_hot = hot
+                self._pack_valid = False
         if self._pack_valid:
             return
         if not self.pack_narrow_leaves or self.device.type != "cuda":
             self._pack = None
             return
-        names = ops.RecordPack.plan(self.storage)
+        names = ops.RecordPack.plan(self.storage, hot)
         if not names:
             self._pack = None
             return

@@ -198,7 +198,9 @@ class GraphedTrainStep:
             self.state = 0
         self.static_indices.copy_(indices)
         self.metadata = dict(metadata)
-        agent.buffer.prepare_sampling()  # the captured gather reads the packed record: keep it current (flag check)
+        # the captured gather reads the per-slot record: keep it current (flag check); once the warm-up has learned which
+        # fields the step reads, the record holds exactly those (two memory lines per sampled slot)
+        agent.buffer.prepare_sampling(self.hot_fields)
         if agent.flat_optimizer is not None:
             agent.flat_optimizer.refresh()  # learning-rate changes reach the captured step through device memory
         signature = (capture_signature(agent), agent.buffer.layout_version)

@@ -27,7 +27,8 @@ extern "C" {
 
 #define CUSRL_ABI_VERSION 2
 #define CUSRL_MAX_FIELDS 24 /* leaves per push / gather launch; larger tables are split by the host */
-#define CUSRL_MAX_PACKED 16 /* narrow leaves interleaved into one per-slot record (cusrl_pack_rows) */
+#define CUSRL_MAX_PACKED 16 /* 1-8 byte entries of the per-slot record (cusrl_pack_rows); wide fields count as leaves */
+#define CUSRL_MAX_RECORD_BYTES 1024
 
 #define CUSRL_E_INVALID (-1)     /* NULL pointer, negative size, inconsistent arguments */
 #define CUSRL_E_TOO_MANY (-2)    /* n_fields > CUSRL_MAX_FIELDS */
@@ -121,14 +122,17 @@ int cusrl_gather_rows(const cusrl_field_t *fields, int n_fields, const int64_t *
  * A minibatch row of a 1-8 byte leaf (action_logp, value, reward, next_value, advantage, return, the three flags of
  * the `ppo` buffer) costs one memory sector per leaf when fetched from a random slot.  cusrl_pack_rows interleaves
  * such leaves ONCE per update into one record per slot — record[s] = { field_0[s], field_1[s], ... } at the given
- * byte offsets, record_bytes in {16, 32, 64}, `record` 16-byte aligned — and cusrl_gather_rows_packed gathers the
- * wide leaves as cusrl_gather_rows does plus, for every sampled slot, ONE record read fanned out to the separate
- * contiguous batch tensors (dst_k[b] = field_k of record[slot(b)]): identical results, one sector instead of ten.
- * The host keeps the record valid (rebuilds it after any write to a packed leaf). */
+ * byte offsets, record_bytes a multiple of 16 up to CUSRL_MAX_RECORD_BYTES, `record` 16-byte aligned — and
+ * cusrl_gather_rows_packed gathers the plain leaves as cusrl_gather_rows does plus, for every sampled slot, ONE record
+ * read fanned out to the separate contiguous batch tensors (dst_k[b] = field_k of record[slot(b)]): identical results.
+ * Wide leaves (a multiple of 16 bytes per slot: observation, action) may live in the record as well: when the record
+ * holds exactly what a training step reads (253 B for the `ppo` preset -> 256 B, two 128-byte memory lines), a sampled
+ * slot costs 256 fetched bytes instead of ~550 (measured 128 B per random row of ANY size <= 128 B on MI355X:
+ * profiles/r02/pmc_summary.json).  The host keeps the record valid (rebuilds it after any write to a packed leaf). */
 typedef struct {
     void *ptr;      /* pack: source leaf base [rows, width] (read only); gather: destination base [B or T*B, width] */
-    int32_t offset; /* byte offset of the field inside the record; a multiple of width */
-    int32_t width;  /* 1, 2, 4 or 8 bytes */
+    int32_t offset; /* byte offset of the field inside the record; a multiple of min(width, 16) */
+    int32_t width;  /* 1, 2, 4, 8 bytes, or any multiple of 16 (wide field) */
 } cusrl_packed_field_t;
 int cusrl_pack_rows(const cusrl_packed_field_t *fields, int n_fields, void *record, int64_t record_bytes,
                     int64_t rows, void *stream);

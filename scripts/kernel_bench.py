@@ -130,6 +130,11 @@ def bench_size(N, T=24, obs=48, act=12, mbs=4, only=None, iters=None):
     hot_bytes = B * (2 * (4 * obs + 4 * act + 17) + 8)
     rows.measure(f"gather hot leaves via record (B={B})",
                  lambda: ops.gather_rows_packed([leaves[0], leaves[3]], pack, hot, idx, T, N), hot_bytes)
+    hot_pack = ops.RecordPack({"observation": leaves[0], "action": leaves[3], "logp": leaves[4], "advantage": leaves[12],
+                               "return": leaves[13], "done": done})
+    rows.measure("pack hot record (once per update)", hot_pack.build, S * (hot_pack.used_bytes + hot_pack.record_bytes))
+    rows.measure(f"gather hot leaves from the 256 B hot record (B={B})",
+                 lambda: ops.gather_rows_packed([], hot_pack, list(hot_pack.leaves), idx, T, N), B * (2 * hot_pack.used_bytes + 8))
     rows.measure(f"gather all leaves via record (B={B})",
                  lambda: ops.gather_rows_packed([leaves[0], leaves[1], leaves[2], leaves[3], leaves[6]], pack, names, idx, T, N),
                  B * (2 * row + 8))

@@ -10,7 +10,8 @@ Calibration cases (sizes far beyond the 256 MB Infinity Cache, distinct rows, so
   random_rows_32B   gather of 8 Mi distinct random rows of a 32-byte-row leaf (what the packed record turns them into)
   random_rows_192B  gather of 2 Mi distinct random rows of a 192-byte-row leaf (an observation row)
 Product cases at config 2 (4096 envs x 24 steps, minibatch of 24 576 slots; working set L2 / MALL resident):
-  gather_minibatch_hot_leaves   what the captured train step launches (7 leaves, 5 of them through the record)
+  gather_minibatch_hot_record   what the captured train step launches: 6 leaves out of the 256-byte hot record
+  gather_minibatch_hot_leaves   the same leaves + value with only the narrow ones in a (32-byte) record
   gather_minibatch_all_leaves   the reference's semantics: all 14 leaves (9 through the record)
   gather_minibatch_all_plain    all 14 leaves without the record (the round-1 kernel's access pattern)
   pack_rows                     building the record (once per update)
@@ -79,6 +80,11 @@ def main(out_dir):
     hot_bytes = B * (2 * (4 * obs + 4 * act + 17) + 8)
     run("gather_minibatch_hot_leaves", lambda: ops.gather_rows_packed([leaves[k] for k in hot_plain], pack, hot_packed, perm, T, N),
         "gather_kernel", wide_blocks(hot_plain) + record_blocks, hot_bytes)
+    hot_pack = ops.RecordPack({k: leaves[k] for k in ("observation", "action", "logp", "advantage", "return", "done")})
+    run("pack_hot_record", hot_pack.build, "gather_kernel", blocks_plain(S, 192, 16) + blocks_plain(S, 48, 16),
+        S * (hot_pack.used_bytes + hot_pack.record_bytes))  # (its narrow entries go through pack_rows_kernel: second launch)
+    run("gather_minibatch_hot_record", lambda: ops.gather_rows_packed([], hot_pack, list(hot_pack.leaves), perm, T, N), "gather_kernel",
+        blocks_plain(B, 192, 16) + blocks_plain(B, 48, 16) + record_blocks, B * (2 * hot_pack.used_bytes + 8))
     all_plain = [k for k in leaves if k not in narrow_names]
     all_bytes = B * (2 * 555 + 8)
     run("gather_minibatch_all_leaves", lambda: ops.gather_rows_packed([leaves[k] for k in all_plain], pack, narrow_names, perm, T, N),

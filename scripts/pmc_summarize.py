@@ -52,7 +52,7 @@ def main(directory, out_path):
     # the read counter tallies each memory-side request at 64 B: a streaming 128-byte request counts half (factor 2);
     # a random row shorter than a request is ONE request (raw ~64 B per 4- or 32-byte row), so for the row part of a
     # gather raw x 2 is an UPPER bound (request = 128 B) and raw x 1 a LOWER bound (request = 64 B)
-    for name in ("gather_minibatch_hot_leaves", "gather_minibatch_all_leaves", "gather_minibatch_all_plain", "pack_rows"):
+    for name in ("gather_minibatch_hot_record", "pack_hot_record", "gather_minibatch_hot_leaves", "gather_minibatch_all_leaves", "gather_minibatch_all_plain", "pack_rows"):
         entry = out["cases"].get(name)
         if entry and entry["fetch_raw"] is not None and entry["write_raw"] is not None:
             lo, hi = entry["fetch_raw"] + entry["write_raw"], 2 * entry["fetch_raw"] + entry["write_raw"]

@@ -34,31 +34,35 @@ def main():
     spent = defaultdict(float)
     clock = time.perf_counter
     begin = clock()
+    from cusrl_amd import ops
+
+    counter = ops.HostCounter()
+    slots = torch.empty(args.envs, dtype=torch.int64, device="cuda:0")
     for _ in range(args.steps):
         t0 = clock()
         action = agent.act(observation, state)
         t1 = clock()
         next_observation, next_state, reward, terminated, truncated, info = env.step(action)
         t2 = clock()
+        done = torch.empty_like(terminated)
+        stats.track_fused(reward, terminated, truncated, done, slots, counter.arm())  # the fused step epilogue
+        t3 = clock()
         agent.inference_mode = True  # keep the buffer from filling: no update inside this loop
-        agent.step(next_observation, reward, terminated, truncated, next_state, **info)
+        agent.step(next_observation, reward, terminated, truncated, next_state, **info, done=done)
         agent.inference_mode = False
         agent.buffer.push(agent.transition)
-        t3 = clock()
-        done = agent.transition["done"]
-        stats.track(reward, done)
         t4 = clock()
-        indices = trainer._done_indices(done)
+        indices = slots[: counter.wait()]
         t5 = clock()
         if indices.numel():
             init_observation, init_state, _ = env.reset(indices=indices)
-            next_observation, next_state = update_observation_and_state(next_observation, next_state, indices, init_observation, init_state)
+            next_observation, next_state = trainer._splice_resets(next_observation, next_state, indices, init_observation, init_state)
         t6 = clock()
         observation, state = next_observation, next_state
         if agent.buffer.full:
             agent.buffer.clear() if hasattr(agent.buffer, "clear") else None
-        for name, a, b in (("act (graph replay)", t0, t1), ("env.step", t1, t2), ("agent.step + push", t2, t3),
-                           ("stats.track", t3, t4), ("done indices (sync)", t4, t5), ("reset + patch", t5, t6)):
+        for name, a, b in (("act (graph replay)", t0, t1), ("env.step", t1, t2), ("step epilogue launch", t2, t3),
+                           ("agent.step + push", t3, t4), ("finished-env count (poll)", t4, t5), ("reset + patch", t5, t6)):
             spent[name] += b - a
     torch.cuda.synchronize()
     total = clock() - begin

@@ -201,7 +201,9 @@ def test_config2_and_3_full_size_iteration(cusrl, num_envs):
         assert torch.equal(batch["reward"], buffer["reward"].flatten(0, 1)[slots])           # through the packed record
         assert torch.equal(batch["done"], buffer["done"].flatten(0, 1)[slots])
     assert bool((seen == 2).all())
-    assert "slot" in buffer._pack.leaves  # int64 slot leaf rides the record as two 4-byte entries
+    # after the first update the record holds exactly what a training step reads: 253 B -> 256 B, two memory lines a slot
+    assert set(buffer._pack.leaves) == {"observation", "action", "action_logp", "advantage", "return", "done"}
+    assert buffer._pack.record_bytes == 256 and buffer._pack.used_bytes == 253
 
 
 # ------------------------------------------------------------------------------------------------ config 4

@@ -167,6 +167,45 @@ def test_packed_gather_bit_exact(ops, T, N, B, kinds):
     assert np.array_equal(host(again), oracle.gather_rows(narrow[first][::-1], idx))
 
 
+@pytest.mark.parametrize("T,N,B", [(24, 256, 1536), (3, 5, 15), (2, 4099, 1000)])
+def test_hot_record_with_wide_leaves_bit_exact(ops, T, N, B):
+    """The per-slot record holding WIDE leaves too (observation 192 B, action 48 B, three floats, a flag = 253 -> 256 B,
+    what a `ppo` training step reads): pack + gather against the oracle's plain gather of the same leaves."""
+    rng = np.random.default_rng(T + N)
+    leaves = {
+        "observation": rng.standard_normal((T, N, 48)).astype(np.float32),
+        "action": rng.standard_normal((T, N, 12)).astype(np.float32),
+        "action_logp": rng.standard_normal((T, N, 1)).astype(np.float32),
+        "advantage": rng.standard_normal((T, N, 1)).astype(np.float32),
+        "return": rng.standard_normal((T, N, 1)).astype(np.float32),
+        "done": rng.random((T, N, 1)) < 0.3,
+    }
+    other = rng.standard_normal((T, N, 3)).astype(np.float32)  # a leaf outside the record, same launch
+    storages = {k: dev(v) for k, v in leaves.items()}
+    assert ops.RecordPack.plan(storages, hot=list(storages)) == list(storages)
+    pack = ops.RecordPack(storages)
+    assert pack.record_bytes == 256 and pack.used_bytes == 253
+    assert pack.offsets["observation"] == 0 and pack.offsets["action"] == 192 and pack.offsets["done"] == 252
+    pack.build()
+    record = host(pack.record).reshape(T * N, 256)
+    assert np.array_equal(record[:, :192].copy().view(np.float32), leaves["observation"].reshape(T * N, 48))
+    assert np.array_equal(record[:, 192:240].copy().view(np.float32), leaves["action"].reshape(T * N, 12))
+    assert np.array_equal(record[:, 252].astype(bool), leaves["done"].reshape(-1))
+    idx = rng.permutation(T * N)[:B].astype(np.int64)
+    names = list(leaves)
+    (plain,), packed = ops.gather_rows_packed([dev(other)], pack, names, dev(idx), T, N)
+    assert np.array_equal(host(plain), oracle.gather_rows(other, idx))
+    for name, out in zip(names, packed):
+        assert out.dtype == storages[name].dtype and out.is_contiguous()
+        assert np.array_equal(host(out), oracle.gather_rows(leaves[name], idx)), name
+    env_idx = rng.permutation(N)[: max(N // 2, 1)].astype(np.int64)
+    _, packed = ops.gather_rows_packed([], pack, ["action", "done", "observation"], dev(env_idx), T, N, temporal=True)
+    for name, out in zip(["action", "done", "observation"], packed):
+        assert np.array_equal(host(out), oracle.gather_rows(leaves[name], env_idx, temporal=True)), name
+    # a leaf that does not fit the plan (3 floats = 12 bytes: neither narrow nor a multiple of 16) keeps the narrow record
+    assert ops.RecordPack.plan({**storages, "odd": dev(other)}, hot=list(storages) + ["odd"]) == ["action_logp", "advantage", "return", "done"]
+
+
 def test_packed_gather_argument_errors(ops):
     """Negative return codes of the two entry points, straight through ctypes."""
     from cusrl_amd import _native
@@ -181,8 +220,9 @@ def test_packed_gather_argument_errors(ops):
     table[1].ptr, table[1].offset, table[1].width = leaf.data_ptr(), 2, 4                      # misaligned, overlapping
     assert lib.cusrl_pack_rows(table, 2, record.data_ptr(), 16, 8, None) == -1                # CUSRL_E_INVALID
     table[1].offset = 4
-    assert lib.cusrl_pack_rows(table, 2, record.data_ptr(), 24, 8, None) == -1                # record size not 16/32/64
-    assert lib.cusrl_pack_rows(table, 17, record.data_ptr(), 16, 8, None) == -2               # CUSRL_E_TOO_MANY
+    assert lib.cusrl_pack_rows(table, 2, record.data_ptr(), 24, 8, None) == -1                # record size not a multiple of 16
+    assert lib.cusrl_pack_rows(table, 2, record.data_ptr(), 2048, 8, None) == -1              # beyond CUSRL_MAX_RECORD_BYTES
+    assert lib.cusrl_pack_rows(table, 41, record.data_ptr(), 16, 8, None) == -2               # CUSRL_E_TOO_MANY
     table[1].width = 3
     assert lib.cusrl_pack_rows(table, 2, record.data_ptr(), 16, 8, None) == -1                # unsupported width
     table[1].width, table[0].ptr = 4, out.data_ptr()
