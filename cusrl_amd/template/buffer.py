@@ -430,7 +430,7 @@ class Buffer(MutableMapping):
         if not self.pack_narrow_leaves or self.device.type != "cuda":
             self._pack = None
             return
-        names = ops.RecordPack.plan(self.storage, hot)
+        names = ops.RecordPack.plan(self.storage, self._pack_hot)
         if not names:
             self._pack = None
             return

@@ -170,7 +170,7 @@ def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--envs", type=int, nargs="+", default=[4096, 1048576])
     parser.add_argument("--json", type=str, default=None)
-    parser.add_argument("--only", type=str, default=None, help="substring filter on row names (PMC passes)")
+    parser.add_argument("--only", type=str, nargs="+", default=None, help="substring filter(s) on row names")
     parser.add_argument("--iters", type=int, default=None)
     parser.add_argument("--mbs", type=int, default=4, help="minibatches per epoch (1 = gather the whole buffer)")
     parser.add_argument("--eager", action="store_true", help="time eager launches (includes host launch overhead)")
@@ -179,7 +179,7 @@ def main():
     USE_GRAPH = not args.eager
     report = {}
     for N in args.envs:
-        rows = bench_size(N, mbs=args.mbs, only=args.only, iters=args.iters)
+        rows = bench_size(N, mbs=args.mbs, only=None if args.only is None else tuple(args.only), iters=args.iters)
         print(f"\n== N = {N} envs, T = 24 ==")
         print(f"{'kernel':42s} {'us/launch':>10s} {'MB':>9s} {'GB/s':>9s} {'% of 8TB/s':>10s}")
         report[str(N)] = {}

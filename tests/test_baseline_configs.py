@@ -201,9 +201,18 @@ def test_config2_and_3_full_size_iteration(cusrl, num_envs):
         assert torch.equal(batch["reward"], buffer["reward"].flatten(0, 1)[slots])           # through the packed record
         assert torch.equal(batch["done"], buffer["done"].flatten(0, 1)[slots])
     assert bool((seen == 2).all())
-    # after the first update the record holds exactly what a training step reads: 253 B -> 256 B, two memory lines a slot
-    assert set(buffer._pack.leaves) == {"observation", "action", "action_logp", "advantage", "return", "done"}
-    assert buffer._pack.record_bytes == 256 and buffer._pack.used_bytes == 253
+    # the next pass of the same consumer finds a record holding exactly the fields it read (observation 192 B, the int64
+    # slot as two 4-byte entries, reward, done = 205 B -> 256 B: two memory lines per sampled slot) and gets the same rows
+    assert sampler.hot_fields >= {"slot", "observation", "reward", "done"}
+    seen.zero_()
+    for metadata, batch in sampler(buffer):
+        assert set(buffer._pack.leaves) == {"observation", "slot", "reward", "done"} and buffer._pack.record_bytes == 256
+        slots = batch["slot"].squeeze(-1)
+        seen[slots] += 1
+        assert torch.equal(batch["observation"], buffer.storage["observation"].flatten(0, 1)[slots])
+        assert torch.equal(batch["reward"], buffer.storage["reward"].flatten(0, 1)[slots])
+        assert torch.equal(batch["done"], buffer.storage["done"].flatten(0, 1)[slots])
+    assert bool((seen == 2).all())
 
 
 # ------------------------------------------------------------------------------------------------ config 4
