@@ -252,6 +252,9 @@ class OneHotCategoricalDist(Distribution):
     Factory = OneHotCategoricalDistFactory
     is_normal = False
     is_categorical = True  # the fused PPO objective has a one-hot categorical form (cusrl_ppo_loss_categorical_fwd_bwd)
+    # torch.distributions.Categorical validates its arguments with a host read-back when it is constructed: sampling from
+    # it cannot be captured into a hipGraph, so `compile=True` leaves the act step of a discrete policy eager
+    capture_safe = False
 
     @staticmethod
     def _dist(dist_params):

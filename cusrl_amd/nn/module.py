@@ -100,7 +100,8 @@ class _WideBatchLinear(torch.autograd.Function):
             ctx.save_for_backward(input, weight)
         ctx.splits, ctx.relu, ctx.has_bias = splits, relu, bias is not None
         ctx.bias_key = bias.data_ptr() if bias is not None else None
-        ctx.narrow = (not relu) and input.is_contiguous() and weight.is_contiguous() and _narrow_head(weight)
+        ctx.narrow = ((not relu) and input.is_contiguous() and weight.is_contiguous() and input.data_ptr() % 16 == 0
+                      and _narrow_head(weight))
         ctx.input_is_relu_output = getattr(input, "_cusrl_relu_output", False)
         return output
 
@@ -160,7 +161,8 @@ class _WideBatchLinear(torch.autograd.Function):
 def _narrow_head(weight: torch.Tensor) -> bool:
     from cusrl_amd import ops
 
-    return weight.shape[0] <= 16 and ops.narrow_linear_supported(weight.shape[1], weight.shape[0])
+    return (weight.shape[0] <= 16 and weight.data_ptr() % 16 == 0
+            and ops.narrow_linear_supported(weight.shape[1], weight.shape[0]))
 
 
 def _batch_splits(rows: int) -> int:

@@ -275,6 +275,7 @@ class GraphedAct:
         agent = self.agent
         return (isinstance(observation, torch.Tensor) and observation.is_cuda and not agent.actor.is_recurrent
                 and not agent.critic.is_recurrent and not agent.inference_mode
+                and getattr(agent.actor.distribution, "capture_safe", True)
                 and "act" not in collective_phases(agent))
 
     def run(self, observation: torch.Tensor, state: torch.Tensor | None) -> torch.Tensor:

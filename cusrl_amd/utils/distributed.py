@@ -302,18 +302,26 @@ class FlatGradients:
     def __init__(self, optimizer: torch.optim.Optimizer):
         self.params = [p for group in optimizer.param_groups for p in group["params"] if p.requires_grad]
         device = self.params[0].device
-        total = sum(p.numel() for p in self.params)
+        # every parameter's window starts on a 16-byte boundary (4 floats): the kernels that read weights / write
+        # gradients with 16-byte lanes (narrow-head backward, assembly, Adam) need it, and a [1]-element bias in front
+        # would otherwise shift everything behind it.  The padding slots stay zero (zero gradient -> Adam leaves them 0).
+        self.offsets: list[int] = []
+        total = 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += -(-p.numel() // 4) * 4
         self.buffer = torch.zeros(total, dtype=torch.float32, device=device)
         self.views = []
         self.absent: list[int] = []
-        offset = 0
-        for p in self.params:
+        for p, offset in zip(self.params, self.offsets):
             if p.dtype != torch.float32:
                 raise TypeError("FlatGradients expects fp32 master parameters")
-            n = p.numel()
-            self.views.append(self.buffer[offset : offset + n].view_as(p))
-            offset += n
+            self.views.append(self.buffer[offset : offset + p.numel()].view_as(p))
         self.attach()
+
+    def packed(self) -> torch.Tensor:
+        """The gradients as the reference's ``torch.cat`` would give them (windows without their alignment padding)."""
+        return torch.cat([view.reshape(-1) for view in self.views])
 
     def attach(self):
         for p, view in zip(self.params, self.views):
@@ -333,12 +341,12 @@ class FlatGradients:
         unsummed ``[S, ...]`` partial gradients its split-batch GEMM left behind (cusrl_amd/nn/module.py)."""
         from cusrl_amd import ops
 
-        pieces, offset = [], 0
+        pieces = []
         # parameters autograd returned no gradient for (unused this step): torch's optimizers skip them; the flat Adam
         # step reads this list and leaves their windows untouched (utils/flat_optimizer.py)
         self.absent = [i for i, (p, grad) in enumerate(zip(self.params, grads))
                        if grad is None and not (split_slabs and p.data_ptr() in split_slabs)]
-        for p, grad in zip(self.params, grads):
+        for p, grad, offset in zip(self.params, grads, self.offsets):
             n = p.numel()
             slabs = split_slabs.pop(p.data_ptr(), None) if split_slabs else None
             pending = isinstance(slabs, ops.DeferredColumns)  # partial rows of a column-sum kernel
@@ -350,7 +358,6 @@ class FlatGradients:
                 pieces.append((grad, offset, n, 1))
             else:
                 pieces.append((None, offset, n, 0))
-            offset += n
         if split_slabs:
             raise RuntimeError("split weight gradients were produced for tensors that are not optimizer parameters")
         ops.assemble_gradients(pieces, self.buffer)

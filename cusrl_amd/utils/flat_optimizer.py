@@ -62,16 +62,13 @@ class FlatAdam:
         self.ticket = torch.zeros(1, dtype=torch.int32, device=device)
         self._pending_clip: tuple[torch.Tensor, float | None, torch.Tensor] | None = None
         self._views: list[tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []
-        offset = 0
         with torch.no_grad():
-            for p in self.params:
-                n = p.numel()
-                window = slice(offset, offset + n)
+            for p, offset in zip(self.params, flat_gradients.offsets):  # the same 16-byte-aligned windows as the gradients
+                window = slice(offset, offset + p.numel())
                 view = self.param_buffer[window].view_as(p)
                 view.copy_(p)
                 p.data = view  # same values, storage now inside the flat buffer
                 self._views.append((view, self.exp_avg[window].view_as(p), self.exp_avg_sq[window].view_as(p)))
-                offset += n
         self.adopt_state()
         optimizer.step = self.step  # GradScaler(enabled=False).step(optimizer) and direct calls land here
 

@@ -40,9 +40,9 @@ def main(out_dir: str):
     loss = model(torch.full((5, 3), float(rank + 1))).square().sum()
     loss.backward()
     assert flat.intact()
-    local = flat.buffer.clone()
+    local = flat.packed()
     distributed.reduce_gradients(optimizer, flat)
-    result["flat_local"], result["flat_reduced"] = local.tolist(), flat.buffer.tolist()
+    result["flat_local"], result["flat_reduced"] = local.tolist(), flat.packed().tolist()
     for p in model.parameters():
         p.grad = None
     model(torch.full((5, 3), float(rank + 1))).square().sum().backward()

@@ -859,7 +859,7 @@ def test_flat_backward_with_deferred_sums_matches_plain_autograd():
     assert sum(g is None for g in grads) == len(flat.params)  # every gradient took the deferred route
     flat.assemble(grads, sink)
     want = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss_of(True), flat.params)])
-    torch.testing.assert_close(flat.buffer, want, rtol=2e-4, atol=1e-4 * float(want.abs().max()))
+    torch.testing.assert_close(flat.packed(), want, rtol=2e-4, atol=1e-4 * float(want.abs().max()))
 
 
 def test_fused_linear_paths_match_plain_autograd():

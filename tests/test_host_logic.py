@@ -195,7 +195,8 @@ def test_agent_builds_on_cpu_with_reference_parameter_layout():
     assert names[:3] == ["actor.backbone.layers.0.weight", "actor.backbone.layers.0.bias", "actor.backbone.layers.2.weight"]
     assert names[-2:] == ["critic.value_head.weight", "critic.value_head.bias"] and len(names) == 13
     assert sum(p.numel() for p in agent.parameters()) == 92569  # 13 tensors, 92 569 parameters
-    assert agent.flat_gradients.buffer.numel() == 92569 and agent.flat_gradients.intact()
+    assert agent.flat_gradients.packed().numel() == 92569 and agent.flat_gradients.intact()
+    assert agent.flat_gradients.buffer.numel() == 92572 and all(o % 4 == 0 for o in agent.flat_gradients.offsets)  # 16-byte windows
     groups = agent.optimizer.param_groups
     assert groups[0]["param_names"] == names
     # orthogonal init: zero biases, small policy head
@@ -370,7 +371,7 @@ def test_flat_gradient_assembly_builds_one_piece_per_parameter(monkeypatch):
     flat.assemble([plain, None, None, None, twice_grad], sink)
     assert not sink and len(captured["pieces"]) == 5
     want = torch.cat([plain.reshape(-1), slabs.sum(0), rows[:, 4:8].sum(0), torch.zeros(6), twice_grad + twice_slabs.sum(0)])
-    torch.testing.assert_close(flat.buffer, want)
+    torch.testing.assert_close(flat.packed(), want)
     assert [piece[3] for piece in captured["pieces"]] == [1, 7, 9, 0, 1]
     with pytest.raises(RuntimeError, match="not optimizer parameters"):
         flat.assemble([plain, None, None, None, twice_grad], {12345: slabs})
