@@ -228,7 +228,9 @@ def run_gpu(args, rank, world):
     traffic, traffic_source = pmc_traffic(args.envs_per_gpu)
     dominant = dominant or {"achieved_GBps": 0.0, "bytes_per_launch": 0, "avg_us": 0.0, "rows": 0, "fields": [], "leaves": 0,
                             "packed_leaves": 0, "row_bytes": 0}
-    backend = torch.distributed.get_backend() if world > 1 else None
+    # a one-rank torchrun job still runs every collective (process group of one): report it as what it is
+    in_group = torch.distributed.is_available() and torch.distributed.is_initialized()
+    backend = torch.distributed.get_backend() if in_group else None
     result = {
         "metric": "env_steps_per_sec",
         "value": round(steps_per_iteration * args.steps / elapsed, 1),
@@ -250,8 +252,8 @@ def run_gpu(args, rank, world):
             "parallelism": f"dp{world}",
             "backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend,
             "rccl_ranks": world if backend == "nccl" else 0,
-            "collectives": ("c-abi (cusrl_allreduce_mean captured in the step graph)" if args.native_collectives and world > 1
-                            else "torch.distributed (eager all-reduce between two graphs per step)" if world > 1 else "none"),
+            "collectives": ("c-abi (cusrl_allreduce_mean captured in the step graph)" if args.native_collectives and in_group
+                            else "torch.distributed (eager all-reduce between two graphs per step)" if in_group else "none"),
             "hipgraph": not args.eager,
             "autoreset": args.autoreset,
             "host_thread_cpus": pinned,

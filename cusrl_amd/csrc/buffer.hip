@@ -193,75 +193,137 @@ __device__ __forceinline__ void gather_bytes_packed(const char *__restrict__ src
 // 2 bytes, the rest 1 byte; an 8-byte leaf is two 4-byte entries with a row stride of 8 — so the kernels are three
 // straight-line, compile-time-indexed passes without any per-entry switch: every descriptor read is a load at a
 // static kernarg offset and no register image of the record has to be indexed at run time (that would live in scratch).
+constexpr int kMaxWideInRecord = 8;
+
+struct WideInRecord {  // a wide leaf (a multiple of 16 bytes per slot) living in the record: chunks [first, first + count)
+    char *ptr;         // gather: destination tensor
+    int32_t pitch;     // its row size in bytes
+    uint16_t first_chunk, num_chunks;
+};
+
 struct RecordTable {
     int32_t n4, n2, n1;
     int32_t record_bytes;               // a multiple of 16, at most CUSRL_MAX_RECORD_BYTES
+    int32_t n_wide, used_chunks;        // gather: wide leaves in the record; 16-byte chunks that hold anything
     uint16_t offset[CUSRL_MAX_PACKED];  // byte offset inside the record
     uint8_t stride[CUSRL_MAX_PACKED];   // bytes between consecutive rows of the leaf (its row size)
     char *ptr[CUSRL_MAX_PACKED];        // pack: source leaf (+ byte offset);  gather: destination tensor (+ byte offset)
+    WideInRecord wide[kMaxWideInRecord];
 };
 
-constexpr int kRecordRowsPerBlock = kBlock;  // one sampled slot per lane; parallelism inside a lane = the fields
 constexpr int kRecordTableDwords = sizeof(RecordTable) / 4;
-static_assert(sizeof(RecordTable) % 4 == 0 && kRecordTableDwords <= kWave, "one dword of the table per lane");
+static_assert(sizeof(RecordTable) % 4 == 0 && kRecordTableDwords <= 2 * kWave, "two dwords of the table per lane");
 
 // The table as seen by one wave: lane k holds dword k of the kernarg copy, fetched by ONE vector load (a single
 // round trip to kernarg memory; scalar loads sunk next to each use would be a chain of microsecond misses), and every
 // descriptor is then a v_readlane with a compile-time lane index, i.e. a scalar value again.
 struct WaveRecordTable {
-    uint32_t mine;
+    uint32_t lo, hi;  // lane k holds dwords k and k + 64 of the table
     __device__ __forceinline__ explicit WaveRecordTable(size_t kernarg_offset) {
         const uint32_t *karg = (const uint32_t *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + kernarg_offset);
         const int lane = threadIdx.x & (kWave - 1);
-        mine = karg[lane < kRecordTableDwords ? lane : 0];
+        lo = karg[lane];
+        hi = karg[lane + kWave < kRecordTableDwords ? lane + kWave : 0];
     }
-    __device__ __forceinline__ uint32_t dword(int k) const { return __builtin_amdgcn_readlane(mine, k); }
+    __device__ __forceinline__ uint32_t dword(int k) const {
+        return k < kWave ? __builtin_amdgcn_readlane(lo, k) : __builtin_amdgcn_readlane(hi, k - kWave);
+    }
     __device__ __forceinline__ int n4() const { return int(dword(0)); }
     __device__ __forceinline__ int n2() const { return int(dword(1)); }
     __device__ __forceinline__ int n1() const { return int(dword(2)); }
     __device__ __forceinline__ int record_bytes() const { return int(dword(3)); }
-    __device__ __forceinline__ int offset(int f) const { return (dword(4 + f / 2) >> (16 * (f % 2))) & 0xffff; }
+    __device__ __forceinline__ int n_wide() const { return int(dword(4)); }
+    __device__ __forceinline__ int used_chunks() const { return int(dword(5)); }
+    __device__ __forceinline__ int offset(int f) const { return (dword(6 + f / 2) >> (16 * (f % 2))) & 0xffff; }
     __device__ __forceinline__ int stride(int f) const {
-        return (dword(4 + CUSRL_MAX_PACKED / 2 + f / 4) >> (8 * (f % 4))) & 0xff;
+        return (dword(6 + CUSRL_MAX_PACKED / 2 + f / 4) >> (8 * (f % 4))) & 0xff;
     }
-    __device__ __forceinline__ char *ptr(int f) const {
-        const int base = 4 + CUSRL_MAX_PACKED / 2 + CUSRL_MAX_PACKED / 4 + 2 * f;
+    __device__ __forceinline__ char *pointer_at(int base) const {
         return reinterpret_cast<char *>(uint64_t(dword(base)) | (uint64_t(dword(base + 1)) << 32));
     }
+    __device__ __forceinline__ char *ptr(int f) const { return pointer_at(6 + CUSRL_MAX_PACKED / 2 + CUSRL_MAX_PACKED / 4 + 2 * f); }
+    static constexpr int kWideBase = 6 + CUSRL_MAX_PACKED / 2 + CUSRL_MAX_PACKED / 4 + 2 * CUSRL_MAX_PACKED;
+    __device__ __forceinline__ char *wide_ptr(int k) const { return pointer_at(kWideBase + 4 * k); }
+    __device__ __forceinline__ int wide_pitch(int k) const { return int(dword(kWideBase + 4 * k + 2)); }
+    __device__ __forceinline__ int wide_first(int k) const { return int(dword(kWideBase + 4 * k + 3) & 0xffff); }
+    __device__ __forceinline__ int wide_count(int k) const { return int(dword(kWideBase + 4 * k + 3) >> 16); }
 };
-static_assert(offsetof(RecordTable, offset) == 16 && offsetof(RecordTable, stride) == 16 + 2 * CUSRL_MAX_PACKED &&
-                  offsetof(RecordTable, ptr) == 16 + 3 * CUSRL_MAX_PACKED,
+static_assert(offsetof(RecordTable, offset) == 24 && offsetof(RecordTable, stride) == 24 + 2 * CUSRL_MAX_PACKED &&
+                  offsetof(RecordTable, ptr) == 24 + 3 * CUSRL_MAX_PACKED &&
+                  offsetof(RecordTable, wide) == 24 + 3 * CUSRL_MAX_PACKED + 8 * CUSRL_MAX_PACKED && sizeof(WideInRecord) == 16,
               "WaveRecordTable decodes this layout");
 
-// One lane = one sampled slot.  Every requested entry is loaded straight from the slot's record (the first load
-// misses, the others hit the same 32/64-byte line); all loads are issued before the first store.
-__device__ __forceinline__ void gather_record(const WaveRecordTable &rec, const char *__restrict__ src,
-                                              const int64_t *__restrict__ idx, int64_t rows, int64_t row0, int64_t B,
-                                              int64_t N, bool temporal) {
-    const int64_t out_row = min(row0, rows - 1);  // clamped, unpredicated (see gather_unit)
-    int64_t src_row;
+// Record-major gather: a lane-op is one 16-byte chunk of one sampled slot's record, consecutive lanes take consecutive
+// chunks of the same record.  Every memory line of a record is therefore requested exactly once, by one CU — when the
+// wide leaves of a record were moved by their own blocks (possibly on other XCDs, each with its own L2), the line
+// shared by the observation tail, the action and the narrow fields was measured fetched three times.  A chunk is
+// either part of a wide leaf (stored as a whole to that leaf's batch tensor) or holds narrow entries (fanned out).
+constexpr int kRecordOpsPerBlock = kBlock * kGatherItems;
+
+__device__ __forceinline__ void gather_record_major(const WaveRecordTable &rec, const char *__restrict__ src,
+                                                    const int64_t *__restrict__ idx, int64_t rows, int64_t op0,
+                                                    int64_t B, int64_t N, bool temporal) {
+    const int chunks = rec.used_chunks();
+    const int64_t ops = rows * chunks;
+    const int64_t pitch = rec.record_bytes();
+    int64_t out_row[kGatherItems], src_row[kGatherItems];
+    int chunk[kGatherItems];
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it) {
+        const int64_t op = min(op0 + int64_t(it) * kBlock, ops - 1);  // clamped, unpredicated (see gather_unit)
+        out_row[it] = op / chunks;
+        chunk[it] = int(op - out_row[it] * chunks);
+    }
     if (temporal) {
-        const int64_t t = out_row / B, b = out_row - t * B;
-        src_row = t * N + idx[b];
+#pragma unroll
+        for (int it = 0; it < kGatherItems; ++it) {
+            const int64_t t = out_row[it] / B, b = out_row[it] - t * B;
+            src_row[it] = t * N + idx[b];
+        }
     } else {
-        src_row = idx[out_row];
+#pragma unroll
+        for (int it = 0; it < kGatherItems; ++it) src_row[it] = idx[out_row[it]];
     }
-    const char *slot = src + src_row * rec.record_bytes();
+    uint4 regs[kGatherItems];
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it)
+        regs[it] = *reinterpret_cast<const uint4 *>(src + src_row[it] * pitch + int64_t(chunk[it]) * 16);
+    pin_loaded(regs);
+    const int n_wide = rec.n_wide();
     const int n4 = rec.n4(), n42 = n4 + rec.n2(), n = n42 + rec.n1();
-    uint32_t word[CUSRL_MAX_PACKED];
 #pragma unroll
-    for (int f = 0; f < CUSRL_MAX_PACKED; ++f) {
-        word[f] = 0;
-        if (f < n) word[f] = *reinterpret_cast<const uint32_t *>(slot + (rec.offset(f) & ~3));
-    }
+    for (int it = 0; it < kGatherItems; ++it) {
+        const int c = chunk[it];
+        // wide leaves: which one owns chunk c (per-lane selects over at most 8 descriptors held in scalar registers)
+        char *dst = nullptr;
 #pragma unroll
-    for (int f = 0; f < CUSRL_MAX_PACKED; ++f) {
-        if (f < n) {  // wave-uniform class tests: entries are sorted 4-byte, 2-byte, 1-byte
-            char *dst = rec.ptr(f) + out_row * rec.stride(f);
-            const uint32_t v = word[f] >> ((rec.offset(f) & 3) * 8);
-            if (f < n4) *reinterpret_cast<uint32_t *>(dst) = v;
-            else if (f < n42) *reinterpret_cast<uint16_t *>(dst) = uint16_t(v);
-            else *reinterpret_cast<uint8_t *>(dst) = uint8_t(v);
+        for (int k = 0; k < kMaxWideInRecord; ++k) {
+            if (k < n_wide) {
+                const int first = rec.wide_first(k);
+                const bool mine = c >= first && c < first + rec.wide_count(k);
+                char *candidate = rec.wide_ptr(k) + out_row[it] * rec.wide_pitch(k) + int64_t(c - first) * 16;
+                dst = mine ? candidate : dst;
+            }
+        }
+        if (dst) *reinterpret_cast<uint4 *>(dst) = regs[it];
+        // narrow entries living in chunk c (sorted 4-byte, 2-byte, 1-byte; class tests are wave-uniform)
+#pragma unroll
+        for (int f = 0; f < CUSRL_MAX_PACKED; ++f) {
+            if (f < n) {
+                const int off = rec.offset(f);
+                if ((off >> 4) == c) {
+                    const int sel = (off >> 2) & 3;
+                    uint32_t word = regs[it].x;
+                    word = sel == 1 ? regs[it].y : word;
+                    word = sel == 2 ? regs[it].z : word;
+                    word = sel == 3 ? regs[it].w : word;
+                    word >>= (off & 3) * 8;
+                    char *out = rec.ptr(f) + out_row[it] * rec.stride(f);
+                    if (f < n4) *reinterpret_cast<uint32_t *>(out) = word;
+                    else if (f < n42) *reinterpret_cast<uint16_t *>(out) = uint16_t(word);
+                    else *reinterpret_cast<uint8_t *>(out) = uint8_t(word);
+                }
+            }
         }
     }
 }
@@ -309,8 +371,8 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const GatherArgs args, c
     if (blk >= tab.block_start[CUSRL_MAX_FIELDS]) {  // the blocks behind the last plain leaf unpack the record
         const WaveRecordTable rec(offsetof(GatherArgs, rec));
         const int64_t rows = temporal ? T * B : B;
-        const int64_t row0 = int64_t(blk - tab.block_start[CUSRL_MAX_FIELDS]) * kRecordRowsPerBlock + threadIdx.x;
-        gather_record(rec, record, idx, rows, row0, B, N, temporal != 0);
+        const int64_t op0 = int64_t(blk - tab.block_start[CUSRL_MAX_FIELDS]) * kRecordOpsPerBlock + threadIdx.x;
+        gather_record_major(rec, record, idx, rows, op0, B, N, temporal != 0);
         return;
     }
     const int f = find_leaf(tab, blk);
@@ -497,8 +559,10 @@ static int fill_record_table(const cusrl_packed_field_t *packed, int n_packed, i
                              RecordTable &rec, WideField *wide, int &n_wide) {
     rec.n4 = rec.n2 = rec.n1 = 0;
     rec.record_bytes = int32_t(record_bytes);
+    rec.n_wide = rec.used_chunks = 0;
     n_wide = 0;
     for (int i = 0; i < CUSRL_MAX_PACKED; ++i) rec.offset[i] = 0, rec.stride[i] = 4, rec.ptr[i] = nullptr;
+    for (int i = 0; i < kMaxWideInRecord; ++i) rec.wide[i] = WideInRecord{nullptr, 16, 0, 0};
     if (n_packed < 0 || n_packed > CUSRL_MAX_PACKED + CUSRL_MAX_FIELDS) return CUSRL_E_TOO_MANY;
     if (n_packed == 0) return 0;
     if (!packed || record_bytes < 16 || record_bytes % 16 != 0 || record_bytes > CUSRL_MAX_RECORD_BYTES)
@@ -524,6 +588,10 @@ static int fill_record_table(const cusrl_packed_field_t *packed, int n_packed, i
         }
     }
     if (entries > CUSRL_MAX_PACKED) return CUSRL_E_TOO_MANY;
+    int last = 0;
+    for (int b = 0; b < record_bytes; ++b)
+        if (used[b]) last = b;
+    rec.used_chunks = last / 16 + 1;  // trailing padding chunks are never read
     int at = 0;
     for (int pass_width : {4, 2, 1}) {  // 4-byte entries first (an 8-byte leaf = two of them), then 2-byte, then 1-byte
         for (int i = 0; i < n_packed; ++i) {
@@ -631,22 +699,12 @@ extern "C" int cusrl_gather_rows_packed(const cusrl_field_t *fields, int n_field
         if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
         ++n;
     }
-    for (int i = 0; i < n_wide; ++i) {  // wide leaves that live in the record: same lanes, source pitch = record size
-        if (n == CUSRL_MAX_FIELDS) return CUSRL_E_TOO_MANY;
-        GatherLeaf &leaf = tab.leaf[n];
-        leaf.src = static_cast<const char *>(record) + wide[i].offset;
-        leaf.dst = wide[i].ptr;
-        leaf.src_pitch = int32_t(record_bytes);
-        leaf.dst_pitch = wide[i].width;
-        leaf.unit = 16;
-        leaf.lanes_per_row = wide[i].width / 16;
-        tab.block_start[n] = int32_t(blocks);
-        blocks += ceil_div(rows * leaf.lanes_per_row, kGatherOpsPerBlock);
-        if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
-        ++n;
-    }
+    if (n_wide > kMaxWideInRecord) return CUSRL_E_TOO_MANY;
+    for (int i = 0; i < n_wide; ++i)  // wide leaves that live in the record: chunk ranges of the record-major pass
+        rec.wide[i] = WideInRecord{wide[i].ptr, wide[i].width, uint16_t(wide[i].offset / 16), uint16_t(wide[i].width / 16)};
+    rec.n_wide = n_wide;
     set_block_tail(tab, n, blocks);
-    if (rec.n4 + rec.n2 + rec.n1 > 0) blocks += ceil_div(rows, kRecordRowsPerBlock);
+    if (n_packed > 0) blocks += ceil_div(rows * rec.used_chunks, kRecordOpsPerBlock);
     if (blocks == 0) return 0;
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     hipLaunchKernelGGL(gather_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), args,

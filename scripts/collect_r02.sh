@@ -24,12 +24,12 @@ for c in "config1" "config2 --compile" "config3 --compile" "config4" "config5" "
   python scripts/run_config.py $c 2>&1 | grep -v amdgpu.ids > "$O/configs/run_$(echo $c | tr ' -' '__').txt"
   tail -2 "$O/configs/run_$(echo $c | tr ' -' '__').txt" | head -1 | cut -c1-160
 done
-bash scripts/gpu_profile.sh r02/prof --steps 20 --warmup 5 > "$O/gpu_profile.log" 2>&1
+bash scripts/gpu_profile.sh r02_prof --steps 20 --warmup 5 > "$O/gpu_profile.log" 2>&1
 tail -45 "$O/gpu_profile.log"
-bash scripts/gpu_pmc.sh r02/pmc > "$O/gpu_pmc.log" 2>&1
+bash scripts/gpu_pmc.sh r02_pmc > "$O/gpu_pmc.log" 2>&1
 python - <<PY
 import json
-d = json.load(open("$O/pmc/pmc_summary.json"))
+d = json.load(open("$R/gpurun_out/r02_pmc/pmc_summary.json"))
 print(json.dumps(d["calibration"], indent=1))
 for k in ("gather_minibatch_hot_record", "gather_minibatch_hot_leaves", "gather_minibatch_all_leaves", "gather_minibatch_all_plain", "pack_rows", "pack_hot_record"):
     if k in d: print(k, d[k]["algorithmic_bytes"], d[k]["fetch_raw"], d[k]["write_raw"], d[k]["traffic_over_algorithmic_bracket"])

@@ -36,14 +36,19 @@ def blocks_plain(rows, row_bytes, unit):
 
 def main(out_dir):
     cases = {}
+    issued = {}  # launches of each of our kernels so far: a case owns the ordinals [first, first + REPEAT * per_call)
     f = lambda *shape: torch.randn(*shape, device=DEV)  # noqa: E731
 
-    def run(name, fn, kernel, grid_blocks, algorithmic_bytes):
+    def run(name, fn, kernel, grid_blocks, algorithmic_bytes, launches_per_call=None):
+        per_call = launches_per_call or {kernel: 1}
+        first = issued.get(kernel, 0)
         for _ in range(REPEAT):
             fn()
         torch.cuda.synchronize()
+        for k, n in per_call.items():
+            issued[k] = issued.get(k, 0) + n * REPEAT
         cases[name] = {"kernel": kernel, "grid_threads": int(grid_blocks) * KBLOCK, "algorithmic_bytes": int(algorithmic_bytes),
-                       "launches": REPEAT}
+                       "launches": REPEAT, "first_ordinal": first, "ordinals": per_call[kernel] * REPEAT}
 
     # ---- calibration
     big = torch.empty(1, 1 << 26, 4, device=DEV).normal_()  # [T=1, N=64 Mi, 4 floats] = 1 GiB, 16-byte rows
@@ -76,19 +81,19 @@ def main(out_dir):
     perm = torch.randperm(S, device=DEV)[:B].contiguous()
     hot_plain, hot_packed = ["observation", "action"], ["logp", "value", "advantage", "return", "done"]
     wide_blocks = lambda names: sum(blocks_plain(B, leaves[k][0, 0].numel() * 4, 16) for k in names)  # noqa: E731
-    record_blocks = -(-B // KBLOCK)
+    record_blocks = lambda p: -(-(B * -(-p.used_bytes // 16)) // (KBLOCK * ITEMS))  # record-major: 16-byte chunks  # noqa: E731
     hot_bytes = B * (2 * (4 * obs + 4 * act + 17) + 8)
     run("gather_minibatch_hot_leaves", lambda: ops.gather_rows_packed([leaves[k] for k in hot_plain], pack, hot_packed, perm, T, N),
-        "gather_kernel", wide_blocks(hot_plain) + record_blocks, hot_bytes)
+        "gather_kernel", wide_blocks(hot_plain) + record_blocks(pack), hot_bytes)
     hot_pack = ops.RecordPack({k: leaves[k] for k in ("observation", "action", "logp", "advantage", "return", "done")})
     run("pack_hot_record", hot_pack.build, "gather_kernel", blocks_plain(S, 192, 16) + blocks_plain(S, 48, 16),
-        S * (hot_pack.used_bytes + hot_pack.record_bytes))  # (its narrow entries go through pack_rows_kernel: second launch)
+        S * (hot_pack.used_bytes + hot_pack.record_bytes), {"gather_kernel": 1, "pack_rows_kernel": 1})  # wide copy + narrow entries
     run("gather_minibatch_hot_record", lambda: ops.gather_rows_packed([], hot_pack, list(hot_pack.leaves), perm, T, N), "gather_kernel",
-        blocks_plain(B, 192, 16) + blocks_plain(B, 48, 16) + record_blocks, B * (2 * hot_pack.used_bytes + 8))
+        record_blocks(hot_pack), B * (2 * hot_pack.used_bytes + 8))
     all_plain = [k for k in leaves if k not in narrow_names]
     all_bytes = B * (2 * 555 + 8)
     run("gather_minibatch_all_leaves", lambda: ops.gather_rows_packed([leaves[k] for k in all_plain], pack, narrow_names, perm, T, N),
-        "gather_kernel", wide_blocks(all_plain) + record_blocks, all_bytes)
+        "gather_kernel", wide_blocks(all_plain) + record_blocks(pack), all_bytes)
     plain_blocks = wide_blocks(all_plain) + 6 * blocks_plain(B, 4, 4) + 3 * (-(-((B + 3) // 4) // KBLOCK))
     run("gather_minibatch_all_plain", lambda: ops.gather_rows(list(leaves.values()), perm, T, N), "gather_kernel", plain_blocks, all_bytes)
     Path(out_dir).mkdir(parents=True, exist_ok=True)

@@ -18,13 +18,19 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def per_launch(path, cases):
-    sums = {name: [] for name in cases}
+    """Average counter value of each case's launches: the rows of the case's kernel, in dispatch order, at the ordinals
+    scripts/pmc_cases.py recorded — and of the expected grid size (several cases share a grid size)."""
+    by_kernel = {}
     with open(path) as fh:
-        for row in csv.DictReader(fh):
-            kernel, grid = row["Kernel_Name"], int(row["Grid_Size"])
-            for name, case in cases.items():
-                if case["kernel"] in kernel and grid == case["grid_threads"]:
-                    sums[name].append(float(row["Counter_Value"]))
+        rows = sorted(csv.DictReader(fh), key=lambda row: int(row["Dispatch_Id"]))
+    for row in rows:
+        for kernel in ("gather_kernel", "push_kernel", "pack_rows_kernel"):
+            if kernel in row["Kernel_Name"]:
+                by_kernel.setdefault(kernel, []).append(row)
+    sums = {}
+    for name, case in cases.items():
+        mine = by_kernel.get(case["kernel"], [])[case["first_ordinal"]: case["first_ordinal"] + case["ordinals"]]
+        sums[name] = [float(row["Counter_Value"]) for row in mine if int(row["Grid_Size"]) == case["grid_threads"]]
     return {name: (sum(v) / len(v) if v else None) for name, v in sums.items()}, {name: len(v) for name, v in sums.items()}
 
 
