@@ -258,14 +258,59 @@ static_assert(offsetof(RecordTable, offset) == 24 && offsetof(RecordTable, strid
 // wide leaves of a record were moved by their own blocks (possibly on other XCDs, each with its own L2), the line
 // shared by the observation tail, the action and the narrow fields was measured fetched three times.  A chunk is
 // either part of a wide leaf (stored as a whole to that leaf's batch tensor) or holds narrow entries (fanned out).
+//
+// What a chunk is comes from a map staged in LDS once per block: thread c of the block resolves chunk c from the
+// descriptor table (one vector load of the table from kernarg memory + one barrier), and a lane-op then costs one
+// 16-byte LDS read.  (Resolving per lane-op from scalar registers — static loops over 8 wide + 16 narrow descriptors —
+// made the kernel instruction-bound: ~3500 instructions per lane, 21 us for a 24 576-slot minibatch.)
 constexpr int kRecordOpsPerBlock = kBlock * kGatherItems;
+constexpr int kMaxRecordChunks = CUSRL_MAX_RECORD_BYTES / 16;
 
-__device__ __forceinline__ void gather_record_major(const WaveRecordTable &rec, const char *__restrict__ src,
+struct ChunkInfo {   // 16 bytes
+    char *ptr;       // wide chunk: destination tensor of its leaf; narrow chunk: nullptr
+    int32_t pitch;   // wide: row size of the leaf
+    int32_t detail;  // wide: first chunk of the leaf inside the record; narrow: bit f set <=> entry f lives in this chunk
+};
+
+struct EntryInfo {  // 16 bytes: one narrow entry
+    char *ptr;
+    int32_t offset;  // byte offset inside the record
+    int32_t stride_width;  // stride | width << 8
+};
+
+__device__ __forceinline__ void gather_record_major(size_t kernarg_offset, const char *__restrict__ src,
                                                     const int64_t *__restrict__ idx, int64_t rows, int64_t op0,
                                                     int64_t B, int64_t N, bool temporal) {
-    const int chunks = rec.used_chunks();
+    __shared__ uint32_t s_raw[kRecordTableDwords];
+    __shared__ ChunkInfo s_chunk[kMaxRecordChunks];
+    __shared__ EntryInfo s_entry[CUSRL_MAX_PACKED];
+    const uint32_t *karg = (const uint32_t *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + kernarg_offset);
+    if (threadIdx.x < kRecordTableDwords) s_raw[threadIdx.x] = karg[threadIdx.x];
+    __syncthreads();
+    const RecordTable &table = *reinterpret_cast<const RecordTable *>(s_raw);
+    const int chunks = table.used_chunks;
+    const int n4 = table.n4, n42 = n4 + table.n2, n = n42 + table.n1;
+    if (int(threadIdx.x) < chunks) {
+        const int c = threadIdx.x;
+        ChunkInfo info{nullptr, 0, 0};
+        for (int k = 0; k < table.n_wide; ++k) {
+            const int first = table.wide[k].first_chunk;
+            if (c >= first && c < first + table.wide[k].num_chunks) info = ChunkInfo{table.wide[k].ptr, table.wide[k].pitch, first};
+        }
+        if (!info.ptr)
+            for (int f = 0; f < n; ++f)
+                if ((table.offset[f] >> 4) == c) info.detail |= 1 << f;
+        s_chunk[c] = info;
+    }
+    if (int(threadIdx.x) < n) {
+        const int f = threadIdx.x;
+        const int width = f < n4 ? 4 : (f < n42 ? 2 : 1);
+        s_entry[f] = EntryInfo{table.ptr[f], table.offset[f], int32_t(table.stride[f]) | (width << 8)};
+    }
+    __syncthreads();
+
     const int64_t ops = rows * chunks;
-    const int64_t pitch = rec.record_bytes();
+    const int64_t pitch = table.record_bytes;
     int64_t out_row[kGatherItems], src_row[kGatherItems];
     int chunk[kGatherItems];
 #pragma unroll
@@ -289,43 +334,34 @@ __device__ __forceinline__ void gather_record_major(const WaveRecordTable &rec, 
     for (int it = 0; it < kGatherItems; ++it)
         regs[it] = *reinterpret_cast<const uint4 *>(src + src_row[it] * pitch + int64_t(chunk[it]) * 16);
     pin_loaded(regs);
-    const int n_wide = rec.n_wide();
-    const int n4 = rec.n4(), n42 = n4 + rec.n2(), n = n42 + rec.n1();
-#pragma unroll
-    for (int it = 0; it < kGatherItems; ++it) {
-        const int c = chunk[it];
-        // wide leaves: which one owns chunk c (per-lane selects over at most 8 descriptors held in scalar registers)
-        char *dst = nullptr;
-#pragma unroll
-        for (int k = 0; k < kMaxWideInRecord; ++k) {
-            if (k < n_wide) {
-                const int first = rec.wide_first(k);
-                const bool mine = c >= first && c < first + rec.wide_count(k);
-                char *candidate = rec.wide_ptr(k) + out_row[it] * rec.wide_pitch(k) + int64_t(c - first) * 16;
-                dst = mine ? candidate : dst;
+    // (a callable applied to the four items by name: inside an unrolled loop the inner bit-walk kept `regs[it]`
+    // dynamically indexed and the array was moved to LDS, 16 KB per block)
+    auto emit = [&](const uint4 value, const int64_t row, const int c) {
+        const ChunkInfo info = s_chunk[c];
+        if (info.ptr) {  // a chunk of a wide leaf: one 16-byte store
+            *reinterpret_cast<uint4 *>(info.ptr + row * info.pitch + int64_t(c - info.detail) * 16) = value;
+        } else {  // narrow entries of this chunk
+            for (uint32_t mask = uint32_t(info.detail); mask; mask &= mask - 1) {
+                const EntryInfo entry = s_entry[__ffs(mask) - 1];
+                const int sel = (entry.offset >> 2) & 3;
+                uint32_t word = value.x;
+                word = sel == 1 ? value.y : word;
+                word = sel == 2 ? value.z : word;
+                word = sel == 3 ? value.w : word;
+                word >>= (entry.offset & 3) * 8;
+                char *out = entry.ptr + row * (entry.stride_width & 0xff);
+                const int width = entry.stride_width >> 8;
+                if (width == 4) *reinterpret_cast<uint32_t *>(out) = word;
+                else if (width == 2) *reinterpret_cast<uint16_t *>(out) = uint16_t(word);
+                else *reinterpret_cast<uint8_t *>(out) = uint8_t(word);
             }
         }
-        if (dst) *reinterpret_cast<uint4 *>(dst) = regs[it];
-        // narrow entries living in chunk c (sorted 4-byte, 2-byte, 1-byte; class tests are wave-uniform)
-#pragma unroll
-        for (int f = 0; f < CUSRL_MAX_PACKED; ++f) {
-            if (f < n) {
-                const int off = rec.offset(f);
-                if ((off >> 4) == c) {
-                    const int sel = (off >> 2) & 3;
-                    uint32_t word = regs[it].x;
-                    word = sel == 1 ? regs[it].y : word;
-                    word = sel == 2 ? regs[it].z : word;
-                    word = sel == 3 ? regs[it].w : word;
-                    word >>= (off & 3) * 8;
-                    char *out = rec.ptr(f) + out_row[it] * rec.stride(f);
-                    if (f < n4) *reinterpret_cast<uint32_t *>(out) = word;
-                    else if (f < n42) *reinterpret_cast<uint16_t *>(out) = uint16_t(word);
-                    else *reinterpret_cast<uint8_t *>(out) = uint8_t(word);
-                }
-            }
-        }
-    }
+    };
+    static_assert(kGatherItems == 4, "the four items are emitted by name");
+    emit(regs[0], out_row[0], chunk[0]);
+    emit(regs[1], out_row[1], chunk[1]);
+    emit(regs[2], out_row[2], chunk[2]);
+    emit(regs[3], out_row[3], chunk[3]);
 }
 
 __global__ __launch_bounds__(kBlock) void pack_rows_kernel(const RecordTable rec_arg, char *__restrict__ record,
@@ -369,10 +405,9 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const GatherArgs args, c
     const GatherTable &tab = args.tab;
     const int blk = blockIdx.x;
     if (blk >= tab.block_start[CUSRL_MAX_FIELDS]) {  // the blocks behind the last plain leaf unpack the record
-        const WaveRecordTable rec(offsetof(GatherArgs, rec));
         const int64_t rows = temporal ? T * B : B;
         const int64_t op0 = int64_t(blk - tab.block_start[CUSRL_MAX_FIELDS]) * kRecordOpsPerBlock + threadIdx.x;
-        gather_record_major(rec, record, idx, rows, op0, B, N, temporal != 0);
+        gather_record_major(offsetof(GatherArgs, rec), record, idx, rows, op0, B, N, temporal != 0);
         return;
     }
     const int f = find_leaf(tab, blk);
