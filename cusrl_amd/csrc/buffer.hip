@@ -278,39 +278,19 @@ struct EntryInfo {  // 16 bytes: one narrow entry
     int32_t stride_width;  // stride | width << 8
 };
 
-__device__ __forceinline__ void gather_record_major(size_t kernarg_offset, const char *__restrict__ src,
-                                                    const int64_t *__restrict__ idx, int64_t rows, int64_t op0,
-                                                    int64_t B, int64_t N, bool temporal) {
+__device__ __forceinline__ void gather_record_major(size_t kernarg_offset, int chunks, int64_t pitch,
+                                                    const char *__restrict__ src, const int64_t *__restrict__ idx,
+                                                    int64_t rows, int64_t op0, int64_t B, int64_t N, bool temporal) {
     __shared__ uint32_t s_raw[kRecordTableDwords];
     __shared__ ChunkInfo s_chunk[kMaxRecordChunks];
     __shared__ EntryInfo s_entry[CUSRL_MAX_PACKED];
+    // (1) the descriptor table starts its trip from kernarg memory (one vector load, threads 0..81) ...
     const uint32_t *karg = (const uint32_t *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + kernarg_offset);
-    if (threadIdx.x < kRecordTableDwords) s_raw[threadIdx.x] = karg[threadIdx.x];
-    __syncthreads();
-    const RecordTable &table = *reinterpret_cast<const RecordTable *>(s_raw);
-    const int chunks = table.used_chunks;
-    const int n4 = table.n4, n42 = n4 + table.n2, n = n42 + table.n1;
-    if (int(threadIdx.x) < chunks) {
-        const int c = threadIdx.x;
-        ChunkInfo info{nullptr, 0, 0};
-        for (int k = 0; k < table.n_wide; ++k) {
-            const int first = table.wide[k].first_chunk;
-            if (c >= first && c < first + table.wide[k].num_chunks) info = ChunkInfo{table.wide[k].ptr, table.wide[k].pitch, first};
-        }
-        if (!info.ptr)
-            for (int f = 0; f < n; ++f)
-                if ((table.offset[f] >> 4) == c) info.detail |= 1 << f;
-        s_chunk[c] = info;
-    }
-    if (int(threadIdx.x) < n) {
-        const int f = threadIdx.x;
-        const int width = f < n4 ? 4 : (f < n42 ? 2 : 1);
-        s_entry[f] = EntryInfo{table.ptr[f], table.offset[f], int32_t(table.stride[f]) | (width << 8)};
-    }
-    __syncthreads();
-
+    uint32_t raw = 0;
+    if (threadIdx.x < kRecordTableDwords) raw = karg[threadIdx.x];
+    // (2) ... while the data loads are issued: they only need the chunk count and the record size (two scalars that
+    // the caller read from the by-value argument), not the map
     const int64_t ops = rows * chunks;
-    const int64_t pitch = table.record_bytes;
     int64_t out_row[kGatherItems], src_row[kGatherItems];
     int chunk[kGatherItems];
 #pragma unroll
@@ -333,6 +313,29 @@ __device__ __forceinline__ void gather_record_major(size_t kernarg_offset, const
 #pragma unroll
     for (int it = 0; it < kGatherItems; ++it)
         regs[it] = *reinterpret_cast<const uint4 *>(src + src_row[it] * pitch + int64_t(chunk[it]) * 16);
+    // (3) the map is staged in LDS while those loads are in flight
+    if (threadIdx.x < kRecordTableDwords) s_raw[threadIdx.x] = raw;
+    __syncthreads();
+    const RecordTable &table = *reinterpret_cast<const RecordTable *>(s_raw);
+    const int n4 = table.n4, n42 = n4 + table.n2, n = n42 + table.n1;
+    if (int(threadIdx.x) < chunks) {
+        const int c = threadIdx.x;
+        ChunkInfo info{nullptr, 0, 0};
+        for (int k = 0; k < table.n_wide; ++k) {
+            const int first = table.wide[k].first_chunk;
+            if (c >= first && c < first + table.wide[k].num_chunks) info = ChunkInfo{table.wide[k].ptr, table.wide[k].pitch, first};
+        }
+        if (!info.ptr)
+            for (int f = 0; f < n; ++f)
+                if ((table.offset[f] >> 4) == c) info.detail |= 1 << f;
+        s_chunk[c] = info;
+    }
+    if (int(threadIdx.x) < n) {
+        const int f = threadIdx.x;
+        const int width = f < n4 ? 4 : (f < n42 ? 2 : 1);
+        s_entry[f] = EntryInfo{table.ptr[f], table.offset[f], int32_t(table.stride[f]) | (width << 8)};
+    }
+    __syncthreads();
     pin_loaded(regs);
     // (a callable applied to the four items by name: inside an unrolled loop the inner bit-walk kept `regs[it]`
     // dynamically indexed and the array was moved to LDS, 16 KB per block)
@@ -407,7 +410,8 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const GatherArgs args, c
     if (blk >= tab.block_start[CUSRL_MAX_FIELDS]) {  // the blocks behind the last plain leaf unpack the record
         const int64_t rows = temporal ? T * B : B;
         const int64_t op0 = int64_t(blk - tab.block_start[CUSRL_MAX_FIELDS]) * kRecordOpsPerBlock + threadIdx.x;
-        gather_record_major(offsetof(GatherArgs, rec), record, idx, rows, op0, B, N, temporal != 0);
+        gather_record_major(offsetof(GatherArgs, rec), args.rec.used_chunks, args.rec.record_bytes, record, idx, rows, op0, B, N,
+                            temporal != 0);
         return;
     }
     const int f = find_leaf(tab, blk);
