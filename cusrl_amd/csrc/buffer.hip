@@ -259,12 +259,14 @@ static_assert(offsetof(RecordTable, offset) == 24 && offsetof(RecordTable, strid
 // shared by the observation tail, the action and the narrow fields was measured fetched three times.  A chunk is
 // either part of a wide leaf (stored as a whole to that leaf's batch tensor) or holds narrow entries (fanned out).
 //
-// What a chunk is comes from a map staged in LDS once per block: thread c of the block resolves chunk c from the
-// descriptor table (one vector load of the table from kernarg memory + one barrier), and a lane-op then costs one
-// 16-byte LDS read.  (Resolving per lane-op from scalar registers — static loops over 8 wide + 16 narrow descriptors —
-// made the kernel instruction-bound: ~3500 instructions per lane, 21 us for a 24 576-slot minibatch.)
+// What a chunk is comes from a map the HOST resolves (chunk -> destination / entry mask) and passes by value.  Each wave
+// fetches it with ONE vector load — lane c holds chunk c's 16-byte descriptor, lane f entry f's — issued together with
+// the data loads, and a lane-op then looks its chunk up with four wave shuffles: no LDS, no barrier.  (Two earlier
+// forms, kept here as a warning: resolving per lane-op from scalar registers with static loops over all descriptors made
+// the kernel instruction-bound, 21 us for a 24 576-slot minibatch; staging the map in LDS behind two barriers, 8.7 us.)
 constexpr int kRecordOpsPerBlock = kBlock * kGatherItems;
 constexpr int kMaxRecordChunks = CUSRL_MAX_RECORD_BYTES / 16;
+static_assert(kMaxRecordChunks == kWave, "one chunk descriptor per lane");
 
 struct ChunkInfo {   // 16 bytes
     char *ptr;       // wide chunk: destination tensor of its leaf; narrow chunk: nullptr
@@ -274,22 +276,23 @@ struct ChunkInfo {   // 16 bytes
 
 struct EntryInfo {  // 16 bytes: one narrow entry
     char *ptr;
-    int32_t offset;  // byte offset inside the record
+    int32_t offset;        // byte offset inside the record
     int32_t stride_width;  // stride | width << 8
 };
 
-__device__ __forceinline__ void gather_record_major(size_t kernarg_offset, int chunks, int64_t pitch,
+struct RecordMap {
+    int32_t chunks, record_bytes, n_entries, pad;
+    ChunkInfo chunk[kMaxRecordChunks];
+    EntryInfo entry[CUSRL_MAX_PACKED];
+};
+
+__device__ __forceinline__ void gather_record_major(size_t map_kernarg_offset, int chunks, int64_t pitch, int n_entries,
                                                     const char *__restrict__ src, const int64_t *__restrict__ idx,
                                                     int64_t rows, int64_t op0, int64_t B, int64_t N, bool temporal) {
-    __shared__ uint32_t s_raw[kRecordTableDwords];
-    __shared__ ChunkInfo s_chunk[kMaxRecordChunks];
-    __shared__ EntryInfo s_entry[CUSRL_MAX_PACKED];
-    // (1) the descriptor table starts its trip from kernarg memory (one vector load, threads 0..81) ...
-    const uint32_t *karg = (const uint32_t *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + kernarg_offset);
-    uint32_t raw = 0;
-    if (threadIdx.x < kRecordTableDwords) raw = karg[threadIdx.x];
-    // (2) ... while the data loads are issued: they only need the chunk count and the record size (two scalars that
-    // the caller read from the by-value argument), not the map
+    const char *karg = (const char *)__builtin_amdgcn_kernarg_segment_ptr() + map_kernarg_offset;
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint4 my_chunk = reinterpret_cast<const uint4 *>(karg + offsetof(RecordMap, chunk))[lane];
+    const uint4 my_entry = reinterpret_cast<const uint4 *>(karg + offsetof(RecordMap, entry))[lane & (CUSRL_MAX_PACKED - 1)];
     const int64_t ops = rows * chunks;
     int64_t out_row[kGatherItems], src_row[kGatherItems];
     int chunk[kGatherItems];
@@ -313,47 +316,34 @@ __device__ __forceinline__ void gather_record_major(size_t kernarg_offset, int c
 #pragma unroll
     for (int it = 0; it < kGatherItems; ++it)
         regs[it] = *reinterpret_cast<const uint4 *>(src + src_row[it] * pitch + int64_t(chunk[it]) * 16);
-    // (3) the map is staged in LDS while those loads are in flight
-    if (threadIdx.x < kRecordTableDwords) s_raw[threadIdx.x] = raw;
-    __syncthreads();
-    const RecordTable &table = *reinterpret_cast<const RecordTable *>(s_raw);
-    const int n4 = table.n4, n42 = n4 + table.n2, n = n42 + table.n1;
-    if (int(threadIdx.x) < chunks) {
-        const int c = threadIdx.x;
-        ChunkInfo info{nullptr, 0, 0};
-        for (int k = 0; k < table.n_wide; ++k) {
-            const int first = table.wide[k].first_chunk;
-            if (c >= first && c < first + table.wide[k].num_chunks) info = ChunkInfo{table.wide[k].ptr, table.wide[k].pitch, first};
-        }
-        if (!info.ptr)
-            for (int f = 0; f < n; ++f)
-                if ((table.offset[f] >> 4) == c) info.detail |= 1 << f;
-        s_chunk[c] = info;
+    // chunk descriptors by wave shuffle (all lanes active here: a bpermute reads nothing from a disabled lane)
+    uint4 info[kGatherItems];
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it) {
+        info[it].x = __shfl(my_chunk.x, chunk[it], kWave);
+        info[it].y = __shfl(my_chunk.y, chunk[it], kWave);
+        info[it].z = __shfl(my_chunk.z, chunk[it], kWave);
+        info[it].w = __shfl(my_chunk.w, chunk[it], kWave);
     }
-    if (int(threadIdx.x) < n) {
-        const int f = threadIdx.x;
-        const int width = f < n4 ? 4 : (f < n42 ? 2 : 1);
-        s_entry[f] = EntryInfo{table.ptr[f], table.offset[f], int32_t(table.stride[f]) | (width << 8)};
-    }
-    __syncthreads();
     pin_loaded(regs);
-    // (a callable applied to the four items by name: inside an unrolled loop the inner bit-walk kept `regs[it]`
-    // dynamically indexed and the array was moved to LDS, 16 KB per block)
-    auto emit = [&](const uint4 value, const int64_t row, const int c) {
-        const ChunkInfo info = s_chunk[c];
-        if (info.ptr) {  // a chunk of a wide leaf: one 16-byte store
-            *reinterpret_cast<uint4 *>(info.ptr + row * info.pitch + int64_t(c - info.detail) * 16) = value;
-        } else {  // narrow entries of this chunk
-            for (uint32_t mask = uint32_t(info.detail); mask; mask &= mask - 1) {
-                const EntryInfo entry = s_entry[__ffs(mask) - 1];
-                const int sel = (entry.offset >> 2) & 3;
+    // (a callable applied to the four items by name: indexing `regs` from inside a loop moved the array to LDS)
+    auto emit = [&](const uint4 value, const uint4 desc, const int64_t row, const int c) {
+        char *wide_dst = reinterpret_cast<char *>(uint64_t(desc.x) | (uint64_t(desc.y) << 32));
+        if (wide_dst) *reinterpret_cast<uint4 *>(wide_dst + row * int(desc.z) + int64_t(c - int(desc.w)) * 16) = value;
+        const uint32_t mask = wide_dst ? 0u : desc.w;
+        for (int f = 0; f < n_entries; ++f) {  // wave-uniform walk: the descriptor comes from lane f by v_readlane
+            const uint32_t e_lo = __builtin_amdgcn_readlane(my_entry.x, f), e_hi = __builtin_amdgcn_readlane(my_entry.y, f);
+            const int offset = int(__builtin_amdgcn_readlane(my_entry.z, f));
+            const int stride_width = int(__builtin_amdgcn_readlane(my_entry.w, f));
+            if ((mask >> f) & 1u) {
+                const int sel = (offset >> 2) & 3;
                 uint32_t word = value.x;
                 word = sel == 1 ? value.y : word;
                 word = sel == 2 ? value.z : word;
                 word = sel == 3 ? value.w : word;
-                word >>= (entry.offset & 3) * 8;
-                char *out = entry.ptr + row * (entry.stride_width & 0xff);
-                const int width = entry.stride_width >> 8;
+                word >>= (offset & 3) * 8;
+                char *out = reinterpret_cast<char *>(uint64_t(e_lo) | (uint64_t(e_hi) << 32)) + row * (stride_width & 0xff);
+                const int width = stride_width >> 8;
                 if (width == 4) *reinterpret_cast<uint32_t *>(out) = word;
                 else if (width == 2) *reinterpret_cast<uint16_t *>(out) = uint16_t(word);
                 else *reinterpret_cast<uint8_t *>(out) = uint8_t(word);
@@ -361,10 +351,10 @@ __device__ __forceinline__ void gather_record_major(size_t kernarg_offset, int c
         }
     };
     static_assert(kGatherItems == 4, "the four items are emitted by name");
-    emit(regs[0], out_row[0], chunk[0]);
-    emit(regs[1], out_row[1], chunk[1]);
-    emit(regs[2], out_row[2], chunk[2]);
-    emit(regs[3], out_row[3], chunk[3]);
+    emit(regs[0], info[0], out_row[0], chunk[0]);
+    emit(regs[1], info[1], out_row[1], chunk[1]);
+    emit(regs[2], info[2], out_row[2], chunk[2]);
+    emit(regs[3], info[3], out_row[3], chunk[3]);
 }
 
 __global__ __launch_bounds__(kBlock) void pack_rows_kernel(const RecordTable rec_arg, char *__restrict__ record,
@@ -397,9 +387,9 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(const RecordTable rec
     }
 }
 
-struct GatherArgs {  // both tables in ONE kernel argument, so that the record table's kernarg offset is offsetof()
+struct GatherArgs {  // both tables in ONE kernel argument, so that the record map's kernarg offset is offsetof()
     GatherTable tab;
-    RecordTable rec;
+    RecordMap map;
 };
 
 __global__ __launch_bounds__(kBlock) void gather_kernel(const GatherArgs args, const char *__restrict__ record,
@@ -410,8 +400,8 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const GatherArgs args, c
     if (blk >= tab.block_start[CUSRL_MAX_FIELDS]) {  // the blocks behind the last plain leaf unpack the record
         const int64_t rows = temporal ? T * B : B;
         const int64_t op0 = int64_t(blk - tab.block_start[CUSRL_MAX_FIELDS]) * kRecordOpsPerBlock + threadIdx.x;
-        gather_record_major(offsetof(GatherArgs, rec), args.rec.used_chunks, args.rec.record_bytes, record, idx, rows, op0, B, N,
-                            temporal != 0);
+        gather_record_major(offsetof(GatherArgs, map), args.map.chunks, args.map.record_bytes, args.map.n_entries, record, idx,
+                            rows, op0, B, N, temporal != 0);
         return;
     }
     const int f = find_leaf(tab, blk);
@@ -658,7 +648,7 @@ extern "C" int cusrl_pack_rows(const cusrl_packed_field_t *fields, int n_fields,
     if (n_fields == 0 || rows == 0) return 0;
     if (!record || rows < 0 || !aligned(record, 16)) return CUSRL_E_INVALID;
     GatherArgs args;
-    RecordTable &rec = args.rec;
+    RecordTable rec;
     WideField wide[CUSRL_MAX_FIELDS];
     int n_wide = 0;
     if (int rc = fill_record_table(fields, n_fields, record_bytes, rec, wide, n_wide)) return rc;
@@ -678,12 +668,9 @@ extern "C" int cusrl_pack_rows(const cusrl_packed_field_t *fields, int n_fields,
             if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
         }
         set_block_tail(tab, n_wide, blocks);
-        RecordTable none = rec;
-        none.n4 = none.n2 = none.n1 = 0;
-        GatherArgs copy_args;
-        copy_args.tab = tab;
-        copy_args.rec = none;
-        hipLaunchKernelGGL(gather_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), copy_args,
+        args.map.chunks = args.map.n_entries = 0;
+        args.map.record_bytes = int32_t(record_bytes);
+        hipLaunchKernelGGL(gather_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), args,
                            static_cast<const char *>(nullptr), static_cast<const int64_t *>(nullptr), rows, int64_t(1),
                            rows, 0);
         if (int rc = launch_status()) return rc;
@@ -708,7 +695,7 @@ extern "C" int cusrl_gather_rows_packed(const cusrl_field_t *fields, int n_field
     const int64_t rows = temporal ? T * B : B;
     GatherArgs args;
     GatherTable &tab = args.tab;
-    RecordTable &rec = args.rec;
+    RecordTable rec;
     WideField wide[CUSRL_MAX_FIELDS];
     int n_wide = 0;
     if (int rc = fill_record_table(packed, n_packed, n_packed > 0 ? record_bytes : 16, rec, wide, n_wide)) return rc;
@@ -738,12 +725,24 @@ extern "C" int cusrl_gather_rows_packed(const cusrl_field_t *fields, int n_field
         if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
         ++n;
     }
-    if (n_wide > kMaxWideInRecord) return CUSRL_E_TOO_MANY;
-    for (int i = 0; i < n_wide; ++i)  // wide leaves that live in the record: chunk ranges of the record-major pass
-        rec.wide[i] = WideInRecord{wide[i].ptr, wide[i].width, uint16_t(wide[i].offset / 16), uint16_t(wide[i].width / 16)};
-    rec.n_wide = n_wide;
+    // the chunk map of the record-major pass: chunk -> wide leaf (destination, pitch, first chunk) or entry mask
+    RecordMap &map = args.map;
+    map.chunks = n_packed > 0 ? rec.used_chunks : 0;
+    map.record_bytes = int32_t(record_bytes);
+    map.n_entries = rec.n4 + rec.n2 + rec.n1;
+    map.pad = 0;
+    for (int c = 0; c < kMaxRecordChunks; ++c) map.chunk[c] = ChunkInfo{nullptr, 0, 0};
+    for (int f = 0; f < CUSRL_MAX_PACKED; ++f) map.entry[f] = EntryInfo{nullptr, 0, 4 | (4 << 8)};
+    for (int i = 0; i < n_wide; ++i)
+        for (int c = wide[i].offset / 16; c < (wide[i].offset + wide[i].width) / 16; ++c)
+            map.chunk[c] = ChunkInfo{wide[i].ptr, wide[i].width, wide[i].offset / 16};
+    for (int f = 0; f < map.n_entries; ++f) {
+        const int width = f < rec.n4 ? 4 : (f < rec.n4 + rec.n2 ? 2 : 1);
+        map.entry[f] = EntryInfo{rec.ptr[f], rec.offset[f], int32_t(rec.stride[f]) | (width << 8)};
+        map.chunk[rec.offset[f] / 16].detail |= 1 << f;
+    }
     set_block_tail(tab, n, blocks);
-    if (n_packed > 0) blocks += ceil_div(rows * rec.used_chunks, kRecordOpsPerBlock);
+    if (n_packed > 0) blocks += ceil_div(rows * map.chunks, kRecordOpsPerBlock);
     if (blocks == 0) return 0;
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     hipLaunchKernelGGL(gather_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), args,
