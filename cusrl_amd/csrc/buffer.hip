@@ -296,10 +296,19 @@ __device__ __forceinline__ void gather_record_major(size_t map_kernarg_offset, i
     const int64_t ops = rows * chunks;
     int64_t out_row[kGatherItems], src_row[kGatherItems];
     int chunk[kGatherItems];
+    // a power-of-two chunk count (16 for the 256-byte `ppo` record, 2 for the 32-byte narrow record) divides the block
+    // size: shifts instead of 64-bit divisions, and a lane keeps the SAME chunk index for all its items
+    const bool pow2 = (chunks & (chunks - 1)) == 0;
+    const int shift = 31 - __clz(chunks);
 #pragma unroll
     for (int it = 0; it < kGatherItems; ++it) {
-        const int64_t op = min(op0 + int64_t(it) * kBlock, ops - 1);  // clamped, unpredicated (see gather_unit)
-        out_row[it] = op / chunks;
+        // clamped, unpredicated (see gather_unit); in the power-of-two form an out-of-range op is folded onto the LAST
+        // record at the lane's own chunk index, so the lane's chunk stays the same for all items (duplicates rewrite
+        // identical bytes)
+        int64_t op = op0 + int64_t(it) * kBlock;
+        if (pow2) op = op < ops ? op : ops - chunks + (op & (chunks - 1));
+        else op = min(op, ops - 1);
+        out_row[it] = pow2 ? (op >> shift) : op / chunks;
         chunk[it] = int(op - out_row[it] * chunks);
     }
     if (temporal) {
@@ -320,41 +329,53 @@ __device__ __forceinline__ void gather_record_major(size_t map_kernarg_offset, i
     uint4 info[kGatherItems];
 #pragma unroll
     for (int it = 0; it < kGatherItems; ++it) {
+        if (it > 0 && pow2) {  // same chunk as item 0 (the clamp at the very end only ever repeats the last op)
+            info[it] = info[0];
+            continue;
+        }
         info[it].x = __shfl(my_chunk.x, chunk[it], kWave);
         info[it].y = __shfl(my_chunk.y, chunk[it], kWave);
         info[it].z = __shfl(my_chunk.z, chunk[it], kWave);
         info[it].w = __shfl(my_chunk.w, chunk[it], kWave);
     }
     pin_loaded(regs);
-    // (a callable applied to the four items by name: indexing `regs` from inside a loop moved the array to LDS)
-    auto emit = [&](const uint4 value, const uint4 desc, const int64_t row, const int c) {
-        char *wide_dst = reinterpret_cast<char *>(uint64_t(desc.x) | (uint64_t(desc.y) << 32));
-        if (wide_dst) *reinterpret_cast<uint4 *>(wide_dst + row * int(desc.z) + int64_t(c - int(desc.w)) * 16) = value;
-        const uint32_t mask = wide_dst ? 0u : desc.w;
-        for (int f = 0; f < n_entries; ++f) {  // wave-uniform walk: the descriptor comes from lane f by v_readlane
-            const uint32_t e_lo = __builtin_amdgcn_readlane(my_entry.x, f), e_hi = __builtin_amdgcn_readlane(my_entry.y, f);
-            const int offset = int(__builtin_amdgcn_readlane(my_entry.z, f));
-            const int stride_width = int(__builtin_amdgcn_readlane(my_entry.w, f));
-            if ((mask >> f) & 1u) {
-                const int sel = (offset >> 2) & 3;
-                uint32_t word = value.x;
-                word = sel == 1 ? value.y : word;
-                word = sel == 2 ? value.z : word;
-                word = sel == 3 ? value.w : word;
-                word >>= (offset & 3) * 8;
-                char *out = reinterpret_cast<char *>(uint64_t(e_lo) | (uint64_t(e_hi) << 32)) + row * (stride_width & 0xff);
-                const int width = stride_width >> 8;
-                if (width == 4) *reinterpret_cast<uint32_t *>(out) = word;
-                else if (width == 2) *reinterpret_cast<uint16_t *>(out) = uint16_t(word);
-                else *reinterpret_cast<uint8_t *>(out) = uint8_t(word);
-            }
+    // wide chunks: one 16-byte store per item
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it) {
+        char *wide_dst = reinterpret_cast<char *>(uint64_t(info[it].x) | (uint64_t(info[it].y) << 32));
+        if (wide_dst)
+            *reinterpret_cast<uint4 *>(wide_dst + out_row[it] * int(info[it].z) + int64_t(chunk[it] - int(info[it].w)) * 16) = regs[it];
+    }
+    // narrow entries: a wave-uniform walk over the entries (descriptor of entry f from lane f by v_readlane); every
+    // entry is tested against the four items of the lane (by name: indexing `regs` with a loop variable here once moved
+    // the array to LDS)
+    auto fan_out = [&](const uint4 value, const uint4 desc, const int64_t row, int f, char *base, int offset, int stride_width) {
+        const bool narrow = (desc.x | desc.y) == 0u;
+        if (narrow && ((desc.w >> f) & 1u)) {
+            const int sel = (offset >> 2) & 3;
+            uint32_t word = value.x;
+            word = sel == 1 ? value.y : word;
+            word = sel == 2 ? value.z : word;
+            word = sel == 3 ? value.w : word;
+            word >>= (offset & 3) * 8;
+            char *out = base + row * (stride_width & 0xff);
+            const int width = stride_width >> 8;
+            if (width == 4) *reinterpret_cast<uint32_t *>(out) = word;
+            else if (width == 2) *reinterpret_cast<uint16_t *>(out) = uint16_t(word);
+            else *reinterpret_cast<uint8_t *>(out) = uint8_t(word);
         }
     };
-    static_assert(kGatherItems == 4, "the four items are emitted by name");
-    emit(regs[0], info[0], out_row[0], chunk[0]);
-    emit(regs[1], info[1], out_row[1], chunk[1]);
-    emit(regs[2], info[2], out_row[2], chunk[2]);
-    emit(regs[3], info[3], out_row[3], chunk[3]);
+    static_assert(kGatherItems == 4, "the four items are visited by name");
+    for (int f = 0; f < n_entries; ++f) {
+        char *base = reinterpret_cast<char *>(uint64_t(__builtin_amdgcn_readlane(my_entry.x, f)) |
+                                              (uint64_t(__builtin_amdgcn_readlane(my_entry.y, f)) << 32));
+        const int offset = int(__builtin_amdgcn_readlane(my_entry.z, f));
+        const int stride_width = int(__builtin_amdgcn_readlane(my_entry.w, f));
+        fan_out(regs[0], info[0], out_row[0], f, base, offset, stride_width);
+        fan_out(regs[1], info[1], out_row[1], f, base, offset, stride_width);
+        fan_out(regs[2], info[2], out_row[2], f, base, offset, stride_width);
+        fan_out(regs[3], info[3], out_row[3], f, base, offset, stride_width);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void pack_rows_kernel(const RecordTable rec_arg, char *__restrict__ record,
