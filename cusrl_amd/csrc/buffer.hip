@@ -367,8 +367,9 @@ __device__ __forceinline__ void gather_record_major(size_t map_kernarg_offset, i
     };
     static_assert(kGatherItems == 4, "the four items are visited by name");
     for (int f = 0; f < n_entries; ++f) {
-        char *base = reinterpret_cast<char *>(uint64_t(__builtin_amdgcn_readlane(my_entry.x, f)) |
-                                              (uint64_t(__builtin_amdgcn_readlane(my_entry.y, f)) << 32));
+        // (v_readlane returns a signed int: go through uint32_t, or a pointer whose low word has bit 31 set sign-extends)
+        char *base = reinterpret_cast<char *>(uint64_t(uint32_t(__builtin_amdgcn_readlane(my_entry.x, f))) |
+                                              (uint64_t(uint32_t(__builtin_amdgcn_readlane(my_entry.y, f))) << 32));
         const int offset = int(__builtin_amdgcn_readlane(my_entry.z, f));
         const int stride_width = int(__builtin_amdgcn_readlane(my_entry.w, f));
         fan_out(regs[0], info[0], out_row[0], f, base, offset, stride_width);
