@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r02
 mkdir -p "$O/configs"
 cd "$R"
+python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee "$O/pytest_gpu.txt"
 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > "$O/bench_line.json"
 python -c "import json;d=json.load(open('$O/bench_line.json'));print('bench', d['value'], d['ms_per_step'], d['ppo_update_ms'], d['roofline']['avg_us'], d['roofline']['frac'], d.get('speedup_vs_cpu_baseline'))"
 for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-pass --no-scale-pass 2>/dev/null | tail -1; done | python -c "
@@ -16,7 +17,7 @@ for flag in "" "--native-collectives"; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 \
       --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-pass --no-scale-pass $flag 2>/dev/null | tail -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.readlines()[-1]); print('rccl-1-rank', d['config']['collectives'][:40], d['value'], d['ms_per_step'], d['ppo_update_ms'])"
+d = json.loads(sys.stdin.readlines()[-1]); print('rccl-1-rank', d['config']['collectives'][:48], '|', d['value'], 'env-steps/s', d['ms_per_step'], 'ms/iteration, update', d['ppo_update_ms'], 'ms')"
 done | tee "$O/bench_rccl_one_rank.txt"
 python scripts/kernel_bench.py --envs 4096 1048576 --json "$O/kernel_bench_graph_timed.json" 2>/dev/null | grep -v amdgpu > "$O/kernel_bench_graph_timed.txt"
 tail -30 "$O/kernel_bench_graph_timed.txt"
