@@ -215,7 +215,8 @@ def run_gpu(args, rank, world):
         import kernel_bench
 
         wanted = {"gae + return + stats": "gae", "ppo loss fwd+bwd, std vector": "ppo_loss_std_vector",
-                  "ppo loss fwd+bwd (": "ppo_loss_std_matrix", "gather hot leaves via record": "gather_hot_leaves"}
+                  "ppo loss fwd+bwd (": "ppo_loss_std_matrix", "gather hot leaves via record": "gather_narrow_record_plus_leaves",
+                  "gather hot leaves from the 256 B hot record": "gather_hot_record"}
         for name, (us, nbytes) in kernel_bench.bench_size(1 << 20, only=("gae + return", "ppo loss", "gather hot"), iters=10).items():
             for prefix, key in wanted.items():
                 if name.startswith(prefix):

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r02
 mkdir -p "$O/configs"
 cd "$R"
-python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee "$O/pytest_gpu.txt"
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tee "$O/pytest_gpu.txt"
 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > "$O/bench_line.json"
 python -c "import json;d=json.load(open('$O/bench_line.json'));print('bench', d['value'], d['ms_per_step'], d['ppo_update_ms'], d['roofline']['avg_us'], d['roofline']['frac'], d.get('speedup_vs_cpu_baseline'))"
 for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-pass --no-scale-pass 2>/dev/null | tail -1; done | python -c "
