@@ -43,6 +43,59 @@ def test_size_helpers_and_argument_validation_without_a_gpu():
     assert lib.cusrl_buffer_push(table, 30, 0, 1, None) == -2
 
 
+def test_every_negative_return_code_of_the_c_abi_is_reachable_without_a_launch():
+    """CUSRL_E_INVALID (-1), CUSRL_E_TOO_MANY (-2), CUSRL_E_UNSUPPORTED (-3), CUSRL_E_COMM (-4): the argument checks sit on
+    the host in front of every launch, so they can be exercised with never-dereferenced placeholder addresses."""
+    lib = _native.lib()
+    p = 0x1000  # a non-null, 16-byte aligned placeholder: these calls must return before touching it
+    odd = p + 4
+    # cusrl_gae: more value channels than one block reduces
+    assert lib.cusrl_gae(p, p, p, p, p, p, None, 4, 8, 257, 0.99, 0.95, -1.0, None) == -3
+    assert lib.cusrl_gae(p, p, p, p, p, p, None, -1, 8, 1, 0.99, 0.95, -1.0, None) == -1
+    # cusrl_gather_rows: too many leaves, missing indices, bad geometry
+    fields = (_native.Field * 30)()
+    for f in fields:
+        f.src, f.dst, f.row_bytes = p, p, 4
+    assert lib.cusrl_gather_rows(fields, 30, p, 8, 2, 4, 0, None) == -2
+    assert lib.cusrl_gather_rows(fields, 3, None, 8, 2, 4, 0, None) == -1
+    assert lib.cusrl_gather_rows(fields, 3, p, 8, 0, 4, 0, None) == -1
+    fields[1].src = None
+    assert lib.cusrl_gather_rows(fields, 3, p, 8, 2, 4, 0, None) == -1
+    # cusrl_ppo_loss_fwd_bwd: std vector (std_rows = 1) needs the 16-byte chunk layout (A % 4 == 0, aligned pointers)
+    loss = lambda **kw: lib.cusrl_ppo_loss_fwd_bwd(  # noqa: E731
+        p, p, p, p, kw.get("std", p), p, p, kw.get("old_value", None), kw.get("B", 64), kw.get("A", 12), 1, 0.2,
+        kw.get("value_clip", -1.0), 1.0, 0.5, 0.01, p, None, None, None, None, p, p, p, p, kw.get("std_rows", 64),
+        kw.get("std_partials", p), None, None)
+    assert loss(std_rows=1, A=7) == -3                      # A not a multiple of 4
+    assert loss(std_rows=1, std=odd) == -3                  # misaligned std vector
+    assert loss(std_rows=1, std_partials=None) == -1        # d_std wanted but no workspace for its column sums
+    assert loss(std_rows=3) == -1                           # std rows must be B or 1
+    assert loss(value_clip=0.2) == -1                       # clipped form without the old value
+    assert loss(B=0) == -1
+    # categorical objective, record tables, statistics, sequence layout, scatter, window indices
+    assert lib.cusrl_ppo_loss_categorical_fwd_bwd(p, p, p, None, p, p, None, 8, 3, 1, 0.2, -1.0, 1.0, 0.5, 0.0, p, None, None, None,
+                                                  None, p, p, p, None) == -1
+    assert lib.cusrl_normalize_from_partials(p, p, 4, 10, 1e-8, 10, 300, p, p, None) == -3
+    assert lib.cusrl_stats_finalize(None, 4, 1, 10, p, p, None) == -1
+    assert lib.cusrl_sequence_count(p, 0, 4, p, p, p, None) == -1
+    assert lib.cusrl_sequence_layout(p, 4, 4, p, p, 0, p, p, p, None, None, None) == -1
+    assert lib.cusrl_gather_memory(None, p, p, p, 4, 64, None) == -1
+    assert lib.cusrl_scatter_rows(p, None, p, 4, 16, None, None) == -1
+    assert lib.cusrl_window_indices(p, p, p, 4, 2, 8, 3, 8, None) == -1   # cursor outside the ring
+    assert lib.cusrl_adam_step(p, p, p, p, p, p, 100, 0.9, 0.999, 1e-8, 0.0, 0, 0, None, 0, -1.0, None, None, None) == -1
+    assert lib.cusrl_adam_step(odd, p, p, p, p, p, 100, 0.9, 0.999, 1e-8, 0.0, 0, 0, None, 0, -1.0, None, p, None) == -3
+    assert lib.cusrl_narrow_linear_supported(128, 12) == 1 and lib.cusrl_narrow_linear_supported(100, 12) == 0
+    assert lib.cusrl_narrow_linear_supported(128, 17) == 0
+    # communicator: argument errors; the text of every code
+    assert lib.cusrl_allreduce_mean(p, 4, None, None) in (-1, -4) and lib.cusrl_comm_create(None, 1, 0, None) in (-1, -4)
+    for code, word in ((-1, b"invalid"), (-2, b"too many"), (-3, b"not supported"), (-4, b"RCCL")):
+        assert word in lib.cusrl_error_string(code)
+    from cusrl_amd._native import NativeError, check
+
+    with pytest.raises(NativeError, match="code -3"):
+        check(-3, "cusrl_gae")
+
+
 def test_hot_path_refuses_cpu_tensors():
     from cusrl_amd import ops
 
