@@ -8,6 +8,7 @@ from cusrl_amd.hook.on_policy import (
     EntropyLoss,
     GeneralizedAdvantageEstimation,
     GradientClipping,
+    MiniBatchWiseLRSchedule,
     OnPolicyPreparation,
     OnPolicyStatistics,
     PpoSurrogateLoss,
@@ -27,6 +28,7 @@ __all__ = [
     "EntropyLoss",
     "GeneralizedAdvantageEstimation",
     "GradientClipping",
+    "MiniBatchWiseLRSchedule",
     "ModuleInitialization",
     "ObservationNormalization",
     "OnPolicyPreparation",

@@ -2,7 +2,7 @@ from cusrl_amd.hook.on_policy.advantage import AdvantageNormalization, Advantage
 from cusrl_amd.hook.on_policy.common import OnPolicyPreparation
 from cusrl_amd.hook.on_policy.gae import GeneralizedAdvantageEstimation
 from cusrl_amd.hook.on_policy.gradient_clipping import GradientClipping
-from cusrl_amd.hook.on_policy.lr_schedule import AdaptiveLRSchedule, ThresholdLRSchedule
+from cusrl_amd.hook.on_policy.lr_schedule import AdaptiveLRSchedule, MiniBatchWiseLRSchedule, ThresholdLRSchedule
 from cusrl_amd.hook.on_policy.ppo import EntropyLoss, PpoSurrogateLoss
 from cusrl_amd.hook.on_policy.stats import OnPolicyStatistics
 from cusrl_amd.hook.on_policy.value import ValueComputation, ValueLoss
@@ -14,6 +14,7 @@ __all__ = [
     "EntropyLoss",
     "GeneralizedAdvantageEstimation",
     "GradientClipping",
+    "MiniBatchWiseLRSchedule",
     "OnPolicyPreparation",
     "OnPolicyStatistics",
     "PpoSurrogateLoss",

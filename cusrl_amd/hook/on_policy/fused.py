@@ -112,6 +112,7 @@ class FusedPpoObjective:
         from cusrl_amd.hook.on_policy.advantage import AdvantageNormalization, AdvantageReduction
         from cusrl_amd.hook.on_policy.common import OnPolicyPreparation
         from cusrl_amd.hook.on_policy.gae import GeneralizedAdvantageEstimation
+        from cusrl_amd.hook.on_policy.lr_schedule import MiniBatchWiseLRSchedule
         from cusrl_amd.hook.on_policy.ppo import EntropyLoss, PpoSurrogateLoss
         from cusrl_amd.hook.on_policy.value import ValueLoss
 
@@ -123,7 +124,7 @@ class FusedPpoObjective:
         terms = (ValueLoss, OnPolicyPreparation, PpoSurrogateLoss, EntropyLoss)
         # hooks whose objective neither reads nor differentiates the policy terms: they keep fusion available
         passive = (GeneralizedAdvantageEstimation, AdvantageNormalization, AdvantageReduction, ObservationNormalization,
-                   RandomNetworkDistillation, AdversarialMotionPrior)
+                   RandomNetworkDistillation, AdversarialMotionPrior, MiniBatchWiseLRSchedule)
         order = []
         for hook in composite:
             if not hook.active:

@@ -12,9 +12,12 @@ After every update the mean KL divergence between the behaviour policy and the u
 Both support a linear warm-up of the scale and rejecting an update whose KL exceeds ``max_kl_divergence`` (the
 pre-update checkpoint is restored, the scale is kept).  The scale is written to ``param_group["lr"]`` of the groups
 that hold actor parameters (all groups with ``scale_all_params``); captured hipGraph steps see the change because the
-flat Adam step reads the learning rate from device memory (cusrl_amd/utils/flat_optimizer.py).  The per-minibatch
-variant of the reference (``MiniBatchWiseLRSchedule``) reads a KL back to the host inside every minibatch step and is
-not provided.
+flat Adam step reads the learning rate from device memory (cusrl_amd/utils/flat_optimizer.py).
+
+:class:`MiniBatchWiseLRSchedule` (``:242-296``) is the RSL-RL style rule: the threshold decision is taken inside every
+minibatch step from that minibatch's own KL, before its optimizer step.  The decision is host arithmetic on a value read
+back from the device, so the hook declares its ``objective`` phase eager (``Hook.eager_phases``) and ``compile=True``
+leaves the minibatch steps of an agent carrying it out of hipGraph capture.
 """
 
 from __future__ import annotations
@@ -22,10 +25,12 @@ from __future__ import annotations
 import copy
 import math
 
+import torch
+
 from cusrl_amd.template.hook import Hook
 from cusrl_amd.utils import distributed
 
-__all__ = ["AdaptiveLRSchedule", "ThresholdLRSchedule"]
+__all__ = ["AdaptiveLRSchedule", "MiniBatchWiseLRSchedule", "ThresholdLRSchedule"]
 
 
 class _KlDrivenSchedule(Hook):
@@ -64,11 +69,7 @@ class _KlDrivenSchedule(Hook):
         distributed.reduce_mean_(kl)
         kl = kl.item()
         if self.agent.iteration >= self.warmup_iterations:
-            factor = self._factor(kl)
-            if factor is not None and factor != 1.0:
-                self._lr_scale *= factor
-                self._write_learning_rates()
-            self.agent.record(lr_scale=self._lr_scale)
+            self._react(kl)
         if self.max_kl_divergence is None:
             return
         snapshot, self._snapshot = self._snapshot, None
@@ -98,6 +99,13 @@ class _KlDrivenSchedule(Hook):
     def _factor(self, kl_divergence: float) -> float | None:
         raise NotImplementedError
 
+    def _react(self, kl_divergence: float):
+        factor = self._factor(kl_divergence)
+        if factor is not None and factor != 1.0:
+            self._lr_scale *= factor
+            self._write_learning_rates()
+        self.agent.record(lr_scale=self._lr_scale)
+
     def _write_learning_rates(self):
         for base, group in zip(self._base_lrs, self.agent.optimizer.param_groups):
             holds_actor = any(name.startswith("actor.") for name in group.get("param_names", ()))
@@ -121,6 +129,38 @@ class ThresholdLRSchedule(_KlDrivenSchedule):
             return 1 / self.scale_factor
         if kl_divergence < self.desired_kl_divergence / self.threshold:
             return self.scale_factor
+        return None
+
+
+class MiniBatchWiseLRSchedule(ThresholdLRSchedule):
+    """Threshold rule applied per minibatch on that minibatch's KL (all parameter groups are scaled, no roll-back)."""
+
+    def __init__(self, desired_kl_divergence: float = 0.01, *, threshold: float = 2.0, scale_factor: float = 1.5,
+                 warmup_iterations: int = 0, initial_scale: float = 0.0):
+        super().__init__(desired_kl_divergence, threshold=threshold, scale_factor=scale_factor, scale_all_params=True,
+                         warmup_iterations=warmup_iterations, initial_scale=initial_scale)
+
+    def post_init(self):
+        from cusrl_amd.hook.on_policy.common import OnPolicyPreparation
+
+        super().post_init()
+        for hook in self.agent.hook:
+            if isinstance(hook, OnPolicyPreparation):
+                hook.calculate_kl_divergence = True  # puts batch["kl_divergence"] in front of objective()
+
+    def post_update(self):
+        pass  # every decision was already taken inside the update
+
+    def eager_phases(self):
+        return ("objective",)  # .item() below
+
+    def objective(self, metadata, batch):
+        if self.agent.iteration < self.warmup_iterations:
+            return None
+        with torch.no_grad():
+            kl = batch["kl_divergence"].mean()
+        distributed.reduce_mean_(kl)
+        self._react(kl.item())
         return None
 
 

@@ -226,9 +226,9 @@ class ActorCritic(Agent):
             recurrent = self.actor.is_recurrent or self.critic.is_recurrent  # dynamic sequence counts: not capturable
             graphed = self.compile and hasattr(self.sampler, "iter_indices") and not recurrent
             if graphed:
-                from cusrl_amd.template.graphs import GraphedTrainStep, collective_phases
+                from cusrl_amd.template.graphs import GraphedTrainStep, eager_phases
 
-                graphed = "objective" not in collective_phases(self)  # a hook's own collective stays out of capture
+                graphed = "objective" not in eager_phases(self)  # a hook's collective / host read-back stays out of capture
             if graphed:
                 for metadata, indices in self.sampler.iter_indices(self.buffer):
                     key = (metadata["mini_batch_index"], metadata["temporal"], indices.numel())

@@ -26,7 +26,7 @@ import torch
 
 from cusrl_amd.utils.metrics import MetricTap
 
-__all__ = ["GraphedAct", "GraphedTrainStep", "capture_signature", "collective_phases"]
+__all__ = ["GraphedAct", "GraphedTrainStep", "capture_signature", "collective_phases", "eager_phases"]
 
 
 def _freeze(value):
@@ -65,6 +65,16 @@ def collective_phases(agent) -> set[str]:
     for hook in agent.hook:
         if hook._active:
             phases |= set(hook.collective_phases())
+    return phases
+
+
+def eager_phases(agent) -> set[str]:
+    """Phases that must not be captured for this agent: those with a hook-issued collective (above) and those a hook
+    declares eager itself (``Hook.eager_phases`` — a host read-back, e.g. MiniBatchWiseLRSchedule)."""
+    phases = collective_phases(agent)
+    for hook in agent.hook:
+        if hook._active:
+            phases |= set(hook.eager_phases())
     return phases
 
 
@@ -151,8 +161,9 @@ class GraphedTrainStep:
 
     def eligible(self) -> bool:
         """False when an objective-phase hook synchronises across ranks (e.g. minibatch-wise advantage normalisation
-        with ``synchronize``): that step runs eagerly instead of baking an RCCL call into a graph."""
-        return "objective" not in collective_phases(self.agent)
+        with ``synchronize``) or reads a value back to the host: that step runs eagerly instead of baking an RCCL call
+        or a stale host decision into a graph."""
+        return "objective" not in eager_phases(self.agent)
 
     def _whole_step(self):
         self._phase_a()
@@ -276,7 +287,7 @@ class GraphedAct:
         return (isinstance(observation, torch.Tensor) and observation.is_cuda and not agent.actor.is_recurrent
                 and not agent.critic.is_recurrent and not agent.inference_mode
                 and getattr(agent.actor.distribution, "capture_safe", True)
-                and "act" not in collective_phases(agent))
+                and "act" not in eager_phases(agent))
 
     def run(self, observation: torch.Tensor, state: torch.Tensor | None) -> torch.Tensor:
         agent = self.agent

@@ -187,6 +187,11 @@ class Hook(Generic[AgentT]):
         phases out of hipGraph capture (template/graphs.py)."""
         return ()
 
+    def eager_phases(self) -> tuple[str, ...]:
+        """Extension: phases (same names) this hook must run outside hipGraph capture whatever the number of ranks —
+        typically because it reads a device value back to the host to branch on it."""
+        return ()
+
     def pre_export(self, graph): ...
 
     def post_export(self, graph): ...

@@ -365,17 +365,19 @@ def make_update_trace(cusrl):
 
     cusrl.config.set_device("cpu")
     out = dict(META)
-    for tag, factory_kwargs in [
-        ("a", dict(num_steps_per_update=6, sampler_epochs=2, sampler_mini_batches=3)),
+    for tag, factory_kwargs, mini_batch_wise_kl in [
+        ("a", dict(num_steps_per_update=6, sampler_epochs=2, sampler_mini_batches=3), None),
         ("b", dict(num_steps_per_update=5, sampler_epochs=2, sampler_mini_batches=2, gae_lamda_value=0.98,
-                   value_loss_clip=0.2)),
+                   value_loss_clip=0.2), None),
+        # MiniBatchWiseLRSchedule right behind the preparation hook: the learning rate moves between minibatch steps
+        ("c", dict(num_steps_per_update=6, sampler_epochs=4, sampler_mini_batches=2), 3e-5),
     ]:
         torch.manual_seed(11)
         env = DummyTorchEnvironment(num_instances=8, observation_dim=16, action_dim=8, reward_dim=1)
         factory = cusrl.preset.PpoAgentFactory(actor_hidden_dims=(32, 16), critic_hidden_dims=(32, 16), **factory_kwargs)
         underlying = factory.to_underlying()
 
-        trace = {"objectives": [], "indices": [], "grads_unclipped": [], "grads": [], "params_after": []}
+        trace = {"objectives": [], "indices": [], "grads_unclipped": [], "grads": [], "params_after": [], "lrs": [], "kls": []}
 
         class Capture(cusrl.Hook):
             def __init__(self, where):
@@ -386,6 +388,8 @@ def make_update_trace(cusrl):
             def pre_optim(self, optimizer):
                 flat = torch.cat([p.grad.reshape(-1) for g in optimizer.param_groups for p in g["params"]])
                 trace["grads_unclipped" if self.where == "pre" else "grads"].append(np_(flat))
+                if self.where == "pre":
+                    trace["lrs"].append([group["lr"] for group in optimizer.param_groups])
 
             def post_optim(self):
                 if self.where == "post":
@@ -395,7 +399,11 @@ def make_update_trace(cusrl):
             def objective(self, metadata, batch):
                 if self.where == "post":
                     trace["indices"].append(np_(batch["flat_index"].squeeze(-1)))
+                    if "kl_divergence" in batch:
+                        trace["kls"].append(batch["kl_divergence"].mean().item())
 
+        if mini_batch_wise_kl is not None:
+            underlying.register_hook(cusrl.hook.MiniBatchWiseLRSchedule(mini_batch_wise_kl), after="on_policy_preparation")
         underlying.register_hook(Capture("pre"), before="gradient_clipping")
         underlying.register_hook(Capture("post"), after="gradient_clipping")
         agent = underlying(env.spec)
@@ -443,6 +451,14 @@ def make_update_trace(cusrl):
         out[p + "grads_unclipped"] = np.stack(trace["grads_unclipped"])
         out[p + "grads"] = np.stack(trace["grads"])
         out[p + "params_after"] = np.stack(trace["params_after"])
+        out[p + "lrs"] = np.asarray(trace["lrs"], dtype=np.float64)
+        if mini_batch_wise_kl is not None:
+            kls = np.asarray(trace["kls"])
+            out[p + "mini_batch_wise_kl"], out[p + "kls"] = np.float64(mini_batch_wise_kl), kls
+            edges = np.array([mini_batch_wise_kl / 2.0, mini_batch_wise_kl * 2.0])
+            margin = np.abs(kls[:, None] / edges[None] - 1.0).min()
+            print(f"  minibatch KLs {kls}, lr {out[p + 'lrs'][:, 0]}, closest decision edge {margin:.1%} away")
+            assert margin > 0.1, "a KL this close to a threshold edge would make the replay flip on rounding"
         out[p + "metric_keys"] = np.array(list(metrics.keys()))
         out[p + "metric_vals"] = np.array(list(metrics.values()), dtype=np.float64)
         print(f"update trace {tag}: {len(trace['objectives'])} train steps, buffer leaves {list(buffer_in)}")
@@ -818,6 +834,7 @@ class ScheduleProbe:
         self.iteration = 0
         self.recorded: list[dict] = []
         self.loads = 0
+        self.hook: list = []
 
     def record(self, **kwargs):
         self.recorded.append(kwargs)
@@ -846,6 +863,36 @@ class ScheduleProbe:
         return np.asarray(rows, dtype=np.float64)
 
 
+    def run_mini_batch_wise(self, hook, preparation, kls, mini_batches: int):
+        """MiniBatchWiseLRSchedule: ``mini_batches`` objective() calls per iteration, each on a [5, 1] KL column whose
+        mean is the listed value; one row per call + one after post_update()."""
+        self.hook = [preparation]
+        hook.agent = self
+        hook.post_init()
+        rows = []
+        spread = torch.tensor([[0.5], [1.5], [1.0], [0.25], [1.75]], dtype=torch.float32)
+        for i in range(0, len(kls), mini_batches):
+            self.iteration = i // mini_batches
+            hook.apply_schedule(self.iteration)
+            hook.pre_update(None)
+            for kl in kls[i:i + mini_batches]:
+                self.recorded.clear()
+                assert hook.objective({}, {"kl_divergence": spread * kl}) is None
+                merged = {k: v for item in self.recorded for k, v in item.items()}
+                rows.append([self.optimizer.param_groups[0]["lr"], self.optimizer.param_groups[1]["lr"],
+                             merged.get("lr_scale", np.nan), float(preparation.calculate_kl_divergence), float(self.loads)])
+            self.recorded.clear()
+            hook.post_update()
+            rows.append([self.optimizer.param_groups[0]["lr"], self.optimizer.param_groups[1]["lr"],
+                         float(len(self.recorded)), np.nan, float(self.loads)])
+        return np.asarray(rows, dtype=np.float64)
+
+
+MINI_BATCH_WISE_CASES = {
+    "mini_batch_wise": dict(desired_kl_divergence=0.01),
+    "mini_batch_wise_warmup": dict(desired_kl_divergence=0.008, threshold=1.5, scale_factor=1.2, warmup_iterations=2,
+                                   initial_scale=0.5),
+}
 SCHEDULE_CASES = {
     "adaptive": ("AdaptiveLRSchedule", dict(desired_kl_divergence=0.01), False),
     "adaptive_all_maxkl": ("AdaptiveLRSchedule", dict(desired_kl_divergence=0.02, max_kl_divergence=0.05, scale_all_params=True,
@@ -862,6 +909,9 @@ def make_lr_schedule(cusrl):
     out = {"torch_version": np.array(torch.__version__), "kls": np.asarray(SCHEDULE_KLS)}
     for tag, (cls_name, kwargs, schedule_first) in SCHEDULE_CASES.items():
         out[tag] = ScheduleProbe().run(getattr(cusrl.hook, cls_name)(**kwargs), SCHEDULE_KLS, schedule_first)
+    for tag, kwargs in MINI_BATCH_WISE_CASES.items():
+        out[tag] = ScheduleProbe().run_mini_batch_wise(cusrl.hook.MiniBatchWiseLRSchedule(**kwargs),
+                                                       cusrl.hook.OnPolicyPreparation(), SCHEDULE_KLS + SCHEDULE_KLS[:2], 4)
     np.savez_compressed(HERE / "lr_schedule.npz", **out)
     print("lr_schedule.npz", {k: v.shape for k, v in out.items() if k not in ("torch_version",)})
 

@@ -346,6 +346,48 @@ def test_kl_driven_lr_schedules_replay_reference_trajectories(tag):
     np.testing.assert_allclose(got, golden[tag], rtol=1e-12, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("tag", ["mini_batch_wise", "mini_batch_wise_warmup"])
+def test_mini_batch_wise_lr_schedule_replays_the_reference_trajectory(tag):
+    """MiniBatchWiseLRSchedule (lr_schedule.py:242-296): learning rates and recorded lr_scale after every minibatch's
+    objective() call, warm-up iterations ignoring the KL, post_update() recording nothing, and post_init() switching on
+    OnPolicyPreparation.calculate_kl_divergence — against the trajectory recorded from the reference."""
+    import sys
+    from pathlib import Path
+
+    import cusrl_amd
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+    from make_golden import MINI_BATCH_WISE_CASES, ScheduleProbe
+
+    golden = np.load(Path(__file__).resolve().parent / "golden" / "lr_schedule.npz")
+    kls = list(golden["kls"]) + list(golden["kls"][:2])
+    hook = cusrl_amd.hook.MiniBatchWiseLRSchedule(**MINI_BATCH_WISE_CASES[tag])
+    preparation = cusrl_amd.hook.OnPolicyPreparation()
+    assert not preparation.calculate_kl_divergence
+    got = ScheduleProbe().run_mini_batch_wise(hook, preparation, kls, 4)
+    np.testing.assert_allclose(got, golden[tag], rtol=1e-12, atol=0, equal_nan=True)
+    assert hook.eager_phases() == ("objective",) and hook.scale_all_params
+
+
+def test_an_agent_with_a_host_reading_hook_keeps_its_minibatch_steps_out_of_capture():
+    import cusrl_amd
+    from cusrl_amd.hook.on_policy.fused import FusedPpoObjective
+    from cusrl_amd.template.graphs import eager_phases
+
+    spec = cusrl_amd.EnvironmentSpec(6, 3, num_instances=4, device="cpu")
+    factory = cusrl_amd.preset.PpoAgentFactory(device="cpu").to_underlying()
+    assert eager_phases(factory(spec)) == set()
+    factory.register_hook(cusrl_amd.hook.MiniBatchWiseLRSchedule(), after="on_policy_preparation")
+    agent = factory(spec)
+    assert eager_phases(agent) == {"objective"}
+    assert agent.hook["on_policy_preparation"].calculate_kl_divergence
+    order = [type(h).__name__ for h in agent.hook]
+    assert order.index("MiniBatchWiseLRSchedule") == order.index("OnPolicyPreparation") + 1
+    # the schedule neither reads nor differentiates the policy terms: the fused objective stays available on a GPU
+    agent.device = torch.device("cuda")
+    assert FusedPpoObjective.eligible(agent.hook)
+
+
 def test_ppo_preset_includes_the_adaptive_lr_schedule_when_asked():
     import cusrl_amd
 
