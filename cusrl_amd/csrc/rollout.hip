@@ -46,6 +46,64 @@ __global__ __launch_bounds__(kBlock) void normal_sample_logp_kernel(const float 
     logp[row] = lp;
 }
 
+// Acting side of a one-hot categorical policy (cusrl/nn/module/distribution.py:332-366, OneHotCategorical.sample +
+// log_prob), the draw done the way torch.multinomial draws ONE sample on the device: idx = argmax_j p_j / q_j with
+// q ~ Exp(1) taken from torch's generator by the caller (the exponential race; p may stay unnormalised, a common
+// positive factor does not move the argmax).  action = one_hot(idx), logp = logits[idx] - logsumexp(logits).
+// kWavePerRow = false: one lane per row (A <= 32, an env step is N short rows: latency-bound); true: one wave per row,
+// lanes stride over the categories, max / sum / arg-max by xor shuffles.  Ties go to the lower index.
+template <bool kWavePerRow>
+__global__ __launch_bounds__(kBlock) void categorical_sample_logp_kernel(const float *__restrict__ logits,
+                                                                         const float *__restrict__ noise,
+                                                                         float *__restrict__ action,
+                                                                         float *__restrict__ logp, int64_t B, int A) {
+    const int64_t thread = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if constexpr (!kWavePerRow) {
+        const int64_t row = thread;
+        if (row >= B) return;
+        const float *z = logits + row * A, *q = noise + row * A;
+        float m = z[0];
+        for (int j = 1; j < A; ++j) m = fmaxf(m, z[j]);
+        float sum = 0.0f;
+        for (int j = 0; j < A; ++j) sum += expf(z[j] - m);
+        float best = -INFINITY;
+        int taken = 0;
+        for (int j = 0; j < A; ++j) {
+            const float race = expf(z[j] - m) / q[j];
+            if (race > best) best = race, taken = j;
+        }
+        for (int j = 0; j < A; ++j) action[row * A + j] = j == taken ? 1.0f : 0.0f;
+        logp[row] = z[taken] - (m + logf(sum));
+    } else {
+        const int64_t row = thread / kWave;
+        const int lane = threadIdx.x & (kWave - 1);
+        if (row >= B) return;  // uniform over the wave
+        const float *z = logits + row * A, *q = noise + row * A;
+        float m = -INFINITY;
+        for (int j = lane; j < A; j += kWave) m = fmaxf(m, z[j]);
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+        float sum = 0.0f, best = -INFINITY;
+        int taken = INT32_MAX;
+        for (int j = lane; j < A; j += kWave) {
+            const float e = expf(z[j] - m);
+            sum += e;
+            const float race = e / q[j];
+            if (race > best) best = race, taken = j;
+        }
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            sum += __shfl_xor(sum, off, kWave);
+            const float other = __shfl_xor(best, off, kWave);
+            const int other_taken = __shfl_xor(taken, off, kWave);
+            if (other > best || (other == best && other_taken < taken)) best = other, taken = other_taken;
+        }
+        if (taken == INT32_MAX) taken = 0;  // every race was NaN
+        for (int j = lane; j < A; j += kWave) action[row * A + j] = j == taken ? 1.0f : 0.0f;
+        if (lane == 0) logp[row] = z[taken] - (m + logf(sum));
+    }
+}
+
 // Ring slots are handed out in ascending env order, like the reference's `(arange(count) + num_episodes) % R`
 // (trainer.py:63-70): a block's first slot = episodes so far + finished envs in all EARLIER blocks, which every block
 // counts for itself from the flag bytes (b x 256 bytes, 16 per lane-load, L2-resident; no count launch, no ticket).
@@ -209,6 +267,24 @@ extern "C" int cusrl_normal_sample_logp(const float *mean, const float *std, con
     else
         hipLaunchKernelGGL(normal_sample_logp_kernel<false>, dim3(uint32_t(blocks)), dim3(kBlock), 0,
                            as_stream(stream), mean, std, eps, action, logp, B, int(A));
+    return launch_status();
+}
+
+extern "C" int cusrl_categorical_sample_logp(const float *logits, const float *noise, float *action, float *logp,
+                                             int64_t B, int64_t A, void *stream) {
+    if (B < 0 || A <= 0) return CUSRL_E_INVALID;
+    if (B == 0) return 0;
+    if (!logits || !noise || !action || !logp) return CUSRL_E_INVALID;
+    if (A > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    const bool wave_per_row = A > 32;
+    const int64_t blocks = ceil_div(wave_per_row ? B * kWave : B, kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    if (wave_per_row)
+        hipLaunchKernelGGL(categorical_sample_logp_kernel<true>, dim3(uint32_t(blocks)), dim3(kBlock), 0,
+                           as_stream(stream), logits, noise, action, logp, B, int(A));
+    else
+        hipLaunchKernelGGL(categorical_sample_logp_kernel<false>, dim3(uint32_t(blocks)), dim3(kBlock), 0,
+                           as_stream(stream), logits, noise, action, logp, B, int(A));
     return launch_status();
 }
 

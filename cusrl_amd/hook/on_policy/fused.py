@@ -101,6 +101,7 @@ class FusedPpoObjective:
         self.policy: tuple | None = None
         self.surrogate: tuple | None = None
         self.entropy: float | None = None
+        self.pending_streams: list = []
 
     # ------------------------------------------------------------------ arming
     @staticmethod
@@ -165,6 +166,10 @@ class FusedPpoObjective:
         self.value = (curr_value, old_value, ret, weight, loss_clip)
         return {"value_loss": None}
 
+    def join(self, stream):
+        """A term was produced on another stream: the loss launch waits for it."""
+        self.pending_streams.append(stream)
+
     def add_policy(self, action_dist, action, old_logp):
         self.policy = (action_dist, action, old_logp)
 
@@ -183,6 +188,9 @@ class FusedPpoObjective:
         curr_value, old_value, ret, w_val, value_clip = self.value
         action_dist, action, old_logp = self.policy
         advantage, clip, w_sur = self.surrogate
+        for stream in self.pending_streams:
+            torch.cuda.current_stream().wait_stream(stream)
+        self.pending_streams.clear()
         if "logits" in action_dist:  # one-hot categorical policy (discrete action space)
             total, losses, logp, entropy, logp_ratio, ratio = _FusedCategoricalPpoFunction.apply(
                 action_dist["logits"].float(), curr_value, advantage, old_logp, action, ret, old_value,

@@ -131,9 +131,24 @@ class ValueLoss(Hook):
 
     def objective(self, metadata, batch):
         state = get_first(batch, "state", "observation")
-        curr_value = self.agent.critic.evaluate(state, memory=batch.get("critic_memory"), done=batch["done"])
+        memory, done = batch.get("critic_memory"), batch["done"]
+        fused = FusedPpoObjective.current(self)
+        branch = getattr(self.agent, "_critic_stream", None) if fused is not None else None
+        if branch is not None:
+            # inside a minibatch step that is (being) captured: the critic's forward — and, because autograd replays
+            # every node on the stream its forward ran on, its backward — goes to a second stream.  The two networks
+            # share nothing until the loss kernel, so the captured graph gets two independent branches whose latency-
+            # bound small kernels fill the gaps of the other branch's GEMM tails.  Joined in FusedPpoObjective.resolve.
+            main = torch.cuda.current_stream()
+            branch.wait_stream(main)  # the gather of `state` was issued on `main`
+            with torch.cuda.stream(branch):
+                curr_value = self.agent.critic.evaluate(state, memory=memory, done=done)
+            curr_value.record_stream(main)
+            fused.join(branch)
+        else:
+            curr_value = self.agent.critic.evaluate(state, memory=memory, done=done)
         batch["curr_value"] = curr_value
-        if (fused := FusedPpoObjective.current(self)) is not None:
+        if fused is not None:
             # the behaviour-policy value is only read by the clipped form: not touching it keeps the leaf out of the
             # lazy minibatch (and of the per-slot record, which then fits 256 bytes for the `ppo` buffer)
             old_value = batch["value"] if self.loss_clip is not None else None

@@ -252,9 +252,9 @@ class OneHotCategoricalDist(Distribution):
     Factory = OneHotCategoricalDistFactory
     is_normal = False
     is_categorical = True  # the fused PPO objective has a one-hot categorical form (cusrl_ppo_loss_categorical_fwd_bwd)
-    # torch.distributions.Categorical validates its arguments with a host read-back when it is constructed: sampling from
-    # it cannot be captured into a hipGraph, so `compile=True` leaves the act step of a discrete policy eager
-    capture_safe = False
+    # acting on a GPU draws through ONE HIP launch (below); torch.distributions' own sample path reads back to the host
+    # (one_hot / argument checks) and could not be captured into a hipGraph
+    capture_safe = True
 
     @staticmethod
     def _dist(dist_params):
@@ -268,6 +268,14 @@ class OneHotCategoricalDist(Distribution):
         return one_hot(logits.argmax(dim=-1), logits.size(-1)).to(dtype=logits.dtype)
 
     def sample_from_dist(self, dist_params):
+        logits = dist_params["logits"]
+        if logits.is_cuda and not torch.is_grad_enabled():
+            # acting path: the Exp(1) race variables come from torch's generator exactly as torch.multinomial would draw
+            # them for one sample, then ONE HIP launch does softmax, arg-max of p / q, one-hot and log-prob
+            from cusrl_amd import ops
+
+            logits = logits.float()
+            return ops.categorical_sample_logp(logits, torch.empty_like(logits).exponential_(1.0))
         with disable_autocast(dist_params["logits"].device.type):
             dist = self._dist(dist_params)
             action = dist.rsample()

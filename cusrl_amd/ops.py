@@ -31,6 +31,7 @@ __all__ = [
     "merge_mean_var",
     "next_value",
     "normal_sample_logp",
+    "categorical_sample_logp",
     "normalize_",
     "normalize_from_partials_",
     "ppo_loss_categorical_fwd_bwd",
@@ -791,6 +792,24 @@ def normal_sample_logp(mean: torch.Tensor, std: torch.Tensor, eps: torch.Tensor)
         "cusrl_normal_sample_logp",
         lambda: B * (16 * A + 4),
         lambda: _native.lib().cusrl_normal_sample_logp(mean.data_ptr(), std.data_ptr(), eps.data_ptr(), action.data_ptr(), logp.data_ptr(), B, A, _stream()),
+    )
+    return action, logp
+
+
+def categorical_sample_logp(logits: torch.Tensor, noise: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """One-hot sample of ``softmax(logits)`` and its log-prob in one launch (cusrl/nn/module/distribution.py:332-366):
+    ``argmax(softmax(logits) / noise)`` with ``noise ~ Exp(1)`` — torch.multinomial's own single-draw rule."""
+    logits, noise = _f32(logits, "logits"), _f32(noise, "noise")
+    if noise.shape != logits.shape:
+        raise ValueError("categorical_sample_logp: shape mismatch")
+    A = logits.shape[-1]
+    B = logits.numel() // A
+    action = torch.empty_like(logits)
+    logp = torch.empty(logits.shape[:-1] + (1,), dtype=torch.float32, device=logits.device)
+    _observed(
+        "cusrl_categorical_sample_logp",
+        lambda: B * (12 * A + 4),
+        lambda: _native.lib().cusrl_categorical_sample_logp(logits.data_ptr(), noise.data_ptr(), action.data_ptr(), logp.data_ptr(), B, A, _stream()),
     )
     return action, logp
 

@@ -11,6 +11,8 @@ Differences that matter on MI355X (semantics unchanged):
 
 from __future__ import annotations
 
+import os
+
 from collections.abc import Iterable, Mapping
 from dataclasses import dataclass
 from typing import Any
@@ -137,6 +139,9 @@ class ActorCritic(Agent):
 
             self._graph_stream = torch.cuda.Stream(device=self.device)
             self._graph_pool = torch.cuda.graph_pool_handle()
+            # second branch of the captured minibatch step (critic forward / backward, hook/on_policy/value.py)
+            self._branch_stream = torch.cuda.Stream(device=self.device)
+            self.concurrent_critic = os.environ.get("CUSRL_CONCURRENT_CRITIC", "1") != "0"
             self._graphed_act = GraphedAct(self)
         self.flat_gradients: FlatGradients | None = None
         self._unit_grad: torch.Tensor | None = None

@@ -180,8 +180,12 @@ class GraphedTrainStep:
         agent.actor.clear_intermediate_repr()
         agent.critic.clear_intermediate_repr()
         agent.hook.pre_objective(self.metadata, batch)
-        with agent.autocast():
-            objectives = agent.hook.objective(self.metadata, batch)
+        agent._critic_stream = agent._branch_stream if agent.concurrent_critic else None
+        try:
+            with agent.autocast():
+                objectives = agent.hook.objective(self.metadata, batch)
+        finally:
+            agent._critic_stream = None
         if objectives is not None:
             loss = objectives.loss()
             agent._zero_grad()

@@ -194,6 +194,13 @@ int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const float *old_
 int cusrl_normal_sample_logp(const float *mean, const float *std, const float *eps, float *action, float *logp,
                              int64_t B, int64_t A, void *stream);
 
+/* One-hot categorical sample + its log-prob in one pass — cusrl/nn/module/distribution.py:332-366
+ * (`OneHotCategorical(logits).sample()`, `log_prob(sample)`): idx = argmax_j softmax(logits)_j / noise_j with
+ * noise ~ Exp(1) supplied by the caller from torch's generator (the way torch.multinomial draws one sample on the
+ * device); action[B, A] = one_hot(idx), logp[B] = logits[idx] - logsumexp(logits).  Ties go to the lower index. */
+int cusrl_categorical_sample_logp(const float *logits, const float *noise, float *action, float *logp, int64_t B,
+                                  int64_t A, void *stream);
+
 /* EnvironmentStats.track_step + track_episode — cusrl/template/trainer.py:54-76, in one launch and without the
  * host round trip of `get_done_indices(...).tolist()` (environment.py:356-362):
  *   episode_rew[n] += reward[n]; episode_len[n] += 1; step_reward_sum[d] += sum_n reward[n,d];

@@ -298,6 +298,28 @@ def ppo_loss(advantage, old_logp, action, mean, std, ret, curr_value, old_value=
     return out
 
 
+def categorical_sample(logits, noise):
+    """Acting side of a one-hot categorical policy, restated in numpy float64: cusrl/nn/module/distribution.py:332-366
+    (``OneHotCategorical(logits).sample()`` and ``log_prob`` of the sample).  The draw itself happens inside
+    ``torch.multinomial`` (PyTorch 2.10, not part of /root/reference): for one sample per row on a device it takes
+    ``argmax_j p_j / q_j`` with ``q ~ Exp(1)``; that rule is restated here and pinned on the GPU against
+    ``torch.multinomial`` fed from the same generator state (tests/test_hip_kernels.py).  Returns the taken index, the
+    one-hot action, log-prob [B, 1] and ``margin`` = best race / runner-up (a row with margin ~ 1 is a numerical tie)."""
+    z = np.asarray(logits, np.float64)
+    q = np.asarray(noise, np.float64)
+    m = z.max(-1, keepdims=True)
+    log_p = z - (m + np.log(np.exp(z - m).sum(-1, keepdims=True)))
+    with np.errstate(divide="ignore"):
+        race = np.exp(log_p) / q
+    taken = race.argmax(-1)  # first maximum
+    rows = np.arange(z.shape[0])
+    ordered = np.sort(race, axis=-1)
+    margin = ordered[:, -1] / ordered[:, -2] if z.shape[-1] > 1 else np.full(z.shape[0], np.inf)
+    action = np.zeros(z.shape, np.float32)
+    action[rows, taken] = 1.0
+    return taken, action, log_p[rows, taken].astype(np.float32)[:, None], margin
+
+
 def categorical_ppo_loss(advantage, old_logp, action, logits, ret, curr_value, old_value=None, *, clip=0.2,
                          value_clip=None, w_sur=1.0, w_val=0.5, w_ent=0.01):
     """The objective of :func:`ppo_loss` for a one-hot categorical policy, restated in numpy (float64 arithmetic, results

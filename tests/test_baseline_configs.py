@@ -160,11 +160,33 @@ def test_config1_rollout_with_observation_normalisation_runs_on_hip(cusrl):
     assert launched["cusrl_masked_col_stats"] >= 2 * 16 and launched["cusrl_rms_merge"] >= 2 * 16
     assert launched["cusrl_rms_normalize"] >= 2 * 2 * 16 and launched["cusrl_buffer_push"] == 2 * 16
     assert launched["cusrl_ppo_loss_categorical_fwd_bwd"] == 2 * 16
+    assert launched["cusrl_categorical_sample_logp"] == 2 * 16  # one draw launch per env step
     buffer = trainer.agent.buffer
     assert {"original_observation", "original_next_observation"} <= set(buffer.storage) and buffer["action"].shape == (16, 8, 3)
     assert torch.equal(buffer["action"].sum(-1), torch.ones(16, 8, device=DEV))  # one-hot actions
     for key in ("Agent/value_loss", "Agent/surrogate_loss", "Agent/kl_divergence"):
         assert np.isfinite(trainer.last_info[key])
+
+
+def test_config1_compiled_captures_the_discrete_act_step_and_trains_like_eager(cusrl):
+    """compile=True on the MountainCar shape: the act step of the one-hot categorical policy (observation normalisation,
+    actor, the HIP draw) replays from a hipGraph, the minibatch steps from theirs, and four iterations end at the
+    parameters of the eager run (same generator stream: the race variables are drawn by torch inside the capture)."""
+    finals = []
+    for compile_ in (False, True):
+        cusrl.set_global_seed(9)
+        env = cusrl.testing.DummyTorchEnvironment(num_instances=8, observation_dim=2, action_dim=3, device=DEV)
+        factory = cusrl.preset.PpoAgentFactory(**MOUNTAIN_CAR_KWARGS, compile=compile_,
+                                               optimizer_kwargs={"capturable": True, "fused": True})
+        trainer = cusrl.Trainer(env, factory, num_iterations=4, verbose=False)
+        trainer.run_training_loop()
+        agent = trainer.agent
+        if compile_:
+            assert agent._graphed_act.state == 2, "the discrete act step was not captured"
+            assert agent._graphed_steps and all(step.state == 2 for step in agent._graphed_steps.values())
+        assert torch.equal(agent.buffer["action"].sum(-1), torch.ones(16, 8, device=DEV))
+        finals.append(torch.cat([p.detach().reshape(-1) for p in agent.parameters()]))
+    assert torch.allclose(finals[0], finals[1], rtol=1e-4, atol=1e-5), (finals[0] - finals[1]).abs().max()
 
 
 # ------------------------------------------------------------------------------------------------ configs 2 / 3

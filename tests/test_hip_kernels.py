@@ -507,6 +507,68 @@ def test_normal_sample_logp_vs_oracle(ops, B, A):
     assert logp.shape == (B, 1)
 
 
+@pytest.mark.parametrize("B,A", [(8, 3), (4096, 12), (1000, 32), (777, 33), (300, 200), (1, 1)])
+def test_categorical_sample_logp_vs_oracle(ops, B, A):
+    """Both layouts of the kernel (one lane per row up to 32 categories, one wave per row above): the taken category is
+    the winner of the exponential race wherever the race is not a numerical tie, the action is its one-hot row and the
+    log-prob is log-softmax at it."""
+    from cusrl_amd import _native
+
+    rng = np.random.default_rng(B + A)
+    logits = (rng.standard_normal((B, A)) * 2.0).astype(np.float32)
+    noise = rng.exponential(1.0, (B, A)).astype(np.float32)
+    before = _native.launch_counts.get("cusrl_categorical_sample_logp", 0)
+    action, logp = ops.categorical_sample_logp(dev(logits), dev(noise))
+    assert _native.launch_counts["cusrl_categorical_sample_logp"] == before + 1
+    taken, expect_action, expect_logp, margin = oracle.categorical_sample(logits, noise)
+    got = host(action)
+    assert action.shape == (B, A) and logp.shape == (B, 1)
+    assert np.array_equal(got.sum(-1), np.ones(B)) and set(np.unique(got)) <= {0.0, 1.0}
+    clear = margin > 1.0 + 1e-4
+    assert clear.mean() > 0.99
+    assert np.array_equal(got.argmax(-1)[clear], taken[clear])
+    assert np.array_equal(got[clear], expect_action[clear])
+    log_softmax = logits - np.log(np.exp(logits - logits.max(-1, keepdims=True)).sum(-1, keepdims=True)) - logits.max(-1, keepdims=True)
+    np.testing.assert_allclose(host(logp)[:, 0], log_softmax[np.arange(B), got.argmax(-1)], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(host(logp)[clear], expect_logp[clear], rtol=1e-5, atol=2e-6)
+
+
+def test_categorical_sample_ties_and_dead_categories(ops):
+    """Equal races go to the lower index (first arg-max); a category of probability zero (logit -inf) is never taken."""
+    logits = torch.tensor([[0.0, 0.0, 0.0], [1.0, -float("inf"), 1.0], [-float("inf"), 2.0, -float("inf")]], device=DEV)
+    noise = torch.ones(3, 3, device=DEV)
+    noise[1, 1] = 1e-30
+    action, logp = ops.categorical_sample_logp(logits, noise)
+    assert host(action).argmax(-1).tolist() == [0, 0, 1]
+    np.testing.assert_allclose(host(logp)[:, 0], [np.log(1 / 3), np.log(0.5), 0.0], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("A", [3, 48])
+def test_categorical_acting_draws_what_torch_multinomial_draws(ops, A):
+    """The acting path of OneHotCategoricalDist takes Exp(1) race variables from torch's generator the way
+    torch.multinomial does for one sample, so from the same generator state it takes the same categories as
+    ``OneHotCategorical(logits).sample()`` on this device — and the frequencies follow softmax(logits)."""
+    from cusrl_amd.nn.distribution import OneHotCategoricalDist
+
+    dist = OneHotCategoricalDist(4, A).to(DEV)
+    logits = torch.randn(20000, A, device=DEV) * 1.5
+    torch.manual_seed(77)
+    reference = torch.distributions.OneHotCategorical(logits=logits, validate_args=False).sample()
+    torch.manual_seed(77)
+    with torch.no_grad():
+        action, logp = dist.sample_from_dist({"logits": logits})
+    same = (action.argmax(-1) == reference.argmax(-1)).float().mean().item()
+    assert same > 0.9995, same
+    expect_logp = torch.log_softmax(logits, -1).gather(-1, action.argmax(-1, keepdim=True))
+    assert torch.allclose(logp, expect_logp, rtol=1e-5, atol=2e-6)
+    # frequencies of one fixed distribution
+    row = torch.tensor([2.0, 0.5, -1.0] + [-3.0] * (A - 3), device=DEV)
+    with torch.no_grad():
+        draws, _ = dist.sample_from_dist({"logits": row.expand(200000, A).contiguous()})
+    freq = draws.mean(0)
+    assert torch.allclose(freq, torch.softmax(row, 0), atol=4e-3)
+
+
 def test_sampling_consumes_the_same_random_stream_as_rsample(ops):
     from cusrl_amd.nn import NormalDist
 
