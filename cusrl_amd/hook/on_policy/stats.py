@@ -22,6 +22,16 @@ class OnPolicyStatistics(Hook):
     def __init__(self, sampler: Sampler | None = None):
         super().__init__(training_only=True)
         self.sampler = Sampler() if sampler is None else sampler
+        self._replay: dict | None = None
+
+    def _in_place(self) -> bool:
+        """ONE shuffled batch of the whole buffer (the preset's ``AutoMiniBatchSampler()``: 1 epoch x 1 minibatch,
+        stats.py:29-32): the statistics are permutation-invariant means, so the pass can read the buffer in place."""
+        from cusrl_amd.sampler.mini_batch_sampler import AutoMiniBatchSampler, MiniBatchSampler
+
+        sampler = self.sampler
+        return (isinstance(sampler, (MiniBatchSampler, AutoMiniBatchSampler)) and sampler.num_epochs == 1
+                and sampler.num_mini_batches in (1, (1,)) and sampler.lazy)
 
     def _batches(self, buffer):
         """The hook's sampler — except that ONE shuffled batch of the whole buffer (the preset's
@@ -30,11 +40,8 @@ class OnPolicyStatistics(Hook):
         (flattened views) and the 110 MB whole-buffer gather disappears.  The permutation is still drawn: the reference
         consumes one ``randperm`` from the global generator here, and the following iterations' index streams stay
         bit-identical only if this one is consumed too."""
-        from cusrl_amd.sampler.mini_batch_sampler import AutoMiniBatchSampler, MiniBatchSampler
-
         sampler = self.sampler
-        if (isinstance(sampler, (MiniBatchSampler, AutoMiniBatchSampler)) and sampler.num_epochs == 1
-                and sampler.num_mini_batches in (1, (1,)) and sampler.lazy):
+        if self._in_place():
             for metadata, _indices in sampler.iter_indices(buffer):
                 if metadata["temporal"]:
                     yield metadata, buffer.sample(lambda _name, tensor: tensor)
@@ -46,6 +53,8 @@ class OnPolicyStatistics(Hook):
     @torch.no_grad()
     def post_update(self):
         agent = self.agent
+        if self._post_update_replayed():
+            return
         for _, batch in self._batches(agent.buffer):
             with agent.autocast():
                 updated, _ = agent.actor(batch["observation"], memory=batch.get("actor_memory"), done=batch["done"])
@@ -55,6 +64,53 @@ class OnPolicyStatistics(Hook):
                 self._record_fused_categorical(batch, updated)
             else:  # other policy families, CPU agents, autocast dtypes: the actor's own compute_* methods
                 self._record_generic(batch, updated)
+
+    # ------------------------------------------------------------------ compile=True: the pass from one hipGraph
+    def _post_update_replayed(self) -> bool:
+        """The in-place pass of a feed-forward actor is shape-static: the actor over ``[T*N]`` rows plus the one-launch
+        reduction replay from a hipGraph (eagerly: ~15 launches for ~0.1 ms of device work).  The three means land in
+        a persistent device tensor and are recorded from there."""
+        agent, buffer = self.agent, self.agent.buffer
+        actor = agent.actor
+        if not (getattr(agent, "compile", False) and getattr(agent, "_graph_stream", None) is not None and self._in_place()
+                and not actor.is_recurrent and agent.device.type == "cuda" and not agent.autocast_enabled):
+            return False
+        family = "normal" if getattr(actor.distribution, "is_normal", False) else (
+            "categorical" if getattr(actor.distribution, "is_categorical", False) else None)
+        if family is None or "advantage" not in buffer.storage:
+            return False
+        from cusrl_amd.template.graphs import GraphedRegion
+
+        metadata = None
+        for metadata, _indices in self.sampler.iter_indices(buffer):  # the reference draws one permutation here: so do we
+            pass
+        if metadata is None or metadata["temporal"]:
+            return False
+        flat = buffer.sample(lambda _name, tensor: tensor.flatten(0, 1))
+        behaviour = flat["action_dist"]
+        leaves = [flat["observation"], flat["done"], flat["action"], flat["action_logp"], flat["advantage"], *behaviour.values()]
+        if any(t.dtype not in (torch.float32, torch.bool) for t in leaves):
+            return False
+        key = (buffer.layout_version, family, tuple(t.data_ptr() for t in leaves))
+        replay = self._replay
+        if replay is None or replay["key"] != key:  # the region closes over these very views
+
+            def region():
+                updated, _ = actor(flat["observation"], memory=None, done=flat["done"])
+                if family == "normal":
+                    return ops.policy_stats(behaviour["mean"], behaviour["std"], updated["mean"], updated["std"],
+                                            flat["action"], flat["action_logp"], flat["advantage"])
+                return ops.categorical_policy_stats(behaviour["logits"], updated["logits"], flat["action"],
+                                                    flat["action_logp"], flat["advantage"])
+
+            replay = self._replay = {"key": key, "region": GraphedRegion(agent, region)}
+        kl, weighted_advantage, std = replay["region"].run(family).unbind(0)
+        rows, metrics = flat["action_logp"].numel(), agent.metrics
+        metrics.record_reduced("kl_divergence", kl, rows)
+        metrics.record_reduced("importance_weighted_advantage", weighted_advantage, flat["advantage"].numel())
+        if family == "normal":
+            metrics.record_reduced("action_std", std, flat["action"].numel())
+        return True
 
     # ------------------------------------------------------------------ Gaussian policy: one launch
     def _gaussian_on_device(self, behaviour, updated) -> bool:

@@ -38,6 +38,7 @@ class ValueComputation(Hook):
         self._critic_memory = None
         self._value_pending = False
         self._auto_defer: bool | None = None
+        self._replay_scratch: dict | None = None
 
     def init(self):
         if self.agent.environment_spec.final_state_is_missing:
@@ -76,6 +77,9 @@ class ValueComputation(Hook):
 
     @torch.no_grad()
     def pre_update(self, buffer: Buffer):
+        if self._value_pending and self._replayable(buffer):
+            self._value_pending = False
+            return self._pre_update_replayed(buffer)
         critic = self.agent.critic
         if self._value_pending:  # deferred: the whole rollout's values from one critic pass
             self._value_pending = False
@@ -110,6 +114,74 @@ class ValueComputation(Hook):
         with self.agent.autocast():
             truncated_next_value = critic.evaluate(truncated_next_state, memory=next_memory)
         ops.scatter_rows(truncated_next_value.float(), slots, next_value)
+
+    # ------------------------------------------------------------------ compile=True: the same work from two hipGraphs
+    # Eagerly the block above is ~25 dependent launches (two critic passes, the shift kernel, the compaction, a gather,
+    # a scatter) whose device time is a quarter of their host launch time.  With a deferred feed-forward critic every
+    # shape in it is static except the number k of truncated slots, so it becomes
+    #   head  : value pass over [T*N], last_value, next_value, compaction (k stored straight into pinned host memory)
+    #   tail_b: gather of the first b slots, critic on b rows, scatter limited to k ON THE DEVICE (b = a power-of-two
+    #           capacity >= 2k that only ever grows; slots past k are stale but valid rows, computed and dropped)
+    # The host polls k between the two replays (no stream synchronisation) and picks the bucket.
+    _MIN_BUCKET = 256
+
+    def _replayable(self, buffer: Buffer) -> bool:
+        agent = self.agent
+        return (bool(getattr(agent, "compile", False)) and getattr(agent, "_graph_stream", None) is not None
+                and "value" in buffer.storage and "next_value" in buffer.storage  # created by the first, eager pass
+                and buffer.get("next_critic_memory") is None and self._critic_memory is None)
+
+    def _pre_update_replayed(self, buffer: Buffer):
+        from cusrl_amd.template.graphs import GraphedRegion
+
+        state: Tensor = get_first(buffer, "state", "observation")
+        value = buffer.field("value", buffer.storage["value"])  # host-side bookkeeping of a write to these fields
+        next_value = buffer.field("next_value", value)
+        next_state: Tensor = get_first(buffer, "next_state", "next_observation")
+        terminated, truncated = buffer["terminated"], buffer["truncated"]
+        T, N = value.shape[:2]
+        scratch = self._replay_scratch
+        key = (buffer.layout_version, state.data_ptr(), next_state.data_ptr(), T, N)
+        if scratch is None or scratch["key"] != key:  # the regions below close over these very tensors
+            scratch = self._replay_scratch = {"key": key, "slots": torch.zeros(T * N, dtype=torch.int64, device=value.device),
+                                              "counter": ops.HostCounter(), "head": None, "tails": {}}
+        slots, counter = scratch["slots"], scratch["counter"]
+        critic, autocast = self.agent.critic, self.agent.autocast
+
+        def head():
+            with autocast():
+                flat_value = critic.evaluate(state.flatten(0, 1))
+                last_value = critic.evaluate(next_state[-1])
+            value.copy_(flat_value.float().view(T, N, -1))
+            counts = ops.next_value(value, terminated, truncated, last_value.float(), self.termination_value,
+                                    truncated_uses_own_value=not self.bootstrap_truncated_states, out=next_value)
+            if self.bootstrap_truncated_states:
+                ops.compact_flags(truncated, counts, counter.tensor,
+                                  scratch={"n": T * N, "device": truncated.device, "indices": slots, "counts": None})
+
+        if scratch["head"] is None:
+            scratch["head"] = GraphedRegion(self.agent, head)
+        counter.arm()
+        scratch["head"].run(self.bootstrap_truncated_states, self.termination_value)
+        if not self.bootstrap_truncated_states:
+            return
+        k = counter.wait()
+        if k == 0:
+            return
+        bucket = scratch.get("bucket", 0)
+        if k > bucket:  # capacities only grow, with headroom: a count hovering around a power of two must not re-capture
+            bucket = scratch["bucket"] = min(max(self._MIN_BUCKET, 1 << (2 * k - 1).bit_length()), T * N)
+
+        def tail():
+            (rows,) = ops.gather_rows([next_state], slots[:bucket], T, N)
+            with autocast():
+                bootstrap = critic.evaluate(rows)
+            ops.scatter_rows(bootstrap.float(), slots[:bucket], next_value, counter.tensor)
+
+        region = scratch["tails"].get(bucket)
+        if region is None:
+            region = scratch["tails"][bucket] = GraphedRegion(self.agent, tail)
+        region.run(bucket)
 
 
 def _clipped_value_loss(value: Tensor, curr_value: Tensor, return_: Tensor, loss_clip: float) -> Tensor:

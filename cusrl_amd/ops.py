@@ -491,9 +491,13 @@ class HostCounter:
                 return value
 
 
-def scatter_rows(src: torch.Tensor, indices: torch.Tensor, dst: torch.Tensor) -> None:
-    """``dst.flatten(0, 1)[indices] = src`` (cusrl/hook/on_policy/value.py:78)."""
+def scatter_rows(src: torch.Tensor, indices: torch.Tensor, dst: torch.Tensor, count: torch.Tensor | None = None) -> None:
+    """``dst.flatten(0, 1)[indices] = src`` (cusrl/hook/on_policy/value.py:78).  With ``count`` (a 1-element int32 on
+    the device or in pinned host memory) only the first ``min(len(indices), count)`` rows are written — the number is
+    read by the kernel, so a fixed-capacity launch can follow an on-device compaction without a host read."""
     require_device(src, "src"), require_device(dst, "dst"), require_device(indices, "indices")
+    if count is not None and (count.dtype != torch.int32 or count.numel() != 1 or not (count.is_cuda or count.is_pinned())):
+        raise TypeError("'count' must be a 1-element int32 tensor on the device or in pinned host memory")
     if src.dtype != dst.dtype or indices.dtype != torch.int64 or not dst.is_contiguous():
         raise TypeError("scatter_rows: dtype/layout mismatch")
     src, indices = src.contiguous(), indices.contiguous()
@@ -501,7 +505,8 @@ def scatter_rows(src: torch.Tensor, indices: torch.Tensor, dst: torch.Tensor) ->
     if K == 0:
         return
     check(
-        _native.lib().cusrl_scatter_rows(src.data_ptr(), indices.data_ptr(), dst.data_ptr(), K, _row_bytes(src, 1), None, _stream()),
+        _native.lib().cusrl_scatter_rows(src.data_ptr(), indices.data_ptr(), dst.data_ptr(), K, _row_bytes(src, 1),
+                                         None if count is None else count.data_ptr(), _stream()),
         "cusrl_scatter_rows",
     )
 

@@ -26,7 +26,7 @@ import torch
 
 from cusrl_amd.utils.metrics import MetricTap
 
-__all__ = ["GraphedAct", "GraphedTrainStep", "capture_signature", "collective_phases", "eager_phases"]
+__all__ = ["GraphedAct", "GraphedRegion", "GraphedTrainStep", "capture_signature", "collective_phases", "eager_phases"]
 
 
 def _freeze(value):
@@ -254,6 +254,47 @@ class GraphedTrainStep:
     def flush_metrics(self):
         self.forward_backward.flush_metrics()
         self.optimize.flush_metrics()
+
+
+class GraphedRegion:
+    """A shape-static, argument-free slice of ``agent.update()`` outside the minibatch loop (the critic pass over the
+    whole buffer in front of GAE, the statistics pass behind the last epoch) replayed from a hipGraph.  Such a slice is
+    a dozen-plus dependent launches whose device time is far below their host launch time; one replay costs one launch.
+
+    ``fn`` must touch persistent memory only — buffer storages, parameters, scratch tensors the caller owns — issue no
+    host read-back and record no metrics; what it returns stays valid until the next :meth:`run`.  Protocol as for the
+    other captures: eager on the capture stream the first time (that run warms rocBLAS and the allocator and IS that
+    call), captured on the second, replayed afterwards, re-captured when anything the capture froze on the host changes
+    (hook mutables, buffer layout, the caller's ``extra`` key)."""
+
+    def __init__(self, agent, fn):
+        self.agent, self.fn = agent, fn
+        self.capture = _Capture(agent)
+        self.stream: torch.cuda.Stream = agent._graph_stream
+        self.state = 0
+        self.signature: tuple | None = None
+        self.outputs = None
+
+    def run(self, *extra):
+        agent = self.agent
+        signature = (capture_signature(agent), agent.buffer.layout_version, extra)
+        if self.state == 2 and signature != self.signature:
+            self.state = 1
+        self.signature = signature
+        if self.state == 2:
+            self.capture.replay()
+            return self.outputs
+        if self.state == 0:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                outputs = self.fn()
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.state = 1
+            return outputs
+        self.outputs = self.capture.capture(self.fn, self.stream, pool=agent._graph_pool)
+        self.state = 2
+        self.capture.replay()
+        return self.outputs
 
 
 class GraphedAct:
