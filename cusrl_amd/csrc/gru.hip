@@ -1,0 +1,199 @@
+// GRU time-step epilogues for gfx950 (recurrent BPTT, config 4).
+//
+// torch.nn.GRU on ROCm is MIOpen's RNN: per time step it issues generic tensor kernels (Op2dTensorLite,
+// SubTensorOpWithSubTensor2d: ~24 000 launches per iteration of config 4) and reduces the bias gradients with
+// Op2dTensorSquash at 7.6 ms a call — 45 % of the device time of that config (profiles/r02/config4_miopen_kernel_stats.csv).
+// Here the layer is what it is algebraically: ONE input-projection GEMM for all time steps, per step one recurrent GEMM
+// (rocBLAS, [B, H] x [H, 3H]) and ONE pass over the gates; backward mirrors it, and the weight / bias gradients are
+// batched GEMMs / column sums over all steps at once.  These kernels are that one pass:
+//
+//   r = sigmoid(gi_r + gh_r + b_hr)      z = sigmoid(gi_z + gh_z + b_hz)
+//   q = gh_n + b_hn                      n = tanh(gi_n + r * q)
+//   h' = (1 - z) * n + z * h             (torch.nn.GRU; gi = W_ih x + b_ih, gh = W_hh h)
+//
+// `lengths` (optional) gives packed-sequence semantics without packing: a sequence that has ended (t >= lengths[b]) keeps
+// its state, emits zeros, and lets the state gradient pass through untouched — so the final state is the state at each
+// sequence's own last step (cusrl/nn/module/rnn.py:273-291 obtains that through a PackedSequence and a host read of the
+// lengths).  Streaming, HBM-bound: 36 B per state element forward, 52 B backward; 16-byte lanes when H % 4 == 0.
+#include "common.hpp"
+
+namespace cusrl {
+
+__device__ __forceinline__ float gru_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct GruGates {
+    float r, z, q, n;
+};
+
+__device__ __forceinline__ GruGates gru_gates(float gi_r, float gi_z, float gi_n, float gh_r, float gh_z, float gh_n,
+                                              float b_r, float b_z, float b_n) {
+    GruGates g;
+    g.r = gru_sigmoid(gi_r + gh_r + b_r);
+    g.z = gru_sigmoid(gi_z + gh_z + b_z);
+    g.q = gh_n + b_n;
+    g.n = tanhf(gi_n + g.r * g.q);
+    return g;
+}
+
+// V = float4 (H % 4 == 0, aligned rows) or float.
+template <typename V>
+__global__ __launch_bounds__(kBlock) void gru_gates_fwd_kernel(const float *__restrict__ gi, const float *__restrict__ gh,
+                                                               const float *__restrict__ b_hh, float *__restrict__ h,
+                                                               float *__restrict__ out,
+                                                               const int64_t *__restrict__ lengths, int64_t t,
+                                                               int64_t B, int H) {
+    constexpr int kW = sizeof(V) / sizeof(float);
+    const int cols = H / kW;
+    const int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= B * cols) return;
+    const int64_t b = e / cols;
+    const int j = int(e - b * cols) * kW;
+    const float *gi_row = gi + b * 3 * H, *gh_row = gh + b * 3 * H;
+    V gir = *reinterpret_cast<const V *>(gi_row + j), giz = *reinterpret_cast<const V *>(gi_row + H + j),
+      gin = *reinterpret_cast<const V *>(gi_row + 2 * H + j);
+    V ghr = *reinterpret_cast<const V *>(gh_row + j), ghz = *reinterpret_cast<const V *>(gh_row + H + j),
+      ghn = *reinterpret_cast<const V *>(gh_row + 2 * H + j);
+    V hp = *reinterpret_cast<const V *>(h + b * H + j);
+    V br, bz, bn;
+    if (b_hh) {
+        br = *reinterpret_cast<const V *>(b_hh + j), bz = *reinterpret_cast<const V *>(b_hh + H + j),
+        bn = *reinterpret_cast<const V *>(b_hh + 2 * H + j);
+    }
+    const bool live = !lengths || t < lengths[b];
+    V hn, o;
+    const float *pgir = reinterpret_cast<const float *>(&gir), *pgiz = reinterpret_cast<const float *>(&giz),
+                *pgin = reinterpret_cast<const float *>(&gin), *pghr = reinterpret_cast<const float *>(&ghr),
+                *pghz = reinterpret_cast<const float *>(&ghz), *pghn = reinterpret_cast<const float *>(&ghn),
+                *php = reinterpret_cast<const float *>(&hp), *pbr = reinterpret_cast<const float *>(&br),
+                *pbz = reinterpret_cast<const float *>(&bz), *pbn = reinterpret_cast<const float *>(&bn);
+    float *phn = reinterpret_cast<float *>(&hn), *po = reinterpret_cast<float *>(&o);
+#pragma unroll
+    for (int k = 0; k < kW; ++k) {
+        const GruGates g = gru_gates(pgir[k], pgiz[k], pgin[k], pghr[k], pghz[k], pghn[k], b_hh ? pbr[k] : 0.0f,
+                                     b_hh ? pbz[k] : 0.0f, b_hh ? pbn[k] : 0.0f);
+        const float next = (1.0f - g.z) * g.n + g.z * php[k];
+        phn[k] = live ? next : php[k];
+        po[k] = live ? next : 0.0f;
+    }
+    *reinterpret_cast<V *>(h + b * H + j) = hn;
+    *reinterpret_cast<V *>(out + b * H + j) = o;
+}
+
+// In place: gi <- d(loss)/d(gi), gh <- d(loss)/d(gh) (the saved pre-activations are consumed), dh <- dh_t * z (the
+// direct path to h_{t-1}; the caller adds d_gh @ W_hh).  dh on entry = gradient arriving from step t + 1.
+template <typename V>
+__global__ __launch_bounds__(kBlock) void gru_gates_bwd_kernel(float *__restrict__ gi, float *__restrict__ gh,
+                                                               const float *__restrict__ b_hh,
+                                                               const float *__restrict__ h_prev,
+                                                               const float *__restrict__ d_out, float *__restrict__ dh,
+                                                               const int64_t *__restrict__ lengths, int64_t t,
+                                                               int64_t B, int H) {
+    constexpr int kW = sizeof(V) / sizeof(float);
+    const int cols = H / kW;
+    const int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= B * cols) return;
+    const int64_t b = e / cols;
+    const int j = int(e - b * cols) * kW;
+    float *gi_row = gi + b * 3 * H, *gh_row = gh + b * 3 * H;
+    const bool live = !lengths || t < lengths[b];
+    if (!live) {  // ended sequence: no gate gradients, the state gradient passes through (dh stays as it is)
+        V zero;
+        float *pz = reinterpret_cast<float *>(&zero);
+#pragma unroll
+        for (int k = 0; k < kW; ++k) pz[k] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            *reinterpret_cast<V *>(gi_row + g * H + j) = zero;
+            *reinterpret_cast<V *>(gh_row + g * H + j) = zero;
+        }
+        return;
+    }
+    V gir = *reinterpret_cast<const V *>(gi_row + j), giz = *reinterpret_cast<const V *>(gi_row + H + j),
+      gin = *reinterpret_cast<const V *>(gi_row + 2 * H + j);
+    V ghr = *reinterpret_cast<const V *>(gh_row + j), ghz = *reinterpret_cast<const V *>(gh_row + H + j),
+      ghn = *reinterpret_cast<const V *>(gh_row + 2 * H + j);
+    V hp = *reinterpret_cast<const V *>(h_prev + b * H + j);
+    V dhn = *reinterpret_cast<const V *>(dh + b * H + j);
+    V dout;
+    if (d_out) dout = *reinterpret_cast<const V *>(d_out + b * H + j);
+    V br, bz, bn;
+    if (b_hh) {
+        br = *reinterpret_cast<const V *>(b_hh + j), bz = *reinterpret_cast<const V *>(b_hh + H + j),
+        bn = *reinterpret_cast<const V *>(b_hh + 2 * H + j);
+    }
+    const float *pgir = reinterpret_cast<const float *>(&gir), *pgiz = reinterpret_cast<const float *>(&giz),
+                *pgin = reinterpret_cast<const float *>(&gin), *pghr = reinterpret_cast<const float *>(&ghr),
+                *pghz = reinterpret_cast<const float *>(&ghz), *pghn = reinterpret_cast<const float *>(&ghn),
+                *php = reinterpret_cast<const float *>(&hp), *pdhn = reinterpret_cast<const float *>(&dhn),
+                *pdout = reinterpret_cast<const float *>(&dout), *pbr = reinterpret_cast<const float *>(&br),
+                *pbz = reinterpret_cast<const float *>(&bz), *pbn = reinterpret_cast<const float *>(&bn);
+    V d_r, d_z, d_n, d_q, d_h;
+    float *pdr = reinterpret_cast<float *>(&d_r), *pdz = reinterpret_cast<float *>(&d_z),
+          *pdn = reinterpret_cast<float *>(&d_n), *pdq = reinterpret_cast<float *>(&d_q),
+          *pdh = reinterpret_cast<float *>(&d_h);
+#pragma unroll
+    for (int k = 0; k < kW; ++k) {
+        const GruGates g = gru_gates(pgir[k], pgiz[k], pgin[k], pghr[k], pghz[k], pghn[k], b_hh ? pbr[k] : 0.0f,
+                                     b_hh ? pbz[k] : 0.0f, b_hh ? pbn[k] : 0.0f);
+        const float dht = pdhn[k] + (d_out ? pdout[k] : 0.0f);
+        const float dn_pre = dht * (1.0f - g.z) * (1.0f - g.n * g.n);
+        pdn[k] = dn_pre;
+        pdq[k] = dn_pre * g.r;
+        pdr[k] = dn_pre * g.q * g.r * (1.0f - g.r);
+        pdz[k] = dht * (php[k] - g.n) * g.z * (1.0f - g.z);
+        pdh[k] = dht * g.z;
+    }
+    *reinterpret_cast<V *>(gi_row + j) = d_r;
+    *reinterpret_cast<V *>(gi_row + H + j) = d_z;
+    *reinterpret_cast<V *>(gi_row + 2 * H + j) = d_n;
+    *reinterpret_cast<V *>(gh_row + j) = d_r;
+    *reinterpret_cast<V *>(gh_row + H + j) = d_z;
+    *reinterpret_cast<V *>(gh_row + 2 * H + j) = d_q;
+    *reinterpret_cast<V *>(dh + b * H + j) = d_h;
+}
+
+inline bool gru_vec4(int64_t H, const void *a, const void *b, const void *c, const void *d, const void *e,
+                     const void *f) {
+    auto ok = [](const void *p) { return p == nullptr || aligned(p, 16); };
+    return H % 4 == 0 && ok(a) && ok(b) && ok(c) && ok(d) && ok(e) && ok(f);
+}
+
+}  // namespace cusrl
+
+extern "C" int cusrl_gru_gates_fwd(const float *gi, const float *gh, const float *b_hh, float *h, float *out,
+                                   const int64_t *lengths, int64_t t, int64_t B, int64_t H, void *stream) {
+    using namespace cusrl;
+    if (B < 0 || H <= 0 || t < 0) return CUSRL_E_INVALID;
+    if (B == 0) return 0;
+    if (!gi || !gh || !h || !out) return CUSRL_E_INVALID;
+    if (H > INT32_MAX / 3) return CUSRL_E_UNSUPPORTED;
+    const bool vec4 = gru_vec4(H, gi, gh, b_hh, h, out, nullptr);
+    const int64_t blocks = ceil_div(B * (vec4 ? H / 4 : H), kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    if (vec4)
+        hipLaunchKernelGGL(gru_gates_fwd_kernel<float4>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), gi,
+                           gh, b_hh, h, out, lengths, t, B, int(H));
+    else
+        hipLaunchKernelGGL(gru_gates_fwd_kernel<float>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), gi,
+                           gh, b_hh, h, out, lengths, t, B, int(H));
+    return launch_status();
+}
+
+extern "C" int cusrl_gru_gates_bwd(float *gi, float *gh, const float *b_hh, const float *h_prev, const float *d_out,
+                                   float *dh, const int64_t *lengths, int64_t t, int64_t B, int64_t H, void *stream) {
+    using namespace cusrl;
+    if (B < 0 || H <= 0 || t < 0) return CUSRL_E_INVALID;
+    if (B == 0) return 0;
+    if (!gi || !gh || !h_prev || !dh) return CUSRL_E_INVALID;
+    if (H > INT32_MAX / 3) return CUSRL_E_UNSUPPORTED;
+    const bool vec4 = gru_vec4(H, gi, gh, b_hh, h_prev, d_out, dh);
+    const int64_t blocks = ceil_div(B * (vec4 ? H / 4 : H), kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    if (vec4)
+        hipLaunchKernelGGL(gru_gates_bwd_kernel<float4>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), gi,
+                           gh, b_hh, h_prev, d_out, dh, lengths, t, B, int(H));
+    else
+        hipLaunchKernelGGL(gru_gates_bwd_kernel<float>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), gi,
+                           gh, b_hh, h_prev, d_out, dh, lengths, t, B, int(H));
+    return launch_status();
+}

@@ -1,0 +1,118 @@
+"""``torch.nn.GRU`` evaluated as GEMMs + one HIP pass per time step (the recurrent backbone of config 4,
+cusrl/nn/module/rnn.py:21-120 wraps ``nn.GRU``).
+
+On ROCm ``nn.GRU`` is MIOpen's RNN, which spends a BPTT minibatch of config 4 in ~1 200 generic tensor kernels and a
+7.6 ms bias-gradient reduction per layer and direction of differentiation (72 ms per minibatch step).  A GRU layer over a
+padded ``[L, B, I]`` batch is
+
+* ``gi = x W_ih^T + b_ih`` for all steps — ONE GEMM;
+* per step ``gh = h W_hh^T`` (rocBLAS) and ONE pass over the gates (``cusrl_gru_gates_fwd``);
+* backward: per step the gate pass in reverse (``cusrl_gru_gates_bwd``, overwriting the saved pre-activations with their
+  gradients) and ``dh += d_gh W_hh``; then dW_ih / dW_hh as batched GEMMs over the L steps (L slabs: enough workgroups
+  for 256 CUs where a single ``[3H, L*B] x [L*B, I]`` GEMM would not split its reduction), the bias gradients as column
+  sums, dx as one GEMM.
+
+Parameters stay those of ``nn.GRU`` (same names, same state dict).  ``lengths`` gives the result a PackedSequence would
+give — the state stops at each sequence's last valid step, ended positions emit zeros — without packing and without
+reading the lengths back to the host.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from cusrl_amd import ops
+
+__all__ = ["gru_forward", "gru_supported"]
+
+
+class _GruLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, h0: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor | None, b_hh: Tensor | None,
+                lengths: Tensor | None):
+        L, B, I = x.shape
+        H = w_hh.shape[1]
+        flat = x.reshape(L * B, I)
+        gi = (torch.mm(flat, w_ih.t()) if b_ih is None else torch.addmm(b_ih, flat, w_ih.t())).view(L, B, 3 * H)
+        keep = any(ctx.needs_input_grad[:6])
+        gh = torch.empty((L if keep else 1, B, 3 * H), dtype=x.dtype, device=x.device)
+        out = torch.empty((L, B, H), dtype=x.dtype, device=x.device)
+        h = h0.clone(memory_format=torch.contiguous_format)
+        w_hh_t = w_hh.t()
+        for t in range(L):
+            gh_t = gh[t if keep else 0]
+            torch.mm(h, w_hh_t, out=gh_t)
+            ops.gru_gates_forward(gi[t], gh_t, b_hh, h, out[t], lengths, t)
+        if keep:
+            ctx.save_for_backward(x, h0, w_ih, w_hh, b_hh, lengths, out)
+            ctx.gi, ctx.gh, ctx.has_b_ih = gi, gh, b_ih is not None
+        return out, h
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out: Tensor | None, d_last: Tensor | None):
+        x, h0, w_ih, w_hh, b_hh, lengths, out = ctx.saved_tensors
+        gi, gh = ctx.gi, ctx.gh
+        if gi is None:
+            raise RuntimeError("the fused GRU layer keeps its pre-activations for ONE backward pass (they are overwritten "
+                               "with their gradients); backward(retain_graph=True) followed by a second pass is not supported")
+        ctx.gi = ctx.gh = None
+        L, B, _ = x.shape
+        H = w_hh.shape[1]
+        dh = torch.zeros((B, H), dtype=x.dtype, device=x.device) if d_last is None else d_last.contiguous().clone()
+        if d_out is not None:
+            d_out = d_out.contiguous()
+        h0 = h0.contiguous()
+        for t in range(L - 1, -1, -1):
+            ops.gru_gates_backward(gi[t], gh[t], b_hh, h0 if t == 0 else out[t - 1], None if d_out is None else d_out[t],
+                                   dh, lengths, t)
+            dh.addmm_(gh[t], w_hh)  # + d_gh_t @ W_hh
+        need = ctx.needs_input_grad
+        d_x = d_w_ih = d_w_hh = d_b_ih = d_b_hh = None
+        if need[0]:
+            d_x = torch.mm(gi.view(L * B, 3 * H), w_ih).view(x.shape)
+        if need[2]:
+            d_w_ih = torch.bmm(gi.transpose(1, 2), x).sum(0) if L > 1 else torch.mm(gi[0].t(), x[0])
+        if need[3]:
+            h_prev = torch.cat([h0.unsqueeze(0), out[:-1]]) if L > 1 else h0.unsqueeze(0)
+            d_w_hh = torch.bmm(gh.transpose(1, 2), h_prev).sum(0) if L > 1 else torch.mm(gh[0].t(), h_prev[0])
+        if ctx.has_b_ih and need[4]:
+            d_b_ih = _column_sums(gi.view(L * B, 3 * H))
+        if b_hh is not None and need[5]:
+            d_b_hh = _column_sums(gh.view(L * B, 3 * H))
+        return d_x, (dh if need[1] else None), d_w_ih, d_w_hh, d_b_ih, d_b_hh, None
+
+
+def _column_sums(matrix: Tensor) -> Tensor:
+    rows = matrix.shape[0]
+    if rows >= 4096 and matrix.shape[1] % 4 == 0:
+        return ops.relu_backward_bias(matrix, None)[1]  # the one-pass column-sum kernel of the MLP's bias gradients
+    return matrix.sum(0)
+
+
+def gru_supported(module: torch.nn.GRU, input) -> bool:
+    """fp32 device tensors through a plain (uni-directional, time-major, dropout-free at this call) ``nn.GRU``."""
+    return (isinstance(input, Tensor) and input.is_cuda and input.dtype == torch.float32 and input.dim() == 3
+            and not module.bidirectional and not module.batch_first and getattr(module, "proj_size", 0) == 0
+            and (module.dropout == 0.0 or not module.training or module.num_layers == 1)
+            and module.weight_ih_l0.dtype == torch.float32 and not torch.is_autocast_enabled("cuda"))
+
+
+def gru_forward(module: torch.nn.GRU, input: Tensor, h0: Tensor | None, lengths: Tensor | None = None):
+    """``module(input, h0)`` for ``input [L, B, I]`` and ``h0 [layers, B, H]`` (zeros if None) -> ``(output [L, B, H],
+    h_n [layers, B, H])``; with ``lengths`` (int64 [B] on the device) as for the packed form of the same batch."""
+    L, B, _ = input.shape
+    H, layers = module.hidden_size, module.num_layers
+    if h0 is None:
+        h0 = torch.zeros((layers, B, H), dtype=input.dtype, device=input.device)
+    if lengths is not None:
+        lengths = lengths.to(device=input.device, dtype=torch.int64).contiguous()
+    x, finals = input.contiguous(), []
+    for layer in range(layers):
+        w_ih, w_hh = getattr(module, f"weight_ih_l{layer}"), getattr(module, f"weight_hh_l{layer}")
+        b_ih = getattr(module, f"bias_ih_l{layer}") if module.bias else None
+        b_hh = getattr(module, f"bias_hh_l{layer}") if module.bias else None
+        x, last = _GruLayer.apply(x, h0[layer].contiguous(), w_ih, w_hh, b_ih, b_hh, lengths)
+        finals.append(last)
+    return x, torch.stack(finals)

@@ -11,6 +11,7 @@ from typing import Any
 from torch import Tensor, nn
 
 from cusrl_amd.nn import recurrent
+from cusrl_amd.nn.gru import gru_forward, gru_supported
 from cusrl_amd.nn.module import Module, ModuleFactory
 from cusrl_amd.utils.nest import map_nested
 
@@ -27,7 +28,16 @@ def _from_layers(state: Tensor) -> Tensor:
 
 
 class _Gru(nn.GRU):
-    def forward(self, input, memory=None):
+    """``nn.GRU`` parameters; fp32 device batches run as GEMMs + one HIP gate pass per step (nn/gru.py) instead of MIOpen's
+    RNN.  ``lengths`` (extension): per-sequence valid lengths on the device — the result of the packed form of the batch."""
+
+    def forward(self, input, memory=None, lengths=None):
+        if gru_supported(self, input):
+            h0 = None if memory is None else _to_layers(memory, self.num_layers, self.hidden_size)
+            output, hn = gru_forward(self, input, h0, lengths)
+            return output, _from_layers(hn)
+        if lengths is not None:
+            raise ValueError("'lengths' needs the fused GRU path (fp32 device tensors); pass a PackedSequence instead")
         if memory is None:
             output, hn = super().forward(input)
         else:
@@ -129,9 +139,13 @@ class Rnn(Module):
             # (The PackedSequence API wants the lengths on the host: one read-back, as in the reference.)
             if input.dim() != 3:
                 raise ValueError(f"Packed RNN input must be 3D, but got {input.dim()} dimensions")
-            packed = nn.utils.rnn.pack_padded_sequence(padded_input, lengths=layout.lengths.cpu(), enforce_sorted=False)
-            packed_latent, scattered_output = self.rnn(packed, scattered)
-            padded_latent, _ = nn.utils.rnn.pad_packed_sequence(packed_latent, total_length=padded_input.size(0))
+            if isinstance(self.rnn, _Gru) and gru_supported(self.rnn, padded_input):
+                # same result, no packing and no host read of the lengths: the gate kernel stops every sequence at its own end
+                padded_latent, scattered_output = self.rnn(padded_input, scattered, lengths=layout.lengths)
+            else:
+                packed = nn.utils.rnn.pack_padded_sequence(padded_input, lengths=layout.lengths.cpu(), enforce_sorted=False)
+                packed_latent, scattered_output = self.rnn(packed, scattered)
+                padded_latent, _ = nn.utils.rnn.pad_packed_sequence(packed_latent, total_length=padded_input.size(0))
             output_memory = recurrent.gather_memory(scattered_output, done, layout)
         else:
             padded_latent, _ = self._forward_tensor(padded_input, scattered)

@@ -32,6 +32,8 @@ __all__ = [
     "next_value",
     "normal_sample_logp",
     "categorical_sample_logp",
+    "gru_gates_forward",
+    "gru_gates_backward",
     "normalize_",
     "normalize_from_partials_",
     "ppo_loss_categorical_fwd_bwd",
@@ -817,6 +819,32 @@ def categorical_sample_logp(logits: torch.Tensor, noise: torch.Tensor) -> tuple[
         lambda: _native.lib().cusrl_categorical_sample_logp(logits.data_ptr(), noise.data_ptr(), action.data_ptr(), logp.data_ptr(), B, A, _stream()),
     )
     return action, logp
+
+
+def gru_gates_forward(gi: torch.Tensor, gh: torch.Tensor, b_hh: torch.Tensor | None, h: torch.Tensor, out: torch.Tensor,
+                      lengths: torch.Tensor | None, t: int) -> None:
+    """One GRU time step's gate pass (``cusrl_gru_gates_fwd``): ``h`` [B, H] is advanced in place, ``out`` [B, H] gets the
+    step's output; ``gi`` / ``gh`` are the [B, 3H] projections.  Called once per step of a sequence: the caller
+    (nn/gru.py) guarantees contiguous fp32 device tensors, only shapes are checked here."""
+    B, H = h.shape
+    if gi.shape != (B, 3 * H) or gh.shape != (B, 3 * H) or out.shape != (B, H):
+        raise ValueError("gru_gates_forward: shape mismatch")
+    check(_native.lib().cusrl_gru_gates_fwd(gi.data_ptr(), gh.data_ptr(), None if b_hh is None else b_hh.data_ptr(),
+                                            h.data_ptr(), out.data_ptr(), None if lengths is None else lengths.data_ptr(),
+                                            t, B, H, _stream()), "cusrl_gru_gates_fwd")
+
+
+def gru_gates_backward(gi: torch.Tensor, gh: torch.Tensor, b_hh: torch.Tensor | None, h_prev: torch.Tensor,
+                       d_out: torch.Tensor | None, dh: torch.Tensor, lengths: torch.Tensor | None, t: int) -> None:
+    """Backward of :func:`gru_gates_forward`, in place: ``gi`` / ``gh`` become their gradients, ``dh`` (the gradient that
+    arrived from step t + 1) becomes the direct-path gradient of ``h_prev`` (``cusrl_gru_gates_bwd``)."""
+    B, H = dh.shape
+    if gi.shape != (B, 3 * H) or gh.shape != (B, 3 * H) or h_prev.shape != (B, H):
+        raise ValueError("gru_gates_backward: shape mismatch")
+    check(_native.lib().cusrl_gru_gates_bwd(gi.data_ptr(), gh.data_ptr(), None if b_hh is None else b_hh.data_ptr(),
+                                            h_prev.data_ptr(), None if d_out is None else d_out.data_ptr(), dh.data_ptr(),
+                                            None if lengths is None else lengths.data_ptr(), t, B, H, _stream()),
+          "cusrl_gru_gates_bwd")
 
 
 def episode_stats(reward, done, episode_rew, episode_len, ring_rew, ring_len, num_episodes, step_reward_sum, parity: int) -> None:

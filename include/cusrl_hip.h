@@ -187,6 +187,21 @@ int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const float *old_
                                        float *logp_out, float *entropy_out, float *logp_ratio_out, float *ratio_out,
                                        float *d_logits, float *d_value, double *partials, void *stream);
 
+/* ---- §8f row 1: GRU time step (torch.nn.GRU, the recurrent backbone of cusrl/nn/module/rnn.py:21-120) ----
+ * One pass over the gates of one time step, between the rocBLAS GEMMs that produce gi = W_ih x + b_ih [B, 3H] (all steps
+ * at once) and gh = W_hh h [B, 3H] (per step):
+ *   r = sigmoid(gi_r + gh_r + b_hr); z = sigmoid(gi_z + gh_z + b_hz); n = tanh(gi_n + r * (gh_n + b_hn));
+ *   h <- (1 - z) * n + z * h (in place); out = h.           b_hh may be NULL (bias=False).
+ * lengths (int64[B], may be NULL): a sequence with t >= lengths[b] keeps h, emits out = 0 (the semantics of a
+ * PackedSequence, cusrl/nn/module/rnn.py:273-291, without packing or a host read of the lengths).
+ * cusrl_gru_gates_bwd consumes the saved pre-activations IN PLACE: gi <- dL/dgi, gh <- dL/dgh, and
+ * dh <- (dh + d_out) * z, the direct path to h_{t-1} (the caller adds dL/dgh @ W_hh); d_out may be NULL; ended
+ * sequences get zero gate gradients and leave dh untouched. */
+int cusrl_gru_gates_fwd(const float *gi, const float *gh, const float *b_hh, float *h, float *out,
+                        const int64_t *lengths, int64_t t, int64_t B, int64_t H, void *stream);
+int cusrl_gru_gates_bwd(float *gi, float *gh, const float *b_hh, const float *h_prev, const float *d_out, float *dh,
+                        const int64_t *lengths, int64_t t, int64_t B, int64_t H, void *stream);
+
 /* ---- rollout-side: sampling and episode statistics ----
  * Normal sample + log-prob of the sample in one pass — cusrl/nn/module/distribution.py:198-205 (`rsample`, then
  * `log_prob(sample).sum(-1, keepdim)`): action = mean + eps * std with eps ~ N(0,1) supplied by the caller (drawn

@@ -298,6 +298,37 @@ def ppo_loss(advantage, old_logp, action, mean, std, ret, curr_value, old_value=
     return out
 
 
+def gru_sequence(x, h0, weights, lengths=None):
+    """``torch.nn.GRU`` over a time-major batch, restated in numpy float64 (the recurrent backbone the reference wraps:
+    cusrl/nn/module/rnn.py:21-120, ``nn.GRU``; the cell itself is PyTorch's — r, z = sigmoid(W_i x + b_i + W_h h + b_h),
+    n = tanh(W_in x + b_in + r * (W_hn h + b_hn)), h' = (1 - z) n + z h — pinned against outputs and memories recorded
+    from the reference's own Rnn wrapper, tests/golden/recurrent.npz).  ``weights``: per layer (w_ih [3H, I], w_hh [3H, H],
+    b_ih [3H] | None, b_hh [3H] | None); ``h0`` [layers, B, H]; ``lengths`` [B]: the packed-sequence result (state frozen and
+    zero output from each sequence's end on).  Returns (output [L, B, H], h_n [layers, B, H])."""
+    x = np.asarray(x, np.float64)
+    L, B, _ = x.shape
+    finals = []
+    for layer, (w_ih, w_hh, b_ih, b_hh) in enumerate(weights):
+        w_ih, w_hh = np.asarray(w_ih, np.float64), np.asarray(w_hh, np.float64)
+        H = w_hh.shape[1]
+        b_ih = np.zeros(3 * H) if b_ih is None else np.asarray(b_ih, np.float64)
+        b_hh = np.zeros(3 * H) if b_hh is None else np.asarray(b_hh, np.float64)
+        h = np.zeros((B, H)) if h0 is None else np.asarray(h0[layer], np.float64).copy()
+        out = np.zeros((L, B, H))
+        for t in range(L):
+            gi, gh = x[t] @ w_ih.T + b_ih, h @ w_hh.T + b_hh
+            r = 1.0 / (1.0 + np.exp(-(gi[:, :H] + gh[:, :H])))
+            z = 1.0 / (1.0 + np.exp(-(gi[:, H:2 * H] + gh[:, H:2 * H])))
+            n = np.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+            nxt = (1.0 - z) * n + z * h
+            live = np.ones(B, bool) if lengths is None else t < np.asarray(lengths)
+            h = np.where(live[:, None], nxt, h)
+            out[t] = np.where(live[:, None], nxt, 0.0)
+        finals.append(h)
+        x = out
+    return x.astype(np.float32), np.stack(finals).astype(np.float32)
+
+
 def categorical_sample(logits, noise):
     """Acting side of a one-hot categorical policy, restated in numpy float64: cusrl/nn/module/distribution.py:332-366
     (``OneHotCategorical(logits).sample()`` and ``log_prob`` of the sample).  The draw itself happens inside

@@ -201,3 +201,134 @@ def test_packed_sequences_recover_the_final_memory(golden, kind):
     torch.testing.assert_close(flat(memory), flat(step_memory), rtol=1e-5, atol=1e-5)
     with pytest.raises(ValueError, match="Packed RNN input must be 3D"):
         rnn(torch.randn(4, 3, 2, 5, device=DEV), done=torch.zeros(4, 3, 1, dtype=torch.bool, device=DEV), pack_sequence=True)
+
+
+# ------------------------------------------------------------------------------------------------ GRU as GEMMs + HIP gate passes
+def _golden_gru_weights(g):
+    return [tuple(g[f"gru_param/rnn.{name}_l{layer}"] for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")) for layer in (0, 1)]
+
+
+def test_oracle_gru_is_pinned_to_the_reference_rollout(golden):
+    """oracle.gru_sequence (the numpy restatement the GPU tests check the HIP gate passes with) against outputs and
+    memories recorded from the reference's Rnn wrapper: the plain sequence, and the step-by-step rollout with resets."""
+    import oracle
+
+    g = golden("recurrent")
+    weights = _golden_gru_weights(g)
+    x, done = g["gru_x"], g["gru_done"]
+    out, _ = oracle.gru_sequence(x, None, weights)
+    np.testing.assert_allclose(out, g["gru_sequence_plain"], rtol=1e-5, atol=1e-6)
+    h = np.zeros((2, x.shape[1], 8), np.float32)
+    for t in range(x.shape[0]):
+        np.testing.assert_allclose(np.concatenate([h[0], h[1]], -1), g["gru_memories"][t], rtol=1e-5, atol=1e-6)
+        y, h = oracle.gru_sequence(x[t:t + 1], h, weights)
+        np.testing.assert_allclose(y[0], g["gru_stepwise"][t], rtol=1e-5, atol=1e-6)
+        h = h * (~done[t]).astype(np.float32)[None]
+    # lengths: the state freezes and the output is zero from each sequence's end on
+    lengths = np.array([7, 3, 1, 5, 7, 2])
+    out_l, h_l = oracle.gru_sequence(x, None, weights, lengths)
+    for b, n in enumerate(lengths):
+        ref_out, ref_h = oracle.gru_sequence(x[:n, b:b + 1], None, weights)
+        np.testing.assert_allclose(out_l[:n, b], ref_out[:, 0], rtol=1e-6, atol=1e-7)
+        assert not out_l[n:, b].any()
+        np.testing.assert_allclose(h_l[:, b], ref_h[:, 0], rtol=1e-6, atol=1e-7)
+
+
+def _twin_grus(I, H, layers, bias):
+    from cusrl_amd.nn.rnn import _Gru
+
+    torch.manual_seed(I * 1000 + H)
+    plain = torch.nn.GRU(I, H, layers, bias=bias).to(DEV)  # MIOpen
+    fused = _Gru(I, H, layers, bias=bias).to(DEV)
+    fused.load_state_dict(plain.state_dict())
+    return plain, fused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,B,I,H,layers,bias", [(24, 300, 48, 256, 2, True), (1, 4096, 48, 256, 2, True), (5, 7, 3, 5, 1, True),
+                                                 (6, 65, 16, 32, 2, False), (24, 5500, 48, 256, 1, True)])
+def test_fused_gru_matches_nn_gru_forward_and_backward(L, B, I, H, layers, bias):
+    """The GEMM + HIP-gate-pass GRU against torch.nn.GRU (MIOpen) with the same parameters: outputs, final state and every
+    gradient (parameters, input, initial state); both 16-byte-lane and scalar layouts (H = 5), with and without biases."""
+    from cusrl_amd import _native
+
+    plain, fused = _twin_grus(I, H, layers, bias)
+    x = torch.randn(L, B, I, device=DEV)
+    h0 = torch.randn(B, layers * H, device=DEV) * 0.5
+    w_out, w_last = torch.randn(L, B, H, device=DEV), torch.randn(layers, B, H, device=DEV)
+    results = []
+    before = dict(_native.launch_counts)
+    for module in (plain, fused):
+        xi, hi = x.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+        if module is fused:
+            out, last = module(xi, hi)
+            last = last.reshape(B, layers, H).transpose(0, 1)
+        else:
+            out, last = module(xi, hi.reshape(B, layers, H).transpose(0, 1).contiguous())
+        ((out * w_out).sum() + (last * w_last).sum()).backward()
+        results.append([out.detach(), last.detach(), xi.grad, hi.grad] + [p.grad for p in module.parameters()])
+    assert _native.launch_counts["cusrl_gru_gates_fwd"] - before.get("cusrl_gru_gates_fwd", 0) == L * layers
+    assert _native.launch_counts["cusrl_gru_gates_bwd"] - before.get("cusrl_gru_gates_bwd", 0) == L * layers
+    names = ["out", "h_n", "d_x", "d_h0"] + [n for n, _ in plain.named_parameters()]
+    for name, want, got in zip(names, *results):
+        scale = float(want.abs().max()) + 1e-6
+        assert float((got - want).abs().max()) <= 2e-5 * max(scale, 1.0) + 1e-4 * scale * (name not in ("out", "h_n")), \
+            (name, float((got - want).abs().max()), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,B,H", [(9, 40, 32), (24, 700, 256), (4, 3, 5)])
+def test_fused_gru_with_lengths_matches_the_packed_sequence(L, B, H):
+    """``lengths`` on the device = what nn.GRU returns for the PackedSequence of the same batch: padded outputs zero, the
+    state of every sequence taken at its own last step, gradients included — and the oracle agrees."""
+    import oracle
+
+    plain, fused = _twin_grus(6, H, 2, True)
+    gen = torch.Generator().manual_seed(L * B)
+    lengths = torch.randint(1, L + 1, (B,), generator=gen)
+    lengths[0] = L
+    x = torch.randn(L, B, 6, device=DEV)
+    h0 = torch.randn(B, 2 * H, device=DEV) * 0.3
+    w_out, w_last = torch.randn(L, B, H, device=DEV), torch.randn(2, B, H, device=DEV)
+    xi = x.clone().requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xi, lengths, enforce_sorted=False)
+    packed_out, want_last = plain(packed, h0.reshape(B, 2, H).transpose(0, 1).contiguous())
+    want_out, _ = torch.nn.utils.rnn.pad_packed_sequence(packed_out, total_length=L)
+    ((want_out * w_out).sum() + (want_last * w_last).sum()).backward()
+    want = [want_out.detach(), want_last.detach(), xi.grad] + [p.grad for p in plain.parameters()]
+    xj = x.clone().requires_grad_(True)
+    out, last = fused(xj, h0, lengths=lengths.to(DEV))
+    last = last.reshape(B, 2, H).transpose(0, 1)
+    ((out * w_out).sum() + (last * w_last).sum()).backward()
+    got = [out.detach(), last.detach(), xj.grad] + [p.grad for p in fused.parameters()]
+    for i, (a, b) in enumerate(zip(want, got)):
+        scale = max(float(a.abs().max()), 1.0)
+        assert float((a - b).abs().max()) <= (2e-5 if i < 2 else 2e-4) * scale, (i, float((a - b).abs().max()), scale)
+    mask = torch.arange(L)[:, None] >= lengths[None]
+    assert not out.detach().cpu()[mask].any()
+    if B <= 40:
+        weights = [tuple(getattr(plain, f"{n}_l{layer}").detach().cpu().numpy() for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+                   for layer in (0, 1)]
+        ref_out, ref_last = oracle.gru_sequence(x.cpu().numpy(), h0.reshape(B, 2, H).transpose(0, 1).cpu().numpy(), weights,
+                                                lengths.numpy())
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref_out, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(last.detach().cpu().numpy(), ref_last, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_fused_gru_refuses_a_second_backward_and_falls_back_where_it_must():
+    from cusrl_amd.nn.gru import gru_supported
+
+    plain, fused = _twin_grus(4, 8, 1, True)
+    x = torch.randn(3, 5, 4, device=DEV, requires_grad=True)
+    out, _ = fused(x)
+    out.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="ONE backward pass"):
+        out.sum().backward()
+    assert not gru_supported(fused, x.double()) and not gru_supported(fused, x.cpu())
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x.detach(), torch.tensor([3, 2, 2, 1, 1]))
+    assert not gru_supported(fused, packed)
+    packed_out, _ = fused(packed)  # a PackedSequence still goes to MIOpen
+    assert isinstance(packed_out, torch.nn.utils.rnn.PackedSequence)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert not gru_supported(fused, x)
