@@ -14,7 +14,7 @@
 // `lengths` (optional) gives packed-sequence semantics without packing: a sequence that has ended (t >= lengths[b]) keeps
 // its state, emits zeros, and lets the state gradient pass through untouched — so the final state is the state at each
 // sequence's own last step (cusrl/nn/module/rnn.py:273-291 obtains that through a PackedSequence and a host read of the
-// lengths).  Streaming, HBM-bound: 36 B per state element forward, 52 B backward; 16-byte lanes when H % 4 == 0.
+// lengths).  Streaming, HBM-bound: 36 B per state element forward, 64 B backward; 16-byte lanes when H % 4 == 0.
 #include "common.hpp"
 
 namespace cusrl {

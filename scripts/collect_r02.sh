@@ -21,7 +21,7 @@ d = json.loads(sys.stdin.readlines()[-1]); print('rccl-1-rank', d['config']['col
 done | tee "$O/bench_rccl_one_rank.txt"
 python scripts/kernel_bench.py --envs 4096 1048576 --json "$O/kernel_bench_graph_timed.json" 2>/dev/null | grep -v amdgpu > "$O/kernel_bench_graph_timed.txt"
 tail -30 "$O/kernel_bench_graph_timed.txt"
-for c in "config1" "config2 --compile" "config3 --compile" "config4" "config5" "config5 --compile"; do
+for c in "config1" "config1 --compile" "config2 --compile" "config3 --compile" "config4" "config5" "config5 --compile"; do
   python scripts/run_config.py $c 2>&1 | grep -v amdgpu.ids > "$O/configs/run_$(echo $c | tr ' -' '__').txt"
   tail -2 "$O/configs/run_$(echo $c | tr ' -' '__').txt" | head -1 | cut -c1-160
 done

@@ -159,6 +159,15 @@ def bench_size(N, T=24, obs=48, act=12, mbs=4, only=None, iters=None):
     flat = f(92569)
     rows.measure("clip_grad_norm (92569 floats)", lambda: ops.clip_grad_norm_(flat, 1.0), flat.numel() * 12)
 
+    # ---- recurrent backbone (config 4): one GRU time step's gate pass over N sequences of 256 hidden units
+    Hs = 256
+    gi, gh, bh = f(N, 3 * Hs), f(N, 3 * Hs), f(3 * Hs)
+    hstate, hout, hprev, dh, dout = f(N, Hs), f(N, Hs), f(N, Hs), f(N, Hs), f(N, Hs)
+    rows.measure(f"gru gates fwd [B,256] (B={N})", lambda: ops.gru_gates_forward(gi, gh, bh, hstate, hout, None, 0), N * Hs * 36)
+    rows.measure(f"gru gates bwd [B,256] (B={N})", lambda: ops.gru_gates_backward(gi, gh, bh, hprev, dout, dh, None, 0), N * Hs * 64)
+    logits3, race3 = f(N, 3), torch.rand(N, 3, device=DEV) + 0.1
+    rows.measure(f"categorical sample + logp [B,3] (B={N})", lambda: ops.categorical_sample_logp(logits3, race3), N * (3 * 12 + 4))
+
     # ---- reference points: a plain device copy of the same bytes (what the memory system gives a streaming kernel)
     big = torch.empty(max(S * 21 // 8, 1024), dtype=torch.float32, device=DEV)
     dst = torch.empty_like(big)
