@@ -1,4 +1,4 @@
-// GRU time-step epilogues for gfx950 (recurrent BPTT, config 4).
+// GRU / LSTM time-step epilogues for gfx950 (recurrent BPTT, config 4).
 //
 // torch.nn.GRU on ROCm is MIOpen's RNN: per time step it issues generic tensor kernels (Op2dTensorLite,
 // SubTensorOpWithSubTensor2d: ~24 000 launches per iteration of config 4) and reduces the bias gradients with
@@ -152,6 +152,126 @@ __global__ __launch_bounds__(kBlock) void gru_gates_bwd_kernel(float *__restrict
     *reinterpret_cast<V *>(dh + b * H + j) = d_h;
 }
 
+
+// ---- LSTM (the default core of RecurrentPpoAgentFactory, cusrl/preset/ppo.py:189) --------------------------------------
+//   pre = gi + gh + b_hh   (gi = W_ih x + b_ih, gh = W_hh h; gate order i, f, g, o as torch.nn.LSTM)
+//   i, f, o = sigmoid(pre_i, pre_f, pre_o);  g = tanh(pre_g);  c' = f * c + i * g;  h' = o * tanh(c')
+// Both biases are additive, so d(pre) is the gradient of gi AND of gh: the forward stores `pre` over gi (kSave) and the
+// backward overwrites it with d(pre) — one [B, 4H] array per step is all the layer keeps besides the cell states.
+template <typename V, bool kSave>
+__global__ __launch_bounds__(kBlock) void lstm_gates_fwd_kernel(float *__restrict__ gi, const float *__restrict__ gh,
+                                                                const float *__restrict__ b_hh, float *__restrict__ h,
+                                                                float *__restrict__ c, float *__restrict__ out,
+                                                                float *__restrict__ c_saved,
+                                                                const int64_t *__restrict__ lengths, int64_t t,
+                                                                int64_t B, int H) {
+    constexpr int kW = sizeof(V) / sizeof(float);
+    const int cols = H / kW;
+    const int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= B * cols) return;
+    const int64_t b = e / cols;
+    const int j = int(e - b * cols) * kW;
+    float *gi_row = gi + b * 4 * H;
+    const float *gh_row = gh + b * 4 * H;
+    V pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const V a = *reinterpret_cast<const V *>(gi_row + g * H + j), r = *reinterpret_cast<const V *>(gh_row + g * H + j);
+        V bias;
+        if (b_hh) bias = *reinterpret_cast<const V *>(b_hh + g * H + j);
+        const float *pa = reinterpret_cast<const float *>(&a), *pr = reinterpret_cast<const float *>(&r),
+                    *pb = reinterpret_cast<const float *>(&bias);
+        float *pp = reinterpret_cast<float *>(&pre[g]);
+#pragma unroll
+        for (int k = 0; k < kW; ++k) pp[k] = pa[k] + pr[k] + (b_hh ? pb[k] : 0.0f);
+    }
+    const V hp = *reinterpret_cast<const V *>(h + b * H + j), cp = *reinterpret_cast<const V *>(c + b * H + j);
+    const bool live = !lengths || t < lengths[b];
+    V hn, cn, o;
+    const float *pi = reinterpret_cast<const float *>(&pre[0]), *pf = reinterpret_cast<const float *>(&pre[1]),
+                *pg = reinterpret_cast<const float *>(&pre[2]), *po = reinterpret_cast<const float *>(&pre[3]),
+                *php = reinterpret_cast<const float *>(&hp), *pcp = reinterpret_cast<const float *>(&cp);
+    float *phn = reinterpret_cast<float *>(&hn), *pcn = reinterpret_cast<float *>(&cn), *pout = reinterpret_cast<float *>(&o);
+#pragma unroll
+    for (int k = 0; k < kW; ++k) {
+        const float c_next = gru_sigmoid(pf[k]) * pcp[k] + gru_sigmoid(pi[k]) * tanhf(pg[k]);
+        const float h_next = gru_sigmoid(po[k]) * tanhf(c_next);
+        pcn[k] = live ? c_next : pcp[k];
+        phn[k] = live ? h_next : php[k];
+        pout[k] = live ? h_next : 0.0f;
+    }
+    *reinterpret_cast<V *>(h + b * H + j) = hn;
+    *reinterpret_cast<V *>(c + b * H + j) = cn;
+    *reinterpret_cast<V *>(out + b * H + j) = o;
+    if constexpr (kSave) {
+        *reinterpret_cast<V *>(c_saved + b * H + j) = cn;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<V *>(gi_row + g * H + j) = pre[g];
+    }
+}
+
+// pre <- d(loss)/d(pre) in place; dc <- gradient of c_{t-1}; dh <- the part of the state gradient that bypasses this step
+// (all of it for an ended sequence, nothing otherwise): the caller then adds d(pre) @ W_hh.
+template <typename V>
+__global__ __launch_bounds__(kBlock) void lstm_gates_bwd_kernel(float *__restrict__ pre, const float *__restrict__ c_prev,
+                                                                const float *__restrict__ c_next,
+                                                                const float *__restrict__ d_out, float *__restrict__ dh,
+                                                                float *__restrict__ dc,
+                                                                const int64_t *__restrict__ lengths, int64_t t,
+                                                                int64_t B, int H) {
+    constexpr int kW = sizeof(V) / sizeof(float);
+    const int cols = H / kW;
+    const int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= B * cols) return;
+    const int64_t b = e / cols;
+    const int j = int(e - b * cols) * kW;
+    float *row = pre + b * 4 * H;
+    const bool live = !lengths || t < lengths[b];
+    V zero;
+    {
+        float *pz = reinterpret_cast<float *>(&zero);
+#pragma unroll
+        for (int k = 0; k < kW; ++k) pz[k] = 0.0f;
+    }
+    if (!live) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<V *>(row + g * H + j) = zero;
+        return;  // dh and dc pass through untouched
+    }
+    const V vi = *reinterpret_cast<const V *>(row + j), vf = *reinterpret_cast<const V *>(row + H + j),
+            vg = *reinterpret_cast<const V *>(row + 2 * H + j), vo = *reinterpret_cast<const V *>(row + 3 * H + j);
+    const V vcp = *reinterpret_cast<const V *>(c_prev + b * H + j), vcn = *reinterpret_cast<const V *>(c_next + b * H + j);
+    const V vdh = *reinterpret_cast<const V *>(dh + b * H + j), vdc = *reinterpret_cast<const V *>(dc + b * H + j);
+    V vdo;
+    if (d_out) vdo = *reinterpret_cast<const V *>(d_out + b * H + j);
+    const float *pi = reinterpret_cast<const float *>(&vi), *pf = reinterpret_cast<const float *>(&vf),
+                *pg = reinterpret_cast<const float *>(&vg), *po = reinterpret_cast<const float *>(&vo),
+                *pcp = reinterpret_cast<const float *>(&vcp), *pcn = reinterpret_cast<const float *>(&vcn),
+                *pdh = reinterpret_cast<const float *>(&vdh), *pdc = reinterpret_cast<const float *>(&vdc),
+                *pdo = reinterpret_cast<const float *>(&vdo);
+    V di, df, dg, dO, dcp;
+    float *qi = reinterpret_cast<float *>(&di), *qf = reinterpret_cast<float *>(&df), *qg = reinterpret_cast<float *>(&dg),
+          *qo = reinterpret_cast<float *>(&dO), *qc = reinterpret_cast<float *>(&dcp);
+#pragma unroll
+    for (int k = 0; k < kW; ++k) {
+        const float i = gru_sigmoid(pi[k]), f = gru_sigmoid(pf[k]), g = tanhf(pg[k]), o = gru_sigmoid(po[k]);
+        const float tc = tanhf(pcn[k]);
+        const float dht = pdh[k] + (d_out ? pdo[k] : 0.0f);
+        const float dct = pdc[k] + dht * o * (1.0f - tc * tc);
+        qo[k] = dht * tc * o * (1.0f - o);
+        qi[k] = dct * g * i * (1.0f - i);
+        qf[k] = dct * pcp[k] * f * (1.0f - f);
+        qg[k] = dct * i * (1.0f - g * g);
+        qc[k] = dct * f;
+    }
+    *reinterpret_cast<V *>(row + j) = di;
+    *reinterpret_cast<V *>(row + H + j) = df;
+    *reinterpret_cast<V *>(row + 2 * H + j) = dg;
+    *reinterpret_cast<V *>(row + 3 * H + j) = dO;
+    *reinterpret_cast<V *>(dc + b * H + j) = dcp;
+    *reinterpret_cast<V *>(dh + b * H + j) = zero;
+}
+
 inline bool gru_vec4(int64_t H, const void *a, const void *b, const void *c, const void *d, const void *e,
                      const void *f) {
     auto ok = [](const void *p) { return p == nullptr || aligned(p, 16); };
@@ -195,5 +315,48 @@ extern "C" int cusrl_gru_gates_bwd(float *gi, float *gh, const float *b_hh, cons
     else
         hipLaunchKernelGGL(gru_gates_bwd_kernel<float>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), gi,
                            gh, b_hh, h_prev, d_out, dh, lengths, t, B, int(H));
+    return launch_status();
+}
+
+extern "C" int cusrl_lstm_gates_fwd(float *gi, const float *gh, const float *b_hh, float *h, float *c, float *out,
+                                    float *c_saved, const int64_t *lengths, int64_t t, int64_t B, int64_t H,
+                                    void *stream) {
+    using namespace cusrl;
+    if (B < 0 || H <= 0 || t < 0) return CUSRL_E_INVALID;
+    if (B == 0) return 0;
+    if (!gi || !gh || !h || !c || !out) return CUSRL_E_INVALID;
+    if (H > INT32_MAX / 4) return CUSRL_E_UNSUPPORTED;
+    const bool vec4 = gru_vec4(H, gi, gh, b_hh, h, c, out) && (c_saved == nullptr || aligned(c_saved, 16));
+    const int64_t blocks = ceil_div(B * (vec4 ? H / 4 : H), kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    const dim3 grid{uint32_t(blocks)}, block{kBlock};
+    hipStream_t s = as_stream(stream);
+    if (vec4 && c_saved)
+        hipLaunchKernelGGL((lstm_gates_fwd_kernel<float4, true>), grid, block, 0, s, gi, gh, b_hh, h, c, out, c_saved, lengths, t, B, int(H));
+    else if (vec4)
+        hipLaunchKernelGGL((lstm_gates_fwd_kernel<float4, false>), grid, block, 0, s, gi, gh, b_hh, h, c, out, c_saved, lengths, t, B, int(H));
+    else if (c_saved)
+        hipLaunchKernelGGL((lstm_gates_fwd_kernel<float, true>), grid, block, 0, s, gi, gh, b_hh, h, c, out, c_saved, lengths, t, B, int(H));
+    else
+        hipLaunchKernelGGL((lstm_gates_fwd_kernel<float, false>), grid, block, 0, s, gi, gh, b_hh, h, c, out, c_saved, lengths, t, B, int(H));
+    return launch_status();
+}
+
+extern "C" int cusrl_lstm_gates_bwd(float *pre, const float *c_prev, const float *c_next, const float *d_out, float *dh,
+                                    float *dc, const int64_t *lengths, int64_t t, int64_t B, int64_t H, void *stream) {
+    using namespace cusrl;
+    if (B < 0 || H <= 0 || t < 0) return CUSRL_E_INVALID;
+    if (B == 0) return 0;
+    if (!pre || !c_prev || !c_next || !dh || !dc) return CUSRL_E_INVALID;
+    if (H > INT32_MAX / 4) return CUSRL_E_UNSUPPORTED;
+    const bool vec4 = gru_vec4(H, pre, c_prev, c_next, d_out, dh, dc);
+    const int64_t blocks = ceil_div(B * (vec4 ? H / 4 : H), kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    if (vec4)
+        hipLaunchKernelGGL(lstm_gates_bwd_kernel<float4>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), pre,
+                           c_prev, c_next, d_out, dh, dc, lengths, t, B, int(H));
+    else
+        hipLaunchKernelGGL(lstm_gates_bwd_kernel<float>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), pre,
+                           c_prev, c_next, d_out, dh, dc, lengths, t, B, int(H));
     return launch_status();
 }

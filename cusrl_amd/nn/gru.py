@@ -1,5 +1,5 @@
-"""``torch.nn.GRU`` evaluated as GEMMs + one HIP pass per time step (the recurrent backbone of config 4,
-cusrl/nn/module/rnn.py:21-120 wraps ``nn.GRU``).
+"""``torch.nn.GRU`` / ``torch.nn.LSTM`` evaluated as GEMMs + one HIP pass per time step (the recurrent backbones
+cusrl/nn/module/rnn.py:21-120 wraps: GRU in config 4, LSTM by default in RecurrentPpoAgentFactory).
 
 On ROCm ``nn.GRU`` is MIOpen's RNN, which spends a BPTT minibatch of config 4 in ~1 200 generic tensor kernels and a
 7.6 ms bias-gradient reduction per layer and direction of differentiation (72 ms per minibatch step).  A GRU layer over a
@@ -24,7 +24,7 @@ from torch import Tensor
 
 from cusrl_amd import ops
 
-__all__ = ["gru_forward", "gru_supported"]
+__all__ = ["gru_forward", "gru_supported", "lstm_forward"]
 
 
 class _GruLayer(torch.autograd.Function):
@@ -84,6 +84,67 @@ class _GruLayer(torch.autograd.Function):
         return d_x, (dh if need[1] else None), d_w_ih, d_w_hh, d_b_ih, d_b_hh, None
 
 
+class _LstmLayer(torch.autograd.Function):
+    """The same decomposition for ``nn.LSTM`` (the default core of RecurrentPpoAgentFactory).  Both biases are additive, so
+    the layer keeps ONE ``[L, B, 4H]`` array (the summed pre-activations, later their gradient) plus the cell states."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, h0: Tensor, c0: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor | None,
+                b_hh: Tensor | None, lengths: Tensor | None):
+        L, B, I = x.shape
+        H = w_hh.shape[1]
+        flat = x.reshape(L * B, I)
+        gi = (torch.mm(flat, w_ih.t()) if b_ih is None else torch.addmm(b_ih, flat, w_ih.t())).view(L, B, 4 * H)
+        keep = any(ctx.needs_input_grad[:7])
+        gh = torch.empty((B, 4 * H), dtype=x.dtype, device=x.device)
+        out = torch.empty((L, B, H), dtype=x.dtype, device=x.device)
+        cells = torch.empty((L, B, H), dtype=x.dtype, device=x.device) if keep else None
+        h, c = h0.clone(memory_format=torch.contiguous_format), c0.clone(memory_format=torch.contiguous_format)
+        w_hh_t = w_hh.t()
+        for t in range(L):
+            torch.mm(h, w_hh_t, out=gh)
+            ops.lstm_gates_forward(gi[t], gh, b_hh, h, c, out[t], None if cells is None else cells[t], lengths, t)
+        if keep:
+            ctx.save_for_backward(x, h0, c0, w_ih, w_hh, lengths, out, cells)
+            ctx.pre, ctx.has_b_ih, ctx.has_b_hh = gi, b_ih is not None, b_hh is not None
+        return out, h, c
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out: Tensor | None, d_last_h: Tensor | None, d_last_c: Tensor | None):
+        x, h0, c0, w_ih, w_hh, lengths, out, cells = ctx.saved_tensors
+        pre = ctx.pre
+        if pre is None:
+            raise RuntimeError("the fused LSTM layer keeps its pre-activations for ONE backward pass (they are overwritten "
+                               "with their gradients); backward(retain_graph=True) followed by a second pass is not supported")
+        ctx.pre = None
+        L, B, _ = x.shape
+        H = w_hh.shape[1]
+        zeros = lambda: torch.zeros((B, H), dtype=x.dtype, device=x.device)  # noqa: E731
+        dh = zeros() if d_last_h is None else d_last_h.contiguous().clone()
+        dc = zeros() if d_last_c is None else d_last_c.contiguous().clone()
+        if d_out is not None:
+            d_out = d_out.contiguous()
+        h0, c0 = h0.contiguous(), c0.contiguous()
+        for t in range(L - 1, -1, -1):
+            ops.lstm_gates_backward(pre[t], c0 if t == 0 else cells[t - 1], cells[t], None if d_out is None else d_out[t],
+                                    dh, dc, lengths, t)
+            dh.addmm_(pre[t], w_hh)  # + d_pre_t @ W_hh (dh holds what bypassed the step: ended sequences only)
+        need = ctx.needs_input_grad
+        d_x = d_w_ih = d_w_hh = d_b = None
+        if need[0]:
+            d_x = torch.mm(pre.view(L * B, 4 * H), w_ih).view(x.shape)
+        if need[3]:
+            d_w_ih = torch.bmm(pre.transpose(1, 2), x).sum(0) if L > 1 else torch.mm(pre[0].t(), x[0])
+        if need[4]:
+            h_prev = torch.cat([h0.unsqueeze(0), out[:-1]]) if L > 1 else h0.unsqueeze(0)
+            d_w_hh = torch.bmm(pre.transpose(1, 2), h_prev).sum(0) if L > 1 else torch.mm(pre[0].t(), h_prev[0])
+        if (ctx.has_b_ih and need[5]) or (ctx.has_b_hh and need[6]):
+            d_b = _column_sums(pre.view(L * B, 4 * H))
+        return (d_x, dh if need[1] else None, dc if need[2] else None, d_w_ih, d_w_hh,
+                d_b if ctx.has_b_ih and need[5] else None, d_b if ctx.has_b_hh and need[6] else None, None)
+
+
 def _column_sums(matrix: Tensor) -> Tensor:
     rows = matrix.shape[0]
     if rows >= 4096 and matrix.shape[1] % 4 == 0:
@@ -91,8 +152,8 @@ def _column_sums(matrix: Tensor) -> Tensor:
     return matrix.sum(0)
 
 
-def gru_supported(module: torch.nn.GRU, input) -> bool:
-    """fp32 device tensors through a plain (uni-directional, time-major, dropout-free at this call) ``nn.GRU``."""
+def gru_supported(module: torch.nn.RNNBase, input) -> bool:
+    """fp32 device tensors through a plain (uni-directional, time-major, dropout-free at this call) ``nn.GRU`` / ``nn.LSTM``."""
     return (isinstance(input, Tensor) and input.is_cuda and input.dtype == torch.float32 and input.dim() == 3
             and not module.bidirectional and not module.batch_first and getattr(module, "proj_size", 0) == 0
             and (module.dropout == 0.0 or not module.training or module.num_layers == 1)
@@ -116,3 +177,24 @@ def gru_forward(module: torch.nn.GRU, input: Tensor, h0: Tensor | None, lengths:
         x, last = _GruLayer.apply(x, h0[layer].contiguous(), w_ih, w_hh, b_ih, b_hh, lengths)
         finals.append(last)
     return x, torch.stack(finals)
+
+
+def lstm_forward(module: torch.nn.LSTM, input: Tensor, state: tuple[Tensor, Tensor] | None, lengths: Tensor | None = None):
+    """``module(input, (h0, c0))`` for ``input [L, B, I]`` and states ``[layers, B, H]`` (zeros if None) ->
+    ``(output, (h_n, c_n))``; ``lengths`` as in :func:`gru_forward`."""
+    L, B, _ = input.shape
+    H, layers = module.hidden_size, module.num_layers
+    if state is None:
+        h0 = c0 = torch.zeros((layers, B, H), dtype=input.dtype, device=input.device)
+    else:
+        h0, c0 = state
+    if lengths is not None:
+        lengths = lengths.to(device=input.device, dtype=torch.int64).contiguous()
+    x, last_h, last_c = input.contiguous(), [], []
+    for layer in range(layers):
+        w_ih, w_hh = getattr(module, f"weight_ih_l{layer}"), getattr(module, f"weight_hh_l{layer}")
+        b_ih = getattr(module, f"bias_ih_l{layer}") if module.bias else None
+        b_hh = getattr(module, f"bias_hh_l{layer}") if module.bias else None
+        x, h, c = _LstmLayer.apply(x, h0[layer].contiguous(), c0[layer].contiguous(), w_ih, w_hh, b_ih, b_hh, lengths)
+        last_h.append(h), last_c.append(c)
+    return x, (torch.stack(last_h), torch.stack(last_c))

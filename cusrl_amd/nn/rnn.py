@@ -11,7 +11,7 @@ from typing import Any
 from torch import Tensor, nn
 
 from cusrl_amd.nn import recurrent
-from cusrl_amd.nn.gru import gru_forward, gru_supported
+from cusrl_amd.nn.gru import gru_forward, gru_supported, lstm_forward
 from cusrl_amd.nn.module import Module, ModuleFactory
 from cusrl_amd.utils.nest import map_nested
 
@@ -55,7 +55,16 @@ class _VanillaRnn(nn.RNN):
 
 
 class _Lstm(nn.LSTM):
-    def forward(self, input, memory=None):
+    """``nn.LSTM`` parameters; fp32 device batches run as GEMMs + one HIP gate pass per step (nn/gru.py)."""
+
+    def forward(self, input, memory=None, lengths=None):
+        if gru_supported(self, input):
+            state = None if memory is None else (_to_layers(memory["hidden"], self.num_layers, self.hidden_size),
+                                                 _to_layers(memory["cell"], self.num_layers, self.hidden_size))
+            output, (hn, cn) = lstm_forward(self, input, state, lengths)
+            return output, {"hidden": _from_layers(hn), "cell": _from_layers(cn)}
+        if lengths is not None:
+            raise ValueError("'lengths' needs the fused LSTM path (fp32 device tensors); pass a PackedSequence instead")
         if memory is None:
             output, (hn, cn) = super().forward(input)
         else:
@@ -139,7 +148,7 @@ class Rnn(Module):
             # (The PackedSequence API wants the lengths on the host: one read-back, as in the reference.)
             if input.dim() != 3:
                 raise ValueError(f"Packed RNN input must be 3D, but got {input.dim()} dimensions")
-            if isinstance(self.rnn, _Gru) and gru_supported(self.rnn, padded_input):
+            if isinstance(self.rnn, (_Gru, _Lstm)) and gru_supported(self.rnn, padded_input):
                 # same result, no packing and no host read of the lengths: the gate kernel stops every sequence at its own end
                 padded_latent, scattered_output = self.rnn(padded_input, scattered, lengths=layout.lengths)
             else:

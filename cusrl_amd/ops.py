@@ -34,6 +34,8 @@ __all__ = [
     "categorical_sample_logp",
     "gru_gates_forward",
     "gru_gates_backward",
+    "lstm_gates_forward",
+    "lstm_gates_backward",
     "normalize_",
     "normalize_from_partials_",
     "ppo_loss_categorical_fwd_bwd",
@@ -845,6 +847,34 @@ def gru_gates_backward(gi: torch.Tensor, gh: torch.Tensor, b_hh: torch.Tensor | 
                                             h_prev.data_ptr(), None if d_out is None else d_out.data_ptr(), dh.data_ptr(),
                                             None if lengths is None else lengths.data_ptr(), t, B, H, _stream()),
           "cusrl_gru_gates_bwd")
+
+
+def lstm_gates_forward(gi: torch.Tensor, gh: torch.Tensor, b_hh: torch.Tensor | None, h: torch.Tensor, c: torch.Tensor,
+                       out: torch.Tensor, c_saved: torch.Tensor | None, lengths: torch.Tensor | None, t: int) -> None:
+    """One LSTM time step's gate pass (``cusrl_lstm_gates_fwd``): ``h`` / ``c`` [B, H] advance in place, ``out`` gets the
+    step's output; with ``c_saved`` (training) the new cell state is stored there and ``gi`` [B, 4H] is overwritten with
+    the summed pre-activations the backward pass consumes."""
+    B, H = h.shape
+    if gi.shape != (B, 4 * H) or gh.shape != (B, 4 * H) or out.shape != (B, H) or c.shape != (B, H):
+        raise ValueError("lstm_gates_forward: shape mismatch")
+    check(_native.lib().cusrl_lstm_gates_fwd(gi.data_ptr(), gh.data_ptr(), None if b_hh is None else b_hh.data_ptr(),
+                                             h.data_ptr(), c.data_ptr(), out.data_ptr(),
+                                             None if c_saved is None else c_saved.data_ptr(),
+                                             None if lengths is None else lengths.data_ptr(), t, B, H, _stream()),
+          "cusrl_lstm_gates_fwd")
+
+
+def lstm_gates_backward(pre: torch.Tensor, c_prev: torch.Tensor, c_next: torch.Tensor, d_out: torch.Tensor | None,
+                        dh: torch.Tensor, dc: torch.Tensor, lengths: torch.Tensor | None, t: int) -> None:
+    """Backward of :func:`lstm_gates_forward`, in place: ``pre`` becomes its gradient, ``dc`` the gradient of the previous
+    cell state, ``dh`` the part of the state gradient that bypasses the step (``cusrl_lstm_gates_bwd``)."""
+    B, H = dh.shape
+    if pre.shape != (B, 4 * H) or c_prev.shape != (B, H) or c_next.shape != (B, H) or dc.shape != (B, H):
+        raise ValueError("lstm_gates_backward: shape mismatch")
+    check(_native.lib().cusrl_lstm_gates_bwd(pre.data_ptr(), c_prev.data_ptr(), c_next.data_ptr(),
+                                             None if d_out is None else d_out.data_ptr(), dh.data_ptr(), dc.data_ptr(),
+                                             None if lengths is None else lengths.data_ptr(), t, B, H, _stream()),
+          "cusrl_lstm_gates_bwd")
 
 
 def episode_stats(reward, done, episode_rew, episode_len, ring_rew, ring_len, num_episodes, step_reward_sum, parity: int) -> None:

@@ -202,6 +202,17 @@ int cusrl_gru_gates_fwd(const float *gi, const float *gh, const float *b_hh, flo
 int cusrl_gru_gates_bwd(float *gi, float *gh, const float *b_hh, const float *h_prev, const float *d_out, float *dh,
                         const int64_t *lengths, int64_t t, int64_t B, int64_t H, void *stream);
 
+/* The same for torch.nn.LSTM (gate order i, f, g, o), the default core of RecurrentPpoAgentFactory (cusrl/preset/ppo.py:189):
+ *   pre = gi + gh + b_hh; c <- sigmoid(pre_f) * c + sigmoid(pre_i) * tanh(pre_g); h <- sigmoid(pre_o) * tanh(c); out = h.
+ * With c_saved != NULL (training) the new cell state is also stored there and `pre` is written over gi — both biases are
+ * additive, so d(pre) is the gradient of gi and of gh alike.  cusrl_lstm_gates_bwd: pre <- dL/dpre in place,
+ * dc <- dL/dc_{t-1}, dh <- the part of the state gradient that bypasses the step (everything for an ended sequence,
+ * zero otherwise; the caller adds dL/dpre @ W_hh).  c_prev / c_next: cell state before / after the step. */
+int cusrl_lstm_gates_fwd(float *gi, const float *gh, const float *b_hh, float *h, float *c, float *out, float *c_saved,
+                         const int64_t *lengths, int64_t t, int64_t B, int64_t H, void *stream);
+int cusrl_lstm_gates_bwd(float *pre, const float *c_prev, const float *c_next, const float *d_out, float *dh, float *dc,
+                         const int64_t *lengths, int64_t t, int64_t B, int64_t H, void *stream);
+
 /* ---- rollout-side: sampling and episode statistics ----
  * Normal sample + log-prob of the sample in one pass — cusrl/nn/module/distribution.py:198-205 (`rsample`, then
  * `log_prob(sample).sum(-1, keepdim)`): action = mean + eps * std with eps ~ N(0,1) supplied by the caller (drawn

@@ -329,6 +329,35 @@ def gru_sequence(x, h0, weights, lengths=None):
     return x.astype(np.float32), np.stack(finals).astype(np.float32)
 
 
+def lstm_sequence(x, state, weights, lengths=None):
+    """``torch.nn.LSTM`` over a time-major batch in numpy float64 (gate order i, f, g, o; c' = f c + i g, h' = o tanh(c')) —
+    the default recurrent core of the reference's preset (cusrl/preset/ppo.py:189, wrapped by nn/module/rnn.py:21-120);
+    pinned like :func:`gru_sequence` against tests/golden/recurrent.npz.  ``state`` = (h0, c0) [layers, B, H] or None.
+    Returns (output [L, B, H], (h_n, c_n))."""
+    x = np.asarray(x, np.float64)
+    L, B, _ = x.shape
+    last_h, last_c = [], []
+    sigmoid = lambda v: 1.0 / (1.0 + np.exp(-v))  # noqa: E731
+    for layer, (w_ih, w_hh, b_ih, b_hh) in enumerate(weights):
+        w_ih, w_hh = np.asarray(w_ih, np.float64), np.asarray(w_hh, np.float64)
+        H = w_hh.shape[1]
+        bias = (0.0 if b_ih is None else np.asarray(b_ih, np.float64)) + (0.0 if b_hh is None else np.asarray(b_hh, np.float64))
+        h = np.zeros((B, H)) if state is None else np.asarray(state[0][layer], np.float64).copy()
+        c = np.zeros((B, H)) if state is None else np.asarray(state[1][layer], np.float64).copy()
+        out = np.zeros((L, B, H))
+        for t in range(L):
+            pre = x[t] @ w_ih.T + h @ w_hh.T + bias
+            i, f, g, o = sigmoid(pre[:, :H]), sigmoid(pre[:, H:2 * H]), np.tanh(pre[:, 2 * H:3 * H]), sigmoid(pre[:, 3 * H:])
+            c_next = f * c + i * g
+            h_next = o * np.tanh(c_next)
+            live = (np.ones(B, bool) if lengths is None else t < np.asarray(lengths))[:, None]
+            h, c = np.where(live, h_next, h), np.where(live, c_next, c)
+            out[t] = np.where(live, h_next, 0.0)
+        last_h.append(h), last_c.append(c)
+        x = out
+    return x.astype(np.float32), (np.stack(last_h).astype(np.float32), np.stack(last_c).astype(np.float32))
+
+
 def categorical_sample(logits, noise):
     """Acting side of a one-hot categorical policy, restated in numpy float64: cusrl/nn/module/distribution.py:332-366
     (``OneHotCategorical(logits).sample()`` and ``log_prob`` of the sample).  The draw itself happens inside

@@ -234,6 +234,24 @@ def test_oracle_gru_is_pinned_to_the_reference_rollout(golden):
         np.testing.assert_allclose(h_l[:, b], ref_h[:, 0], rtol=1e-6, atol=1e-7)
 
 
+def test_oracle_lstm_is_pinned_to_the_reference_rollout(golden):
+    import oracle
+
+    g = golden("recurrent")
+    weights = [tuple(g[f"lstm_param/rnn.{name}_l{layer}"] for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")) for layer in (0, 1)]
+    x, done = g["lstm_x"], g["lstm_done"]
+    out, _ = oracle.lstm_sequence(x, None, weights)
+    np.testing.assert_allclose(out, g["lstm_sequence_plain"], rtol=1e-5, atol=1e-6)
+    h = c = np.zeros((2, x.shape[1], 8), np.float32)
+    for t in range(x.shape[0]):
+        flat = np.concatenate([h[0], h[1], c[0], c[1]], -1)
+        np.testing.assert_allclose(flat, g["lstm_memories"][t], rtol=1e-5, atol=1e-6)
+        y, (h, c) = oracle.lstm_sequence(x[t:t + 1], (h, c), weights)
+        np.testing.assert_allclose(y[0], g["lstm_stepwise"][t], rtol=1e-5, atol=1e-6)
+        keep = (~done[t]).astype(np.float32)[None]
+        h, c = h * keep, c * keep
+
+
 def _twin_grus(I, H, layers, bias):
     from cusrl_amd.nn.rnn import _Gru
 
@@ -332,3 +350,63 @@ def test_fused_gru_refuses_a_second_backward_and_falls_back_where_it_must():
     assert isinstance(packed_out, torch.nn.utils.rnn.PackedSequence)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert not gru_supported(fused, x)
+
+
+def _twin_lstms(I, H, layers, bias):
+    from cusrl_amd.nn.rnn import _Lstm
+
+    torch.manual_seed(I * 1000 + H + 1)
+    plain = torch.nn.LSTM(I, H, layers, bias=bias).to(DEV)  # MIOpen
+    fused = _Lstm(I, H, layers, bias=bias).to(DEV)
+    fused.load_state_dict(plain.state_dict())
+    return plain, fused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,B,I,H,layers,bias,with_lengths", [(24, 300, 48, 256, 2, True, False), (1, 4096, 48, 256, 2, True, False),
+                                                              (5, 7, 3, 5, 1, True, True), (6, 65, 16, 32, 2, False, False),
+                                                              (24, 700, 48, 256, 2, True, True)])
+def test_fused_lstm_matches_nn_lstm_forward_and_backward(L, B, I, H, layers, bias, with_lengths):
+    """The GEMM + HIP-gate-pass LSTM against torch.nn.LSTM (MIOpen): outputs, both final states and every gradient, in the
+    padded form and (``with_lengths``) against the PackedSequence of the same batch; oracle.lstm_sequence on the small one."""
+    import oracle
+    from cusrl_amd import _native
+
+    plain, fused = _twin_lstms(I, H, layers, bias)
+    x = torch.randn(L, B, I, device=DEV)
+    h0, c0 = torch.randn(B, layers * H, device=DEV) * 0.5, torch.randn(B, layers * H, device=DEV) * 0.5
+    lengths = None
+    if with_lengths:
+        lengths = torch.randint(1, L + 1, (B,), generator=torch.Generator().manual_seed(B))
+        lengths[0] = L
+    w_out, w_h, w_c = torch.randn(L, B, H, device=DEV), torch.randn(layers, B, H, device=DEV), torch.randn(layers, B, H, device=DEV)
+    to_layers = lambda m: m.reshape(B, layers, H).transpose(0, 1).contiguous()  # noqa: E731
+    before = dict(_native.launch_counts)
+    results = []
+    for module in (plain, fused):
+        xi, hi, ci = (v.clone().requires_grad_(True) for v in (x, h0, c0))
+        if module is fused:
+            out, memory = module(xi, {"hidden": hi, "cell": ci}, lengths=None if lengths is None else lengths.to(DEV))
+            hn, cn = to_layers(memory["hidden"]), to_layers(memory["cell"])
+        elif lengths is None:
+            out, (hn, cn) = module(xi, (to_layers(hi), to_layers(ci)))
+        else:
+            packed = torch.nn.utils.rnn.pack_padded_sequence(xi, lengths, enforce_sorted=False)
+            packed_out, (hn, cn) = module(packed, (to_layers(hi), to_layers(ci)))
+            out, _ = torch.nn.utils.rnn.pad_packed_sequence(packed_out, total_length=L)
+        ((out * w_out).sum() + (hn * w_h).sum() + (cn * w_c).sum()).backward()
+        results.append([out.detach(), hn.detach(), cn.detach(), xi.grad, hi.grad, ci.grad] + [p.grad for p in module.parameters()])
+    assert _native.launch_counts["cusrl_lstm_gates_fwd"] - before.get("cusrl_lstm_gates_fwd", 0) == L * layers
+    assert _native.launch_counts["cusrl_lstm_gates_bwd"] - before.get("cusrl_lstm_gates_bwd", 0) == L * layers
+    names = ["out", "h_n", "c_n", "d_x", "d_h0", "d_c0"] + [n for n, _ in plain.named_parameters()]
+    for i, (name, want, got) in enumerate(zip(names, *results)):
+        scale = max(float(want.abs().max()), 1.0)
+        assert float((got - want).abs().max()) <= (2e-5 if i < 3 else 2e-4) * scale, (name, float((got - want).abs().max()), scale)
+    if B <= 7:
+        weights = [tuple(getattr(plain, f"{n}_l{layer}").detach().cpu().numpy() for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+                   for layer in range(layers)]
+        ref_out, (ref_h, ref_c) = oracle.lstm_sequence(x.cpu().numpy(), (to_layers(h0).cpu().numpy(), to_layers(c0).cpu().numpy()),
+                                                       weights, None if lengths is None else lengths.numpy())
+        np.testing.assert_allclose(results[1][0].cpu().numpy(), ref_out, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(results[1][1].cpu().numpy(), ref_h, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(results[1][2].cpu().numpy(), ref_c, rtol=1e-5, atol=2e-6)
