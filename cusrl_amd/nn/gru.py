@@ -19,6 +19,8 @@ reading the lengths back to the host.
 
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -154,6 +156,8 @@ def _column_sums(matrix: Tensor) -> Tensor:
 
 def gru_supported(module: torch.nn.RNNBase, input) -> bool:
     """fp32 device tensors through a plain (uni-directional, time-major, dropout-free at this call) ``nn.GRU`` / ``nn.LSTM``."""
+    if os.environ.get("CUSRL_FUSED_RNN", "1") == "0":  # escape hatch / A-B switch: MIOpen's RNN for everything
+        return False
     return (isinstance(input, Tensor) and input.is_cuda and input.dtype == torch.float32 and input.dim() == 3
             and not module.bidirectional and not module.batch_first and getattr(module, "proj_size", 0) == 0
             and (module.dropout == 0.0 or not module.training or module.num_layers == 1)
