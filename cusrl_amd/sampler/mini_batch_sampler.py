@@ -11,6 +11,7 @@ stream on a GPU buffer (indices are then uploaded, 8 B per sample).  The gather 
 
 from __future__ import annotations
 
+import os
 from collections.abc import Sequence
 
 import torch
@@ -18,6 +19,16 @@ import torch
 from cusrl_amd.template.buffer import Buffer, Sampler
 
 __all__ = ["AutoMiniBatchSampler", "MiniBatchSampler", "TemporalMiniBatchSampler"]
+
+
+_PREFETCH_STREAMS: dict[torch.device, torch.cuda.Stream] = {}
+
+
+def _prefetch_stream(device: torch.device) -> torch.cuda.Stream:
+    stream = _PREFETCH_STREAMS.get(device)
+    if stream is None:
+        stream = _PREFETCH_STREAMS[device] = torch.cuda.Stream(device=device)
+    return stream
 
 
 class MiniBatchSampler(Sampler):
@@ -31,6 +42,7 @@ class MiniBatchSampler(Sampler):
         *,
         permutation_device: str | torch.device | None = None,
         lazy: bool = True,
+        prefetch: bool = True,
     ):
         if num_epochs <= 0:
             raise ValueError("'num_epochs' must be positive")
@@ -54,6 +66,9 @@ class MiniBatchSampler(Sampler):
         # somebody reads are gathered (template/buffer.py); lazy=False gathers every leaf up front like the reference
         self.lazy = lazy
         self.hot_fields: set[str] = set()
+        # prefetch (extension, default): a device permutation for the next epoch is drawn on a second stream while the
+        # current epoch's minibatches run (same generator stream of values; see iter_indices)
+        self.prefetch = prefetch and os.environ.get("CUSRL_PREFETCH_PERMUTATIONS", "1") != "0"
 
     def iter_indices(self, buffer: Buffer):
         """Yield ``(metadata, device index slice)`` per minibatch — the permutation logic of ``__call__`` without
@@ -67,12 +82,36 @@ class MiniBatchSampler(Sampler):
         staged = perm_device != buffer.device
         epoch_indices = torch.randperm(num_samples, device=perm_device)
         device_indices = epoch_indices.to(buffer.device, non_blocking=True) if staged else epoch_indices
+        # A device permutation is a dozen launches (keys, radix / merge sort, de-duplication: ~60 us of device time) in
+        # front of an epoch whose minibatch steps are device-bound.  The permutation of epoch e + 1 depends on nothing
+        # epoch e computes, so it is drawn at the START of epoch e on a second stream, into the other of two index
+        # buffers; the main stream picks it up with one event wait.  The generator is still asked for one randperm per
+        # epoch in epoch order; the only thing that moves is that draw relative to random numbers the minibatch steps
+        # themselves consume, which is why ActorCritic switches `prefetch` off when a hook or a dropout layer draws
+        # inside the steps (then the interleaving is the reference's).
+        ahead = (self.prefetch and self.shuffle and not staged and epoch_indices.is_cuda and self.num_epochs > 1
+                 and not torch.cuda.is_current_stream_capturing())
+        if ahead:
+            side = _prefetch_stream(buffer.device)
+            spare, pending = torch.empty_like(epoch_indices), False
         for epoch in range(self.num_epochs):
             count = self.num_mini_batches if isinstance(self.num_mini_batches, int) else self.num_mini_batches[epoch]
             if count > num_samples:
                 raise ValueError(f"'num_mini_batches' ({count}) cannot exceed the number of samples ({num_samples})")
             size = num_samples // count
-            if self.shuffle and epoch > 0:
+            if ahead:
+                main = torch.cuda.current_stream()
+                if pending:  # drawn during the previous epoch
+                    main.wait_stream(side)
+                    epoch_indices, spare = spare, epoch_indices
+                    device_indices = epoch_indices
+                    pending = False
+                if epoch + 1 < self.num_epochs:
+                    side.wait_stream(main)  # `spare` was last read by the epoch before this one
+                    with torch.cuda.stream(side):
+                        torch.randperm(num_samples, device=perm_device, out=spare)
+                    pending = True
+            elif self.shuffle and epoch > 0:
                 torch.randperm(num_samples, device=perm_device, out=epoch_indices)
                 if staged:
                     device_indices = epoch_indices.to(buffer.device, non_blocking=True)
@@ -116,19 +155,20 @@ class AutoMiniBatchSampler(Sampler):
     """Temporal sampling iff some top-level field name ends with ``memory`` (``:136-140``)."""
 
     def __init__(self, num_epochs: int = 1, num_mini_batches: int | Sequence[int] = 1, shuffle: bool = True,
-                 *, permutation_device: str | torch.device | None = None, lazy: bool = True):
+                 *, permutation_device: str | torch.device | None = None, lazy: bool = True, prefetch: bool = True):
         self.num_epochs = num_epochs
         self.num_mini_batches = num_mini_batches
         self.shuffle = shuffle
         self.permutation_device = permutation_device
         self.lazy = lazy
+        self.prefetch = prefetch
         self.hot_fields: set[str] = set()
 
     def _dispatch(self, buffer: Buffer) -> MiniBatchSampler:
         temporal = any(key.split(".")[0].endswith("memory") for key in buffer)
         cls = TemporalMiniBatchSampler if temporal else MiniBatchSampler
         sampler = cls(self.num_epochs, self.num_mini_batches, self.shuffle, permutation_device=self.permutation_device,
-                      lazy=self.lazy)
+                      lazy=self.lazy, prefetch=self.prefetch)
         sampler.hot_fields = self.hot_fields  # the per-call sampler objects share what earlier passes learned
         return sampler
 

@@ -225,7 +225,19 @@ class ActorCritic(Agent):
         ready = super().step(next_observation, reward, terminated, truncated, next_state, **kwargs)
         return ready and self.hook.should_update(transition)
 
+    def _steps_draw_random(self) -> bool:
+        """Does anything between two permutation draws consume torch's generator (a hook's objective, a dropout layer)?"""
+        if any(hook.active and hook.objective_draws_random for hook in self.hook):
+            return True
+        modules = [self.actor, self.critic] + [m for hook in self.hook for m in hook._modules.values() if m is not None]
+        return any(isinstance(layer, torch.nn.modules.dropout._DropoutNd) and layer.p > 0
+                   for module in modules for layer in module.modules())
+
     def update(self):
+        if hasattr(self.sampler, "prefetch") and getattr(self, "_sampler_prefetch_checked", None) is not self.sampler:
+            self._sampler_prefetch_checked = self.sampler
+            if self._steps_draw_random():
+                self.sampler.prefetch = False  # keep the reference's interleaving of permutation and in-step draws
         self.hook.pre_update(self.buffer)  # a3-a6: next_value, GAE, advantage normalisation
         with self._training_mode():
             recurrent = self.actor.is_recurrent or self.critic.is_recurrent  # dynamic sequence counts: not capturable

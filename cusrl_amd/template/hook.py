@@ -46,6 +46,9 @@ class Objectives(dict):
 
 class Hook(Generic[AgentT]):
     agent: AgentT
+    # Extension: the hook draws from torch's global generator between pre_objective and post_objective (e.g. AMP samples
+    # a discriminator batch).  The sampler then keeps every permutation draw exactly where the reference has it.
+    objective_draws_random: bool = False
 
     def __init__(self, training_only: bool = False):
         self._modules: dict[str, nn.Module | None] = {}
