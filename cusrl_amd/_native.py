@@ -75,6 +75,8 @@ _SIGNATURES = {
     "cusrl_gru_gates_bwd": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P]),
     "cusrl_lstm_gates_fwd": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, _P]),
     "cusrl_lstm_gates_bwd": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P]),
+    "cusrl_rnn_cell_fwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, c_int, _P]),
+    "cusrl_rnn_cell_bwd": (c_int, [_P] * 5 + [c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_episode_stats": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_step_epilogue": (c_int, [_P] * 12 + [c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_step_epilogue_max_envs": (c_int64, []),

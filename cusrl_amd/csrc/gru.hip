@@ -272,6 +272,77 @@ __global__ __launch_bounds__(kBlock) void lstm_gates_bwd_kernel(float *__restric
     *reinterpret_cast<V *>(dh + b * H + j) = zero;
 }
 
+// ---- vanilla RNN (torch.nn.RNN, tanh | relu): h' = act(gi + gh + b_hh).  The output IS the saved state: the backward
+// needs act'(h') only, so nothing but `out` is kept; d(pre) is written over gi.
+template <typename V, bool kRelu>
+__global__ __launch_bounds__(kBlock) void rnn_cell_fwd_kernel(const float *__restrict__ gi, const float *__restrict__ gh,
+                                                              const float *__restrict__ b_hh, float *__restrict__ h,
+                                                              float *__restrict__ out,
+                                                              const int64_t *__restrict__ lengths, int64_t t, int64_t B,
+                                                              int H) {
+    constexpr int kW = sizeof(V) / sizeof(float);
+    const int cols = H / kW;
+    const int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= B * cols) return;
+    const int64_t b = e / cols;
+    const int j = int(e - b * cols) * kW;
+    const V a = *reinterpret_cast<const V *>(gi + b * H + j), r = *reinterpret_cast<const V *>(gh + b * H + j);
+    const V hp = *reinterpret_cast<const V *>(h + b * H + j);
+    V bias;
+    if (b_hh) bias = *reinterpret_cast<const V *>(b_hh + j);
+    const bool live = !lengths || t < lengths[b];
+    const float *pa = reinterpret_cast<const float *>(&a), *pr = reinterpret_cast<const float *>(&r),
+                *pb = reinterpret_cast<const float *>(&bias), *php = reinterpret_cast<const float *>(&hp);
+    V hn, o;
+    float *phn = reinterpret_cast<float *>(&hn), *po = reinterpret_cast<float *>(&o);
+#pragma unroll
+    for (int k = 0; k < kW; ++k) {
+        const float pre = pa[k] + pr[k] + (b_hh ? pb[k] : 0.0f);
+        const float next = kRelu ? fmaxf(pre, 0.0f) : tanhf(pre);
+        phn[k] = live ? next : php[k];
+        po[k] = live ? next : 0.0f;
+    }
+    *reinterpret_cast<V *>(h + b * H + j) = hn;
+    *reinterpret_cast<V *>(out + b * H + j) = o;
+}
+
+template <typename V, bool kRelu>
+__global__ __launch_bounds__(kBlock) void rnn_cell_bwd_kernel(float *__restrict__ d_pre, const float *__restrict__ out,
+                                                              const float *__restrict__ d_out, float *__restrict__ dh,
+                                                              const int64_t *__restrict__ lengths, int64_t t, int64_t B,
+                                                              int H) {
+    constexpr int kW = sizeof(V) / sizeof(float);
+    const int cols = H / kW;
+    const int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (e >= B * cols) return;
+    const int64_t b = e / cols;
+    const int j = int(e - b * cols) * kW;
+    const bool live = !lengths || t < lengths[b];
+    V g;
+    float *pg = reinterpret_cast<float *>(&g);
+    if (!live) {
+#pragma unroll
+        for (int k = 0; k < kW; ++k) pg[k] = 0.0f;
+        *reinterpret_cast<V *>(d_pre + b * H + j) = g;
+        return;  // dh passes through
+    }
+    const V y = *reinterpret_cast<const V *>(out + b * H + j), vdh = *reinterpret_cast<const V *>(dh + b * H + j);
+    V vdo;
+    if (d_out) vdo = *reinterpret_cast<const V *>(d_out + b * H + j);
+    const float *py = reinterpret_cast<const float *>(&y), *pdh = reinterpret_cast<const float *>(&vdh),
+                *pdo = reinterpret_cast<const float *>(&vdo);
+    V zero;
+    float *pz = reinterpret_cast<float *>(&zero);
+#pragma unroll
+    for (int k = 0; k < kW; ++k) {
+        const float dht = pdh[k] + (d_out ? pdo[k] : 0.0f);
+        pg[k] = kRelu ? (py[k] > 0.0f ? dht : 0.0f) : dht * (1.0f - py[k] * py[k]);
+        pz[k] = 0.0f;
+    }
+    *reinterpret_cast<V *>(d_pre + b * H + j) = g;
+    *reinterpret_cast<V *>(dh + b * H + j) = zero;
+}
+
 inline bool gru_vec4(int64_t H, const void *a, const void *b, const void *c, const void *d, const void *e,
                      const void *f) {
     auto ok = [](const void *p) { return p == nullptr || aligned(p, 16); };
@@ -358,5 +429,43 @@ extern "C" int cusrl_lstm_gates_bwd(float *pre, const float *c_prev, const float
     else
         hipLaunchKernelGGL(lstm_gates_bwd_kernel<float>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), pre,
                            c_prev, c_next, d_out, dh, dc, lengths, t, B, int(H));
+    return launch_status();
+}
+
+extern "C" int cusrl_rnn_cell_fwd(const float *gi, const float *gh, const float *b_hh, float *h, float *out,
+                                  const int64_t *lengths, int64_t t, int64_t B, int64_t H, int relu, void *stream) {
+    using namespace cusrl;
+    if (B < 0 || H <= 0 || t < 0) return CUSRL_E_INVALID;
+    if (B == 0) return 0;
+    if (!gi || !gh || !h || !out) return CUSRL_E_INVALID;
+    if (H > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    const bool vec4 = gru_vec4(H, gi, gh, b_hh, h, out, nullptr);
+    const int64_t blocks = ceil_div(B * (vec4 ? H / 4 : H), kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    const dim3 grid{uint32_t(blocks)}, block{kBlock};
+    hipStream_t s = as_stream(stream);
+    if (vec4 && relu) hipLaunchKernelGGL((rnn_cell_fwd_kernel<float4, true>), grid, block, 0, s, gi, gh, b_hh, h, out, lengths, t, B, int(H));
+    else if (vec4) hipLaunchKernelGGL((rnn_cell_fwd_kernel<float4, false>), grid, block, 0, s, gi, gh, b_hh, h, out, lengths, t, B, int(H));
+    else if (relu) hipLaunchKernelGGL((rnn_cell_fwd_kernel<float, true>), grid, block, 0, s, gi, gh, b_hh, h, out, lengths, t, B, int(H));
+    else hipLaunchKernelGGL((rnn_cell_fwd_kernel<float, false>), grid, block, 0, s, gi, gh, b_hh, h, out, lengths, t, B, int(H));
+    return launch_status();
+}
+
+extern "C" int cusrl_rnn_cell_bwd(float *d_pre, const float *out, const float *d_out, float *dh, const int64_t *lengths,
+                                  int64_t t, int64_t B, int64_t H, int relu, void *stream) {
+    using namespace cusrl;
+    if (B < 0 || H <= 0 || t < 0) return CUSRL_E_INVALID;
+    if (B == 0) return 0;
+    if (!d_pre || !out || !dh) return CUSRL_E_INVALID;
+    if (H > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    const bool vec4 = gru_vec4(H, d_pre, out, d_out, dh, nullptr, nullptr);
+    const int64_t blocks = ceil_div(B * (vec4 ? H / 4 : H), kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    const dim3 grid{uint32_t(blocks)}, block{kBlock};
+    hipStream_t s = as_stream(stream);
+    if (vec4 && relu) hipLaunchKernelGGL((rnn_cell_bwd_kernel<float4, true>), grid, block, 0, s, d_pre, out, d_out, dh, lengths, t, B, int(H));
+    else if (vec4) hipLaunchKernelGGL((rnn_cell_bwd_kernel<float4, false>), grid, block, 0, s, d_pre, out, d_out, dh, lengths, t, B, int(H));
+    else if (relu) hipLaunchKernelGGL((rnn_cell_bwd_kernel<float, true>), grid, block, 0, s, d_pre, out, d_out, dh, lengths, t, B, int(H));
+    else hipLaunchKernelGGL((rnn_cell_bwd_kernel<float, false>), grid, block, 0, s, d_pre, out, d_out, dh, lengths, t, B, int(H));
     return launch_status();
 }

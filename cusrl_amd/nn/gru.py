@@ -26,7 +26,7 @@ from torch import Tensor
 
 from cusrl_amd import ops
 
-__all__ = ["gru_forward", "gru_supported", "lstm_forward"]
+__all__ = ["gru_forward", "gru_supported", "lstm_forward", "rnn_forward"]
 
 
 class _GruLayer(torch.autograd.Function):
@@ -147,6 +147,57 @@ class _LstmLayer(torch.autograd.Function):
                 d_b if ctx.has_b_ih and need[5] else None, d_b if ctx.has_b_hh and need[6] else None, None)
 
 
+class _RnnLayer(torch.autograd.Function):
+    """``nn.RNN`` (tanh | relu): the output is the only saved state; the projection buffer becomes the gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, h0: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor | None, b_hh: Tensor | None,
+                lengths: Tensor | None, relu: bool):
+        L, B, I = x.shape
+        H = w_hh.shape[1]
+        flat = x.reshape(L * B, I)
+        gi = (torch.mm(flat, w_ih.t()) if b_ih is None else torch.addmm(b_ih, flat, w_ih.t())).view(L, B, H)
+        gh = torch.empty((B, H), dtype=x.dtype, device=x.device)
+        out = torch.empty((L, B, H), dtype=x.dtype, device=x.device)
+        h = h0.clone(memory_format=torch.contiguous_format)
+        w_hh_t = w_hh.t()
+        for t in range(L):
+            torch.mm(h, w_hh_t, out=gh)
+            ops.rnn_cell_forward(gi[t], gh, b_hh, h, out[t], lengths, t, relu)
+        if any(ctx.needs_input_grad[:6]):
+            ctx.save_for_backward(x, h0, w_ih, w_hh, lengths, out)
+            ctx.scratch, ctx.relu, ctx.has_b_ih, ctx.has_b_hh = gi, relu, b_ih is not None, b_hh is not None
+        return out, h
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out: Tensor | None, d_last: Tensor | None):
+        x, h0, w_ih, w_hh, lengths, out = ctx.saved_tensors
+        d_pre = ctx.scratch  # the projections are no longer needed: reuse their memory for the gradients
+        L, B, _ = x.shape
+        H = w_hh.shape[1]
+        dh = torch.zeros((B, H), dtype=x.dtype, device=x.device) if d_last is None else d_last.contiguous().clone()
+        if d_out is not None:
+            d_out = d_out.contiguous()
+        h0 = h0.contiguous()
+        for t in range(L - 1, -1, -1):
+            ops.rnn_cell_backward(d_pre[t], out[t], None if d_out is None else d_out[t], dh, lengths, t, ctx.relu)
+            dh.addmm_(d_pre[t], w_hh)
+        need = ctx.needs_input_grad
+        d_x = d_w_ih = d_w_hh = d_b = None
+        if need[0]:
+            d_x = torch.mm(d_pre.view(L * B, H), w_ih).view(x.shape)
+        if need[2]:
+            d_w_ih = torch.bmm(d_pre.transpose(1, 2), x).sum(0) if L > 1 else torch.mm(d_pre[0].t(), x[0])
+        if need[3]:
+            h_prev = torch.cat([h0.unsqueeze(0), out[:-1]]) if L > 1 else h0.unsqueeze(0)
+            d_w_hh = torch.bmm(d_pre.transpose(1, 2), h_prev).sum(0) if L > 1 else torch.mm(d_pre[0].t(), h_prev[0])
+        if (ctx.has_b_ih and need[4]) or (ctx.has_b_hh and need[5]):
+            d_b = _column_sums(d_pre.view(L * B, H))
+        return (d_x, dh if need[1] else None, d_w_ih, d_w_hh, d_b if ctx.has_b_ih and need[4] else None,
+                d_b if ctx.has_b_hh and need[5] else None, None, None)
+
+
 def _column_sums(matrix: Tensor) -> Tensor:
     rows = matrix.shape[0]
     if rows >= 4096 and matrix.shape[1] % 4 == 0:
@@ -202,3 +253,22 @@ def lstm_forward(module: torch.nn.LSTM, input: Tensor, state: tuple[Tensor, Tens
         x, h, c = _LstmLayer.apply(x, h0[layer].contiguous(), c0[layer].contiguous(), w_ih, w_hh, b_ih, b_hh, lengths)
         last_h.append(h), last_c.append(c)
     return x, (torch.stack(last_h), torch.stack(last_c))
+
+
+def rnn_forward(module: torch.nn.RNN, input: Tensor, h0: Tensor | None, lengths: Tensor | None = None):
+    """``module(input, h0)`` for a tanh / relu ``nn.RNN``; arguments and results as :func:`gru_forward`."""
+    L, B, _ = input.shape
+    H, layers = module.hidden_size, module.num_layers
+    if h0 is None:
+        h0 = torch.zeros((layers, B, H), dtype=input.dtype, device=input.device)
+    if lengths is not None:
+        lengths = lengths.to(device=input.device, dtype=torch.int64).contiguous()
+    relu = module.nonlinearity == "relu"
+    x, finals = input.contiguous(), []
+    for layer in range(layers):
+        w_ih, w_hh = getattr(module, f"weight_ih_l{layer}"), getattr(module, f"weight_hh_l{layer}")
+        b_ih = getattr(module, f"bias_ih_l{layer}") if module.bias else None
+        b_hh = getattr(module, f"bias_hh_l{layer}") if module.bias else None
+        x, last = _RnnLayer.apply(x, h0[layer].contiguous(), w_ih, w_hh, b_ih, b_hh, lengths, relu)
+        finals.append(last)
+    return x, torch.stack(finals)

@@ -1,5 +1,5 @@
-"""Recurrent backbones (counterpart of cusrl/nn/module/rnn.py:21-449): ``nn.GRU`` / ``nn.LSTM`` / ``nn.RNN`` (MIOpen on the
-GPU) behind one wrapper that keeps memories as ``[N, layers * hidden]`` tensors (a dict ``{"hidden", "cell"}`` for LSTM),
+"""Recurrent backbones (counterpart of cusrl/nn/module/rnn.py:21-449): ``nn.GRU`` / ``nn.LSTM`` / ``nn.RNN`` (on the GPU: rocBLAS
+GEMMs + one HIP gate pass per time step, nn/gru.py; MIOpen only for what that path does not take) behind one wrapper that keeps memories as ``[N, layers * hidden]`` tensors (a dict ``{"hidden", "cell"}`` for LSTM),
 steps one env step at a time during rollout and, on temporal minibatches, cuts the batch at episode boundaries so every
 segment restarts from a zero memory (done-split layout from cusrl_amd/nn/recurrent.py — HIP kernels)."""
 
@@ -11,7 +11,7 @@ from typing import Any
 from torch import Tensor, nn
 
 from cusrl_amd.nn import recurrent
-from cusrl_amd.nn.gru import gru_forward, gru_supported, lstm_forward
+from cusrl_amd.nn.gru import gru_forward, gru_supported, lstm_forward, rnn_forward
 from cusrl_amd.nn.module import Module, ModuleFactory
 from cusrl_amd.utils.nest import map_nested
 
@@ -46,7 +46,13 @@ class _Gru(nn.GRU):
 
 
 class _VanillaRnn(nn.RNN):
-    def forward(self, input, memory=None):
+    def forward(self, input, memory=None, lengths=None):
+        if gru_supported(self, input):
+            h0 = None if memory is None else _to_layers(memory, self.num_layers, self.hidden_size)
+            output, hn = rnn_forward(self, input, h0, lengths)
+            return output, _from_layers(hn)
+        if lengths is not None:
+            raise ValueError("'lengths' needs the fused RNN path (fp32 device tensors); pass a PackedSequence instead")
         if memory is None:
             output, hn = super().forward(input)
         else:
@@ -148,7 +154,7 @@ class Rnn(Module):
             # (The PackedSequence API wants the lengths on the host: one read-back, as in the reference.)
             if input.dim() != 3:
                 raise ValueError(f"Packed RNN input must be 3D, but got {input.dim()} dimensions")
-            if isinstance(self.rnn, (_Gru, _Lstm)) and gru_supported(self.rnn, padded_input):
+            if isinstance(self.rnn, (_Gru, _Lstm, _VanillaRnn)) and gru_supported(self.rnn, padded_input):
                 # same result, no packing and no host read of the lengths: the gate kernel stops every sequence at its own end
                 padded_latent, scattered_output = self.rnn(padded_input, scattered, lengths=layout.lengths)
             else:

@@ -36,6 +36,8 @@ __all__ = [
     "gru_gates_backward",
     "lstm_gates_forward",
     "lstm_gates_backward",
+    "rnn_cell_forward",
+    "rnn_cell_backward",
     "normalize_",
     "normalize_from_partials_",
     "ppo_loss_categorical_fwd_bwd",
@@ -875,6 +877,29 @@ def lstm_gates_backward(pre: torch.Tensor, c_prev: torch.Tensor, c_next: torch.T
                                              None if d_out is None else d_out.data_ptr(), dh.data_ptr(), dc.data_ptr(),
                                              None if lengths is None else lengths.data_ptr(), t, B, H, _stream()),
           "cusrl_lstm_gates_bwd")
+
+
+def rnn_cell_forward(gi: torch.Tensor, gh: torch.Tensor, b_hh: torch.Tensor | None, h: torch.Tensor, out: torch.Tensor,
+                     lengths: torch.Tensor | None, t: int, relu: bool) -> None:
+    """One ``nn.RNN`` time step: ``h = act(gi + gh + b_hh)`` in place, ``out`` = the step's output (``cusrl_rnn_cell_fwd``)."""
+    B, H = h.shape
+    if gi.shape != (B, H) or gh.shape != (B, H) or out.shape != (B, H):
+        raise ValueError("rnn_cell_forward: shape mismatch")
+    check(_native.lib().cusrl_rnn_cell_fwd(gi.data_ptr(), gh.data_ptr(), None if b_hh is None else b_hh.data_ptr(),
+                                           h.data_ptr(), out.data_ptr(), None if lengths is None else lengths.data_ptr(),
+                                           t, B, H, int(relu), _stream()), "cusrl_rnn_cell_fwd")
+
+
+def rnn_cell_backward(d_pre: torch.Tensor, out: torch.Tensor, d_out: torch.Tensor | None, dh: torch.Tensor,
+                      lengths: torch.Tensor | None, t: int, relu: bool) -> None:
+    """Backward of :func:`rnn_cell_forward`: ``d_pre`` receives the pre-activation gradient, ``dh`` keeps what bypasses the
+    step (``cusrl_rnn_cell_bwd``)."""
+    B, H = dh.shape
+    if d_pre.shape != (B, H) or out.shape != (B, H):
+        raise ValueError("rnn_cell_backward: shape mismatch")
+    check(_native.lib().cusrl_rnn_cell_bwd(d_pre.data_ptr(), out.data_ptr(), None if d_out is None else d_out.data_ptr(),
+                                           dh.data_ptr(), None if lengths is None else lengths.data_ptr(), t, B, H,
+                                           int(relu), _stream()), "cusrl_rnn_cell_bwd")
 
 
 def episode_stats(reward, done, episode_rew, episode_len, ring_rew, ring_len, num_episodes, step_reward_sum, parity: int) -> None:

@@ -213,6 +213,14 @@ int cusrl_lstm_gates_fwd(float *gi, const float *gh, const float *b_hh, float *h
 int cusrl_lstm_gates_bwd(float *pre, const float *c_prev, const float *c_next, const float *d_out, float *dh, float *dc,
                          const int64_t *lengths, int64_t t, int64_t B, int64_t H, void *stream);
 
+/* ... and for torch.nn.RNN (relu != 0: ReLU, else tanh): h <- act(gi + gh + b_hh), out = h.  The output is the only
+ * saved state (act' is a function of it); cusrl_rnn_cell_bwd writes dL/dpre = (dh + d_out) * act'(out) into d_pre (the
+ * caller passes the gi slice) and leaves in dh what bypasses the step, as the LSTM form does. */
+int cusrl_rnn_cell_fwd(const float *gi, const float *gh, const float *b_hh, float *h, float *out, const int64_t *lengths,
+                       int64_t t, int64_t B, int64_t H, int relu, void *stream);
+int cusrl_rnn_cell_bwd(float *d_pre, const float *out, const float *d_out, float *dh, const int64_t *lengths, int64_t t,
+                       int64_t B, int64_t H, int relu, void *stream);
+
 /* ---- rollout-side: sampling and episode statistics ----
  * Normal sample + log-prob of the sample in one pass — cusrl/nn/module/distribution.py:198-205 (`rsample`, then
  * `log_prob(sample).sum(-1, keepdim)`): action = mean + eps * std with eps ~ N(0,1) supplied by the caller (drawn

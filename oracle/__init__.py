@@ -329,6 +329,29 @@ def gru_sequence(x, h0, weights, lengths=None):
     return x.astype(np.float32), np.stack(finals).astype(np.float32)
 
 
+def rnn_sequence(x, h0, weights, lengths=None, relu=False):
+    """``torch.nn.RNN`` (h' = tanh | relu(W_ih x + b_ih + W_hh h + b_hh)) in numpy float64, arguments as :func:`gru_sequence`;
+    pinned against the reference's recorded packed-sequence run (tests/golden/recurrent_packed.npz, rnn_* entries)."""
+    x = np.asarray(x, np.float64)
+    L, B, _ = x.shape
+    finals = []
+    for layer, (w_ih, w_hh, b_ih, b_hh) in enumerate(weights):
+        w_ih, w_hh = np.asarray(w_ih, np.float64), np.asarray(w_hh, np.float64)
+        H = w_hh.shape[1]
+        bias = (0.0 if b_ih is None else np.asarray(b_ih, np.float64)) + (0.0 if b_hh is None else np.asarray(b_hh, np.float64))
+        h = np.zeros((B, H)) if h0 is None else np.asarray(h0[layer], np.float64).copy()
+        out = np.zeros((L, B, H))
+        for t in range(L):
+            pre = x[t] @ w_ih.T + h @ w_hh.T + bias
+            nxt = np.maximum(pre, 0.0) if relu else np.tanh(pre)
+            live = (np.ones(B, bool) if lengths is None else t < np.asarray(lengths))[:, None]
+            h = np.where(live, nxt, h)
+            out[t] = np.where(live, nxt, 0.0)
+        finals.append(h)
+        x = out
+    return x.astype(np.float32), np.stack(finals).astype(np.float32)
+
+
 def lstm_sequence(x, state, weights, lengths=None):
     """``torch.nn.LSTM`` over a time-major batch in numpy float64 (gate order i, f, g, o; c' = f c + i g, h' = o tanh(c')) —
     the default recurrent core of the reference's preset (cusrl/preset/ppo.py:189, wrapped by nn/module/rnn.py:21-120);

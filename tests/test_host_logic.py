@@ -95,6 +95,9 @@ def test_every_negative_return_code_of_the_c_abi_is_reachable_without_a_launch()
     assert lib.cusrl_lstm_gates_fwd(p, p, None, p, None, p, None, None, 0, 4, 8, None) == -1  # no cell state
     assert lib.cusrl_lstm_gates_bwd(p, p, p, None, p, p, None, -1, 4, 8, None) == -1        # negative step
     assert lib.cusrl_lstm_gates_bwd(None, None, None, None, None, None, None, 0, 0, 8, None) == 0
+    assert lib.cusrl_rnn_cell_fwd(p, p, None, None, p, None, 0, 4, 8, 0, None) == -1        # no state
+    assert lib.cusrl_rnn_cell_bwd(p, p, None, p, None, 0, 4, 0, 1, None) == -1              # H = 0
+    assert lib.cusrl_rnn_cell_bwd(None, None, None, None, None, 0, 0, 8, 1, None) == 0
     assert lib.cusrl_narrow_linear_supported(128, 12) == 1 and lib.cusrl_narrow_linear_supported(100, 12) == 0
     assert lib.cusrl_narrow_linear_supported(128, 17) == 0
     # communicator: argument errors; the text of every code

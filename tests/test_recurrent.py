@@ -252,6 +252,23 @@ def test_oracle_lstm_is_pinned_to_the_reference_rollout(golden):
         h, c = h * keep, c * keep
 
 
+def test_oracle_rnn_is_pinned_to_the_reference_packed_run(golden):
+    """oracle.rnn_sequence against the reference's own vanilla-RNN run (recurrent_packed.npz): the warm-up's final state,
+    every output of the done-split sequence (== stepping with resets), and the per-env final memory."""
+    import oracle
+
+    g = golden("recurrent_packed")
+    weights = [tuple(g[f"rnn_param/rnn.{name}_l{layer}"] for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")) for layer in (0, 1)]
+    _, h = oracle.rnn_sequence(g["rnn_warmup"], None, weights)
+    np.testing.assert_allclose(np.concatenate([h[0], h[1]], -1), g["rnn_initial_memory"], rtol=1e-5, atol=1e-6)
+    x, done = g["rnn_x"], g["rnn_done"]
+    for t in range(x.shape[0]):
+        y, h = oracle.rnn_sequence(x[t:t + 1], h, weights)
+        np.testing.assert_allclose(y[0], g["rnn_packed_output"][t], rtol=1e-5, atol=2e-6)
+        h = h * (~done[t]).astype(np.float32)[None]
+    np.testing.assert_allclose(np.concatenate([h[0], h[1]], -1), g["rnn_packed_memory"], rtol=1e-5, atol=2e-6)
+
+
 def _twin_grus(I, H, layers, bias):
     from cusrl_amd.nn.rnn import _Gru
 
@@ -410,3 +427,52 @@ def test_fused_lstm_matches_nn_lstm_forward_and_backward(L, B, I, H, layers, bia
         np.testing.assert_allclose(results[1][0].cpu().numpy(), ref_out, rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(results[1][1].cpu().numpy(), ref_h, rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(results[1][2].cpu().numpy(), ref_c, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nonlinearity", ["tanh", "relu"])
+@pytest.mark.parametrize("L,B,I,H,layers,bias,with_lengths", [(24, 300, 48, 256, 2, True, False), (5, 7, 3, 5, 1, True, True),
+                                                              (6, 65, 16, 32, 2, False, True)])
+def test_fused_rnn_matches_nn_rnn_forward_and_backward(nonlinearity, L, B, I, H, layers, bias, with_lengths):
+    """The GEMM + HIP-cell vanilla RNN against torch.nn.RNN (MIOpen), tanh and relu, padded and packed forms."""
+    import oracle
+    from cusrl_amd import _native
+    from cusrl_amd.nn.rnn import _VanillaRnn
+
+    torch.manual_seed(L * B + H)
+    plain = torch.nn.RNN(I, H, layers, nonlinearity=nonlinearity, bias=bias).to(DEV)
+    fused = _VanillaRnn(I, H, layers, nonlinearity=nonlinearity, bias=bias).to(DEV)
+    fused.load_state_dict(plain.state_dict())
+    x, h0 = torch.randn(L, B, I, device=DEV), torch.randn(B, layers * H, device=DEV) * 0.5
+    lengths = None
+    if with_lengths:
+        lengths = torch.randint(1, L + 1, (B,), generator=torch.Generator().manual_seed(B))
+        lengths[0] = L
+    w_out, w_h = torch.randn(L, B, H, device=DEV), torch.randn(layers, B, H, device=DEV)
+    to_layers = lambda m: m.reshape(B, layers, H).transpose(0, 1).contiguous()  # noqa: E731
+    before = dict(_native.launch_counts)
+    results = []
+    for module in (plain, fused):
+        xi, hi = x.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+        if module is fused:
+            out, memory = module(xi, hi, lengths=None if lengths is None else lengths.to(DEV))
+            hn = to_layers(memory)
+        elif lengths is None:
+            out, hn = module(xi, to_layers(hi))
+        else:
+            packed_out, hn = module(torch.nn.utils.rnn.pack_padded_sequence(xi, lengths, enforce_sorted=False), to_layers(hi))
+            out, _ = torch.nn.utils.rnn.pad_packed_sequence(packed_out, total_length=L)
+        ((out * w_out).sum() + (hn * w_h).sum()).backward()
+        results.append([out.detach(), hn.detach(), xi.grad, hi.grad] + [p.grad for p in module.parameters()])
+    assert _native.launch_counts["cusrl_rnn_cell_fwd"] - before.get("cusrl_rnn_cell_fwd", 0) == L * layers
+    assert _native.launch_counts["cusrl_rnn_cell_bwd"] - before.get("cusrl_rnn_cell_bwd", 0) == L * layers
+    for i, (want, got) in enumerate(zip(*results)):
+        scale = max(float(want.abs().max()), 1.0)
+        assert float((got - want).abs().max()) <= (2e-5 if i < 2 else 2e-4) * scale, (i, float((got - want).abs().max()), scale)
+    if B <= 7:
+        weights = [tuple(getattr(plain, f"{n}_l{layer}").detach().cpu().numpy() for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+                   for layer in range(layers)]
+        ref_out, ref_h = oracle.rnn_sequence(x.cpu().numpy(), to_layers(h0).cpu().numpy(), weights,
+                                             None if lengths is None else lengths.numpy(), relu=nonlinearity == "relu")
+        np.testing.assert_allclose(results[1][0].cpu().numpy(), ref_out, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(results[1][1].cpu().numpy(), ref_h, rtol=1e-5, atol=2e-6)
