@@ -162,6 +162,11 @@ class Rnn(Module):
                 packed_latent, scattered_output = self.rnn(packed, scattered)
                 padded_latent, _ = nn.utils.rnn.pad_packed_sequence(packed_latent, total_length=padded_input.size(0))
             output_memory = recurrent.gather_memory(scattered_output, done, layout)
+        elif padded_input.dim() == 3 and isinstance(self.rnn, (_Gru, _Lstm, _VanillaRnn)) and gru_supported(self.rnn, padded_input):
+            # the fused cores skip the padded steps (length-sorted, shrinking per-step launches); what they would have
+            # produced there is dropped by the unpad below anyway
+            padded_latent, _ = self.rnn(padded_input, scattered, lengths=layout.lengths)
+            output_memory = None
         else:
             padded_latent, _ = self._forward_tensor(padded_input, scattered)
             # the RNN also consumed padded steps, so its final state is not the state at each episode's last valid step

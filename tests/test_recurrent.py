@@ -269,6 +269,23 @@ def test_oracle_rnn_is_pinned_to_the_reference_packed_run(golden):
     np.testing.assert_allclose(np.concatenate([h[0], h[1]], -1), g["rnn_packed_memory"], rtol=1e-5, atol=2e-6)
 
 
+def test_length_plan_is_the_packed_sequence_schedule():
+    """The host-side plan of the fused cores (sort by length, per-step prefix sizes) against torch's PackedSequence."""
+    from cusrl_amd.nn.gru import _LengthPlan
+
+    gen = torch.Generator().manual_seed(3)
+    for L, B in ((7, 6), (24, 300), (1, 5), (5, 1)):
+        lengths = torch.randint(1, L + 1, (B,), generator=gen)
+        plan = _LengthPlan(lengths, L + 2)  # two steps past the longest sequence: nothing runs there
+        x = torch.randn(L, B, 3, generator=gen)
+        packed = torch.nn.utils.rnn.pack_padded_sequence(x, lengths, enforce_sorted=False)
+        sizes = packed.batch_sizes.tolist()
+        assert plan.sizes == sizes + [0] * (L + 2 - len(sizes))
+        assert torch.equal(lengths[plan.order], lengths[packed.sorted_indices])  # ties may be ordered differently
+        assert torch.equal(plan.inverse[plan.order], torch.arange(B))
+        assert torch.equal(plan.unsort(plan.sort(x, 1), 1), x)
+
+
 def _twin_grus(I, H, layers, bias):
     from cusrl_amd.nn.rnn import _Gru
 
