@@ -63,6 +63,17 @@ def main(out_dir: str):
     result["averaged_with_none"] = distributed.average_dict({"a": 1.0 + rank, "b": None if rank else 2.0})
     result["gathered"] = distributed.gather_obj(rank * 10)
     result["stack"] = distributed.gather_stack(torch.tensor([float(rank)])).tolist()
+    # KL-driven learning-rate control: every rank acts on the MEAN KL over ranks (lr_schedule.py:60-62, 287-296), so the
+    # ranks, fed different KLs, must take the same decisions
+    sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    from make_golden import ScheduleProbe  # noqa: PLC0415
+
+    kls = [0.004 + 0.002 * rank, 0.05 - 0.04 * rank, 0.011, 0.0001 + 0.03 * rank]
+    rows = ScheduleProbe().run(cusrl.hook.ThresholdLRSchedule(desired_kl_divergence=0.01), kls, False)
+    result["threshold_lrs"] = rows[:, 0].tolist()
+    rows = ScheduleProbe().run_mini_batch_wise(cusrl.hook.MiniBatchWiseLRSchedule(desired_kl_divergence=0.01),
+                                               cusrl.hook.OnPolicyPreparation(), kls, 2)
+    result["mini_batch_wise_lrs"] = rows[:, 0].tolist()
     distributed.barrier()
     Path(out_dir, f"rank{rank}.json").write_text(json.dumps(result))
 

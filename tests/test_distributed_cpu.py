@@ -65,3 +65,23 @@ def test_parameter_broadcast_and_metric_averaging(ranks):
         assert r["averaged_same_keys"] == {"a": 5.0, "b": 0.5, "c": 3.0} and r["fast_path_taken"] is True
         assert r["averaged_with_none"] == {"a": 1.5, "b": 2.0}
         assert r["gathered"] == [0, 10] and r["stack"] == [[0.0], [1.0]]
+
+
+def test_kl_driven_schedules_act_on_the_mean_kl_over_ranks(ranks):
+    """Fed different KLs, both ranks take the decisions of the averaged sequence (lr_schedule.py:60-62, 287-296)."""
+    import sys
+
+    import cusrl_amd
+
+    sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    from make_golden import ScheduleProbe
+
+    assert ranks[0]["threshold_lrs"] == ranks[1]["threshold_lrs"]
+    assert ranks[0]["mini_batch_wise_lrs"] == ranks[1]["mini_batch_wise_lrs"]
+    mean_kls = [(0.004 + 0.006) / 2, (0.05 + 0.01) / 2, 0.011, (0.0001 + 0.0301) / 2]
+    single = ScheduleProbe().run(cusrl_amd.hook.ThresholdLRSchedule(desired_kl_divergence=0.01), mean_kls, False)
+    np.testing.assert_allclose(ranks[0]["threshold_lrs"], single[:, 0], rtol=1e-9)
+    single = ScheduleProbe().run_mini_batch_wise(cusrl_amd.hook.MiniBatchWiseLRSchedule(desired_kl_divergence=0.01),
+                                                 cusrl_amd.hook.OnPolicyPreparation(), mean_kls, 2)
+    np.testing.assert_allclose(ranks[0]["mini_batch_wise_lrs"], single[:, 0], rtol=1e-9)
+    assert len(set(ranks[0]["threshold_lrs"])) > 1  # the sequence does move the learning rate
