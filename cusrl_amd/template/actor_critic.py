@@ -124,6 +124,10 @@ class ActorCritic(Agent):
         self.actor_memory = None
         self.hook.init()
 
+        if self.device.type == "cuda":
+            from cusrl_amd.utils.tuning import enable_tuned_gemms
+
+            enable_tuned_gemms()  # measured rocBLAS / hipBLASLt kernel choice for this workload's GEMM shapes
         self.actor = self.setup_module(self.actor)
         self.critic = self.setup_module(self.critic)
         self.optimizer = build_optimizer(optimizer_factory, self.named_parameters())
