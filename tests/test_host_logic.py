@@ -535,3 +535,22 @@ def test_lazy_batch_is_a_dict_that_gathers_on_first_access():
         pass
     else:
         raise AssertionError
+
+
+def test_tuned_gemm_selection_file_is_well_formed_and_inert_without_a_gpu():
+    """cusrl_amd/tuned_gemms_gfx950.csv (scripts/tune_gemms.py): TunableOp's validators first, then one
+    (operator, shape, kernel, milliseconds) row per GEMM shape of configs 2 and 3; nothing is loaded in a process
+    without a GPU."""
+    from cusrl_amd.utils import tuning
+
+    rows = [line.split(",") for line in tuning.TUNED_GEMMS_FILE.read_text().splitlines() if line]
+    validators = {row[1]: row[2] for row in rows if row[0] == "Validator"}
+    assert {"PT_VERSION", "HIP_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"} <= set(validators)
+    assert validators["GCN_ARCH_NAME"].startswith("gfx950")
+    entries = [row for row in rows if row[0] != "Validator"]
+    assert len(entries) >= 20 and all(len(row) == 4 and float(row[3]) > 0 for row in entries)
+    shapes = {row[1] for row in entries}
+    assert "tn_256_24576_48_ld_48_48_256" in shapes and "tn_128_24576_256_ld_256_256_128" in shapes  # the minibatch step's layers
+    assert all(row[0].split("_")[0] in ("GemmTunableOp", "GemmAndBiasTunableOp", "GemmStridedBatchedTunableOp") for row in entries)
+    if not torch.cuda.is_available():
+        assert tuning.enable_tuned_gemms() is False
