@@ -321,3 +321,22 @@ def test_sequence_layout_restatement_vs_reference(golden):
         valid = np.zeros(mask.size, bool)
         valid[dest] = True
         assert np.array_equal(valid.reshape(mask.shape), mask)
+
+
+def test_categorical_draw_restatement_is_the_exponential_race():
+    """oracle.categorical_sample (checker of cusrl_categorical_sample_logp): the winner of p_j / q_j, one-hot, with the
+    log-softmax of the taken category — and, fed Exp(1) race variables, it draws category j with probability p_j."""
+    rng = np.random.default_rng(5)
+    logits = rng.standard_normal((4000, 5)) * 1.5
+    noise = rng.exponential(1.0, logits.shape)
+    taken, action, logp, margin = oracle.categorical_sample(logits, noise)
+    p = np.exp(logits - logits.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    assert np.array_equal(taken, (p / noise).argmax(-1)) and np.array_equal(action.argmax(-1), taken)
+    assert np.array_equal(action.sum(-1), np.ones(len(taken))) and (margin >= 1.0).all()
+    np.testing.assert_allclose(logp[:, 0], np.log(p[np.arange(len(taken)), taken]), rtol=1e-5, atol=1e-6)
+    row = np.array([2.0, 0.5, -1.0, -3.0])
+    draws, _, _, _ = oracle.categorical_sample(np.tile(row, (200000, 1)), rng.exponential(1.0, (200000, 4)))
+    freq = np.bincount(draws, minlength=4) / draws.size
+    expect = np.exp(row) / np.exp(row).sum()
+    np.testing.assert_allclose(freq, expect, atol=4e-3)
