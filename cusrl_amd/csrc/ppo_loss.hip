@@ -10,6 +10,8 @@
 // are exchanged through LDS so that one lane per row finishes the scalar part (ratio, clipping, value loss),
 // publishes d(loss)/d(logp) through LDS, and the chunk owners (who still hold action/mean/std in registers)
 // emit the gradients.  Scalar statistics use wave64 shuffle reductions, fp64 partials per block, fixed order.
+#include <float.h>
+
 #include "common.hpp"
 
 namespace cusrl {
@@ -378,10 +380,13 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
             if (a[j] > best) best = a[j], taken = j;
         }
         const float log_norm = zmax + logf(sum);  // logsumexp
+        // A masked action (logit = -inf) has p = 0 and log p = -inf: torch.distributions.Categorical.entropy clamps
+        // the log-prob to finfo.min before the product, so the term is 0 * (-3.4e38) = -0 instead of 0 * (-inf) = NaN —
+        // and so are the row's entropy, the loss and every d_logits of the row.
         float entropy = 0.0f;
         for (int j = 0; j < A; ++j) {
             const float lp = z[j] - log_norm;
-            entropy -= expf(lp) * lp;  // -(probs * logits).sum(-1)
+            entropy -= expf(lp) * fmaxf(lp, -FLT_MAX);  // -(probs * clamp(logits, min=finfo.min)).sum(-1)
         }
         const float logp = z[taken] - log_norm;
         float ratio, lr;
@@ -393,7 +398,8 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
         if (d_logits) {
             for (int j = 0; j < A; ++j) {
                 const float lp = z[j] - log_norm, pj = expf(lp);
-                d_logits[row * A + j] = dlp * ((j == taken ? 1.0f : 0.0f) - pj) - p.g_ent * (pj * (lp + entropy));
+                d_logits[row * A + j] =
+                    dlp * ((j == taken ? 1.0f : 0.0f) - pj) - p.g_ent * (pj * (fmaxf(lp, -FLT_MAX) + entropy));
             }
         }
         value_terms(ret, curr_value, old_value, d_value, row, D, p, acc[0], acc[4]);

@@ -69,6 +69,9 @@ class AdversarialMotionPrior(Hook):
         self.criterion = nn.BCEWithLogitsLoss()
         self.grad_penalty = GradientPenaltyLoss()
 
+    def collective_phases(self):
+        return ("step",)  # transition_rms.update synchronises across ranks on every env step (amp.py:123-124)
+
     @torch.no_grad()
     def post_step(self, transition):
         agent_transition = transition.pop("amp_obs", None)

@@ -65,6 +65,13 @@ class ObservationNormalization(Hook):
         # every statistics update all-gathers (mean, var, count) unless synchronisation is deferred to pre_update
         return () if (self.defer_synchronization or self.frozen) else ("act",)
 
+    def on_replay(self, phase):
+        # a replayed statistics update happened on the device only: the modules' "synchronised" flags are host state
+        if self.defer_synchronization and not (self.frozen or self.agent.inference_mode):
+            for rms in (self.observation_rms, self.state_rms):
+                if rms is not None:
+                    rms._is_synchronized = False
+
     # ---- rollout
     def pre_act(self, transition):
         observation, state = transition["observation"], transition.get("state")

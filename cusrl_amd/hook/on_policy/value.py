@@ -75,6 +75,10 @@ class ValueComputation(Hook):
             return
         self.agent.critic.reset_memory(self._critic_memory, transition["done"])
 
+    def on_replay(self, phase):
+        if phase == "step" and self._deferred():  # the host half of post_step
+            self._value_pending = True
+
     @torch.no_grad()
     def pre_update(self, buffer: Buffer):
         if self._value_pending and self._replayable(buffer):

@@ -229,6 +229,15 @@ class ActorCritic(Agent):
         ready = super().step(next_observation, reward, terminated, truncated, next_state, **kwargs)
         return ready and self.hook.should_update(transition)
 
+    def replay_step(self) -> bool:
+        """Host half of :meth:`step` for an env step whose device work was replayed from a hipGraph
+        (template/graphs.py GraphedRolloutStep): hooks' host effects, buffer cursor, update cadence."""
+        self.hook.on_replay("step")
+        if not self.inference_mode:
+            self.buffer.replay_push()
+        ready = Agent.step(self, None, None, None, None)
+        return ready and self.hook.should_update(self.transition)
+
     def _steps_draw_random(self) -> bool:
         """Does anything between two permutation draws consume torch's generator (a hook's objective, a dropout layer)?"""
         if any(hook.active and hook.objective_draws_random for hook in self.hook):

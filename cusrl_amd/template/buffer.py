@@ -397,6 +397,17 @@ class Buffer(MutableMapping):
         self._advance()
         return True
 
+    def replay_push(self):
+        """Host bookkeeping of a steady-state :meth:`push` whose launch was replayed from a hipGraph (the cursor the
+        graph was captured at is baked into it; the caller keys its graphs on ``cursor``)."""
+        plan = self._push_plan
+        if plan is None:
+            raise RuntimeError("replay_push: no steady-state append has been planned for this buffer")
+        if self._derived:
+            for name in plan[0]:
+                self._derived.pop(name, None)
+        self._advance()
+
     # ------------------------------------------------------------------ a7/a8: sampling
     def sample(self, sampler: Callable[[str, torch.Tensor], torch.Tensor]) -> dict[str, Any]:
         """Generic per-leaf callback form of the reference (buffer.py:153-162)."""

@@ -79,6 +79,22 @@ class Environment(ABC):
     def step(self, action):
         """-> (next_observation, next_state | None, reward [N, Dr], terminated [N,1] bool, truncated [N,1] bool, info)."""
 
+    # ---- extension: the capturable protocol (template/graphs.py GraphedRolloutStep)
+    capturable: bool = False
+    """True promises that ``step`` and ``reset_static`` only enqueue shape-static device work on torch's current stream:
+    no host read-back, no Python state that changes from step to step, outputs that are fresh tensors.  ``Trainer``
+    then drives such an env without a single host synchronisation per step and, under ``compile=True``, replays a whole
+    env step (act -> step -> episode statistics -> post_step hooks -> buffer push -> resets) from ONE hipGraph."""
+
+    def reset_static(self, indices: torch.Tensor, count: torch.Tensor):
+        """Fixed-shape form of ``reset(indices=...)`` (environment.py:300-317 of the reference takes a host index list):
+        ``indices`` is an int64 device vector of env ids of which only the first ``count`` (1-element int32 device
+        tensor, read by kernels — never by the host) are finished envs, in ascending order; entries past ``count`` are
+        stale but valid env ids whose returned rows are dropped.  Returns ``(observation [len(indices), Do],
+        state [len(indices), Ds] | None, info)``; row ``k`` belongs to env ``indices[k]``.  An env with per-instance
+        state of its own must only re-initialise the first ``count`` entries (mask by ``arange < count``)."""
+        raise NotImplementedError(f"{type(self).__name__} does not implement the capturable reset protocol")
+
     def get_metrics(self) -> dict[str, float]:
         return {}
 

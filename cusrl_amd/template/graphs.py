@@ -26,7 +26,8 @@ import torch
 
 from cusrl_amd.utils.metrics import MetricTap
 
-__all__ = ["GraphedAct", "GraphedRegion", "GraphedTrainStep", "capture_signature", "collective_phases", "eager_phases"]
+__all__ = ["GraphedAct", "GraphedRegion", "GraphedRolloutStep", "GraphedTrainStep", "capture_signature", "collective_phases",
+           "eager_phases"]
 
 
 def _freeze(value):
@@ -352,6 +353,7 @@ class GraphedAct:
             self.capture.replay()
             agent.transition.clear()
             agent.transition.update(self.transition)
+            agent.hook.on_replay("act")
             return agent.transition["action"]
         if self.state == 0:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -365,3 +367,148 @@ class GraphedAct:
         self.state = 2
         self.capture.replay()
         return agent.transition["action"]
+
+
+class GraphedRolloutStep:
+    """ONE env step of the rollout loop (cusrl/template/trainer.py:296-321) as one hipGraph replay:
+
+        pre_act hooks -> actor.explore -> post_act hooks            (what GraphedAct replays on its own)
+        env.step(action)                                            (a `capturable` env: shape-static device work)
+        cusrl_step_epilogue: done flag, episode statistics, ordered finished-env ids + their count ON THE DEVICE
+        agent.step: post_step hooks, cusrl_buffer_push at this graph's cursor
+        env.reset_static(ids, count) -> cusrl_scatter_rows(count)   (reset rows spliced in by a device-side count)
+        the spliced observation -> the act input of the next step
+
+    Nothing on this path is read by the host: the trainer issues 24 replays back to back and the update's graphs behind
+    them, the device never waits for Python.  One graph per (buffer cursor, statistics parity) — both are baked into
+    kernel arguments — captured under the usual protocol (first use eager on the capture stream, second use capture,
+    later uses replay; re-capture when the host-side signature changes).  What a replay skips on the HOST is replayed
+    explicitly: the agent's step counter, the buffer cursor, the statistics counters, ``Hook.on_replay("step")``.
+
+    Requirements (checked by :meth:`supported`): ``compile=True`` agent with a capturable act step, an env with
+    ``capturable = True`` and no autoreset, device-resident episode statistics, fp32 rewards / bool flags of the shapes
+    the fused epilogue takes, and no active hook that declares the ``"step"`` phase eager.  Anything else keeps the
+    host-driven loop."""
+
+    def __init__(self, trainer):
+        self.trainer = trainer
+        self.agent = trainer.agent
+        self.stream: torch.cuda.Stream = self.agent._graph_stream
+        self.steps: dict[tuple, dict] = {}
+        self.signature: tuple | None = None
+        # persistent device state shared by every step graph
+        env, device = trainer.environment, self.agent.device
+        n = env.num_instances
+        self.done = torch.zeros(n, 1, dtype=torch.bool, device=device)
+        self.indices = torch.zeros(n, dtype=torch.int64, device=device)  # zeros: stale entries must be valid env ids
+        self.count = torch.zeros(1, dtype=torch.int32, device=device)
+        self.static_observation: torch.Tensor | None = None
+        self.static_state: torch.Tensor | None = None
+        self.replays = 0
+
+    # ------------------------------------------------------------------ eligibility
+    def supported(self, observation, state) -> bool:
+        trainer, agent = self.trainer, self.agent
+        env = trainer.environment
+        act = agent._graphed_act
+        if act is None or not getattr(env, "capturable", False) or env.spec.autoreset or not trainer.stats.on_device:
+            return False
+        if not trainer._static_resets or trainer._epilogue_ok is not True:
+            return False
+        if not act.supported(observation, state) or "step" in eager_phases(agent):
+            return False
+        from cusrl_amd.template.hook import Hook
+
+        for hook in agent.hook:
+            # post_step / should_update of a hook this package does not know may keep Python state per step (a list of
+            # rewards, a counter): such a hook opts in with `rollout_capture_safe = True`, otherwise the loop stays
+            # host-driven (pre_act / post_act are already part of the compile=True contract, see GraphedAct)
+            custom = type(hook).post_step is not Hook.post_step or type(hook).should_update is not Hook.should_update
+            if (hook._active and custom and not type(hook).__module__.startswith("cusrl_amd.")
+                    and not getattr(hook, "rollout_capture_safe", False)):
+                return False
+        return agent.buffer._push_plan is not None  # the steady-state append (one launch, nothing allocated)
+
+    # ------------------------------------------------------------------ the step, written once
+    def _body(self):
+        trainer, agent = self.trainer, self.agent
+        env, stats, act = trainer.environment, trainer.stats, agent._graphed_act
+        act._body()  # reads act.static_observation / static_state
+        transition = agent.transition
+        next_observation, next_state, reward, terminated, truncated, info = env.step(transition["action"])
+        stats.track_fused(reward, terminated, truncated, self.done, self.indices, self.count)
+        self.ready = agent.step(next_observation, reward, terminated, truncated, next_state, **{**info, "done": self.done})
+        init_observation, init_state, _ = env.reset_static(self.indices, self.count)
+        trainer._splice_static(next_observation, next_state, self.indices, self.count, init_observation, init_state)
+        act.static_observation.copy_(next_observation)
+        if act.static_state is not None:
+            act.static_state.copy_(next_state)
+
+    def _replay_host_effects(self) -> bool:
+        """The Python-side effects of one step that a replay does not perform."""
+        trainer, agent = self.trainer, self.agent
+        trainer.stats.count_step()
+        ready = agent.replay_step()
+        return ready
+
+    # ------------------------------------------------------------------ driver
+    def begin(self):
+        """Once per rollout: compare what the captures froze on the host (hook mutables, inference / deterministic flags,
+        buffer layout) with the current values; a change sends every step graph back to capture."""
+        agent = self.agent
+        signature = (capture_signature(agent), agent.buffer.layout_version)
+        if signature != self.signature:
+            self.flush_metrics()
+            for entry in self.steps.values():
+                entry["state"] = min(entry["state"], 1)
+            self.signature = signature
+
+    def run(self, observation, state):
+        """One env step; returns ``(next_observation, next_state, ready)`` (the static act inputs of the next step)."""
+        agent, trainer = self.agent, self.trainer
+        act = agent._graphed_act
+        if act.static_observation is None or act.static_observation.shape != observation.shape:
+            act.static_observation = torch.empty_like(observation)
+            act.static_state = None if state is None else torch.empty_like(state)
+            act.state = 0
+            self.steps.clear()
+        if observation is not act.static_observation:
+            act.static_observation.copy_(observation)
+            if state is not None:
+                act.static_state.copy_(state)
+        if self.signature is None:
+            self.begin()
+        key = (agent.buffer.cursor, trainer.stats._parity)
+        entry = self.steps.get(key)
+        if entry is None:
+            entry = self.steps[key] = {"state": 0, "capture": _Capture(agent), "transition": None}
+        if entry["state"] == 2:
+            entry["capture"].replay()
+            agent.transition.clear()
+            agent.transition.update(entry["transition"])
+            agent.hook.on_replay("act")
+            ready = self._replay_host_effects()
+            self.replays += 1
+            return act.static_observation, act.static_state, ready
+        if entry["state"] == 0:  # eager on the capture stream: the real step, and the warm-up of this key
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._body()
+            torch.cuda.current_stream().wait_stream(self.stream)
+            entry["state"] = 1
+            return act.static_observation, act.static_state, self.ready
+        # capture: the body's host effects happen once here (they belong to this very step), the replay right behind
+        # the capture performs the device work
+        entry["capture"].capture(self._body, self.stream, pool=agent._graph_pool)
+        entry["transition"] = dict(agent.transition)
+        entry["state"] = 2
+        entry["capture"].replay()
+        return act.static_observation, act.static_state, self.ready
+
+    def flush_metrics(self):
+        for entry in self.steps.values():
+            entry["capture"].flush_metrics()
+
+    @property
+    def captured(self) -> int:
+        return sum(1 for entry in self.steps.values() if entry["state"] == 2)

@@ -49,6 +49,10 @@ class Hook(Generic[AgentT]):
     # Extension: the hook draws from torch's global generator between pre_objective and post_objective (e.g. AMP samples
     # a discriminator batch).  The sampler then keeps every permutation draw exactly where the reference has it.
     objective_draws_random: bool = False
+    # Extension: this hook's post_step / should_update only enqueue shape-static device work (no Python state that changes
+    # per step, no host read-back), so a whole env step may be replayed from a hipGraph (template/graphs.py
+    # GraphedRolloutStep).  Stock hooks qualify; a user-defined hook that overrides either method sets this to opt in.
+    rollout_capture_safe: bool = False
 
     def __init__(self, training_only: bool = False):
         self._modules: dict[str, nn.Module | None] = {}
@@ -191,9 +195,15 @@ class Hook(Generic[AgentT]):
         return ()
 
     def eager_phases(self) -> tuple[str, ...]:
-        """Extension: phases (same names) this hook must run outside hipGraph capture whatever the number of ranks —
-        typically because it reads a device value back to the host to branch on it."""
+        """Extension: phases (same names, plus ``"step"`` = post_step inside a captured env step) this hook must run
+        outside hipGraph capture whatever the number of ranks — typically because it reads a device value back to the
+        host to branch on it."""
         return ()
+
+    def on_replay(self, phase: str):
+        """Extension: called instead of the hook's ``pre_act`` / ``post_act`` (``phase == "act"``) or ``post_step``
+        (``"step"``) when that phase was replayed from a hipGraph — the device work happened, the Python body did not.
+        A hook whose body also changes HOST state (a flag, a counter) repeats that part here."""
 
     def pre_export(self, graph): ...
 
@@ -275,6 +285,7 @@ class HookComposite(Hook):
     post_objective = _fan_out("post_objective")
     post_update = _fan_out("post_update")
     apply_schedule = _fan_out("apply_schedule")
+    on_replay = _fan_out("on_replay")
 
     def should_update(self, transition) -> bool:
         return all(hook.should_update(transition) for hook in self.active_hooks())

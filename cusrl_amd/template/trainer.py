@@ -4,6 +4,7 @@ dumps, trial folders and console boxes of the reference are out of scope (SURVEY
 
 from __future__ import annotations
 
+import os
 from collections.abc import Callable, Iterable, Mapping
 from typing import Any
 
@@ -55,10 +56,14 @@ class EnvironmentStats:
         ``track_step`` / ``track_episode`` and ``get_done_indices``."""
         from cusrl_amd import ops
 
-        self.total_steps += self.num_envs
-        self.num_steps += 1
         ops.step_epilogue(reward, terminated, truncated, done_out, self.episode_rew, self.episode_len, self.rew_buffer,
                           self.len_buffer, self._episodes_dev, self._reward_sum, indices_out, count_out, self._parity)
+        self.count_step()
+
+    def count_step(self):
+        """Host counters of one fused step (all a hipGraph replay of :meth:`track_fused` leaves to do)."""
+        self.total_steps += self.num_envs
+        self.num_steps += 1
         self._parity ^= 1
 
     @property
@@ -173,6 +178,15 @@ class Trainer:
         self._done_counter = None
         self._done_scratch: dict = {}
         self._last_checkpoint_iteration: int | None = None
+        # capturable envs (template/environment.py): fixed-shape resets spliced by a device-side count — no host read
+        # per step — and, under compile=True, whole env steps replayed from hipGraphs (template/graphs.py)
+        env = self.environment
+        self._static_resets = bool(getattr(env, "capturable", False)) and self.stats.on_device and not env.spec.autoreset
+        self._static_scratch: dict = {}
+        self._epilogue_ok: bool | None = None
+        self._graphed_rollout = None
+        self._rollout_split: tuple[float, float] | None = None
+        self.capture_rollout = os.environ.get("CUSRL_CAPTURE_ROLLOUT", "1") != "0"  # A/B switch of the captured env step
 
     def run_training_loop(self):
         """Checkpoints as the reference does (trainer.py:280-294): once before the loop, every ``checkpoint_interval``
@@ -192,6 +206,48 @@ class Trainer:
             self.environment.close()
 
     def _rollout_and_update(self, observation, state):
+        agent, timer = self.agent, self.timer
+        graphed = self._rollout_graphs(observation, state)
+        if graphed is not None:
+            observation, state = self._rollout_captured(graphed, observation, state)
+        else:
+            observation, state = self._rollout_eager(observation, state)
+        with timer.record("agent"):
+            agent_info = agent.update()
+        self._log_info(agent_info)
+        for hook in self.hooks:
+            hook.post_update()
+        return observation, state
+
+    def _rollout_graphs(self, observation, state):
+        """The captured-step driver when this rollout can go through it (template/graphs.py GraphedRolloutStep): a
+        ``compile=True`` agent, a capturable env, and one host-driven iteration behind us (it allocates the buffer,
+        plans the steady-state push, proves that the fused step epilogue takes this env's outputs and measures how a
+        step's time splits between agent and environment)."""
+        agent = self.agent
+        if not (self.capture_rollout and self._static_resets and getattr(agent, "_graphed_act", None) is not None and self._epilogue_ok
+                and self._rollout_split is not None and isinstance(observation, torch.Tensor)):
+            return None
+        if self._graphed_rollout is None:
+            from cusrl_amd.template.graphs import GraphedRolloutStep
+
+            self._graphed_rollout = GraphedRolloutStep(self)
+        graphed = self._graphed_rollout
+        observation_t = observation if observation.device == agent.device else observation.to(agent.device)
+        return graphed if graphed.supported(observation_t, state) else None
+
+    def _rollout_captured(self, graphed, observation, state):
+        timer = self.timer
+        graphed.begin()
+        with timer.record("rollout"):
+            while True:
+                observation, state, ready = graphed.run(observation, state)
+                if ready:
+                    break
+        graphed.flush_metrics()
+        return observation, state
+
+    def _rollout_eager(self, observation, state):
         agent, env, timer, stats = self.agent, self.environment, self.timer, self.stats
         every = self.timer_sampling  # the four sections of an env step are bracketed on every k-th step only
         while True:
@@ -207,21 +263,29 @@ class Trainer:
                     # their count (into pinned host memory).  agent.step's host work (hooks, push) runs while it
                     # executes, so the count is already there when the resets need it — no blocking read-back.
                     fused = True
-                    if self._done_counter is None:
-                        from cusrl_amd import ops
-
-                        self._done_counter = ops.HostCounter()
                     done = torch.empty_like(terminated)
-                    indices = self._done_scratch.get("epilogue")
-                    if indices is None or indices.numel() != terminated.numel() or indices.device != terminated.device:
-                        indices = self._done_scratch["epilogue"] = torch.empty(terminated.numel(), dtype=torch.int64,
-                                                                               device=terminated.device)
-                    stats.track_fused(reward, terminated, truncated, done, indices, self._done_counter.arm())
+                    if self._static_resets:
+                        indices, count = self._static_buffers(terminated)
+                        stats.track_fused(reward, terminated, truncated, done, indices, count)
+                    else:
+                        if self._done_counter is None:
+                            from cusrl_amd import ops
+
+                            self._done_counter = ops.HostCounter()
+                        indices = self._done_scratch.get("epilogue")
+                        if indices is None or indices.numel() != terminated.numel() or indices.device != terminated.device:
+                            indices = self._done_scratch["epilogue"] = torch.empty(
+                                terminated.numel(), dtype=torch.int64, device=terminated.device)
+                        stats.track_fused(reward, terminated, truncated, done, indices, self._done_counter.arm())
                     info = {**info, "done": done}
             with timer.record("agent", every):
                 ready = agent.step(next_observation, reward, terminated, truncated, next_state, **info)
             with timer.record("environment", every):
-                if fused:
+                if fused and self._static_resets:
+                    # rows for every index slot, spliced by the kernel up to the device-side count: no host read
+                    init_observation, init_state, _ = env.reset_static(indices, count)
+                    self._splice_static(next_observation, next_state, indices, count, init_observation, init_state)
+                elif fused:
                     if not env.spec.autoreset:
                         done_indices = indices[: self._done_counter.wait()]
                         if done_indices.numel():
@@ -251,14 +315,39 @@ class Trainer:
             observation, state = next_observation, next_state
             if ready:
                 break
-        with timer.record("agent"):
-            agent_info = agent.update()
-        self._log_info(agent_info)
-        for hook in self.hooks:
-            hook.post_update()
+        if self._static_resets and getattr(agent, "_graphed_act", None) is not None and self._rollout_split is None:
+            # how an env step's device time splits between the agent and the environment: a captured step is one graph
+            # whose inside cannot be bracketed, so Perf/agent_time / Perf/environment_time of captured rollouts are
+            # the bracketed rollout time in these proportions (one event synchronisation, once)
+            agent_time, env_time = timer["agent"], timer["environment"]
+            total = agent_time + env_time
+            self._rollout_split = (agent_time / total, env_time / total) if total > 0 else (0.5, 0.5)
         return observation, state
 
+    def _static_buffers(self, terminated):
+        scratch = self._static_scratch
+        if scratch.get("n") != terminated.numel() or scratch.get("device") != terminated.device:
+            scratch.update(n=terminated.numel(), device=terminated.device,
+                           indices=torch.zeros(terminated.numel(), dtype=torch.int64, device=terminated.device),
+                           count=torch.zeros(1, dtype=torch.int32, device=terminated.device))
+        return scratch["indices"], scratch["count"]
+
+    @staticmethod
+    def _splice_static(observation, state, indices, count, init_observation, init_state):
+        """``update_observation_and_state`` (environment.py:365-379) for the capturable reset protocol: row ``k`` of the
+        reset tensors goes to env ``indices[k]`` for ``k < count``, with ``count`` read by the kernel."""
+        from cusrl_amd import ops
+
+        ops.scatter_rows(init_observation, indices, observation.unsqueeze(0), count)
+        if state is not None:
+            ops.scatter_rows(init_state, indices, state.unsqueeze(0), count)
+
     def _epilogue_applies(self, reward, terminated, truncated, info) -> bool:
+        ok = self._epilogue_applies_now(reward, terminated, truncated, info)
+        self._epilogue_ok = ok if self._epilogue_ok is None else (self._epilogue_ok and ok)
+        return ok
+
+    def _epilogue_applies_now(self, reward, terminated, truncated, info) -> bool:
         """Device tensors of the shapes the fused step epilogue takes ([N, D] fp32 reward, [N, 1] bool flags)."""
         stats = self.stats
         limit = getattr(self, "_epilogue_limit", None)
@@ -326,8 +415,10 @@ class Trainer:
             info.update({f"Metric/reward.{i}": v for i, v in enumerate(step_reward)})
         else:
             info["Metric/episode_reward"], info["Metric/reward"] = episode_reward, step_reward
-        info["Perf/environment_time"] = self.timer["environment"]
-        info["Perf/agent_time"] = self.timer["agent"]
+        rollout = self.timer["rollout"]  # captured rollouts: one bracket, split as measured on the host-driven iteration
+        split = self._rollout_split or (0.5, 0.5)
+        info["Perf/environment_time"] = self.timer["environment"] + rollout * split[1]
+        info["Perf/agent_time"] = self.timer["agent"] + rollout * split[0]
         info = distributed.average_dict(info)
         world = distributed.world_size()
         steps = self.stats.num_steps * self.environment.num_instances * world

@@ -19,18 +19,26 @@ __all__ = ["DummyTorchEnvironment", "SyntheticEnvironment"]
 class SyntheticEnvironment(Environment):
     def __init__(self, num_instances: int = 4096, observation_dim: int = 48, action_dim: int = 12, *,
                  state_dim: int | None = None, reward_dim: int = 1, terminate_prob: float = 0.01,
-                 truncate_prob: float = 0.005, device=None, autoreset: bool = False, **properties):
+                 truncate_prob: float = 0.005, device=None, autoreset: bool = False, capturable: bool = True,
+                 **properties):
         device = resolve_device(device)
         super().__init__(observation_dim, action_dim, num_instances=num_instances, state_dim=state_dim,
                          reward_dim=reward_dim, device=device, autoreset=autoreset, **properties)
         self.device = device
         self.terminate_prob, self.truncate_prob = terminate_prob, truncate_prob
+        # every step / reset is shape-static device work from torch's generator: the trainer may drive it without
+        # host synchronisation and replay whole env steps from hipGraphs (template/environment.py `capturable`)
+        self.capturable = bool(capturable) and self.device.type == "cuda"
 
     def _randn(self, rows: int, cols: int | None):
         return None if cols is None else torch.randn(rows, cols, device=self.device)
 
     def reset(self, *, indices=None, randomize_episode_progress: bool = False):
         rows = self.num_instances if indices is None else len(indices)
+        return self._randn(rows, self.observation_dim), self._randn(rows, self.state_dim), {}
+
+    def reset_static(self, indices, count):
+        rows = indices.numel()  # one fresh row per index slot; the trainer's splice only takes the first `count`
         return self._randn(rows, self.observation_dim), self._randn(rows, self.state_dim), {}
 
     def step(self, action):

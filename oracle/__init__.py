@@ -298,6 +298,70 @@ def ppo_loss(advantage, old_logp, action, mean, std, ret, curr_value, old_value=
     return out
 
 
+def ppo_loss_f64(advantage, old_logp, action, mean, std, ret, curr_value, old_value=None, *, clip=0.2, value_clip=None,
+                 w_sur=1.0, w_val=0.5, w_ent=0.01, flip_clip_side=None):
+    """:func:`ppo_loss` evaluated in float64 from the same float32 inputs — the yardstick for GRADIENT parity.
+
+    Why a second restatement: the fp32 forms (the reference's torch ops, ``oracle_ppo_loss``, the HIP kernel) each round
+    ``logp`` (a sum of A terms of magnitude ~|logp|) in their own order, and ``ratio = exp(logp - old_logp)`` turns that
+    absolute noise (~6e-8 * |logp|) into a RELATIVE error of every gradient element of the row — 1e-6..1e-5 at |logp| ~ 15-60
+    — before any element-wise cancellation.  Two fp32 evaluations therefore cannot be held to 1e-5 against each other, but each
+    can be held to the float64 value.  Same formulas and citations as :func:`ppo_loss` (distribution.py:207-213, common.py:35-41,
+    ppo.py:10-18, value.py:85-89,121-137); ``std`` may be the [A] vector (then ``d_std`` is its [A] gradient).
+    ``flip_clip_side``: bool [B] — rows whose ratio is to be treated as lying on the OTHER side of the clip bound it is
+    nearest to (a ratio within fp32 noise of ``1 +- clip`` may legitimately fall on either side; tests accept both)."""
+    f = lambda x: np.asarray(x, np.float64)  # noqa: E731
+    adv, old_logp = f(advantage).reshape(-1), f(old_logp).reshape(-1)
+    x, mu, sg, R, cv = f(action), f(mean), f(std), f(ret), f(curr_value)
+    B, A = mu.shape
+    D = R.shape[-1]
+    vector = sg.ndim == 1
+    sgb = np.broadcast_to(sg, mu.shape)
+    diff = x - mu
+    logp = (-(diff * diff) / (2.0 * sgb * sgb) - np.log(sgb) - np.log(np.sqrt(2.0 * np.pi))).sum(-1)
+    entropy = (0.5 + 0.5 * np.log(2.0 * np.pi) + np.log(sgb)).sum(-1)
+    ratio = np.exp(logp - old_logp)
+    lo, hi = np.float64(np.float32(1.0 - clip)), np.float64(np.float32(1.0 + clip))
+    inside = (ratio >= lo) & (ratio <= hi)
+    clipped = np.clip(ratio, lo, hi)
+    if flip_clip_side is not None:
+        flip = np.asarray(flip_clip_side, bool).reshape(-1)
+        nearest = np.where(np.abs(ratio - lo) < np.abs(ratio - hi), lo, hi)
+        clipped = np.where(flip, np.where(inside, nearest, ratio), clipped)
+        inside = inside ^ flip
+    s1, s2 = adv * ratio, adv * clipped
+    d_ratio = np.where(s1 < s2, adv, np.where(s1 > s2, np.where(inside, adv, 0.0), 0.5 * adv + np.where(inside, 0.5 * adv, 0.0)))
+    dlp = (-w_sur / B) * d_ratio * ratio
+    var = sgb * sgb
+    d_mean = dlp[:, None] * (diff / var)
+    d_std = dlp[:, None] * ((diff * diff) / (var * sgb) - 1.0 / sgb) + (-w_ent / B) / sgb
+    e1 = cv - R
+    if value_clip is None:
+        value_loss, g = (e1 * e1).mean() * w_val, 2.0 * e1
+    else:
+        v = f(old_value)
+        dv = cv - v
+        e2 = (v + np.clip(dv, -value_clip, value_clip)) - R
+        l1, l2 = e1 * e1, e2 * e2
+        g2 = np.where((dv >= -value_clip) & (dv <= value_clip), 2.0 * e2, 0.0)
+        value_loss = np.maximum(l1, l2).mean() * w_val
+        g = np.where(l1 > l2, 2.0 * e1, np.where(l1 < l2, g2, 0.5 * (2.0 * e1 + g2)))
+    return dict(
+        losses=np.array([value_loss, -np.minimum(s1, s2).mean() * w_sur, -entropy.mean() * w_ent]),
+        logp=logp[:, None], entropy=entropy[:, None], ratio=ratio[:, None], d_mean=d_mean,
+        d_std=d_std.sum(0) if vector else d_std, d_value=(w_val / (B * D)) * g,
+        clip_margin=np.minimum(np.abs(ratio - lo), np.abs(ratio - hi)),
+    )
+
+
+def gradient_error(candidate, reference) -> float:
+    """max |candidate - reference| / max |reference|: the error of a gradient TENSOR in units of its largest entry (what
+    the optimizer step sees), robust against elements that cancel to ~0 where an element-wise relative error is meaningless."""
+    reference = np.asarray(reference, np.float64)
+    scale = np.abs(reference).max()
+    return float(np.abs(np.asarray(candidate, np.float64) - reference).max() / (scale if scale > 0 else 1.0))
+
+
 def gru_sequence(x, h0, weights, lengths=None):
     """``torch.nn.GRU`` over a time-major batch, restated in numpy float64 (the recurrent backbone the reference wraps:
     cusrl/nn/module/rnn.py:21-120, ``nn.GRU``; the cell itself is PyTorch's — r, z = sigmoid(W_i x + b_i + W_h h + b_h),
@@ -404,7 +468,7 @@ def categorical_sample(logits, noise):
 
 
 def categorical_ppo_loss(advantage, old_logp, action, logits, ret, curr_value, old_value=None, *, clip=0.2,
-                         value_clip=None, w_sur=1.0, w_val=0.5, w_ent=0.01):
+                         value_clip=None, w_sur=1.0, w_val=0.5, w_ent=0.01, flip_clip_side=None):
     """The objective of :func:`ppo_loss` for a one-hot categorical policy, restated in numpy (float64 arithmetic, results
     rounded to float32): cusrl/nn/module/distribution.py:332-366 (``OneHotCategorical``: log-prob of the first arg-max
     of the one-hot action under log-softmax(logits), entropy ``-sum p log p``), hook/on_policy/ppo.py:10-18,82-84,
@@ -419,17 +483,26 @@ def categorical_ppo_loss(advantage, old_logp, action, logits, ret, curr_value, o
     log_p = z - (z.max(-1, keepdims=True) + np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1, keepdims=True)))
     prob = np.exp(log_p)
     logp = log_p[np.arange(B), taken]
-    entropy = -(prob * log_p).sum(-1)
+    # torch.distributions.Categorical.entropy (which OneHotCategorical delegates to) clamps the normalised logits to
+    # finfo(float32).min before multiplying by the probabilities: a masked action (logit -inf) contributes 0, not NaN
+    log_p_clamped = np.maximum(log_p, np.float64(np.finfo(np.float32).min))
+    entropy = -(prob * log_p_clamped).sum(-1)
     ratio = np.exp(logp - old_logp)
     lo, hi = np.float64(np.float32(1.0 - clip)), np.float64(np.float32(1.0 + clip))
-    s1, s2 = adv * ratio, adv * np.clip(ratio, lo, hi)
-    surrogate = -np.minimum(s1, s2).mean() * w_sur
     inside = (ratio >= lo) & (ratio <= hi)
+    clipped = np.clip(ratio, lo, hi)
+    if flip_clip_side is not None:  # see ppo_loss_f64: rows within fp32 noise of a clip bound, taken on the other side
+        flip = np.asarray(flip_clip_side, bool).reshape(-1)
+        nearest = np.where(np.abs(ratio - lo) < np.abs(ratio - hi), lo, hi)
+        clipped = np.where(flip, np.where(inside, nearest, ratio), clipped)
+        inside = inside ^ flip
+    s1, s2 = adv * ratio, adv * clipped
+    surrogate = -np.minimum(s1, s2).mean() * w_sur
     d_ratio = np.where(s1 < s2, adv, np.where(s1 > s2, np.where(inside, adv, 0.0), 0.5 * adv + np.where(inside, 0.5 * adv, 0.0)))
     dlp = (-w_sur / B) * d_ratio * ratio
     onehot = np.zeros_like(z)
     onehot[np.arange(B), taken] = 1.0
-    d_logits = dlp[:, None] * (onehot - prob) - (-w_ent / B) * prob * (log_p + entropy[:, None])
+    d_logits = dlp[:, None] * (onehot - prob) - (-w_ent / B) * prob * (log_p_clamped + entropy[:, None])
     e1 = cv - ret
     if value_clip is None:
         value_loss, g = (e1 * e1).mean() * w_val, 2.0 * e1
@@ -446,4 +519,4 @@ def categorical_ppo_loss(advantage, old_logp, action, logits, ret, curr_value, o
     f = np.float32
     return dict(losses=np.array([value_loss, surrogate, entropy_loss], f), logp=logp.astype(f)[:, None],
                 entropy=entropy.astype(f)[:, None], ratio=ratio.astype(f)[:, None], d_logits=d_logits.astype(f),
-                d_value=d_value.astype(f))
+                d_value=d_value.astype(f), clip_margin=np.minimum(np.abs(ratio - lo), np.abs(ratio - hi)))

@@ -26,3 +26,39 @@ def golden():
         return cache[name]
 
     return load
+
+
+_GRADIENT_PARITY: list[dict] = []
+
+
+@pytest.fixture(scope="session")
+def gradient_parity():
+    """``check(label, candidate, reference, bound)``: assert that a gradient tensor is within ``bound`` of its reference in
+    units of the reference's largest entry (``oracle.gradient_error``) and record the achieved error; the session writes
+    every record to ``gpurun_out/gradient_parity.json`` (copied to ``profiles/`` as the evidence behind the bounds)."""
+    import oracle
+
+    def check(label, candidate, reference, bound):
+        achieved = oracle.gradient_error(candidate, reference)
+        _GRADIENT_PARITY.append({"check": label, "achieved": achieved, "bound": bound})
+        assert achieved <= bound, f"{label}: gradient error {achieved:.3e} of the largest entry exceeds {bound:.0e}"
+        return achieved
+
+    return check
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _GRADIENT_PARITY:
+        return
+    import json
+
+    worst: dict[str, dict] = {}
+    for record in _GRADIENT_PARITY:
+        family = record["check"].split("[")[0]
+        if family not in worst or record["achieved"] > worst[family]["achieved"]:
+            worst[family] = record
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    (out / "gradient_parity.json").write_text(json.dumps(
+        {"measure": "max |candidate - reference| / max |reference| per gradient tensor", "worst_per_family": worst,
+         "records": _GRADIENT_PARITY}, indent=1))

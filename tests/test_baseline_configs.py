@@ -61,7 +61,7 @@ MOUNTAIN_CAR_KWARGS = dict(  # cusrl/zoo/gym/classic_control.py:65-80
 
 
 @pytest.mark.parametrize("mode", ["fused", "hook_by_hook", "hipgraph"])
-def test_config1_mountain_car_update_replays_the_reference(cusrl, golden, mode):
+def test_config1_mountain_car_update_replays_the_reference(cusrl, golden, mode, gradient_parity):
     g = golden("update_trace_config1")
     overrides = {"compile": True} if mode == "hipgraph" else {}
     underlying = cusrl.preset.PpoAgentFactory(**MOUNTAIN_CAR_KWARGS, device=DEV, **overrides).to_underlying()
@@ -128,9 +128,10 @@ def test_config1_mountain_car_update_replays_the_reference(cusrl, golden, mode):
     kept = [(row, steps.index(int(step))) for row, step in enumerate(g["kept_steps"]) if int(step) in steps]
     rows = [row for row, _ in kept]
     pick = lambda name: host(torch.stack([trace[name][i] for _, i in kept]))  # noqa: E731
-    np.testing.assert_allclose(pick("grads_unclipped"), g["grads_unclipped"][rows], rtol=1e-3, atol=2e-6)
-    clipped = g["grads_unclipped" if agent.flat_optimizer is not None else "grads"][rows]
-    np.testing.assert_allclose(pick("grads"), clipped, rtol=1e-3, atol=2e-6)
+    clipped = g["grads_unclipped" if agent.flat_optimizer is not None else "grads"]
+    for (row, _), raw, after in zip(kept, pick("grads_unclipped"), pick("grads")):  # 1e-5 of each step's largest entry
+        gradient_parity(f"config1_trace.grads_unclipped[{mode},{row}]", raw, g["grads_unclipped"][row], 1e-5)
+        gradient_parity(f"config1_trace.grads[{mode},{row}]", after, clipped[row], 1e-5)
     np.testing.assert_allclose(pick("params_after"), g["params_after"][rows], rtol=1e-4, atol=2e-6)
     final = torch.cat([p.detach().reshape(-1) for _, p in agent.named_parameters()])
     np.testing.assert_allclose(host(final), g["params_after"][-1], rtol=1e-4, atol=2e-6)  # end state of all 16 steps

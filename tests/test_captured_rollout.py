@@ -1,0 +1,154 @@
+"""The captured env step (template/graphs.py GraphedRolloutStep) against the host-driven rollout loop (GPU).
+
+A `capturable` env (template/environment.py) is driven with fixed-shape resets spliced by a device-side count; under
+``compile=True`` a whole env step — act, env.step, episode statistics, post_step hooks, buffer push, resets — replays
+from ONE hipGraph.  Both loops issue the same kernels on the same operands and consume torch's generator identically
+(the reference loop is cusrl/template/trainer.py:296-321), so from the same seed every buffer leaf, every parameter and
+the episode statistics must be bit-identical.
+"""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def cusrl():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    import cusrl_amd
+
+    cusrl_amd.config.set_device(DEV)
+    return cusrl_amd
+
+
+def _factory(cusrl, kind, T):
+    common = dict(num_steps_per_update=T, sampler_epochs=2, sampler_mini_batches=2, compile=True,
+                  optimizer_kwargs={"capturable": True, "fused": True})
+    if kind == "continuous":
+        return cusrl.preset.PpoAgentFactory(**common)
+    if kind == "discrete_obs_norm":  # BASELINE config 1's shape: categorical policy + observation normalisation
+        return cusrl.preset.PpoAgentFactory(action_space_type="discrete", normalize_observation=True,
+                                            actor_hidden_dims=(64, 64), critic_hidden_dims=(64, 64), activation_fn="Tanh", **common)
+    if kind == "amp":  # BASELINE config 5's per-step hook: discriminator forward + style reward inside the step
+        k = 6
+        dataset = torch.randn(4096, 2 * k, device=DEV)
+        return cusrl.preset.AmpAgentFactory(amp_dataset_source=dataset, amp_state_indices=slice(k), extrinsic_reward_scale=0.5,
+                                            amp_reward_scale=2.0, **common)
+    raise AssertionError(kind)
+
+
+def _run(cusrl, kind, capture, iterations=6, N=256, T=8):
+    cusrl.set_global_seed(21)
+    env = cusrl.testing.DummyTorchEnvironment(num_instances=N, observation_dim=12, action_dim=4, device=DEV)
+    trainer = cusrl.Trainer(env, _factory(cusrl, kind, T), num_iterations=iterations, verbose=False)
+    trainer.capture_rollout = capture
+    trainer.run_training_loop()
+    return trainer
+
+
+@pytest.mark.parametrize("kind", ["continuous", "discrete_obs_norm", "amp"])
+def test_captured_rollout_is_bit_identical_to_the_host_driven_loop(cusrl, kind):
+    from cusrl_amd import _native
+
+    T = 8
+    host = _run(cusrl, kind, capture=False, T=T)
+    assert host._graphed_rollout is None and host._static_resets
+    pushes_before = _native.launch_counts.get("cusrl_buffer_push", 0)
+    captured = _run(cusrl, kind, capture=True, T=T)
+    graphed = captured._graphed_rollout
+    assert graphed is not None and graphed.captured == T, (graphed and graphed.captured)
+    # iteration 0 host-driven, 1 eager bodies, 2 captures (+ the replay behind each), 3.. pure replays
+    assert graphed.replays == T * 3
+    # ... and a replayed step issues no C call at all: the push entry point was only called in iterations 0-2
+    assert _native.launch_counts["cusrl_buffer_push"] - pushes_before == T * 3
+    a, b = host.agent, captured.agent
+    assert set(a.buffer.storage) == set(b.buffer.storage)
+    for key in a.buffer.storage:
+        assert torch.equal(a.buffer.storage[key], b.buffer.storage[key]), key
+    for (name, p), q in zip(a.named_parameters(), b.parameters()):
+        assert torch.equal(p, q), name
+    for attr in ("episode_rew", "episode_len", "rew_buffer", "len_buffer"):
+        assert torch.equal(getattr(host.stats, attr), getattr(captured.stats, attr)), attr
+    assert host.stats.num_episodes == captured.stats.num_episodes and host.stats.num_episodes > 0
+    assert host.stats.total_steps == captured.stats.total_steps == 6 * T * 256
+    assert a.buffer["terminated"].any() and a.buffer["truncated"].any()  # resets were exercised
+    for key, value in host.last_info.items():
+        if key.startswith("Perf/"):
+            continue
+        assert captured.last_info[key] == pytest.approx(value, rel=1e-6, abs=1e-7), key
+    assert captured.last_info["Perf/environment_time"] > 0 and captured.last_info["Perf/agent_time"] > 0
+
+
+def test_static_reset_rows_reach_only_the_finished_envs_in_order(cusrl):
+    """``Trainer._splice_static``: row k of the reset tensors goes to env ``indices[k]`` for k < count (read on the device);
+    stale index entries past the count leave their envs untouched (environment.py:365-379 semantics)."""
+    observation = torch.arange(8 * 3, dtype=torch.float32, device=DEV).view(8, 3).clone()
+    state = -observation.clone()
+    before_obs, before_state = observation.clone(), state.clone()
+    indices = torch.tensor([1, 4, 6, 0, 0, 0, 0, 0], dtype=torch.int64, device=DEV)
+    count = torch.tensor([3], dtype=torch.int32, device=DEV)
+    init_obs = 100 + torch.arange(8 * 3, dtype=torch.float32, device=DEV).view(8, 3)
+    init_state = 200 + torch.arange(8 * 3, dtype=torch.float32, device=DEV).view(8, 3)
+    cusrl.Trainer._splice_static(observation, state, indices, count, init_obs, init_state)
+    expect_obs, expect_state = before_obs.clone(), before_state.clone()
+    expect_obs[[1, 4, 6]] = init_obs[:3]
+    expect_state[[1, 4, 6]] = init_state[:3]
+    assert torch.equal(observation, expect_obs) and torch.equal(state, expect_state)
+    count.zero_()
+    cusrl.Trainer._splice_static(observation, None, indices, count, init_obs + 1, None)
+    assert torch.equal(observation, expect_obs)
+
+
+def test_a_user_hook_with_per_step_python_state_keeps_the_loop_host_driven(cusrl):
+    """A hook from outside the package that overrides ``post_step`` may keep Python state per step: the captured step is
+    only taken when it opts in (``rollout_capture_safe``)."""
+    seen = []
+
+    class Recorder(cusrl.Hook):
+        def post_step(self, transition):
+            seen.append(float(transition["reward"].sum()))
+
+    class Shaper(cusrl.Hook):
+        rollout_capture_safe = True
+
+        def post_step(self, transition):
+            transition["reward"].mul_(0.5)
+
+    for hook_type, expect_capture in ((Recorder, False), (Shaper, True)):
+        cusrl.set_global_seed(5)
+        env = cusrl.testing.DummyTorchEnvironment(num_instances=64, observation_dim=12, action_dim=4, device=DEV)
+        factory = _factory(cusrl, "continuous", 4).to_underlying()
+        factory.register_hook(hook_type(), index=0)
+        trainer = cusrl.Trainer(env, factory, num_iterations=4, verbose=False)
+        trainer.run_training_loop()
+        graphed = trainer._graphed_rollout
+        if expect_capture:
+            assert graphed is not None and graphed.captured == 4 and graphed.replays == 4 * 2
+        else:
+            assert graphed is None or graphed.captured == 0
+            assert len(seen) == 4 * 4
+
+
+def test_a_non_capturable_env_keeps_the_reference_reset_path(cusrl):
+    cusrl.set_global_seed(5)
+    env = cusrl.testing.DummyTorchEnvironment(num_instances=64, observation_dim=12, action_dim=4, device=DEV, capturable=False)
+    trainer = cusrl.Trainer(env, _factory(cusrl, "continuous", 4), num_iterations=3, verbose=False)
+    assert not trainer._static_resets
+    trainer.run_training_loop()
+    assert trainer._graphed_rollout is None and trainer.stats.num_episodes > 0
+
+
+def test_a_changed_hook_attribute_recaptures_the_step_graphs(cusrl):
+    cusrl.set_global_seed(5)
+    env = cusrl.testing.DummyTorchEnvironment(num_instances=64, observation_dim=12, action_dim=4, device=DEV)
+    trainer = cusrl.Trainer(env, _factory(cusrl, "continuous", 4), num_iterations=4, verbose=False)
+    trainer.run_training_loop()
+    graphed = trainer._graphed_rollout
+    assert graphed.captured == 4
+    trainer.agent.hook["entropy_loss"].update_attribute("weight", 0.02)  # part of the capture signature
+    trainer.num_iterations += 1
+    observation, state, _ = env.reset()
+    trainer._rollout_and_update(observation, state)
+    assert graphed.captured == 4 and all(torch.isfinite(p).all() for p in trainer.agent.parameters())
