@@ -256,6 +256,7 @@ def run_gpu(args, rank, world):
             "collectives": ("c-abi (cusrl_allreduce_mean captured in the step graph)" if args.native_collectives and in_group
                             else "torch.distributed (eager all-reduce between two graphs per step)" if in_group else "none"),
             "hipgraph": not args.eager,
+            "captured_env_steps": (trainer._graphed_rollout.captured if trainer._graphed_rollout is not None else 0),
             "autoreset": args.autoreset,
             "host_thread_cpus": pinned,
         },

@@ -430,6 +430,7 @@ class GraphedRolloutStep:
         return agent.buffer._push_plan is not None  # the steady-state append (one launch, nothing allocated)
 
     # ------------------------------------------------------------------ the step, written once
+    @torch.no_grad()  # like Agent.act / Agent.step, whose decorated entry points this body bypasses
     def _body(self):
         trainer, agent = self.trainer, self.agent
         env, stats, act = trainer.environment, trainer.stats, agent._graphed_act

@@ -125,7 +125,7 @@ def test_a_user_hook_with_per_step_python_state_keeps_the_loop_host_driven(cusrl
         trainer.run_training_loop()
         graphed = trainer._graphed_rollout
         if expect_capture:
-            assert graphed is not None and graphed.captured == 4 and graphed.replays == 4 * 2
+            assert graphed is not None and graphed.captured == 4 and graphed.replays == 4  # iteration 3 only
         else:
             assert graphed is None or graphed.captured == 0
             assert len(seen) == 4 * 4
