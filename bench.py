@@ -46,7 +46,12 @@ def parse_args():
     parser.add_argument("--no-kernel-pass", action="store_true")
     parser.add_argument("--no-scale-pass", action="store_true", help="skip the 1 048 576-env roofline-scale kernel pass")
     parser.add_argument("--native-collectives", action="store_true",
-                        help="collectives through the C ABI (cusrl_allreduce_mean ...): all-reduce captured inside the step graph")
+                        help="(default since round 3, kept for old command lines) collectives through the C ABI")
+    parser.add_argument("--torch-collectives", action="store_true",
+                        help="force torch.distributed's collectives: eager all-reduce between two graphs per minibatch step")
+    parser.add_argument("--share-gpu", action="store_true",
+                        help="TEST ONLY: all ranks drive cuda:0 over a gloo process group (exercises launch_ranks, the "
+                             "multi-rank agent path and the rank-0 line on a 1-GPU box; the number is not a scaling result)")
     parser.add_argument("--cpu-seconds", type=float, default=15.0)
     parser.add_argument("--eager", action="store_true", help="disable hipGraph replay (compile=False)")
     parser.add_argument("--no-timer", action="store_true", help="replace the trainer's section timer by a no-op (diagnostic)")
@@ -129,15 +134,15 @@ def run_gpu(args, rank, world):
     from cusrl_amd import ops
 
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    device = torch.device(f"cuda:{local_rank}")
+    device = torch.device(f"cuda:{0 if args.share_gpu else local_rank}")
     torch.cuda.set_device(device)
     pinned = []
     if not args.no_pin:
         from cusrl_amd.utils.affinity import pin_host_thread
 
-        pinned = pin_host_thread(local_rank, cores=8, slot=local_rank)
+        pinned = pin_host_thread(0 if args.share_gpu else local_rank, cores=8, slot=local_rank)
     cusrl.config.set_device(device)
-    cusrl.config.native_collectives = bool(args.native_collectives)
+    cusrl.config.native_collectives = not args.torch_collectives
     if world > 1:
         cusrl.utils.configure_distributed()
     cusrl.set_global_seed(42)
@@ -253,8 +258,9 @@ def run_gpu(args, rank, world):
             "parallelism": f"dp{world}",
             "backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend,
             "rccl_ranks": world if backend == "nccl" else 0,
-            "collectives": ("c-abi (cusrl_allreduce_mean captured in the step graph)" if args.native_collectives and in_group
-                            else "torch.distributed (eager all-reduce between two graphs per step)" if in_group else "none"),
+            "collectives": cusrl.utils.distributed.collective_route(),
+            **({"share_gpu": True, "test_only": "all ranks drive cuda:0 over gloo: exercises the multi-rank path on one GPU, "
+                                                "NOT a scaling measurement"} if args.share_gpu else {}),
             "hipgraph": not args.eager,
             "captured_env_steps": (trainer._graphed_rollout.captured if trainer._graphed_rollout is not None else 0),
             "autoreset": args.autoreset,
@@ -353,11 +359,13 @@ def launch_ranks(args) -> int:
     import subprocess
 
     visible = torch.cuda.device_count()
-    if visible < args.gpus:
+    if visible < args.gpus and not args.share_gpu:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {visible} GPU(s) visible; refusing to report a smaller job as n_gpus={args.gpus}")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
     env.setdefault("OMP_NUM_THREADS", "8")
+    if args.share_gpu:
+        env["CUSRL_SHARE_GPU"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
     return subprocess.run(cmd, env=env).returncode
@@ -369,6 +377,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
+    if args.share_gpu:
+        os.environ["CUSRL_SHARE_GPU"] = "1"  # before cusrl_amd reads its process configuration
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:

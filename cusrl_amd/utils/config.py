@@ -25,13 +25,19 @@ class _Config:
         self.local_rank = int(env.get("LOCAL_RANK", 0)) if self.distributed else 0
         self.world_size = int(env.get("WORLD_SIZE", 1)) if self.distributed else 1
         self.local_world_size = int(env.get("LOCAL_WORLD_SIZE", self.world_size)) if self.distributed else 1
-        self._device = torch.device(f"cuda:{self.local_rank}" if self.cuda else "cpu")
+        # Test-only: every rank of the job drives cuda:0 and the process group is gloo (RCCL refuses two ranks on one
+        # device; gloo stages device tensors through the host).  Lets a 1-GPU box run the whole multi-rank agent path —
+        # parameter broadcast, per-step gradient averaging, merged advantage statistics, rank-averaged logs — end to end.
+        self.share_gpu = self.distributed and env.get("CUSRL_SHARE_GPU", "0") == "1"
+        self._device = torch.device((f"cuda:{0 if self.share_gpu else self.local_rank}") if self.cuda else "cpu")
         # Collectives of the hot path through the C ABI (cusrl_allreduce_mean / cusrl_allgather / cusrl_broadcast on a
         # communicator owned by libcusrl_hip.so) instead of torch.distributed: they are enqueued on the step's stream,
-        # so with compile=True the gradient all-reduce is captured INSIDE the minibatch step's hipGraph.  Opt-in
-        # (CUSRL_NATIVE_COLLECTIVES=1 or CONFIG.native_collectives = True before the agent is built): the default
-        # keeps torch.distributed's process group, whose multi-rank behaviour is exercised far more widely.
-        self.native_collectives = env.get("CUSRL_NATIVE_COLLECTIVES", "0") == "1"
+        # so with compile=True the gradient all-reduce is captured INSIDE the minibatch step's hipGraph.  This is the
+        # DEFAULT route of an RCCL job (utils/distributed.py native_comm: the communicator is created over the existing
+        # process group and checked against it once; a failure is logged and the job falls back to torch.distributed's
+        # collectives).  CUSRL_NATIVE_COLLECTIVES=0 (or CONFIG.native_collectives = False before the agent is built)
+        # forces the torch.distributed route: eager all-reduce between two graphs per minibatch step.
+        self.native_collectives = env.get("CUSRL_NATIVE_COLLECTIVES", "1") != "0"
 
     @property
     def device(self) -> torch.device:
@@ -63,10 +69,11 @@ def configure_distributed(backend: str | None = None, **kwargs) -> bool:
         return False
     if not torch.distributed.is_initialized():
         if backend is None:
-            backend = "nccl" if CONFIG.device.type == "cuda" else "gloo"  # nccl == RCCL on ROCm
+            backend = "nccl" if CONFIG.device.type == "cuda" and not CONFIG.share_gpu else "gloo"  # nccl == RCCL on ROCm
         if CONFIG.device.type == "cuda":
             torch.cuda.set_device(CONFIG.device)
-            kwargs.setdefault("device_id", CONFIG.device)
+            if backend == "nccl":
+                kwargs.setdefault("device_id", CONFIG.device)
         torch.distributed.init_process_group(backend=backend, world_size=CONFIG.world_size, rank=CONFIG.rank, **kwargs)
     return True
 

@@ -28,6 +28,7 @@ __all__ = [
     "average_dict",
     "barrier",
     "broadcast_parameters",
+    "collective_route",
     "enabled",
     "gather_obj",
     "gather_stack",
@@ -157,20 +158,59 @@ class RcclComm:
 
 
 _native_comm: RcclComm | None = None
+_native_comm_failed: str | None = None
 
 
 def native_comm() -> RcclComm | None:
-    """The process-wide C-ABI communicator when ``CONFIG.native_collectives`` is on (created on first use; collective
-    over all ranks, so every rank must reach its first use together — it happens in ``broadcast_parameters`` at agent
-    construction).  ``None`` = collectives go through torch.distributed."""
-    global _native_comm
+    """The process-wide C-ABI communicator — the default route of an RCCL job (``CONFIG.native_collectives``).  Created
+    on first use, collectively: every rank must reach its first use together, which happens in ``broadcast_parameters``
+    at agent construction.  Creation is verified before anything depends on it: a small all-reduce through the new
+    communicator must reproduce torch.distributed's result on every rank; an error or a mismatch on ANY rank (agreed
+    through the process group) is logged once and the whole job uses torch.distributed's collectives instead.
+    ``None`` = collectives go through torch.distributed."""
+    global _native_comm, _native_comm_failed
     if not (CONFIG.native_collectives and CONFIG.device.type == "cuda" and configure_distributed()):
         return None
     if torch.distributed.get_backend() != torch.distributed.Backend.NCCL:
         return None
-    if _native_comm is None:
-        _native_comm = RcclComm.from_process_group()
+    if _native_comm is None and _native_comm_failed is None:
+        comm, problem = None, ""
+        try:
+            comm = RcclComm.from_process_group()
+            probe = torch.arange(64, dtype=torch.float32, device=CONFIG.device) * (CONFIG.rank + 1)
+            expect = probe.clone()
+            comm.allreduce_mean_(probe)
+            torch.distributed.all_reduce(expect, op=torch.distributed.ReduceOp.AVG)
+            if not torch.allclose(probe, expect, rtol=1e-6, atol=0):
+                problem = "cusrl_allreduce_mean disagrees with torch.distributed.all_reduce"
+        except Exception as error:  # creation / first collective failed on this rank
+            problem = f"{type(error).__name__}: {error}"
+        # every rank must take the same route: agree over the process group
+        verdict = torch.tensor([1.0 if problem else 0.0], device=CONFIG.device)
+        torch.distributed.all_reduce(verdict, op=torch.distributed.ReduceOp.MAX)
+        if verdict.item() > 0:
+            _native_comm_failed = problem or "another rank could not create its communicator"
+            if comm is not None:
+                comm.close()
+            print(f"\033[1;33mcusrl_amd: C-ABI RCCL communicator unavailable on rank {CONFIG.rank} ({_native_comm_failed}); "
+                  "falling back to torch.distributed collectives (eager all-reduce between two graphs per step)\033[0m",
+                  flush=True)
+        else:
+            _native_comm = comm
     return _native_comm
+
+
+def collective_route() -> str:
+    """Human-readable name of the route the hot path's collectives take in this process (bench / logs)."""
+    if not configure_distributed():
+        return "none (single process)"
+    backend = torch.distributed.get_backend()
+    if native_comm() is not None:
+        return "c-abi rccl (cusrl_allreduce_mean / cusrl_allgather captured inside the step graph)"
+    if backend == torch.distributed.Backend.NCCL:
+        reason = f"; c-abi route unavailable: {_native_comm_failed}" if _native_comm_failed else ""
+        return "torch.distributed rccl (eager all-reduce between two graphs per step)" + reason
+    return f"torch.distributed {backend} (host-staged; eager all-reduce between two graphs per step)"
 
 
 def gather_obj(obj: _T) -> list[_T]:

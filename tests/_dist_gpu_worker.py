@@ -20,7 +20,9 @@ def main(out_dir: str, compile_: str, native: str):
     assert distributed.enabled()
     cusrl.config.native_collectives = native == "1"
     cusrl.utils.configure_distributed()
-    assert torch.distributed.get_backend() == "nccl"
+    shared = cusrl.config.share_gpu  # test-only: every rank on cuda:0, gloo process group (CUSRL_SHARE_GPU=1)
+    assert torch.distributed.get_backend() == ("gloo" if shared else "nccl")
+    assert not shared or torch.cuda.current_device() == 0
     rank, world = distributed.rank(), distributed.world_size()
     cusrl.set_global_seed(5)
     env = cusrl.testing.SyntheticEnvironment(256, 20, 6)
@@ -44,7 +46,9 @@ def main(out_dir: str, compile_: str, native: str):
         "local_mean": local_mean.tolist(), "local_var": local_var.tolist(), "mean": mean.tolist(), "var": var.tolist(),
         "flat_mean": flat[0].item(), "param_sum": params.double().sum().item(), "param_head": params[:64].tolist(),
         "param_bytes": params.cpu().numpy().tobytes().hex()[:4096],
-        "native": distributed.native_comm() is not None, "single_graph": graphs,
+        "native": distributed.native_comm() is not None, "single_graph": graphs, "route": distributed.collective_route(),
+        "captured_env_steps": trainer._graphed_rollout.captured if trainer._graphed_rollout is not None else 0,
+        "advantage_head": trainer.agent.buffer["advantage"].flatten()[:8].tolist(),
         "allreduce_calls": _native.launch_counts.get("cusrl_allreduce_mean", 0),
         "allgather_calls": _native.launch_counts.get("cusrl_allgather", 0),
     }))

@@ -20,13 +20,15 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _run(tmp_path, world: int, compile_: str, native: str):
+def _run(tmp_path, world: int, compile_: str, native: str, share_gpu: bool = False):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "_dist_gpu_worker.py"), str(tmp_path), compile_, native]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if share_gpu:
+        env["CUSRL_SHARE_GPU"] = "1"
     done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
     return [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(world)]
@@ -54,17 +56,59 @@ def test_two_rccl_ranks_stay_in_lockstep(tmp_path, compile_, native):
     """Two ranks, 3 iterations of the preset: every rank ends with bit-identical parameters (same broadcast start, same
     averaged gradients), drew different permutations, and merged the advantage statistics like the oracle."""
     ranks = _run(tmp_path, 2, compile_, native)
-    assert ranks[0]["first_perm"] != ranks[1]["first_perm"]
+    _assert_lockstep(ranks)
+    for r in ranks:
+        assert r["native"] == (native == "1"), r["route"]
+
+
+def _assert_lockstep(ranks):
+    assert ranks[0]["first_perm"] != ranks[1]["first_perm"]  # per-rank generator streams (seed + rank, misc.py:163)
     assert ranks[0]["param_bytes"] == ranks[1]["param_bytes"] and ranks[0]["param_sum"] == ranks[1]["param_sum"]
+    assert ranks[0]["advantage_head"] != ranks[1]["advantage_head"]  # different envs, different data ...
     means = np.array([r["local_mean"] for r in ranks], np.float32)
     vars_ = np.array([r["local_var"] for r in ranks], np.float32)
     mean, var = oracle.merge_mean_var(means, vars_)
     for r in ranks:
-        np.testing.assert_allclose(r["mean"], mean, rtol=1e-6)
+        np.testing.assert_allclose(r["mean"], mean, rtol=1e-6)  # ... merged by the reference's equal-weight formula
         np.testing.assert_allclose(r["var"], var, rtol=1e-6)
         assert r["flat_mean"] == 1.5
         for key in ("Agent/value_loss", "Agent/surrogate_loss", "Agent/entropy_loss", "Agent/kl_divergence"):
             assert math.isfinite(r["info"][key]) and r["info"][key] == ranks[0]["info"][key]  # rank-averaged logs
+
+
+@pytest.mark.parametrize("compile_", ["0", "1"])
+def test_two_ranks_sharing_one_gpu_over_gloo_stay_in_lockstep(tmp_path, compile_):
+    """The whole multi-rank agent path on the ONE GPU a test box has: two torchrun ranks both drive cuda:0, the process
+    group is gloo (RCCL refuses two ranks on one device).  3 iterations of the preset: parameter broadcast at init
+    (actor_critic.py:224), flat gradient averaging after every backward (distributed.py:145-172), advantage statistics merged
+    across ranks (distributed.py:175-183), rank-averaged logs (trainer.py:387) — every rank must end with bit-identical
+    parameters although it saw different envs and drew different permutations.  Under compile=True the env steps replay from
+    hipGraphs and every minibatch step is two graphs with the (host-staged) all-reduce between them."""
+    ranks = _run(tmp_path, 2, compile_, "1", share_gpu=True)
+    _assert_lockstep(ranks)
+    for r in ranks:
+        assert r["world"] == 2 and not r["native"] and "gloo" in r["route"]
+        if compile_ == "1":
+            assert r["single_graph"] and not any(r["single_graph"])  # collective outside capture on this route
+            assert r["captured_env_steps"] == 8
+
+
+def test_bench_launches_its_own_ranks_and_prints_one_line(tmp_path):
+    """``python bench.py --gpus 2 --share-gpu`` (test-only flag): bench.py starts its own two ranks under
+    torch.distributed.run, both drive cuda:0 over gloo, rank 0 prints ONE JSON line that says what it is."""
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "4", "--envs-per-gpu", "512",
+           "--no-cpu-baseline", "--no-kernel-pass", "--no-scale-pass", "--no-pin"]
+    done = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=420)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, done.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    config = line["config"]
+    assert config["share_gpu"] and "NOT a scaling measurement" in config["test_only"]
+    assert config["backend"] == "gloo" and config["rccl_ranks"] == 0 and "gloo" in config["collectives"]
+    assert config["parallelism"] == "dp2" and config["env_steps_per_iteration"] == 2 * 512 * 24
+    assert config["captured_env_steps"] == 24
 
 
 def test_c_abi_communicator_of_one_rank_inside_a_hipgraph():
