@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "libcusrl_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_FIELDS = 24
 MAX_PACKED = 16
 
@@ -64,11 +64,12 @@ _SIGNATURES = {
     "cusrl_window_indices": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int64, _P]),
     "cusrl_ppo_loss_fwd_bwd": (
         c_int,
-        [_P] * 8 + [c_int64] * 3 + [c_double] * 5 + [_P] * 8 + [_P, c_int64, _P, _P, _P],
+        [_P] * 8 + [c_int64] * 3 + [c_double] * 5 + [_P] * 8 + [_P, c_int64, _P, c_int, _P],
     ),
-    "cusrl_ppo_loss_categorical_fwd_bwd": (c_int, [_P] * 7 + [c_int64] * 3 + [c_double] * 5 + [_P] * 7 + [_P, _P]),
+    "cusrl_ppo_loss_categorical_fwd_bwd": (c_int, [_P] * 7 + [c_int64] * 3 + [c_double] * 5 + [_P] * 7 + [_P, c_int, _P]),
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
     "cusrl_ppo_loss_std_partial_rows": (c_int64, [c_int64]),
+    "cusrl_ppo_loss_blocks": (c_int64, [c_int64, c_int64]),
     "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
     "cusrl_categorical_sample_logp": (c_int, [_P] * 4 + [c_int64, c_int64, _P]),
     "cusrl_gru_gates_fwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, _P]),

@@ -86,236 +86,215 @@ __device__ __forceinline__ void value_terms(const float *__restrict__ ret, const
 
 constexpr int kLossSums = 5;  // value loss, surrogate, entropy, |logp ratio|, value
 
-// All five sums through ONE LDS exchange (one barrier instead of two per sum): wave-shuffle each, lane 0 of every
-// wave parks its five totals, the first five threads add the four waves up in fixed order.
-template <bool kPublish = false>
-__device__ __forceinline__ void write_block_partials(const double (&acc)[kLossSums], double *__restrict__ partials) {
-    __shared__ double scratch[kWavesPerBlock][kLossSums];
+// All five sums through ONE LDS exchange: wave-shuffle each, lane 0 of every wave parks its five totals, the first five
+// threads add the four waves up in fixed order.  kAccumulate: the block ADDS to its row instead of overwriting it — the
+// row belongs to this block alone, so a plain read-modify-write is race-free and launches of the same grid, ordered on
+// one stream, build up per-block running sums in a fixed order (CUSRL_LOSS_DEFER, see cusrl_ppo_loss_fwd_bwd).
+__device__ __forceinline__ void park_wave_sums(const double (&acc)[kLossSums], double (*scratch)[kLossSums]) {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
     for (int k = 0; k < kLossSums; ++k) {
         const double total = wave_sum(acc[k]);
         if (lane == 0) scratch[wave][k] = total;
     }
-    __syncthreads();
+}
+
+__device__ __forceinline__ void store_block_partials(double (*scratch)[kLossSums], double *__restrict__ partials,
+                                                     bool accumulate) {
     if (threadIdx.x < kLossSums) {
         double total = 0.0;
 #pragma unroll
         for (int w = 0; w < kWavesPerBlock; ++w) total += scratch[w][threadIdx.x];
         double *slot = partials + int64_t(blockIdx.x) * kLossSums + threadIdx.x;
-        if (kPublish)  // 8-byte agent-scope store: written through, visible to the finishing block without any fence
-            __hip_atomic_store(slot, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
-            *slot = total;
+        *slot = accumulate ? *slot + total : total;
     }
 }
 
-// Hand-off of the per-block partial rows to whichever block finishes last, WITHOUT release / acquire fences: an
-// agent-scope release writes back every dirty line of the XCD's L2 — here the ~70 KB of gradients each block has just
-// stored — and measured slower than the separate finalize launch it was meant to save.  Instead the few partial values
-// are published with 8-byte agent-scope stores (write-through) and read back with agent-scope loads (L1 bypass), the
-// "8-byte agent atomics on both sides" form of the MI355X guide; the ticket is a relaxed agent-scope counter taken
-// after a barrier (which waits for the stores of every wave of the block).
-__device__ __forceinline__ double load_published(const double *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float load_published(const float *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void write_block_partials(const double (&acc)[kLossSums], double *__restrict__ partials,
+                                                     bool accumulate = false) {
+    __shared__ double scratch[kWavesPerBlock][kLossSums];
+    park_wave_sums(acc, scratch);
+    __syncthreads();
+    store_block_partials(scratch, partials, accumulate);
 }
 
-constexpr int kRowsPerBlock = kBlock;
-
-template <bool kPublished = false>
 __device__ __forceinline__ void reduce_std_rows(const float *in, int64_t rows, int A, float *__restrict__ out);
-template <bool kPublished = false>
 __device__ __forceinline__ void finalize_losses(const double *partials, int64_t P, int64_t B, int D,
                                                 const LossParams &p, float *__restrict__ losses_out,
                                                 const float *d_std_partials, int A, float *__restrict__ d_std_vector);
 
-// Last-block-done hand-off: every block publishes its partial rows, then takes a ticket; the block that draws the
-// last one reduces all rows in the same launch (no separate 1-block finalize launch).  The ticket re-arms itself, so
-// replayed hipGraphs need no memset.
-__device__ __forceinline__ bool last_block_done(unsigned int *__restrict__ ticket) {
-    __shared__ int is_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's published stores have been acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = drawn == gridDim.x - 1;
-        if (is_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ---- the row-group layout of the [B, A] streams (A = 4 * LPR) --------------------------------------------------------
+// A row is LPR 16-byte chunks.  The LPR chunks of a row are held by LPR ADJACENT LANES OF ONE WAVE, a wave covers
+// kRowsPerWave = 64 / LPR consecutive rows per round (64 % LPR lanes idle: 1 of 64 at A = 12), so
+//   * every global access is a dwordx4 and a wave's load covers kActive * 16 contiguous bytes (coalesced);
+//   * the row reductions (log-prob, entropy) are LPR wave shuffles among neighbours — no LDS tile, no barrier — and every
+//     lane of the row then evaluates the scalar part (ratio, clip, d loss / d logp) itself: nothing to publish;
+//   * a lane's chunks all belong to ONE column group (lane % LPR), so with a std vector its d_std contributions add up
+//     in four registers and the column sums of a wave are a strided shuffle tree — no select chain.
+// One barrier per block (the cross-wave exchange of the five loss sums and the d_std column sums), against four in the
+// flat-chunk layout this replaces (round 2: 0.41 of the HBM roofline with a std vector, bound by its own barriers).
+// kRounds chunks per lane are requested before anything is computed (memory-level parallelism).
+template <int LPR>
+struct RowGroup {
+    static constexpr int kRowsPerWave = kWave / LPR;
+    static constexpr int kActive = kRowsPerWave * LPR;
+    static constexpr int kRounds = LPR >= 4 ? 4 : LPR;
+    static constexpr int kRowsPerBlock = kWavesPerBlock * kRowsPerWave * kRounds;
+    static constexpr int kTreeStart = kRowsPerWave > 32 ? 32 : kRowsPerWave > 16 ? 16 : kRowsPerWave > 8 ? 8 : 4;
+};
+
+static int loss_rows_per_block(int64_t A) {
+    if (A % 4 != 0 || A / 4 > 8) return kBlock;  // row-wise kernel: one lane per row
+    switch (A / 4) {
+        case 1: return RowGroup<1>::kRowsPerBlock;
+        case 2: return RowGroup<2>::kRowsPerBlock;
+        case 3: return RowGroup<3>::kRowsPerBlock;
+        case 4: return RowGroup<4>::kRowsPerBlock;
+        case 5: return RowGroup<5>::kRowsPerBlock;
+        case 6: return RowGroup<6>::kRowsPerBlock;
+        case 7: return RowGroup<7>::kRowsPerBlock;
+        default: return RowGroup<8>::kRowsPerBlock;
     }
-    __syncthreads();
-    return is_last != 0;
 }
+constexpr int kMinLossRowsPerBlock = RowGroup<8>::kRowsPerBlock;  // the smallest of them: workspace bound for any A
 
 // kStdVec: `std` is ONE row [A] shared by every sample (a state-independent std vector, distribution.py:228-247)
-// instead of a [B, A] matrix: it is read from L1 instead of streamed, and d_std leaves the kernel as per-block
+// instead of a [B, A] matrix: it is read once per lane instead of streamed, and d_std leaves the kernel as per-block
 // column sums [A] (the gradient of the vector) instead of a [B, A] matrix that a sum(0) launch would have to reduce —
 // 96 of the 264 bytes per sample disappear.
-constexpr int kStdRowGroups = 16;
-
 template <int LPR, bool kStdVec>
-__global__ __launch_bounds__(kBlock) void ppo_loss_chunked_kernel(
+__global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
     const float *__restrict__ advantage, const float *__restrict__ old_logp, const float *__restrict__ action,
     const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ ret,
     const float *__restrict__ curr_value, const float *__restrict__ old_value, int64_t B, int D, LossParams p,
     float *__restrict__ logp_out, float *__restrict__ entropy_out, float *__restrict__ lr_out,
     float *__restrict__ ratio_out, float *__restrict__ d_mean, float *__restrict__ d_std,
-    float *__restrict__ d_value, double *__restrict__ partials, float *__restrict__ d_std_partials,
-    unsigned int *__restrict__ ticket, float *__restrict__ losses_out) {
-    __shared__ float lp_part[kRowsPerBlock * LPR];
-    __shared__ float en_part[kRowsPerBlock * LPR];
-    __shared__ float dlp_row[kRowsPerBlock];
-    __shared__ float4 ds_wave[kStdVec ? kWavesPerBlock * LPR : 1];  // per-wave column sums of d_std
-    const int64_t row0 = int64_t(blockIdx.x) * kRowsPerBlock;
-    const int64_t chunk0 = row0 * LPR;
-    const int64_t total_chunks = B * LPR;
+    float *__restrict__ d_value, double *__restrict__ partials, float *__restrict__ d_std_partials, int accumulate) {
+    using G = RowGroup<LPR>;
+    constexpr int R = G::kRounds;
+    __shared__ double acc_wave[kWavesPerBlock][kLossSums];
+    __shared__ float4 ds_wave[kStdVec ? kWavesPerBlock * LPR : 1];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int sub = lane % LPR, rloc = lane / LPR;  // chunk within the row, row within the wave's round
+    const bool holder = lane < G::kActive;
+    const int64_t block_row0 = int64_t(blockIdx.x) * G::kRowsPerBlock;
     const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(action);
     const float4 *__restrict__ m4 = reinterpret_cast<const float4 *>(mean);
     const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(std);
-
-    // the per-row scalars of the second phase are requested together with the matrix chunks: one memory round trip
-    // per block instead of two dependent ones (the row phase used to start its own loads behind the first barrier)
-    const int64_t my_row = row0 + threadIdx.x;
-    const bool row_ok = my_row < B;
-    float pre_old_logp = 0.f, pre_adv = 0.f, pre_ret = 0.f, pre_cv = 0.f, pre_ov = 0.f;
-    if (row_ok) {
-        pre_old_logp = old_logp[my_row];
-        pre_adv = advantage[my_row];
-        if (D == 1) {
-            pre_ret = ret[my_row];
-            pre_cv = curr_value[my_row];
-            if (p.value_clip >= 0.0f) pre_ov = old_value[my_row];
-        }
-    }
-    float4 x[LPR], mu[LPR], sg[LPR];
-#pragma unroll
-    for (int k = 0; k < LPR; ++k) {
-        const int64_t q = chunk0 + k * kBlock + threadIdx.x;
-        if (q < total_chunks) {
-            x[k] = x4[q];
-            mu[k] = m4[q];
-            sg[k] = s4[kStdVec ? int64_t((k * kBlock + int(threadIdx.x)) % LPR) : q];  // chunk0 is a multiple of LPR
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < LPR; ++k) {
-        const int64_t q = chunk0 + k * kBlock + threadIdx.x;
-        float lp = 0.0f, en = 0.0f;
-        if (q < total_chunks) {
-            const float xs[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
-            const float ms[4] = {mu[k].x, mu[k].y, mu[k].z, mu[k].w};
-            const float ss[4] = {sg[k].x, sg[k].y, sg[k].z, sg[k].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float diff = xs[j] - ms[j], ls = logf(ss[j]);
-                // -((x - mu)^2) / (2 sigma^2) - log(sigma) - log(sqrt(2 pi))     distribution.py:207-209
-                lp += -(diff * diff) / (2.0f * (ss[j] * ss[j])) - ls - log_sqrt_2pi();
-                en += entropy_const() + ls;  // distribution.py:211-213
-            }
-        }
-        lp_part[k * kBlock + threadIdx.x] = lp;
-        en_part[k * kBlock + threadIdx.x] = en;
-    }
-    __syncthreads();
-
-    double acc[kLossSums] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    {
-        const int64_t row = row0 + threadIdx.x;
-        float dlp = 0.0f;
-        if (row < B) {
-            float logp = 0.0f, entropy = 0.0f;
-#pragma unroll
-            for (int j = 0; j < LPR; ++j) {
-                logp += lp_part[threadIdx.x * LPR + j];
-                entropy += en_part[threadIdx.x * LPR + j];
-            }
-            float ratio, lr;
-            dlp = row_terms(logp, entropy, pre_old_logp, pre_adv, p, acc[1], acc[2], acc[3], ratio, lr);
-            if (logp_out) logp_out[row] = logp;
-            if (entropy_out) entropy_out[row] = entropy;
-            if (lr_out) lr_out[row] = lr;
-            if (ratio_out) ratio_out[row] = ratio;
-            if (D == 1)
-                value_term(pre_cv, pre_ret, pre_ov, d_value ? d_value + row : nullptr, p, acc[0], acc[4]);
-            else
-                value_terms(ret, curr_value, old_value, d_value, row, D, p, acc[0], acc[4]);
-        }
-        dlp_row[threadIdx.x] = dlp;
-    }
-    __syncthreads();
-
     float4 *__restrict__ dm4 = reinterpret_cast<float4 *>(d_mean);
     float4 *__restrict__ ds4 = reinterpret_cast<float4 *>(d_std);
-    // std-vector mode: a lane's k-th chunk belongs to column group (k * 256 + tid) % LPR; its d_std contribution is
-    // accumulated into that group's slot (compile-time slots, selected by comparison — a few v_cndmask, no scratch),
-    // so that afterwards plain wave-wide shuffle sums give the wave's [A] column sums: no [256, A] LDS tile, one barrier.
-    float4 ds_acc[kStdVec ? LPR : 1];
+
+    // ---- every load of the block's rows is requested up front: the matrix chunks and the per-row scalars the scalar
+    // part needs (one memory round trip per block)
+    int64_t row[R];
+    bool ok[R];
+    float4 x[R], mu[R], sg[kStdVec ? 1 : R];
+    float adv[R], olp[R], pre_ret[R], pre_cv[R], pre_ov[R];
+    if (kStdVec) sg[0] = s4[sub];
 #pragma unroll
-    for (int g = 0; g < (kStdVec ? LPR : 1); ++g) ds_acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < R; ++k) {
+        row[k] = block_row0 + int64_t(k * kWavesPerBlock + wave) * G::kRowsPerWave + rloc;
+        ok[k] = holder && row[k] < B;
+        x[k] = mu[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!kStdVec) sg[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+        adv[k] = olp[k] = pre_ret[k] = pre_cv[k] = pre_ov[k] = 0.f;
+        if (ok[k]) {
+            const int64_t q = row[k] * LPR + sub;
+            x[k] = x4[q];
+            mu[k] = m4[q];
+            if (!kStdVec) sg[k] = s4[q];
+            adv[k] = advantage[row[k]];
+            olp[k] = old_logp[row[k]];
+            if (sub == 0 && D == 1) {
+                pre_ret[k] = ret[row[k]];
+                pre_cv[k] = curr_value[row[k]];
+                if (p.value_clip >= 0.0f) pre_ov[k] = old_value[row[k]];
+            }
+        }
+    }
+
+    double acc[kLossSums] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    float4 ds_acc = make_float4(0.f, 0.f, 0.f, 0.f);  // std-vector mode: this lane's column group, summed over its rows
+    const int row_lane0 = lane - sub;
 #pragma unroll
-    for (int k = 0; k < LPR; ++k) {
-        const int local = k * kBlock + threadIdx.x;
-        const int64_t q = chunk0 + local;
-        if (q < total_chunks) {
-            const float dlp = dlp_row[local / LPR];
-            const float xs[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
-            const float ms[4] = {mu[k].x, mu[k].y, mu[k].z, mu[k].w};
-            const float ss[4] = {sg[k].x, sg[k].y, sg[k].z, sg[k].w};
+    for (int k = 0; k < R; ++k) {
+        const float4 sgk = sg[kStdVec ? 0 : k];
+        const float xs[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+        const float ms[4] = {mu[k].x, mu[k].y, mu[k].z, mu[k].w};
+        const float ss[4] = {sgk.x, sgk.y, sgk.z, sgk.w};
+        float lp = 0.0f, en = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float diff = xs[j] - ms[j], ls = logf(ss[j]);
+            // -((x - mu)^2) / (2 sigma^2) - log(sigma) - log(sqrt(2 pi))     distribution.py:207-209
+            lp += -(diff * diff) / (2.0f * (ss[j] * ss[j])) - ls - log_sqrt_2pi();
+            en += entropy_const() + ls;  // distribution.py:211-213
+        }
+        // the row's sums, chunk 0 first (the order of a sequential sum over the row): LPR neighbour shuffles
+        float logp = 0.0f, entropy = 0.0f;
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) {
+            logp += __shfl(lp, row_lane0 + j, kWave);
+            entropy += __shfl(en, row_lane0 + j, kWave);
+        }
+        // every lane of the row evaluates the scalar part; lane `sub == 0` owns the row's outputs and sums
+        const bool owner = ok[k] && sub == 0;
+        double sur = 0.0, ent = 0.0, abs_lr = 0.0;
+        float ratio, lr;
+        const float dlp = row_terms(logp, entropy, olp[k], adv[k], p, sur, ent, abs_lr, ratio, lr);
+        if (owner) {
+            acc[1] += sur, acc[2] += ent, acc[3] += abs_lr;
+            if (logp_out) logp_out[row[k]] = logp;
+            if (entropy_out) entropy_out[row[k]] = entropy;
+            if (lr_out) lr_out[row[k]] = lr;
+            if (ratio_out) ratio_out[row[k]] = ratio;
+            if (D == 1)
+                value_term(pre_cv[k], pre_ret[k], pre_ov[k], d_value ? d_value + row[k] : nullptr, p, acc[0], acc[4]);
+            else
+                value_terms(ret, curr_value, old_value, d_value, row[k], D, p, acc[0], acc[4]);
+        }
+        if (ok[k]) {
             float gm[4], gs[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float diff = xs[j] - ms[j], var = ss[j] * ss[j];
-                gm[j] = dlp * (diff / var);                                           // d logp / d mean
+                gm[j] = dlp * (diff / var);                                                       // d logp / d mean
                 gs[j] = dlp * ((diff * diff) / (var * ss[j]) - 1.0f / ss[j]) + p.g_ent / ss[j];  // + d entropy / d std
             }
+            const int64_t q = row[k] * LPR + sub;
             if (d_mean) dm4[q] = make_float4(gm[0], gm[1], gm[2], gm[3]);
-            if (kStdVec) {
-                const int group = local % LPR;
-#pragma unroll
-                for (int g = 0; g < LPR; ++g) {
-                    const bool hit = group == g;
-                    ds_acc[g].x += hit ? gs[0] : 0.f, ds_acc[g].y += hit ? gs[1] : 0.f;
-                    ds_acc[g].z += hit ? gs[2] : 0.f, ds_acc[g].w += hit ? gs[3] : 0.f;
-                }
-            } else if (d_std) {
+            if (kStdVec)
+                ds_acc.x += gs[0], ds_acc.y += gs[1], ds_acc.z += gs[2], ds_acc.w += gs[3];
+            else if (d_std)
                 ds4[q] = make_float4(gs[0], gs[1], gs[2], gs[3]);
-            }
         }
     }
-    if (kStdVec) {  // column sums of the block's [256, A] d_std tile, fixed order: lanes of a wave, then the 4 waves
-        const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+
+    if (kStdVec) {
+        // column sums over the wave's rows: lanes of equal `sub` sit LPR apart -> a shuffle tree with stride LPR; the
+        // first step folds the rows beyond the largest power of two below kRowsPerWave.  Fixed order.
 #pragma unroll
-        for (int g = 0; g < LPR; ++g) {
-            const float4 total = make_float4(wave_sum(ds_acc[g].x), wave_sum(ds_acc[g].y), wave_sum(ds_acc[g].z),
-                                             wave_sum(ds_acc[g].w));
-            if (lane == 0) ds_wave[wave * LPR + g] = total;
+        for (int off = G::kTreeStart; off >= 1; off >>= 1) {
+            if (off >= G::kRowsPerWave) continue;
+            const float ox = __shfl_down(ds_acc.x, off * LPR, kWave), oy = __shfl_down(ds_acc.y, off * LPR, kWave);
+            const float oz = __shfl_down(ds_acc.z, off * LPR, kWave), ow = __shfl_down(ds_acc.w, off * LPR, kWave);
+            if (holder && rloc + off < G::kRowsPerWave) ds_acc.x += ox, ds_acc.y += oy, ds_acc.z += oz, ds_acc.w += ow;
         }
-        __syncthreads();
-        if (t < LPR && d_std_partials) {
-            float4 total = ds_wave[t];
-#pragma unroll
-            for (int w = 1; w < kWavesPerBlock; ++w) {
-                const float4 v = ds_wave[w * LPR + t];
-                total.x += v.x, total.y += v.y, total.z += v.z, total.w += v.w;
-            }
-            float4 *slot = reinterpret_cast<float4 *>(d_std_partials) + int64_t(blockIdx.x) * LPR + t;
-            if (ticket) {  // published as two 8-byte agent-scope stores (see load_published)
-                unsigned long long *q = reinterpret_cast<unsigned long long *>(slot);
-                __hip_atomic_store(q, (unsigned long long)__float_as_uint(total.x) | ((unsigned long long)__float_as_uint(total.y) << 32),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(total.z) | ((unsigned long long)__float_as_uint(total.w) << 32),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                *slot = total;
-            }
-        }
+        if (lane < LPR) ds_wave[wave * LPR + lane] = ds_acc;
     }
-    if (ticket) write_block_partials<true>(acc, partials);
-    else write_block_partials<false>(acc, partials);
-    if (ticket && last_block_done(ticket))  // uniform per block
-        finalize_losses<true>(partials, gridDim.x, B, D, p, losses_out, (kStdVec && d_std) ? d_std_partials : nullptr,
-                              LPR * 4, d_std);
+    park_wave_sums(acc, acc_wave);
+    __syncthreads();  // the only barrier of the block
+    store_block_partials(acc_wave, partials, accumulate != 0);
+    if (kStdVec && d_std_partials && threadIdx.x < LPR) {
+        const int t = threadIdx.x;
+        float4 total = ds_wave[t];
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            const float4 v = ds_wave[w * LPR + t];
+            total.x += v.x, total.y += v.y, total.z += v.z, total.w += v.w;
+        }
+        reinterpret_cast<float4 *>(d_std_partials)[int64_t(blockIdx.x) * LPR + t] = total;
+    }
 }
 
 // Any action width: one lane per row, scalar accesses.
@@ -325,8 +304,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowwise_kernel(
     const float *__restrict__ curr_value, const float *__restrict__ old_value, int64_t B, int A, int D, LossParams p,
     float *__restrict__ logp_out, float *__restrict__ entropy_out, float *__restrict__ lr_out,
     float *__restrict__ ratio_out, float *__restrict__ d_mean, float *__restrict__ d_std,
-    float *__restrict__ d_value, double *__restrict__ partials, unsigned int *__restrict__ ticket,
-    float *__restrict__ losses_out) {
+    float *__restrict__ d_value, double *__restrict__ partials, int accumulate) {
     double acc[kLossSums] = {0.0, 0.0, 0.0, 0.0, 0.0};
     const int64_t row = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (row < B) {
@@ -351,10 +329,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowwise_kernel(
         }
         value_terms(ret, curr_value, old_value, d_value, row, D, p, acc[0], acc[4]);
     }
-    if (ticket) write_block_partials<true>(acc, partials);
-    else write_block_partials<false>(acc, partials);
-    if (ticket && last_block_done(ticket))
-        finalize_losses<true>(partials, gridDim.x, B, D, p, losses_out, nullptr, A, nullptr);
+    write_block_partials(acc, partials, accumulate != 0);
 }
 
 // One-hot categorical policies (discrete action spaces, cusrl/nn/module/distribution.py:332-366 on top of
@@ -366,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
     const float *__restrict__ logits, const float *__restrict__ ret, const float *__restrict__ curr_value,
     const float *__restrict__ old_value, int64_t B, int A, int D, LossParams p, float *__restrict__ logp_out,
     float *__restrict__ entropy_out, float *__restrict__ lr_out, float *__restrict__ ratio_out,
-    float *__restrict__ d_logits, float *__restrict__ d_value, double *__restrict__ partials) {
+    float *__restrict__ d_logits, float *__restrict__ d_value, double *__restrict__ partials, int accumulate) {
     double acc[kLossSums] = {0.0, 0.0, 0.0, 0.0, 0.0};
     const int64_t row = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (row < B) {
@@ -404,26 +379,24 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_categorical_kernel(
         }
         value_terms(ret, curr_value, old_value, d_value, row, D, p, acc[0], acc[4]);
     }
-    write_block_partials<false>(acc, partials);
+    write_block_partials(acc, partials, accumulate != 0);
 }
 
 // Column sums of `rows` partial rows [rows][A] (A <= 32) by one block, fixed order: lane (a, g) walks rows g, g + 8, ...
 // four loads at a time, the 8 row groups are combined through LDS.  out[a] for a < A.
 constexpr int kStdSliceRows = 128;  // partial rows one block of the staged reduction takes
 
-template <bool kPublished>
 __device__ __forceinline__ void reduce_std_rows(const float *in, int64_t rows, int A, float *__restrict__ out) {
     __shared__ float part[kBlock];
     const int a = threadIdx.x & 31, g = threadIdx.x >> 5;
-    auto at = [&](int64_t i) { return kPublished ? load_published(in + i) : in[i]; };
     float total = 0.f;
     if (a < A) {
         int64_t r = g;
         for (; r + 24 < rows; r += 32) {
-            const float v0 = at(r * A + a), v1 = at((r + 8) * A + a), v2 = at((r + 16) * A + a), v3 = at((r + 24) * A + a);
+            const float v0 = in[r * A + a], v1 = in[(r + 8) * A + a], v2 = in[(r + 16) * A + a], v3 = in[(r + 24) * A + a];
             total += (v0 + v1) + (v2 + v3);
         }
-        for (; r < rows; r += 8) total += at(r * A + a);
+        for (; r < rows; r += 8) total += in[r * A + a];
     }
     part[threadIdx.x] = total;
     __syncthreads();
@@ -440,12 +413,12 @@ __device__ __forceinline__ void reduce_std_rows(const float *in, int64_t rows, i
 __global__ __launch_bounds__(kBlock) void std_rows_stage_kernel(const float *__restrict__ in, int64_t rows, int A,
                                                                 float *__restrict__ stage) {
     const int64_t first = int64_t(blockIdx.x) * kStdSliceRows;
-    reduce_std_rows<false>(in + first * A, min(int64_t(kStdSliceRows), rows - first), A, stage + int64_t(blockIdx.x) * A);
+    reduce_std_rows(in + first * A, min(int64_t(kStdSliceRows), rows - first), A, stage + int64_t(blockIdx.x) * A);
 }
 
 __global__ __launch_bounds__(kBlock) void std_rows_final_kernel(const float *__restrict__ stage, int64_t rows, int A,
                                                                 float *__restrict__ out) {
-    reduce_std_rows<false>(stage, rows, A, out);
+    reduce_std_rows(stage, rows, A, out);
 }
 
 // Many blocks (> 256, i.e. minibatches beyond 65 536 rows): one block cannot walk all partial rows at memory latency,
@@ -459,18 +432,16 @@ __global__ __launch_bounds__(kBlock) void loss_partials_stage_kernel(const doubl
     write_block_partials(acc, stage);
 }
 
-template <bool kPublished>
 __device__ __forceinline__ void finalize_losses(const double *partials, int64_t P, int64_t B, int D,
                                                 const LossParams &p, float *__restrict__ losses_out,
                                                 const float *d_std_partials, int A, float *__restrict__ d_std_vector) {
     __shared__ double scratch[kWavesPerBlock];
-    if (d_std_partials) reduce_std_rows<kPublished>(d_std_partials, P, A, d_std_vector);  // std-vector mode, few blocks
+    if (d_std_partials) reduce_std_rows(d_std_partials, P, A, d_std_vector);  // std-vector mode, few blocks
     double sums[kLossSums];
 #pragma unroll
     for (int k = 0; k < kLossSums; ++k) {
         double s = 0.0;
-        for (int64_t i = threadIdx.x; i < P; i += kBlock)
-            s += kPublished ? load_published(partials + i * kLossSums + k) : partials[i * kLossSums + k];
+        for (int64_t i = threadIdx.x; i < P; i += kBlock) s += partials[i * kLossSums + k];
         sums[k] = block_sum(s, scratch);
     }
     if (threadIdx.x == 0) {
@@ -490,24 +461,61 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double 
                                                                    float *__restrict__ losses_out,
                                                                    const float *__restrict__ d_std_partials, int A,
                                                                    float *__restrict__ d_std_vector) {
-    finalize_losses<false>(partials, P, B, D, p, losses_out, d_std_partials, A, d_std_vector);
+    finalize_losses(partials, P, B, D, p, losses_out, d_std_partials, A, d_std_vector);
 }
 
 }  // namespace cusrl
 
 using namespace cusrl;
 
-static int64_t loss_blocks(int64_t B) { return B <= 0 ? 0 : ceil_div(B, kRowsPerBlock); }
+// partial rows (= blocks) the main kernel of a [B, A] minibatch writes; A = 0: the categorical / row-wise form
+extern "C" int64_t cusrl_ppo_loss_blocks(int64_t B, int64_t A) {
+    return B <= 0 ? 0 : ceil_div(B, A > 0 ? loss_rows_per_block(A) : kBlock);
+}
 
-// rows of the fp64 workspace: one per block, plus one per 256-block slice when the reduction is staged
+// rows of the fp64 workspace, enough for any action width: one per block, plus one per 256-block slice when the
+// reduction is staged
 extern "C" int64_t cusrl_ppo_loss_num_partials(int64_t B) {
-    const int64_t blocks = loss_blocks(B);
+    const int64_t blocks = B <= 0 ? 0 : ceil_div(B, kMinLossRowsPerBlock);
     return blocks + (blocks > kBlock ? ceil_div(blocks, kBlock) : 0);
 }
 
 extern "C" int64_t cusrl_ppo_loss_std_partial_rows(int64_t B) {
-    const int64_t blocks = loss_blocks(B);
+    const int64_t blocks = B <= 0 ? 0 : ceil_div(B, kMinLossRowsPerBlock);
     return blocks + (blocks > kStdSliceRows ? ceil_div(blocks, kStdSliceRows) : 0);
+}
+
+static LossParams loss_params(int64_t B, int64_t D, double clip, double value_clip, double w_sur, double w_val, double w_ent) {
+    LossParams p;
+    p.lo = float(1.0 - clip);
+    p.hi = float(1.0 + clip);
+    p.value_clip = value_clip < 0.0 ? -1.0f : float(value_clip);
+    p.g_sur = float(-w_sur / double(B));
+    p.g_ent = float(-w_ent / double(B));
+    p.g_val = float(w_val / double(B * D));
+    p.w_sur = float(w_sur);
+    p.w_val = float(w_val);
+    p.w_ent = float(w_ent);
+    return p;
+}
+
+// losses_out from the block partial rows (staged over 256-row slices beyond 256 blocks), optionally with the std-vector
+// column sums of up to kStdSliceRows rows
+static int launch_finalize(double *partials, int64_t blocks, int64_t B, int64_t A, int64_t D, const LossParams &p,
+                           float *losses_out, const float *d_std_partials, float *d_std, hipStream_t s) {
+    const double *loss_rows = partials;
+    int64_t num_loss_rows = blocks;
+    if (blocks > kBlock) {
+        num_loss_rows = ceil_div(blocks, kBlock);
+        double *stage = partials + blocks * kLossSums;
+        hipLaunchKernelGGL(loss_partials_stage_kernel, dim3(uint32_t(num_loss_rows)), dim3(kBlock), 0, s, partials, blocks,
+                           stage);
+        if (int rc = launch_status()) return rc;
+        loss_rows = stage;
+    }
+    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, loss_rows, num_loss_rows, B, int(D), p,
+                       losses_out, d_std_partials, int(A), d_std);
+    return launch_status();
 }
 
 extern "C" int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const float *old_logp, const float *action,
@@ -516,55 +524,36 @@ extern "C" int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const 
                                                   double value_clip, double w_sur, double w_val, double w_ent,
                                                   float *losses_out, float *logp_out, float *entropy_out,
                                                   float *logp_ratio_out, float *ratio_out, float *d_logits,
-                                                  float *d_value, double *partials, void *stream) {
+                                                  float *d_value, double *partials, int flags, void *stream) {
     if (B <= 0 || A <= 0 || D <= 0) return CUSRL_E_INVALID;
-    if (!advantage || !old_logp || !action || !logits || !ret || !curr_value || !losses_out || !partials)
+    const bool defer = (flags & CUSRL_LOSS_DEFER) != 0;
+    if (!advantage || !old_logp || !action || !logits || !ret || !curr_value || (!losses_out && !defer) || !partials)
         return CUSRL_E_INVALID;
     if (value_clip >= 0.0 && !old_value) return CUSRL_E_INVALID;
     if (A > INT32_MAX || D > INT32_MAX) return CUSRL_E_UNSUPPORTED;
-    LossParams p;
-    p.lo = float(1.0 - clip);
-    p.hi = float(1.0 + clip);
-    p.value_clip = value_clip < 0.0 ? -1.0f : float(value_clip);
-    p.g_sur = float(-w_sur / double(B));
-    p.g_ent = float(-w_ent / double(B));
-    p.g_val = float(w_val / double(B * D));
-    p.w_sur = float(w_sur);
-    p.w_val = float(w_val);
-    p.w_ent = float(w_ent);
+    const LossParams p = loss_params(B, D, clip, value_clip, w_sur, w_val, w_ent);
     hipStream_t s = as_stream(stream);
-    const int64_t blocks = loss_blocks(B);
+    const int64_t blocks = ceil_div(B, kBlock);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     hipLaunchKernelGGL(ppo_loss_categorical_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, old_logp,
                        action, logits, ret, curr_value, old_value, B, int(A), int(D), p, logp_out, entropy_out,
-                       logp_ratio_out, ratio_out, d_logits, d_value, partials);
+                       logp_ratio_out, ratio_out, d_logits, d_value, partials, int(defer));
     if (int rc = launch_status()) return rc;
-    const double *loss_rows = partials;
-    int64_t num_loss_rows = blocks;
-    if (blocks > kBlock) {
-        num_loss_rows = ceil_div(blocks, kBlock);
-        double *stage = partials + blocks * kLossSums;
-        hipLaunchKernelGGL(loss_partials_stage_kernel, dim3(uint32_t(num_loss_rows)), dim3(kBlock), 0, s, partials, blocks,
-                           stage);
-        if (int rc = launch_status()) return rc;
-        loss_rows = stage;
-    }
-    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, loss_rows, num_loss_rows, B, int(D), p,
-                       losses_out, nullptr, int(A), nullptr);
-    return launch_status();
+    if (defer) return 0;
+    return launch_finalize(partials, blocks, B, A, D, p, losses_out, nullptr, nullptr, s);
 }
 
-#define CUSRL_LAUNCH_CHUNKED(LPR)                                                                                      \
+#define CUSRL_LAUNCH_ROWGROUP(LPR)                                                                                     \
     if (std_vector)                                                                                                    \
-        hipLaunchKernelGGL((ppo_loss_chunked_kernel<LPR, true>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, \
-                           old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out,            \
-                           entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,   \
-                           in_kernel, losses_out);                                                                     \
-    else                                                                                                               \
-        hipLaunchKernelGGL((ppo_loss_chunked_kernel<LPR, false>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s,           \
+        hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, true>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s,          \
                            advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out, \
                            entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,   \
-                           in_kernel, losses_out)
+                           int(defer));                                                                                \
+    else                                                                                                               \
+        hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, false>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s,         \
+                           advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out, \
+                           entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,   \
+                           int(defer))
 
 extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action,
                                       const float *mean, const float *std, const float *ret, const float *curr_value,
@@ -572,70 +561,49 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
                                       double value_clip, double w_sur, double w_val, double w_ent, float *losses_out,
                                       float *logp_out, float *entropy_out, float *logp_ratio_out, float *ratio_out,
                                       float *d_mean, float *d_std, float *d_value, double *partials,
-                                      int64_t std_rows, float *d_std_partials, uint32_t *ticket, void *stream) {
+                                      int64_t std_rows, float *d_std_partials, int flags, void *stream) {
     if (B <= 0 || A <= 0 || D <= 0) return CUSRL_E_INVALID;
     if (std_rows != B && std_rows != 1) return CUSRL_E_INVALID;
+    const bool defer = (flags & CUSRL_LOSS_DEFER) != 0;
     const bool std_vector = std_rows == 1 && B != 1;
-    if (std_vector && d_std && !d_std_partials) return CUSRL_E_INVALID;
-    if (!advantage || !old_logp || !action || !mean || !std || !ret || !curr_value || !losses_out || !partials)
+    if (std_vector && (d_std || defer) && !d_std_partials) return CUSRL_E_INVALID;
+    if (!advantage || !old_logp || !action || !mean || !std || !ret || !curr_value || (!losses_out && !defer) || !partials)
         return CUSRL_E_INVALID;
     if (value_clip >= 0.0 && !old_value) return CUSRL_E_INVALID;
     if (A > INT32_MAX || D > INT32_MAX) return CUSRL_E_UNSUPPORTED;
-    LossParams p;
-    p.lo = float(1.0 - clip);
-    p.hi = float(1.0 + clip);
-    p.value_clip = value_clip < 0.0 ? -1.0f : float(value_clip);
-    p.g_sur = float(-w_sur / double(B));
-    p.g_ent = float(-w_ent / double(B));
-    p.g_val = float(w_val / double(B * D));
-    p.w_sur = float(w_sur);
-    p.w_val = float(w_val);
-    p.w_ent = float(w_ent);
+    const LossParams p = loss_params(B, D, clip, value_clip, w_sur, w_val, w_ent);
     hipStream_t s = as_stream(stream);
-    const int64_t blocks = loss_blocks(B);
-    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     const bool chunked = A % 4 == 0 && A / 4 <= 8 && aligned(action, 16) && aligned(mean, 16) && aligned(std, 16) &&
-                         (!d_mean || aligned(d_mean, 16)) && (!d_std || aligned(d_std, 16));
+                         (!d_mean || aligned(d_mean, 16)) && (!d_std || std_vector || aligned(d_std, 16)) &&
+                         (!d_std_partials || aligned(d_std_partials, 16));
     if (std_vector && !chunked) return CUSRL_E_UNSUPPORTED;  // the row-vector form exists for the 16-byte-chunk layout
-    // few enough blocks for ONE block to reduce every partial row at memory latency: the last block to finish does it
-    // inside the launch (ticket); larger minibatches keep the staged reduction launches below
-    const bool fused_finalize = ticket && blocks <= kBlock && (!(std_vector && d_std) || blocks <= kStdSliceRows);
-    unsigned int *in_kernel = fused_finalize ? ticket : nullptr;
+    const int64_t blocks = ceil_div(B, chunked ? loss_rows_per_block(A) : kBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     if (chunked) {
         switch (A / 4) {
-            case 1: CUSRL_LAUNCH_CHUNKED(1); break;
-            case 2: CUSRL_LAUNCH_CHUNKED(2); break;
-            case 3: CUSRL_LAUNCH_CHUNKED(3); break;
-            case 4: CUSRL_LAUNCH_CHUNKED(4); break;
-            case 5: CUSRL_LAUNCH_CHUNKED(5); break;
-            case 6: CUSRL_LAUNCH_CHUNKED(6); break;
-            case 7: CUSRL_LAUNCH_CHUNKED(7); break;
-            default: CUSRL_LAUNCH_CHUNKED(8); break;
+            case 1: CUSRL_LAUNCH_ROWGROUP(1); break;
+            case 2: CUSRL_LAUNCH_ROWGROUP(2); break;
+            case 3: CUSRL_LAUNCH_ROWGROUP(3); break;
+            case 4: CUSRL_LAUNCH_ROWGROUP(4); break;
+            case 5: CUSRL_LAUNCH_ROWGROUP(5); break;
+            case 6: CUSRL_LAUNCH_ROWGROUP(6); break;
+            case 7: CUSRL_LAUNCH_ROWGROUP(7); break;
+            default: CUSRL_LAUNCH_ROWGROUP(8); break;
         }
     } else {
         hipLaunchKernelGGL(ppo_loss_rowwise_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, old_logp,
                            action, mean, std, ret, curr_value, old_value, B, int(A), int(D), p, logp_out, entropy_out,
-                           logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, in_kernel, losses_out);
+                           logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, int(defer));
     }
     if (int rc = launch_status()) return rc;
-    if (fused_finalize) return 0;
+    if (defer) return 0;  // the caller reduces the block rows itself (losses: whenever it wants totals; d_std: assembly)
     // gradient of the std vector = column sums of the per-block sums: inside the finalize launch for up to 128 blocks
     // (a 32 768-row minibatch), staged over 128-row slices beyond that
     const bool reduce_std = std_vector && d_std;
     const bool staged = reduce_std && blocks > kStdSliceRows;
-    const double *loss_rows = partials;
-    int64_t num_loss_rows = blocks;
-    if (blocks > kBlock) {
-        num_loss_rows = ceil_div(blocks, kBlock);
-        double *stage = partials + blocks * kLossSums;
-        hipLaunchKernelGGL(loss_partials_stage_kernel, dim3(uint32_t(num_loss_rows)), dim3(kBlock), 0, s, partials, blocks,
-                           stage);
-        if (int rc = launch_status()) return rc;
-        loss_rows = stage;
-    }
-    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, loss_rows, num_loss_rows, B, int(D), p,
-                       losses_out, (reduce_std && !staged) ? d_std_partials : nullptr, int(A), d_std);
-    if (int rc = launch_status()) return rc;
+    if (int rc = launch_finalize(partials, blocks, B, A, D, p, losses_out, (reduce_std && !staged) ? d_std_partials : nullptr,
+                                 d_std, s))
+        return rc;
     if (staged) {
         const int64_t slices = ceil_div(blocks, kStdSliceRows);
         float *stage = d_std_partials + blocks * A;  // the workspace holds the slices' rows behind the blocks' rows

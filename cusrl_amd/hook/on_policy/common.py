@@ -34,6 +34,8 @@ class OnPolicyPreparation(Hook):
 
     def post_objective(self, metadata, batch):
         if (reduced := batch.get("_fused_metrics")) is not None:
+            if reduced.get("deferred"):  # captured step: the kernel's running sums are read once per update (ops.DeferredLoss)
+                return
             self.agent.metrics.record_reduced("ratio", *reduced["ratio"])
             self.agent.metrics.record_reduced("entropy", *reduced["entropy"])
         else:

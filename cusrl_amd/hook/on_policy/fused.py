@@ -24,24 +24,77 @@ from cusrl_amd import ops
 __all__ = ["FusedPpoObjective"]
 
 
+def _side_outputs(out, deferred, like):
+    """(total, losses) of a launch: the kernel's own scalars, or — deferred finalize — placeholders nobody reads: the
+    backward runs with a unit gradient and the values reach the metrics through ``ops.DeferredLoss``."""
+    if deferred is None:
+        losses = out["losses"]
+        return losses[6], losses  # total = (value + surrogate) + entropy, summed by the kernel
+    return torch.empty((), dtype=torch.float32, device=like.device), torch.empty(0, dtype=torch.float32, device=like.device)
+
+
 class _FusedPpoFunction(torch.autograd.Function):
     """total = value_loss + surrogate_loss + entropy_loss; gradients precomputed by the forward kernel."""
 
     @staticmethod
     def forward(ctx, mean, std, curr_value, advantage, old_logp, action, ret, old_value, clip, value_clip,
-                w_sur, w_val, w_ent, unit_grad):
+                w_sur, w_val, w_ent, unit_grad, deferred):
         out = ops.ppo_loss_fwd_bwd(
             advantage, old_logp, action, mean, std, ret, curr_value, old_value,
-            clip=clip, value_clip=value_clip, w_sur=w_sur, w_val=w_val, w_ent=w_ent, want_grads=True,
+            clip=clip, value_clip=value_clip, w_sur=w_sur, w_val=w_val, w_ent=w_ent, want_grads=True, deferred=deferred,
         )
-        ctx.save_for_backward(out["d_mean"], out["d_std"], out["d_value"])
+        d_std = out["d_std"]
+        ctx.deferred_std = None
+        if isinstance(d_std, ops.DeferredColumns):
+            # the blocks' column sums of d_std: `std` is the parameter itself here, so they go straight to the flat
+            # gradient assembly (backward) instead of through a reduction launch
+            ctx.deferred_std, ctx.std_key = d_std, std.data_ptr()
+            ctx.save_for_backward(out["d_mean"], out["d_value"])
+        else:
+            ctx.save_for_backward(out["d_mean"], d_std, out["d_value"])
         # the five side outputs never receive a gradient; without this autograd would materialise a zero tensor for
         # each of them on every backward (5 fill launches per minibatch)
         ctx.set_materialize_grads(False)
         ctx.unit_grad = unit_grad
         ctx.shapes = (mean.shape, std.shape, curr_value.shape)
-        losses = out["losses"]
-        total = losses[6]  # (value + surrogate) + entropy, summed by the kernel
+        total, losses = _side_outputs(out, deferred, mean)
+        side = (losses, out["logp"], out["entropy"], out["logp_ratio"], out["ratio"])
+        ctx.mark_non_differentiable(*side)
+        return (total, *side)
+
+    @staticmethod
+    def backward(ctx, grad_total, *_unused):
+        if grad_total is None:
+            return (None,) * 15
+        shapes = ctx.shapes
+        if ctx.deferred_std is not None:
+            from cusrl_amd.nn import module as nn_module
+
+            d_mean, d_value = ctx.saved_tensors
+            d_std = nn_module._hand_over(nn_module._split_grad_sink, ctx.std_key, ctx.deferred_std)
+            return (d_mean.view(shapes[0]), None if d_std is None else d_std.view(shapes[1]), d_value.view(shapes[2]),
+                    *([None] * 12))
+        d_mean, d_std, d_value = ctx.saved_tensors
+        if not ctx.unit_grad:  # GradScaler (fp16 autocast) or a caller that rescales the loss
+            d_mean, d_std, d_value = d_mean * grad_total, d_std * grad_total, d_value * grad_total
+        return (d_mean.view(shapes[0]), d_std.view(shapes[1]), d_value.view(shapes[2]), *([None] * 12))
+
+
+class _FusedCategoricalPpoFunction(torch.autograd.Function):
+    """The same objective for a one-hot categorical policy: gradients wrt ``logits`` and ``curr_value``."""
+
+    @staticmethod
+    def forward(ctx, logits, curr_value, advantage, old_logp, action, ret, old_value, clip, value_clip, w_sur, w_val, w_ent,
+                unit_grad, deferred):
+        out = ops.ppo_loss_categorical_fwd_bwd(
+            advantage, old_logp, action, logits, ret, curr_value, old_value,
+            clip=clip, value_clip=value_clip, w_sur=w_sur, w_val=w_val, w_ent=w_ent, want_grads=True, deferred=deferred,
+        )
+        ctx.save_for_backward(out["d_logits"], out["d_value"])
+        ctx.set_materialize_grads(False)
+        ctx.unit_grad = unit_grad
+        ctx.shapes = (logits.shape, curr_value.shape)
+        total, losses = _side_outputs(out, deferred, logits)
         side = (losses, out["logp"], out["entropy"], out["logp_ratio"], out["ratio"])
         ctx.mark_non_differentiable(*side)
         return (total, *side)
@@ -50,40 +103,10 @@ class _FusedPpoFunction(torch.autograd.Function):
     def backward(ctx, grad_total, *_unused):
         if grad_total is None:
             return (None,) * 14
-        d_mean, d_std, d_value = ctx.saved_tensors
-        if not ctx.unit_grad:  # GradScaler (fp16 autocast) or a caller that rescales the loss
-            d_mean, d_std, d_value = d_mean * grad_total, d_std * grad_total, d_value * grad_total
-        shapes = ctx.shapes
-        return (d_mean.view(shapes[0]), d_std.view(shapes[1]), d_value.view(shapes[2]), *([None] * 11))
-
-
-class _FusedCategoricalPpoFunction(torch.autograd.Function):
-    """The same objective for a one-hot categorical policy: gradients wrt ``logits`` and ``curr_value``."""
-
-    @staticmethod
-    def forward(ctx, logits, curr_value, advantage, old_logp, action, ret, old_value, clip, value_clip, w_sur, w_val, w_ent,
-                unit_grad):
-        out = ops.ppo_loss_categorical_fwd_bwd(
-            advantage, old_logp, action, logits, ret, curr_value, old_value,
-            clip=clip, value_clip=value_clip, w_sur=w_sur, w_val=w_val, w_ent=w_ent, want_grads=True,
-        )
-        ctx.save_for_backward(out["d_logits"], out["d_value"])
-        ctx.set_materialize_grads(False)
-        ctx.unit_grad = unit_grad
-        ctx.shapes = (logits.shape, curr_value.shape)
-        losses = out["losses"]
-        side = (losses, out["logp"], out["entropy"], out["logp_ratio"], out["ratio"])
-        ctx.mark_non_differentiable(*side)
-        return (losses[6], *side)
-
-    @staticmethod
-    def backward(ctx, grad_total, *_unused):
-        if grad_total is None:
-            return (None,) * 13
         d_logits, d_value = ctx.saved_tensors
         if not ctx.unit_grad:
             d_logits, d_value = d_logits * grad_total, d_value * grad_total
-        return (d_logits.view(ctx.shapes[0]), d_value.view(ctx.shapes[1]), *([None] * 11))
+        return (d_logits.view(ctx.shapes[0]), d_value.view(ctx.shapes[1]), *([None] * 12))
 
 
 def _overrides(hook, method: str) -> bool:
@@ -95,8 +118,9 @@ def _overrides(hook, method: str) -> bool:
 class FusedPpoObjective:
     """Collects the terms of one minibatch step; ``resolve`` turns them into real tensors."""
 
-    def __init__(self, unit_grad: bool):
+    def __init__(self, unit_grad: bool, owner=None):
         self.unit_grad = unit_grad
+        self.owner = owner  # the GraphedTrainStep this objective is evaluated for, if any (deferred loss finalize)
         self.value: tuple | None = None
         self.policy: tuple | None = None
         self.surrogate: tuple | None = None
@@ -149,7 +173,7 @@ class FusedPpoObjective:
             cached = composite._fusion_cache = (key, cls.eligible(composite))
         if not cached[1]:
             return None
-        context = cls(unit_grad=not agent.grad_scaler_enabled)
+        context = cls(unit_grad=not agent.grad_scaler_enabled, owner=getattr(agent, "_deferred_loss_owner", None))
         agent._fused_objective = context
         return context
 
@@ -192,28 +216,60 @@ class FusedPpoObjective:
             torch.cuda.current_stream().wait_stream(stream)
         self.pending_streams.clear()
         if "logits" in action_dist:  # one-hot categorical policy (discrete action space)
+            logits = action_dist["logits"].float()
+            deferred = self._deferred(logits.device, logits.shape[-1], ret.shape[-1], logits.numel() // logits.shape[-1], True, None)
             total, losses, logp, entropy, logp_ratio, ratio = _FusedCategoricalPpoFunction.apply(
-                action_dist["logits"].float(), curr_value, advantage, old_logp, action, ret, old_value,
-                clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad,
+                logits, curr_value, advantage, old_logp, action, ret, old_value,
+                clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad, deferred,
             )
-            self._publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio)
+            self._publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio, deferred)
             return
         std = action_dist["std"]
         row_vector = getattr(std, "_cusrl_row_vector", None)
         if row_vector is not None and std.dim() == 2 and std.stride(0) == 0 and ops.ppo_loss_accepts_std_vector(std.shape[-1]):
             std = row_vector  # the [A] vector the batch view repeats: broadcast inside the kernel, d_std comes back as [A]
+        mean = action_dist["mean"]
+        deferred = self._deferred(mean.device, mean.shape[-1], ret.shape[-1], mean.numel() // mean.shape[-1], False, std)
         total, losses, logp, entropy, logp_ratio, ratio = _FusedPpoFunction.apply(
-            action_dist["mean"], std, curr_value, advantage, old_logp, action, ret, old_value,
-            clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad,
+            mean, std, curr_value, advantage, old_logp, action, ret, old_value,
+            clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad, deferred,
         )
-        self._publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio)
+        self._publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio, deferred)
+
+    def _deferred(self, device, A: int, D: int, B: int, categorical: bool, std):
+        """The :class:`ops.DeferredLoss` of the captured minibatch step this objective belongs to, or None.  Taken only
+        while the step is being CAPTURED (its eager warm-up creates the rows, outside any capture), with a unit-gradient
+        backward, fp32 inputs, few enough blocks — and, for a std vector, only when that vector is the parameter itself
+        (identity bijector: its block column sums then go straight into the parameter's gradient slot)."""
+        owner = self.owner
+        if owner is None or not self.unit_grad:
+            return None
+        if std is not None and std.dim() == 1 and not (isinstance(std, torch.nn.Parameter) and std.is_leaf):
+            return None
+        capturing = torch.cuda.is_current_stream_capturing()
+        current = owner.deferred_loss
+        if current is None or (current.B, current.A, current.D) != (B, A, D):
+            if capturing:
+                return None
+            current = owner.deferred_loss = ops.DeferredLoss(B, A, D, device, categorical)
+        if not capturing or current.blocks > ops.DeferredLoss.MAX_BLOCKS:
+            return None
+        return current
 
     @staticmethod
-    def _publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio):
+    def _publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio, deferred=None):
         batch["curr_action_logp"] = logp
         batch["curr_entropy"] = entropy
         batch["action_logp_ratio"] = logp_ratio
         batch["action_prob_ratio"] = ratio
+        objectives.total = total
+        objectives.fused_keys = ("value_loss", "surrogate_loss", "entropy_loss")
+        if deferred is not None:
+            # captured step without a finalize launch: the loss values exist as running block sums (ops.DeferredLoss),
+            # read once per update by GraphedTrainStep.flush_metrics; agent.record skips the None entries
+            batch["_fused_metrics"] = {"deferred": True}
+            objectives["value_loss"] = objectives["surrogate_loss"] = objectives["entropy_loss"] = None
+            return
         value_loss, surrogate_loss, entropy_loss, mean_abs_ratio, mean_entropy, mean_value, _ = losses.unbind(0)
         # the means the hooks record after every minibatch, already reduced by the kernel (no extra launches)
         rows = advantage.numel()

@@ -238,7 +238,8 @@ class ValueLoss(Hook):
     def post_objective(self, metadata, batch):
         curr_value: Tensor = batch["curr_value"]
         if (reduced := batch.get("_fused_metrics")) is not None:
-            self.agent.metrics.record_reduced("value", *reduced["value"])
+            if not reduced.get("deferred"):  # (captured step: read once per update from the kernel's running sums)
+                self.agent.metrics.record_reduced("value", *reduced["value"])
         else:
             self.agent.record(value=curr_value.sum(dim=-1))
         if (dim := curr_value.size(-1)) != 1:

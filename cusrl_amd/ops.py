@@ -17,6 +17,7 @@ from cusrl_amd import _native
 from cusrl_amd._native import Field, PackedField, check
 
 __all__ = [
+    "DeferredLoss",
     "LaunchObserver",
     "RecordPack",
     "adv_stats_finalize",
@@ -630,6 +631,45 @@ def merge_mean_var(gathered: torch.Tensor, mean: torch.Tensor, var: torch.Tensor
 
 
 # ------------------------------------------------------------------------------------------------ a9 - a13
+LOSS_DEFER = 1  # CUSRL_LOSS_DEFER
+
+
+class DeferredLoss:
+    """Running sums of the objective's five block partials over the replays of ONE captured minibatch step
+    (``CUSRL_LOSS_DEFER``): nothing inside an optimizer step reads the loss VALUES — the backward takes a unit gradient —
+    so the captured step skips the one-block finalize launch; every block adds its sums to its own row of ``rows``
+    (persistent, zero-filled here, outside the capture) and :meth:`drain` forms the per-replay means once per update on
+    the host.  ``weights`` = (w_val, w_sur, w_ent) the capture froze."""
+
+    __slots__ = ("rows", "B", "A", "D", "weights", "blocks", "armed")
+
+    def __init__(self, B: int, A: int, D: int, device, categorical: bool):
+        self.B, self.A, self.D = B, A, D
+        self.blocks = int(_native.lib().cusrl_ppo_loss_blocks(B, 0 if categorical else A))
+        self.rows = torch.zeros((max(int(_native.lib().cusrl_ppo_loss_num_partials(B)), 1), 5), dtype=torch.float64, device=device)
+        self.weights: tuple[float, float, float] | None = None
+        self.armed = False  # a launch has been recorded against these rows
+
+    MAX_BLOCKS = 256  # beyond this the per-row read-modify-write and the host-side sum stop being negligible
+
+    def drain(self, replays: int) -> dict[str, tuple[float, int]] | None:
+        """``{metric: (sum over replays of the per-step mean, samples per step)}`` and a reset of the rows."""
+        if not self.armed or replays <= 0 or self.weights is None:
+            return None
+        sums = self.rows[: self.blocks].sum(0).tolist()
+        self.rows.zero_()
+        w_val, w_sur, w_ent = self.weights
+        B, D = self.B, self.D
+        return {
+            "value_loss": (sums[0] / (B * D) * w_val, 1),
+            "surrogate_loss": (-sums[1] / B * w_sur, 1),
+            "entropy_loss": (-sums[2] / B * w_ent, 1),
+            "ratio": (sums[3] / B, B),
+            "entropy": (sums[2] / B, B),
+            "value": (sums[4] / B, B),
+        }
+
+
 def ppo_loss_fwd_bwd(
     advantage: torch.Tensor,
     old_logp: torch.Tensor,
@@ -646,13 +686,18 @@ def ppo_loss_fwd_bwd(
     w_val: float,
     w_ent: float,
     want_grads: bool = True,
+    deferred: DeferredLoss | None = None,
 ) -> dict[str, torch.Tensor]:
     """One pass: losses[0:3] = (value, surrogate, entropy) weighted losses, losses[3:6] = means of |logp ratio|, entropy
     and value (the metrics of common.py:45-49 / value.py:139-141), losses[6] = their sum, per-sample logp/entropy/ratios, and the gradients.
 
     ``std`` is either the ``[B, A]`` matrix or the ``[A]`` vector it repeats (a state-independent std,
     :func:`ppo_loss_accepts_std_vector`): then it is broadcast inside the kernel and ``d_std`` is the ``[A]`` gradient of
-    the vector."""
+    the vector.
+
+    ``deferred`` (a :class:`DeferredLoss` of this shape): ONE launch, no finalize — ``losses`` is absent from the result,
+    the block sums accumulate in ``deferred.rows``, and with a std vector ``d_std`` comes back as
+    :class:`DeferredColumns` (the blocks' column sums, reduced by ``assemble_gradients``)."""
     advantage, old_logp = _f32(advantage, "advantage"), _f32(old_logp, "action_logp")
     action, mean, std = _f32(action, "action"), _f32(mean, "mean"), _f32(std, "std")
     ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
@@ -670,24 +715,36 @@ def ppo_loss_fwd_bwd(
         if old_value is None:
             raise ValueError("ppo_loss: the clipped value loss needs the old value")
         old_value = _f32(old_value, "value")
+    if deferred is not None and (deferred.B, deferred.A, deferred.D) != (B, A, D):
+        raise ValueError("ppo_loss: the deferred-loss rows belong to another minibatch shape")
     dev = mean.device
     lib = _native.lib()
     out = {
-        "losses": torch.empty(7, dtype=torch.float32, device=dev),  # 3 weighted losses, 3 metric means, total
         "logp": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
         "entropy": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
         "logp_ratio": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
         "ratio": torch.empty(advantage.shape, dtype=torch.float32, device=dev),
     }
+    if deferred is None:
+        out["losses"] = torch.empty(7, dtype=torch.float32, device=dev)  # 3 weighted losses, 3 metric means, total
+    defer_std = deferred is not None and std_vector and want_grads
     if want_grads:
-        out["d_mean"], out["d_std"], out["d_value"] = torch.empty_like(mean), torch.empty_like(std), torch.empty_like(curr_value)
-    num_partials = int(lib.cusrl_ppo_loss_num_partials(B))
-    partials = torch.empty((num_partials, 5), dtype=torch.float64, device=dev)
+        out["d_mean"], out["d_value"] = torch.empty_like(mean), torch.empty_like(curr_value)
+        if not defer_std:
+            out["d_std"] = torch.empty_like(std)
+    if deferred is None:
+        partials = torch.empty((int(lib.cusrl_ppo_loss_num_partials(B)), 5), dtype=torch.float64, device=dev)
+    else:
+        partials = deferred.rows
+        deferred.weights, deferred.armed = (float(w_val), float(w_sur), float(w_ent)), True
     std_partials = (torch.empty((int(lib.cusrl_ppo_loss_std_partial_rows(B)), A), dtype=torch.float32, device=dev)
                     if std_vector and want_grads else None)
+    if defer_std:
+        out["d_std"] = DeferredColumns(std_partials, int(lib.cusrl_ppo_loss_blocks(B, A)), A, 0, A)
 
     def ptr(name):
-        return out[name].data_ptr() if name in out else None
+        value = out.get(name)
+        return value.data_ptr() if isinstance(value, torch.Tensor) else None
 
     _observed(
         "cusrl_ppo_loss_fwd_bwd",
@@ -699,17 +756,10 @@ def ppo_loss_fwd_bwd(
             B, A, D, float(clip), -1.0 if value_clip is None else float(value_clip), float(w_sur), float(w_val), float(w_ent),
             ptr("losses"), ptr("logp"), ptr("entropy"), ptr("logp_ratio"), ptr("ratio"), ptr("d_mean"), ptr("d_std"), ptr("d_value"),
             partials.data_ptr(), 1 if std_vector else B, None if std_partials is None else std_partials.data_ptr(),
-            _ticket(dev).data_ptr() if _LOSS_TICKET else None, _stream(),
+            LOSS_DEFER if deferred is not None else 0, _stream(),
         ),
     )
     return out
-
-
-# Separate one-block finalize launch (default) vs last-block finalize inside the loss launch (CUSRL_LOSS_TICKET=1).
-# Measured on MI355X at a 24 576-row minibatch, graph-timed: two launches 9.85 us, one launch with the fence-free
-# ticket 10.4 us, one launch with release / acquire fences 11.1 us — the last block's extra dependent round trip costs
-# more than the 1.5 us kernel boundary it removes, so the ticket stays an opt-in (a test keeps both forms pinned).
-_LOSS_TICKET = os.environ.get("CUSRL_LOSS_TICKET", "0") != "0"
 
 
 def ppo_loss_categorical_fwd_bwd(
@@ -727,9 +777,10 @@ def ppo_loss_categorical_fwd_bwd(
     w_val: float,
     w_ent: float,
     want_grads: bool = True,
+    deferred: DeferredLoss | None = None,
 ) -> dict[str, torch.Tensor]:
     """:func:`ppo_loss_fwd_bwd` for one-hot categorical policies (``action`` one-hot ``[B, A]``, ``logits [B, A]``):
-    same ``losses`` layout and per-sample outputs, gradients ``d_logits`` / ``d_value``."""
+    same ``losses`` layout and per-sample outputs, gradients ``d_logits`` / ``d_value``; ``deferred`` as there."""
     advantage, old_logp = _f32(advantage, "advantage"), _f32(old_logp, "action_logp")
     action, logits = _f32(action, "action"), _f32(logits, "logits")
     ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
@@ -744,13 +795,19 @@ def ppo_loss_categorical_fwd_bwd(
         if old_value is None:
             raise ValueError("ppo_loss_categorical: the clipped value loss needs the old value")
         old_value = _f32(old_value, "value")
+    if deferred is not None and (deferred.B, deferred.A, deferred.D) != (B, A, D):
+        raise ValueError("ppo_loss_categorical: the deferred-loss rows belong to another minibatch shape")
     dev = logits.device
     lib = _native.lib()
     out = {name: torch.empty(advantage.shape, dtype=torch.float32, device=dev) for name in ("logp", "entropy", "logp_ratio", "ratio")}
-    out["losses"] = torch.empty(7, dtype=torch.float32, device=dev)
+    if deferred is None:
+        out["losses"] = torch.empty(7, dtype=torch.float32, device=dev)
+        partials = torch.empty((int(lib.cusrl_ppo_loss_num_partials(B)), 5), dtype=torch.float64, device=dev)
+    else:
+        partials = deferred.rows
+        deferred.weights, deferred.armed = (float(w_val), float(w_sur), float(w_ent)), True
     if want_grads:
         out["d_logits"], out["d_value"] = torch.empty_like(logits), torch.empty_like(curr_value)
-    partials = torch.empty((int(lib.cusrl_ppo_loss_num_partials(B)), 5), dtype=torch.float64, device=dev)
 
     def ptr(name):
         return out[name].data_ptr() if name in out else None
@@ -762,25 +819,11 @@ def ppo_loss_categorical_fwd_bwd(
             advantage.data_ptr(), old_logp.data_ptr(), action.data_ptr(), logits.data_ptr(), ret.data_ptr(), curr_value.data_ptr(),
             None if old_value is None or value_clip is None else old_value.data_ptr(), B, A, D, float(clip),
             -1.0 if value_clip is None else float(value_clip), float(w_sur), float(w_val), float(w_ent), ptr("losses"), ptr("logp"),
-            ptr("entropy"), ptr("logp_ratio"), ptr("ratio"), ptr("d_logits"), ptr("d_value"), partials.data_ptr(), _stream(),
+            ptr("entropy"), ptr("logp_ratio"), ptr("ratio"), ptr("d_logits"), ptr("d_value"), partials.data_ptr(),
+            LOSS_DEFER if deferred is not None else 0, _stream(),
         ),
     )
     return out
-
-
-_tickets: dict = {}
-
-
-def _ticket(device: torch.device) -> torch.Tensor:
-    """Zero-initialised uint32 a kernel's last-block-done hand-off counts on (self re-arming, so one per device and
-    stream serves every launch; allocated on first use, i.e. in an eager warm-up and never inside a capture)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
-    ticket = _tickets.get(key)
-    if ticket is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("the first launch of a ticketed kernel on a stream must happen outside hipGraph capture")
-        ticket = _tickets[key] = torch.zeros(1, dtype=torch.int32, device=device)
-    return ticket
 
 
 def ppo_loss_accepts_std_vector(action_dim: int) -> bool:

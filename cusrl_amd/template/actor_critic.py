@@ -146,6 +146,8 @@ class ActorCritic(Agent):
             # second branch of the captured minibatch step (critic forward / backward, hook/on_policy/value.py)
             self._branch_stream = torch.cuda.Stream(device=self.device)
             self.concurrent_critic = os.environ.get("CUSRL_CONCURRENT_CRITIC", "1") != "0"
+            # captured minibatch steps run the fused objective without its one-block finalize launch (ops.DeferredLoss)
+            self.defer_loss_finalize = os.environ.get("CUSRL_DEFER_LOSS_FINALIZE", "1") != "0"
             self._graphed_act = GraphedAct(self)
         self.flat_gradients: FlatGradients | None = None
         self._unit_grad: torch.Tensor | None = None

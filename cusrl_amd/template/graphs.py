@@ -159,6 +159,9 @@ class GraphedTrainStep:
         # fields of the batch the step reads: learned by the eager warm-up (which gathers everything), so that the
         # captured gather moves only those leaves (LazyBatch, template/buffer.py)
         self.hot_fields: set[str] = set()
+        # running block sums of the fused objective (ops.DeferredLoss): the captured step runs the loss kernel without its
+        # finalize launch; created by the eager warm-up, read and reset by flush_metrics
+        self.deferred_loss = None
 
     def eligible(self) -> bool:
         """False when an objective-phase hook synchronises across ranks (e.g. minibatch-wise advantage normalisation
@@ -182,11 +185,13 @@ class GraphedTrainStep:
         agent.critic.clear_intermediate_repr()
         agent.hook.pre_objective(self.metadata, batch)
         agent._critic_stream = agent._branch_stream if agent.concurrent_critic else None
+        agent._deferred_loss_owner = self if agent.defer_loss_finalize else None
         try:
             with agent.autocast():
                 objectives = agent.hook.objective(self.metadata, batch)
         finally:
             agent._critic_stream = None
+            agent._deferred_loss_owner = None
         if objectives is not None:
             loss = objectives.loss()
             agent._zero_grad()
@@ -253,8 +258,12 @@ class GraphedTrainStep:
         self.optimize.replay()
 
     def flush_metrics(self):
+        replays = self.forward_backward.replays
         self.forward_backward.flush_metrics()
         self.optimize.flush_metrics()
+        if self.deferred_loss is not None and (drained := self.deferred_loss.drain(replays)) is not None:
+            for name, (total, count) in drained.items():  # total = sum over the replays of the step's mean
+                self.agent.metrics.add_resolved(name, total * count, count * replays)
 
 
 class GraphedRegion:

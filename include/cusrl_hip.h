@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CUSRL_ABI_VERSION 2
+#define CUSRL_ABI_VERSION 3
 #define CUSRL_MAX_FIELDS 24 /* leaves per push / gather launch; larger tables are split by the host */
 #define CUSRL_MAX_PACKED 16 /* 1-8 byte entries of the per-slot record (cusrl_pack_rows); wide fields count as leaves */
 #define CUSRL_MAX_RECORD_BYTES 1024
@@ -163,29 +163,42 @@ int cusrl_window_indices(const int64_t *start, const int64_t *env, int64_t *out,
  * std_rows = 1: `std` is that vector itself, [A] — it is broadcast inside the kernel and d_std is the gradient of the
  * vector, [A] (= the column sums a sum(0) over [B,A] would give); needs A % 4 == 0, A <= 32 and the workspace
  * d_std_partials: float[cusrl_ppo_loss_std_partial_rows(B)][A] (may be NULL otherwise).
- * ticket: device uint32[1], zero-initialised once by the caller and owned by this entry point afterwards (it re-arms
- * itself): with it, minibatches of up to 65 536 rows (32 768 with a std vector) are reduced to losses_out / d_std by
- * the last block of the SAME launch instead of a second, one-block launch; NULL keeps the two-launch form. */
+ * flags: 0, or CUSRL_LOSS_DEFER — ONE launch, no finalize: nothing inside an optimizer step consumes the loss VALUES
+ * (actor_critic.py:311-312 differentiates them with a unit gradient; the values only feed the metrics read once per
+ * update), so the caller may own the reductions instead of paying a one-block launch per minibatch step:
+ *   - every block ADDS its five partial sums {sum sq. value error, sum min(..) surrogate, sum entropy, sum |logp ratio|,
+ *     sum value} to ITS row of `partials` (cusrl_ppo_loss_blocks(B, A) rows; zero-fill once): launches of the same
+ *     shape on one stream build running sums in a fixed order, the caller forms the means whenever it reads them;
+ *   - with a std vector every block leaves its [A] column sums of d_std in its row of d_std_partials — exactly the
+ *     "partial rows" form cusrl_assemble_gradients reduces into the parameter's slot (row_stride = A);
+ *   - losses_out and (std vector) d_std are not written and may be NULL. */
+#define CUSRL_LOSS_DEFER 1
 int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action, const float *mean,
                            const float *std, const float *ret, const float *curr_value, const float *old_value,
                            int64_t B, int64_t A, int64_t D, double clip, double value_clip, double w_sur,
                            double w_val, double w_ent, float *losses_out, float *logp_out, float *entropy_out,
                            float *logp_ratio_out, float *ratio_out, float *d_mean, float *d_std, float *d_value,
-                           double *partials, int64_t std_rows, float *d_std_partials, uint32_t *ticket, void *stream);
+                           double *partials, int64_t std_rows, float *d_std_partials, int flags, void *stream);
+/* workspace rows (enough for any action width) and the exact number of blocks = partial rows of one launch
+ * (A = 0: the categorical form) */
 int64_t cusrl_ppo_loss_num_partials(int64_t B);
 int64_t cusrl_ppo_loss_std_partial_rows(int64_t B);
+int64_t cusrl_ppo_loss_blocks(int64_t B, int64_t A);
 
 /* The same objective for one-hot categorical policies (discrete action spaces) —
  * cusrl/nn/module/distribution.py:332-366 over torch.distributions.OneHotCategorical: action [B,A] one-hot (the taken
  * action is its first arg-max), logits [B,A] unnormalised; logp = log_softmax(logits)[taken],
  * entropy = -sum_j p_j log p_j, ratio / surrogate / value / entropy terms and losses_out[7] exactly as above;
- * d_logits [B,A], d_value [B,D] = d(total loss)/d(.).  partials: double[cusrl_ppo_loss_num_partials(B)][5]. */
+ * d_logits [B,A], d_value [B,D] = d(total loss)/d(.).  partials: double[cusrl_ppo_loss_num_partials(B)][5];
+ * flags as above (CUSRL_LOSS_DEFER: block rows accumulate into `partials`, cusrl_ppo_loss_blocks(B, 0) of them;
+ * a masked action's logit may be -inf: p = 0 and, as in torch.distributions.Categorical.entropy, its log p is clamped to
+ * the smallest finite float before the product, so every output of the row stays finite and its d_logits is 0). */
 int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const float *old_logp, const float *action,
                                        const float *logits, const float *ret, const float *curr_value,
                                        const float *old_value, int64_t B, int64_t A, int64_t D, double clip,
                                        double value_clip, double w_sur, double w_val, double w_ent, float *losses_out,
                                        float *logp_out, float *entropy_out, float *logp_ratio_out, float *ratio_out,
-                                       float *d_logits, float *d_value, double *partials, void *stream);
+                                       float *d_logits, float *d_value, double *partials, int flags, void *stream);
 
 /* ---- §8f row 1: GRU time step (torch.nn.GRU, the recurrent backbone of cusrl/nn/module/rnn.py:21-120) ----
  * One pass over the gates of one time step, between the rocBLAS GEMMs that produce gi = W_ih x + b_ih [B, 3H] (all steps

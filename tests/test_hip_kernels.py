@@ -508,6 +508,7 @@ def test_categorical_ppo_loss_with_masked_actions_stays_finite(ops, gradient_par
 
 
 @pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 7, 1), (513, 32, 2), (3, 40, 1), (255, 4, 3),
+                                   (300, 8, 2), (4096, 16, 1), (1000, 20, 1), (2049, 24, 1), (777, 28, 1),  # every row-group width
                                    (70001, 12, 1)])  # last: > 256 blocks, staged reduction of the block partials
 @pytest.mark.parametrize("vclip", [None, 0.2])
 def test_ppo_loss_vs_oracle(ops, B, A, D, vclip, gradient_parity):
@@ -877,7 +878,8 @@ def test_assemble_gradients_sums_slabs_into_slots(ops):
     np.testing.assert_array_equal(got[:offset], expect[:offset])
 
 
-@pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 4, 2), (257, 32, 1), (2, 8, 1), (70001, 12, 1)])  # last: staged reduction
+@pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 4, 2), (257, 32, 1), (2, 8, 1), (5000, 16, 1), (999, 20, 1),
+                                   (513, 24, 1), (64, 28, 1), (70001, 12, 1)])  # last: staged reduction
 @pytest.mark.parametrize("vclip", [None, 0.2])
 def test_ppo_loss_std_vector_equals_repeated_matrix(ops, B, A, D, vclip):
     """A state-independent std passed as its [A] vector: same forward numbers as the repeated [B, A] matrix, d_std =
@@ -900,6 +902,56 @@ def test_ppo_loss_std_vector_equals_repeated_matrix(ops, B, A, D, vclip):
     want = full["d_std"].double().sum(0)
     torch.testing.assert_close(vec["d_std"].double(), want, rtol=1e-5, atol=1e-5 * float(full["d_std"].abs().sum(0).max()))
     assert not ops.ppo_loss_accepts_std_vector(7)
+
+
+@pytest.mark.parametrize("form", ["std_vector", "std_matrix", "categorical"])
+def test_ppo_loss_deferred_finalize_accumulates_block_rows(ops, form):
+    """CUSRL_LOSS_DEFER (what a captured minibatch step runs): one launch, no finalize.  Two launches add their block sums
+    into the caller's rows — drained, they are the two launches' losses and metric means; the per-sample outputs and
+    gradients are bit-identical to the two-launch form; a std vector's d_std arrives as the blocks' column sums, which
+    ``assemble_gradients`` reduces to the same vector."""
+    rng = np.random.default_rng(7)
+    B, A, D = 24576, 12, 1
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    adv, ret = f(B, 1), f(B, D)
+    curr_value = ret + 0.3 * f(B, D)
+    kw = dict(clip=0.2, value_clip=None, w_sur=1.0, w_val=0.5, w_ent=0.01)
+    if form == "categorical":
+        logits = 2.0 * f(B, A)
+        action = np.eye(A, dtype=np.float32)[rng.integers(0, A, B)]
+        old_logp = oracle.categorical_ppo_loss(adv, np.zeros((B, 1), np.float32), action, logits + 0.05 * f(B, A), ret, curr_value)["logp"]
+        args = tuple(dev(x) for x in (adv, old_logp, action, logits, ret, curr_value)) + (None,)
+        call, grads = ops.ppo_loss_categorical_fwd_bwd, ("d_logits", "d_value")
+    else:
+        mean = f(B, A)
+        vector = (rng.random(A) + 0.5).astype(np.float32)
+        std = vector if form == "std_vector" else np.repeat(vector[None], B, 0)
+        action = (mean + vector * f(B, A)).astype(np.float32)
+        old_logp, _ = oracle.normal_logp_entropy(action, mean + 0.02 * f(B, A), np.repeat(vector[None], B, 0))
+        args = tuple(dev(x) for x in (adv, old_logp, action, mean, std, ret, curr_value)) + (None,)
+        call, grads = ops.ppo_loss_fwd_bwd, ("d_mean", "d_value") + (("d_std",) if form == "std_matrix" else ())
+    plain = call(*args, **kw)
+    rows = ops.DeferredLoss(B, A, D, torch.device(DEV), categorical=form == "categorical")
+    assert rows.blocks == (96 if form == "categorical" else 98) and rows.drain(1) is None  # nothing recorded yet
+    first = call(*args, deferred=rows, **kw)
+    second = call(*args, deferred=rows, **kw)
+    assert "losses" not in first
+    for key in ("logp", "entropy", "ratio", "logp_ratio") + grads:
+        assert torch.equal(first[key], plain[key]) and torch.equal(second[key], plain[key]), key
+    drained = rows.drain(2)
+    losses = host(plain["losses"]).astype(np.float64)
+    for name, index in (("value_loss", 0), ("surrogate_loss", 1), ("entropy_loss", 2), ("ratio", 3), ("entropy", 4), ("value", 5)):
+        total, count = drained[name]
+        assert count == (1 if index < 3 else B)
+        np.testing.assert_allclose(total / 2, losses[index], rtol=2e-7, atol=1e-12, err_msg=name)  # fp32 rounding of `losses`
+    assert float(rows.rows.abs().sum()) == 0.0  # drained rows start over
+    if form == "std_vector":
+        columns = first["d_std"]
+        assert isinstance(columns, ops.DeferredColumns) and columns.splits == 98 and columns.numel == A
+        torch.testing.assert_close(columns.materialize(), plain["d_std"], rtol=1e-5, atol=1e-9)
+        flat = torch.full((A + 4,), float("nan"), device=DEV)
+        ops.assemble_gradients([(columns, 4, A, columns.splits)], flat)
+        torch.testing.assert_close(flat[4:], plain["d_std"], rtol=1e-5, atol=1e-9)
 
 
 @pytest.mark.parametrize("B,A,D", [(98304, 12, 1), (1000, 7, 1), (3, 40, 2), (257, 4, 3)])

@@ -34,7 +34,12 @@ def test_size_helpers_and_argument_validation_without_a_gpu():
     lib = _native.lib()
     assert lib.cusrl_flag_blocks(0) == 0 and lib.cusrl_flag_blocks(1) == 1 and lib.cusrl_flag_blocks(4097) == 2
     assert lib.cusrl_gae_num_partials(24, 4096, 1) == 64  # one row per 64-column wave block (small-rollout shape)
-    assert lib.cusrl_ppo_loss_num_partials(24576) == 96
+    # blocks of one loss launch: 252 rows per block at A = 12 (21 rows x 4 waves x 3 rounds), 256 for A = 16, 128 for
+    # A = 32, 256 for the categorical / row-wise forms; the workspace bound covers the smallest of them
+    assert lib.cusrl_ppo_loss_blocks(24576, 12) == 98 and lib.cusrl_ppo_loss_blocks(24576, 16) == 96
+    assert lib.cusrl_ppo_loss_blocks(24576, 32) == 192 and lib.cusrl_ppo_loss_blocks(24576, 0) == 96
+    assert lib.cusrl_ppo_loss_blocks(24576, 7) == 96 and lib.cusrl_ppo_loss_blocks(0, 12) == 0
+    assert lib.cusrl_ppo_loss_num_partials(24576) == 192 and lib.cusrl_ppo_loss_std_partial_rows(24576) == 192 + 2
     assert lib.cusrl_col_stats_num_partials(98304, 1) == 24
     # invalid arguments are rejected on the host before any launch
     assert lib.cusrl_gae(None, None, None, None, None, None, None, 2, 2, 1, 0.9, 0.9, -1.0, None) == -1
@@ -65,16 +70,17 @@ def test_every_negative_return_code_of_the_c_abi_is_reachable_without_a_launch()
     loss = lambda **kw: lib.cusrl_ppo_loss_fwd_bwd(  # noqa: E731
         p, p, p, p, kw.get("std", p), p, p, kw.get("old_value", None), kw.get("B", 64), kw.get("A", 12), 1, 0.2,
         kw.get("value_clip", -1.0), 1.0, 0.5, 0.01, p, None, None, None, None, p, p, p, p, kw.get("std_rows", 64),
-        kw.get("std_partials", p), None, None)
+        kw.get("std_partials", p), kw.get("flags", 0), None)
     assert loss(std_rows=1, A=7) == -3                      # A not a multiple of 4
     assert loss(std_rows=1, std=odd) == -3                  # misaligned std vector
     assert loss(std_rows=1, std_partials=None) == -1        # d_std wanted but no workspace for its column sums
     assert loss(std_rows=3) == -1                           # std rows must be B or 1
     assert loss(value_clip=0.2) == -1                       # clipped form without the old value
     assert loss(B=0) == -1
+    assert loss(std_rows=1, std_partials=None, flags=1) == -1  # CUSRL_LOSS_DEFER with a std vector leaves block rows there
     # categorical objective, record tables, statistics, sequence layout, scatter, window indices
     assert lib.cusrl_ppo_loss_categorical_fwd_bwd(p, p, p, None, p, p, None, 8, 3, 1, 0.2, -1.0, 1.0, 0.5, 0.0, p, None, None, None,
-                                                  None, p, p, p, None) == -1
+                                                  None, p, p, p, 0, None) == -1
     assert lib.cusrl_normalize_from_partials(p, p, 4, 10, 1e-8, 10, 300, p, p, None) == -3
     assert lib.cusrl_stats_finalize(None, 4, 1, 10, p, p, None) == -1
     assert lib.cusrl_sequence_count(p, 0, 4, p, p, p, None) == -1
