@@ -90,12 +90,31 @@ constexpr int kLossSums = 5;  // value loss, surrogate, entropy, |logp ratio|, v
 // threads add the four waves up in fixed order.  kAccumulate: the block ADDS to its row instead of overwriting it — the
 // row belongs to this block alone, so a plain read-modify-write is race-free and launches of the same grid, ordered on
 // one stream, build up per-block running sums in a fixed order (CUSRL_LOSS_DEFER, see cusrl_ppo_loss_fwd_bwd).
+// Wave-wide sum of a double by DPP moves of its two halves (quad swaps, row rotations, row broadcasts): six steps of
+// 2 v_mov_dpp + 1 v_add_f64 instead of six ds_bpermute round trips per half; fixed order; the total lands in lane 63.
+template <int kCtrl>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), kCtrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), kCtrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_to_last_lane(double v) {
+    v += dpp_move<0xb1>(v);   // quad_perm:[1,0,3,2]
+    v += dpp_move<0x4e>(v);   // quad_perm:[2,3,0,1]
+    v += dpp_move<0x124>(v);  // row_ror:4
+    v += dpp_move<0x128>(v);  // row_ror:8   -> every lane holds its row's (16 lanes) sum
+    v += dpp_move<0x142>(v);  // row_bcast:15 -> rows 1 and 3 add the row in front of them
+    v += dpp_move<0x143>(v);  // row_bcast:31 -> the upper half adds lane 31: lane 63 holds the wave's sum
+    return v;
+}
+
 __device__ __forceinline__ void park_wave_sums(const double (&acc)[kLossSums], double (*scratch)[kLossSums]) {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
     for (int k = 0; k < kLossSums; ++k) {
-        const double total = wave_sum(acc[k]);
-        if (lane == 0) scratch[wave][k] = total;
+        const double total = wave_sum_to_last_lane(acc[k]);
+        if (lane == kWave - 1) scratch[wave][k] = total;
     }
 }
 
@@ -162,7 +181,43 @@ constexpr int kMinLossRowsPerBlock = RowGroup<8>::kRowsPerBlock;  // the smalles
 // instead of a [B, A] matrix: it is read once per lane instead of streamed, and d_std leaves the kernel as per-block
 // column sums [A] (the gradient of the vector) instead of a [B, A] matrix that a sum(0) launch would have to reduce —
 // 96 of the 264 bytes per sample disappear.
-template <int LPR, bool kStdVec>
+// The scalar part of a row with float results (the row-group kernel sums at most kRounds of them per lane in fp32 before the
+// fp64 wave / block reduction): same decisions as row_terms / value_term above.
+struct RowScalars {
+    float dlp, ratio, lr, min_term, abs_lr;
+};
+
+__device__ __forceinline__ RowScalars row_scalars(float logp, float old_logp, float adv, const LossParams &p) {
+    RowScalars r;
+    r.lr = logp - old_logp;                             // action_logp_ratio        common.py:35
+    r.abs_lr = fabsf(r.lr);                             // metric `ratio` = |logp ratio|   common.py:47
+    r.ratio = expf(r.lr);                               // action_prob_ratio        common.py:41
+    const float s1 = adv * r.ratio;                     // ppo.py:14
+    const float rc = fminf(fmaxf(r.ratio, p.lo), p.hi); // clamp                    ppo.py:16
+    const float s2 = adv * rc;
+    r.min_term = fminf(s1, s2);
+    const bool inside = r.ratio >= p.lo && r.ratio <= p.hi;
+    // autograd of min(): ties split evenly, clamp passes on the closed interval
+    const float d_ratio = s1 < s2 ? adv : (s1 > s2 ? (inside ? adv : 0.0f) : 0.5f * adv + (inside ? 0.5f * adv : 0.0f));
+    r.dlp = p.g_sur * d_ratio * r.ratio;
+    return r;
+}
+
+__device__ __forceinline__ void value_scalars(float cv, float R, float v, const LossParams &p, float &loss, float &grad) {
+    const float e1 = cv - R, l1 = e1 * e1, g1 = 2.0f * e1;
+    if (p.value_clip < 0.0f) {  // uniform
+        loss = l1, grad = p.g_val * g1;  // mse_loss(return, curr_value)             value.py:132
+        return;
+    }
+    const float c = p.value_clip, dv = cv - v;
+    const float e2 = (v + fminf(fmaxf(dv, -c), c)) - R, l2 = e2 * e2;   // value.py:85-89
+    const float g2 = (dv >= -c && dv <= c) ? 2.0f * e2 : 0.0f;
+    loss = fmaxf(l1, l2);
+    grad = p.g_val * (l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * (g1 + g2)));
+}
+
+// kFull: every optional output is wanted (the training step) — no per-store pointer tests.
+template <int LPR, bool kStdVec, bool kFull>
 __global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
     const float *__restrict__ advantage, const float *__restrict__ old_logp, const float *__restrict__ action,
     const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ ret,
@@ -174,100 +229,126 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
     constexpr int R = G::kRounds;
     __shared__ double acc_wave[kWavesPerBlock][kLossSums];
     __shared__ float4 ds_wave[kStdVec ? kWavesPerBlock * LPR : 1];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const int sub = lane % LPR, rloc = lane / LPR;  // chunk within the row, row within the wave's round
-    const bool holder = lane < G::kActive;
+    const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const unsigned sub = lane % LPR, rloc = lane / LPR;  // chunk within the row, row within the wave's round
+    const bool holder = lane < unsigned(G::kActive);
+    // block-relative addressing: the block's base pointers are uniform (scalar registers) and everything a lane adds to
+    // them is an unsigned 32-bit offset — no 64-bit vector address arithmetic in the rounds
     const int64_t block_row0 = int64_t(blockIdx.x) * G::kRowsPerBlock;
-    const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(action);
-    const float4 *__restrict__ m4 = reinterpret_cast<const float4 *>(mean);
-    const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(std);
-    float4 *__restrict__ dm4 = reinterpret_cast<float4 *>(d_mean);
-    float4 *__restrict__ ds4 = reinterpret_cast<float4 *>(d_std);
+    const unsigned rows_here = unsigned(min(int64_t(G::kRowsPerBlock), B - block_row0));
+    const float4 *__restrict__ xb = reinterpret_cast<const float4 *>(action) + block_row0 * LPR;
+    const float4 *__restrict__ mb = reinterpret_cast<const float4 *>(mean) + block_row0 * LPR;
+    const float4 *__restrict__ sb = reinterpret_cast<const float4 *>(std) + (kStdVec ? 0 : block_row0 * LPR);
+    const float *__restrict__ advb = advantage + block_row0, *__restrict__ olpb = old_logp + block_row0;
+    const float *__restrict__ retb = ret + block_row0 * D, *__restrict__ cvb = curr_value + block_row0 * D;
+    const float *__restrict__ ovb = old_value ? old_value + block_row0 * D : nullptr;
+    float4 *__restrict__ dmb = d_mean ? reinterpret_cast<float4 *>(d_mean) + block_row0 * LPR : nullptr;
+    float4 *__restrict__ dsb = (!kStdVec && d_std) ? reinterpret_cast<float4 *>(d_std) + block_row0 * LPR : nullptr;
+    float *__restrict__ dvb = d_value ? d_value + block_row0 * D : nullptr;
+    float *__restrict__ lpo = logp_out ? logp_out + block_row0 : nullptr, *__restrict__ eno = entropy_out ? entropy_out + block_row0 : nullptr;
+    float *__restrict__ lro = lr_out ? lr_out + block_row0 : nullptr, *__restrict__ rao = ratio_out ? ratio_out + block_row0 : nullptr;
 
-    // ---- every load of the block's rows is requested up front: the matrix chunks and the per-row scalars the scalar
-    // part needs (one memory round trip per block)
-    int64_t row[R];
-    bool ok[R];
+    // ---- every load of the block's rows is requested up front, unpredicated (rows past the end re-read the block's last
+    // row; their results are never stored): the matrix chunks and the per-row scalars of the scalar part
+    unsigned lrow[R], q[R];
+    bool valid[R];
     float4 x[R], mu[R], sg[kStdVec ? 1 : R];
     float adv[R], olp[R], pre_ret[R], pre_cv[R], pre_ov[R];
-    if (kStdVec) sg[0] = s4[sub];
+    if (kStdVec) sg[0] = sb[sub];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        row[k] = block_row0 + int64_t(k * kWavesPerBlock + wave) * G::kRowsPerWave + rloc;
-        ok[k] = holder && row[k] < B;
-        x[k] = mu[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!kStdVec) sg[k] = make_float4(1.f, 1.f, 1.f, 1.f);
-        adv[k] = olp[k] = pre_ret[k] = pre_cv[k] = pre_ov[k] = 0.f;
-        if (ok[k]) {
-            const int64_t q = row[k] * LPR + sub;
-            x[k] = x4[q];
-            mu[k] = m4[q];
-            if (!kStdVec) sg[k] = s4[q];
-            adv[k] = advantage[row[k]];
-            olp[k] = old_logp[row[k]];
-            if (sub == 0 && D == 1) {
-                pre_ret[k] = ret[row[k]];
-                pre_cv[k] = curr_value[row[k]];
-                if (p.value_clip >= 0.0f) pre_ov[k] = old_value[row[k]];
-            }
+        lrow[k] = (unsigned(k) * kWavesPerBlock + wave) * G::kRowsPerWave + rloc;
+        valid[k] = holder && lrow[k] < rows_here;
+        const unsigned crow = min(lrow[k], rows_here - 1u);
+        q[k] = crow * LPR + sub;
+        x[k] = xb[q[k]];
+        mu[k] = mb[q[k]];
+        if (!kStdVec) sg[k] = sb[q[k]];
+        adv[k] = advb[crow];
+        olp[k] = olpb[crow];
+        pre_ret[k] = pre_cv[k] = pre_ov[k] = 0.f;
+        if (D == 1) {  // uniform
+            pre_ret[k] = retb[crow];
+            pre_cv[k] = cvb[crow];
+            if (p.value_clip >= 0.0f) pre_ov[k] = ovb[crow];
         }
     }
 
-    double acc[kLossSums] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    // Arithmetic: per element ONE hardware reciprocal of sigma (v_rcp_f32, <= 1 ulp) and multiplications instead of the five
+    // IEEE divisions of the textbook form — with those the kernel is bound by its VALU instructions, not by HBM (round 2:
+    // matrix and vector form both took 340 us at 1 M envs for 1.74 and 1.13 GB).  z = (x - mu) / sigma:
+    //   log-prob term  -z^2 / 2 - log sigma - log sqrt(2 pi)                 distribution.py:207-209
+    //   d logp/d mu = z / sigma,  d logp/d sigma = (z^2 - 1) / sigma,  d entropy/d sigma = 1 / sigma
+    // A few ulp from the reference's op order, far inside the 1e-5 the losses and gradients are held to.  With a std vector
+    // reciprocal, logarithm and the row's entropy do not depend on the row at all: once per lane.
+    // A lane sums its (at most kRounds) rows' scalars in fp32; waves and blocks are reduced in fp64.
+    float lane_sum[kLossSums] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float4 ds_acc = make_float4(0.f, 0.f, 0.f, 0.f);  // std-vector mode: this lane's column group, summed over its rows
-    const int row_lane0 = lane - sub;
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const float4 sgk = sg[kStdVec ? 0 : k];
-        const float xs[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
-        const float ms[4] = {mu[k].x, mu[k].y, mu[k].z, mu[k].w};
-        const float ss[4] = {sgk.x, sgk.y, sgk.z, sgk.w};
-        float lp = 0.0f, en = 0.0f;
+    const unsigned row_lane0 = lane - sub;
+    float inv[4], ls[4], entropy = 0.0f;
+    auto prepare_std = [&](const float4 &s) {
+        const float ss[4] = {s.x, s.y, s.z, s.w};
+        float en = 0.0f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float diff = xs[j] - ms[j], ls = logf(ss[j]);
-            // -((x - mu)^2) / (2 sigma^2) - log(sigma) - log(sqrt(2 pi))     distribution.py:207-209
-            lp += -(diff * diff) / (2.0f * (ss[j] * ss[j])) - ls - log_sqrt_2pi();
-            en += entropy_const() + ls;  // distribution.py:211-213
+            inv[j] = __builtin_amdgcn_rcpf(ss[j]);
+            ls[j] = logf(ss[j]);
+            en += entropy_const() + ls[j];  // distribution.py:211-213
         }
-        // the row's sums, chunk 0 first (the order of a sequential sum over the row): LPR neighbour shuffles
-        float logp = 0.0f, entropy = 0.0f;
+        entropy = 0.0f;  // the row's sum, chunk 0 first (the order of a sequential sum over the row)
 #pragma unroll
-        for (int j = 0; j < LPR; ++j) {
-            logp += __shfl(lp, row_lane0 + j, kWave);
-            entropy += __shfl(en, row_lane0 + j, kWave);
+        for (int j = 0; j < LPR; ++j) entropy += __shfl(en, int(row_lane0) + j, kWave);
+    };
+    if (kStdVec) prepare_std(sg[0]);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if (!kStdVec) prepare_std(sg[k]);
+        const float xs[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+        const float ms[4] = {mu[k].x, mu[k].y, mu[k].z, mu[k].w};
+        float z[4], zz[4], lp = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            z[j] = (xs[j] - ms[j]) * inv[j];
+            zz[j] = z[j] * z[j];
+            lp += (-0.5f * zz[j] - ls[j]) - log_sqrt_2pi();
         }
+        float logp = 0.0f;
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) logp += __shfl(lp, int(row_lane0) + j, kWave);
         // every lane of the row evaluates the scalar part; lane `sub == 0` owns the row's outputs and sums
-        const bool owner = ok[k] && sub == 0;
-        double sur = 0.0, ent = 0.0, abs_lr = 0.0;
-        float ratio, lr;
-        const float dlp = row_terms(logp, entropy, olp[k], adv[k], p, sur, ent, abs_lr, ratio, lr);
-        if (owner) {
-            acc[1] += sur, acc[2] += ent, acc[3] += abs_lr;
-            if (logp_out) logp_out[row[k]] = logp;
-            if (entropy_out) entropy_out[row[k]] = entropy;
-            if (lr_out) lr_out[row[k]] = lr;
-            if (ratio_out) ratio_out[row[k]] = ratio;
-            if (D == 1)
-                value_term(pre_cv[k], pre_ret[k], pre_ov[k], d_value ? d_value + row[k] : nullptr, p, acc[0], acc[4]);
-            else
-                value_terms(ret, curr_value, old_value, d_value, row[k], D, p, acc[0], acc[4]);
-        }
-        if (ok[k]) {
-            float gm[4], gs[4];
+        const RowScalars r = row_scalars(logp, olp[k], adv[k], p);
+        float v_loss = 0.0f, v_grad = 0.0f;
+        if (D == 1) value_scalars(pre_cv[k], pre_ret[k], pre_ov[k], p, v_loss, v_grad);
+        float gm[4], gs[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float diff = xs[j] - ms[j], var = ss[j] * ss[j];
-                gm[j] = dlp * (diff / var);                                                       // d logp / d mean
-                gs[j] = dlp * ((diff * diff) / (var * ss[j]) - 1.0f / ss[j]) + p.g_ent / ss[j];  // + d entropy / d std
-            }
-            const int64_t q = row[k] * LPR + sub;
-            if (d_mean) dm4[q] = make_float4(gm[0], gm[1], gm[2], gm[3]);
-            if (kStdVec)
-                ds_acc.x += gs[0], ds_acc.y += gs[1], ds_acc.z += gs[2], ds_acc.w += gs[3];
-            else if (d_std)
-                ds4[q] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+        for (int j = 0; j < 4; ++j) {
+            gm[j] = r.dlp * (z[j] * inv[j]);                       // d logp / d mean
+            gs[j] = inv[j] * (r.dlp * (zz[j] - 1.0f) + p.g_ent);  // d logp / d std + d entropy / d std
         }
+        const float own = (valid[k] && sub == 0) ? 1.0f : 0.0f, live = valid[k] ? 1.0f : 0.0f;
+        lane_sum[1] += own * r.min_term, lane_sum[2] += own * entropy, lane_sum[3] += own * r.abs_lr;
+        if (D == 1) lane_sum[0] += own * v_loss, lane_sum[4] += own * pre_cv[k];  // metric `value` = curr_value.sum(-1)
+        if (kStdVec) ds_acc.x += live * gs[0], ds_acc.y += live * gs[1], ds_acc.z += live * gs[2], ds_acc.w += live * gs[3];
+        if (valid[k]) {
+            if (kFull || dmb) dmb[lrow[k] * LPR + sub] = make_float4(gm[0], gm[1], gm[2], gm[3]);
+            if (!kStdVec && (kFull || dsb)) dsb[lrow[k] * LPR + sub] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+            if (sub == 0) {
+                if (kFull || lpo) lpo[lrow[k]] = logp;
+                if (kFull || eno) eno[lrow[k]] = entropy;
+                if (kFull || lro) lro[lrow[k]] = r.lr;
+                if (kFull || rao) rao[lrow[k]] = r.ratio;
+                if (D == 1 && (kFull || dvb)) dvb[lrow[k]] = v_grad;
+            }
+        }
+    }
+    double acc[kLossSums];
+#pragma unroll
+    for (int k = 0; k < kLossSums; ++k) acc[k] = double(lane_sum[k]);
+    if (D != 1) {  // several value channels (uniform, rare): the generic per-row walk, fp64 sums
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            if (valid[k] && sub == 0)
+                value_terms(ret, curr_value, old_value, d_value, block_row0 + lrow[k], D, p, acc[0], acc[4]);
     }
 
     if (kStdVec) {
@@ -543,17 +624,15 @@ extern "C" int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const 
     return launch_finalize(partials, blocks, B, A, D, p, losses_out, nullptr, nullptr, s);
 }
 
+#define CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, FULL)                                                                        \
+    hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, VEC, FULL>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, \
+                       old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out, entropy_out,      \
+                       logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials, int(defer))
 #define CUSRL_LAUNCH_ROWGROUP(LPR)                                                                                     \
-    if (std_vector)                                                                                                    \
-        hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, true>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s,          \
-                           advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out, \
-                           entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,   \
-                           int(defer));                                                                                \
-    else                                                                                                               \
-        hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, false>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s,         \
-                           advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out, \
-                           entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,   \
-                           int(defer))
+    if (std_vector && full) CUSRL_LAUNCH_ROWGROUP_AS(LPR, true, true);                                                 \
+    else if (std_vector) CUSRL_LAUNCH_ROWGROUP_AS(LPR, true, false);                                                   \
+    else if (full) CUSRL_LAUNCH_ROWGROUP_AS(LPR, false, true);                                                         \
+    else CUSRL_LAUNCH_ROWGROUP_AS(LPR, false, false)
 
 extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action,
                                       const float *mean, const float *std, const float *ret, const float *curr_value,
@@ -579,6 +658,8 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
     if (std_vector && !chunked) return CUSRL_E_UNSUPPORTED;  // the row-vector form exists for the 16-byte-chunk layout
     const int64_t blocks = ceil_div(B, chunked ? loss_rows_per_block(A) : kBlock);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    // the training step wants every output: that variant carries no per-store pointer tests
+    const bool full = logp_out && entropy_out && logp_ratio_out && ratio_out && d_mean && d_value && (std_vector || d_std);
     if (chunked) {
         switch (A / 4) {
             case 1: CUSRL_LAUNCH_ROWGROUP(1); break;

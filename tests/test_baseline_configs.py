@@ -109,7 +109,8 @@ def test_config1_mountain_car_update_replays_the_reference(cusrl, golden, mode, 
 
     def wrapped(metadata, batch):
         result = original(metadata, batch)
-        trace["objectives"].append(torch.stack([result["value_loss"], result["surrogate_loss"], result["entropy_loss"]]).detach())
+        if result["value_loss"] is not None:  # None while a step is being captured: deferred finalize (ops.DeferredLoss)
+            trace["objectives"].append(torch.stack([result["value_loss"], result["surrogate_loss"], result["entropy_loss"]]).detach())
         return result
 
     agent.hook.objective = wrapped
@@ -124,7 +125,9 @@ def test_config1_mountain_car_update_replays_the_reference(cusrl, golden, mode, 
     assert np.array_equal(host(torch.stack(trace["indices"])), g["indices"][steps]), "minibatch permutations differ"
     for key in ("next_value", "advantage", "return"):
         np.testing.assert_allclose(host(agent.buffer[key]), g[f"buffer_out/{key}"], rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(host(torch.stack(trace["objectives"])), g["objectives"][steps], rtol=2e-5, atol=1e-6)
+    seen = len(trace["objectives"])  # under compile=True: the eager warm-up epoch (captured steps defer their loss values)
+    assert seen == (16 if mode != "hipgraph" else 4)
+    np.testing.assert_allclose(host(torch.stack(trace["objectives"])), g["objectives"][steps[:seen]], rtol=2e-5, atol=1e-6)
     kept = [(row, steps.index(int(step))) for row, step in enumerate(g["kept_steps"]) if int(step) in steps]
     rows = [row for row, _ in kept]
     pick = lambda name: host(torch.stack([trace[name][i] for _, i in kept]))  # noqa: E731
