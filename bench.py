@@ -271,8 +271,8 @@ def run_gpu(args, rank, world):
             "bound": "hbm",
             "kernel": f"cusrl::gather_kernel — the minibatch gather of a captured train step (20 launches per iteration): "
                       f"{dominant['rows']} sampled slots x {dominant['leaves']} leaves the step reads ({', '.join(dominant['fields'])}; "
-                      f"{dominant['packed_leaves']} narrow ones through the packed per-slot record), {dominant['row_bytes']} B/slot "
-                      "read + written + 8 B index",
+                      f"{dominant['packed_leaves']} of them through the per-slot record — none while the sampled leaves fit L2 + "
+                      f"Infinity Cache, Buffer.record_threshold_bytes), {dominant['row_bytes']} B/slot read + written + 8 B index",
             "timing": "graph-timed: hipGraph of 10 identical launches x 20 replays between one HIP-event pair, right after "
                       "the timed region, on the graph's stream (the in-step launch cannot be bracketed from the host); "
                       "rocprofv3 per-grid averages of the same command: profiles/r02/",

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "cusrl_abi_version": (c_int, []),
     "cusrl_error_string": (c_char_p, [c_int]),
     "cusrl_buffer_push": (c_int, [POINTER(Field), c_int, c_int64, c_int64, _P]),
+    "cusrl_buffer_push_through": (c_int, [POINTER(Field), c_int, c_int64, c_int64, _P, c_int64, POINTER(ctypes.c_int32), _P]),
     "cusrl_next_value": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, c_int64, c_int64, c_int64, _P]),
     "cusrl_flag_blocks": (c_int64, [c_int64]),
     "cusrl_compact_flags": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P]),

@@ -18,6 +18,10 @@ struct PushLeaf {
     const char *src;
     char *dst;
     int64_t bytes;
+    // write-through into the per-slot record (cusrl_buffer_push_through): the step's row n additionally goes to
+    // dst2 + n * pitch2; nullptr = the leaf does not live in the record
+    char *dst2;
+    uint32_t row_bytes, pitch2;
 };
 
 struct PushTable {
@@ -53,6 +57,17 @@ __global__ __launch_bounds__(kBlock) void push_kernel(const PushTable tab) {
         if (p1) r1 = *reinterpret_cast<const uint4 *>(src + o1);
         if (p0) *reinterpret_cast<uint4 *>(dst + o0) = r0;
         if (p1) *reinterpret_cast<uint4 *>(dst + o1) = r1;
+        if (leaf.dst2) {  // uniform per block: the same 16 bytes, once more, at the row's place inside its record
+            const uint32_t rb = leaf.row_bytes;  // a multiple of 16, so a 16-byte lane-op never straddles two rows
+            if (p0) {
+                const uint32_t row = uint32_t(o0) / rb;
+                *reinterpret_cast<uint4 *>(leaf.dst2 + uint64_t(row) * leaf.pitch2 + (uint32_t(o0) - row * rb)) = r0;
+            }
+            if (p1) {
+                const uint32_t row = uint32_t(o1) / rb;
+                *reinterpret_cast<uint4 *>(leaf.dst2 + uint64_t(row) * leaf.pitch2 + (uint32_t(o1) - row * rb)) = r1;
+            }
+        }
     } else if ((align & 3) == 0) {
         for (int64_t o = begin + int64_t(threadIdx.x) * 4; o < end; o += int64_t(kBlock) * 4)
             *reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(src + o);
@@ -571,20 +586,35 @@ static int pick_unit(const void *a, const void *b, int64_t row_bytes) {
 
 using namespace cusrl;
 
-extern "C" int cusrl_buffer_push(const cusrl_field_t *fields, int n_fields, int64_t cursor, int64_t N, void *stream) {
+static int push_fields(const cusrl_field_t *fields, int n_fields, int64_t cursor, int64_t N, char *record,
+                       int64_t record_bytes, const int32_t *record_offset, void *stream) {
     if (n_fields == 0) return 0;
     if (!fields || n_fields < 0 || cursor < 0 || N < 0) return CUSRL_E_INVALID;
     if (n_fields > CUSRL_MAX_FIELDS) return CUSRL_E_TOO_MANY;
+    if (record_offset && (!record || record_bytes < 16 || record_bytes % 16 != 0 || record_bytes > CUSRL_MAX_RECORD_BYTES ||
+                          !aligned(record, 16)))
+        return CUSRL_E_INVALID;
     PushTable tab;
     int32_t blocks = 0;
     int n = 0;
     for (int i = 0; i < n_fields; ++i) {
         const int64_t bytes = N * fields[i].row_bytes;
         if (fields[i].row_bytes < 0 || (bytes > 0 && (!fields[i].src || !fields[i].dst))) return CUSRL_E_INVALID;
+        const int32_t offset = record_offset ? record_offset[i] : -1;
+        if (offset >= 0) {
+            // a leaf written through must take the 16-byte-lane path: whole 16-byte chunks at a 16-byte offset of the record
+            const int64_t rb = fields[i].row_bytes;
+            if (rb <= 0 || rb % 16 != 0 || offset % 16 != 0 || offset + rb > record_bytes) return CUSRL_E_INVALID;
+            if (!aligned(fields[i].src, 16) || !aligned(fields[i].dst, 16) || bytes > int64_t(UINT32_MAX))
+                return CUSRL_E_UNSUPPORTED;
+        }
         if (bytes == 0) continue;
         tab.leaf[n].src = static_cast<const char *>(fields[i].src);
         tab.leaf[n].dst = static_cast<char *>(fields[i].dst) + cursor * bytes;
         tab.leaf[n].bytes = bytes;
+        tab.leaf[n].dst2 = offset >= 0 ? record + cursor * N * record_bytes + offset : nullptr;
+        tab.leaf[n].row_bytes = uint32_t(fields[i].row_bytes);
+        tab.leaf[n].pitch2 = uint32_t(record_bytes);
         tab.block_start[n] = blocks;
         const int64_t nb = ceil_div(bytes, kPushBlockBytes);
         if (nb + blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
@@ -596,6 +626,17 @@ extern "C" int cusrl_buffer_push(const cusrl_field_t *fields, int n_fields, int6
     tab.n = n;
     hipLaunchKernelGGL(push_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream), tab);
     return launch_status();
+}
+
+extern "C" int cusrl_buffer_push(const cusrl_field_t *fields, int n_fields, int64_t cursor, int64_t N, void *stream) {
+    return push_fields(fields, n_fields, cursor, N, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int cusrl_buffer_push_through(const cusrl_field_t *fields, int n_fields, int64_t cursor, int64_t N,
+                                         void *record, int64_t record_bytes, const int32_t *record_offset,
+                                         void *stream) {
+    if (!record_offset) return CUSRL_E_INVALID;
+    return push_fields(fields, n_fields, cursor, N, static_cast<char *>(record), record_bytes, record_offset, stream);
 }
 
 // Splits the packed-field list into (a) narrow entries (1 / 2 / 4 / 8 bytes) for the record kernels' RecordTable and

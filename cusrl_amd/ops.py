@@ -173,14 +173,24 @@ def make_push_table(leaves: Sequence[tuple[torch.Tensor, tuple]]):
     return table
 
 
-def push_table(table, count: int, cursor: int, parallelism: int) -> None:
-    """Launch ``cusrl_buffer_push`` on a table whose ``src`` pointers were just filled."""
+def push_table(table, count: int, cursor: int, parallelism: int, through: tuple | None = None) -> None:
+    """Launch ``cusrl_buffer_push`` on a table whose ``src`` pointers were just filled.  ``through`` =
+    ``(record tensor, record_bytes, int32 offsets array)``: the leaves with an offset >= 0 are also written into the
+    per-slot record from the same registers (``cusrl_buffer_push_through``)."""
     lib = _native.lib()
     stream = _stream()
+    if through is None:
+        _observed(
+            "cusrl_buffer_push",
+            lambda: sum(2 * parallelism * table[i].row_bytes for i in range(count)),
+            lambda: lib.cusrl_buffer_push(table, count, cursor, parallelism, stream),
+        )
+        return
+    record, record_bytes, offsets = through
     _observed(
-        "cusrl_buffer_push",
-        lambda: sum(2 * parallelism * table[i].row_bytes for i in range(count)),
-        lambda: lib.cusrl_buffer_push(table, count, cursor, parallelism, stream),
+        "cusrl_buffer_push_through",
+        lambda: sum((2 + (offsets[i] >= 0)) * parallelism * table[i].row_bytes for i in range(count)),
+        lambda: lib.cusrl_buffer_push_through(table, count, cursor, parallelism, record.data_ptr(), record_bytes, offsets, stream),
     )
 
 
@@ -325,13 +335,40 @@ class RecordPack:
         for slot, (name, storage) in zip(self._table, self.leaves.items()):
             slot.ptr, slot.offset, slot.width = storage.data_ptr(), self.offsets[name], _row_bytes(storage, 2)
 
-    def build(self) -> None:
+    def build(self, names: Sequence[str] | None = None) -> None:
+        """(Re)write the record from the leaves — all of them, or only ``names`` (the leaves that changed since the
+        record last held them: the other bytes of every record stay as they are)."""
+        if names is None:
+            table, count, moved = self._table, len(self.leaves), self.used_bytes
+        else:
+            chosen = [name for name in self.leaves if name in set(names)]
+            if not chosen:
+                return
+            table = (PackedField * len(chosen))()
+            for slot, name in zip(table, chosen):
+                storage = self.leaves[name]
+                slot.ptr, slot.offset, slot.width = storage.data_ptr(), self.offsets[name], _row_bytes(storage, 2)
+            count, moved = len(chosen), sum(_row_bytes(self.leaves[name], 2) for name in chosen)
         _observed(
             "cusrl_pack_rows",
-            lambda: self.rows * (self.used_bytes + self.record_bytes),
-            lambda: _native.lib().cusrl_pack_rows(self._table, len(self.leaves), self.record.data_ptr(), self.record_bytes,
-                                                  self.rows, _stream()),
+            lambda: self.rows * 2 * moved,
+            lambda: _native.lib().cusrl_pack_rows(table, count, self.record.data_ptr(), self.record_bytes, self.rows, _stream()),
         )
+
+    def through_offsets(self, leaves: Sequence[str]):
+        """int32 array for ``cusrl_buffer_push_through``: the record offset of every pushed leaf that can be written
+        through (a wide leaf of this record: whole 16-byte chunks), -1 for the others; None when there is none."""
+        import ctypes
+
+        offsets = (ctypes.c_int32 * max(len(leaves), 1))()
+        any_through = False
+        for i, name in enumerate(leaves):
+            storage = self.leaves.get(name)
+            wide = (storage is not None and _row_bytes(storage, 2) % 16 == 0 and storage.data_ptr() % 16 == 0
+                    and storage.shape[1] * _row_bytes(storage, 2) < 2**32)
+            offsets[i] = self.offsets[name] if wide else -1
+            any_through |= wide
+        return offsets if any_through else None
 
 
 def gather_rows_packed(
@@ -463,6 +500,7 @@ def assign_rows(dst: torch.Tensor, indices: torch.Tensor, src: torch.Tensor) -> 
         _native.lib().cusrl_scatter_rows(src.data_ptr(), indices.data_ptr(), dst.data_ptr(), K, _row_bytes(src, 1), None, _stream()),
         "cusrl_scatter_rows",
     )
+    _modified_in_place(dst)
 
 
 class HostCounter:
@@ -516,6 +554,7 @@ def scatter_rows(src: torch.Tensor, indices: torch.Tensor, dst: torch.Tensor, co
                                          None if count is None else count.data_ptr(), _stream()),
         "cusrl_scatter_rows",
     )
+    _modified_in_place(dst)
 
 
 # ------------------------------------------------------------------------------------------------ a4
@@ -586,6 +625,12 @@ def adv_stats_finalize(partials: torch.Tensor, count: int) -> tuple[torch.Tensor
     return var, mean
 
 
+def _modified_in_place(tensor: torch.Tensor) -> None:
+    """Tell torch that a raw kernel wrote into ``tensor``: bumps the version counter every alias shares — what
+    ``Buffer`` compares to know whether the per-slot record still mirrors a leaf (and what autograd checks)."""
+    torch.autograd.graph.increment_version(tensor)
+
+
 def normalize_(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
     """``x.sub_(mean).div_((var + eps).sqrt())`` in place (advantage.py:114-115)."""
     require_device(x, "x")
@@ -598,6 +643,7 @@ def normalize_(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, eps: floa
         lambda: x.numel() * 8,
         lambda: _native.lib().cusrl_normalize(x.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, x.numel() // max(D, 1), D, _stream()),
     )
+    _modified_in_place(x)
     return x
 
 
@@ -617,6 +663,7 @@ def normalize_from_partials_(x: torch.Tensor, partials: torch.Tensor, count: int
         lambda: _native.lib().cusrl_normalize_from_partials(x.data_ptr(), partials.data_ptr(), P, count, eps, x.numel() // max(D, 1), D,
                                                             mean.data_ptr(), var.data_ptr(), _stream()),
     )
+    _modified_in_place(x)
     return var, mean
 
 
@@ -1254,6 +1301,7 @@ def rnd_reward_(reward: torch.Tensor, target: torch.Tensor, prediction: torch.Te
     bonus = torch.empty_like(reward)
     check(_native.lib().cusrl_rnd_reward(target.data_ptr(), prediction.data_ptr(), reward.data_ptr(), bonus.data_ptr(),
                                          float(scale), rows, K, _stream()), "cusrl_rnd_reward")
+    _modified_in_place(reward)
     return bonus
 
 
@@ -1267,4 +1315,5 @@ def amp_style_reward_(reward: torch.Tensor, logit: torch.Tensor, scale: float) -
     bonus = torch.empty_like(reward)
     check(_native.lib().cusrl_amp_style_reward(logit.data_ptr(), reward.data_ptr(), bonus.data_ptr(), float(scale),
                                                logit.numel(), _stream()), "cusrl_amp_style_reward")
+    _modified_in_place(reward)
     return bonus

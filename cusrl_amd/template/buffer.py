@@ -15,6 +15,7 @@ env axis is unit-stride for C = 1 leaves (reward, value, flags) and rows are C*4
 
 from __future__ import annotations
 
+import os
 from collections.abc import Callable, Iterator, Mapping, MutableMapping, Sequence
 from typing import Any
 
@@ -183,18 +184,29 @@ class Buffer(MutableMapping):
         # {sum, sumsq} partials the GAE kernel emits for the normalisation hook)
         self._derived: dict[str, Any] = {}
         self._push_plan = None
-        # narrow leaves interleaved into one record per slot for the minibatch gather (ops.RecordPack); rebuilt by
-        # prepare_sampling() after anything could have written to a packed leaf
+        # Leaves interleaved into one record per slot for the minibatch gather (ops.RecordPack), kept coherent LEAF BY LEAF:
+        # `_record_clean[leaf]` is the leaf tensor's version counter at the moment the record mirrored it.  Any in-place
+        # edit through torch — by whoever holds an alias handed out by `buffer[key]`, like the reference allows
+        # (buffer.py:119-122) — bumps that counter; this package's raw kernels either go through `field()` / `push()`
+        # (which drop the entry) or bump the counter themselves (ops._modified_in_place).  `prepare_sampling()` re-packs
+        # exactly the stale leaves, `gather()` reads a leaf through the record only while it is provably current.
         self.pack_narrow_leaves = True
         self.pack_hot_fields = True
+        # the record pays when sampled rows miss the caches (a random row costs whole 128-byte lines out of HBM); while the
+        # packed leaves fit L2 + Infinity Cache the plain per-leaf gather is faster and needs no pack launch at all
+        # (config 2: 25 MB, 5.5 vs 6.7 us per minibatch; measured break-even between 64 and 256 MB)
+        self.record_threshold_bytes = int(os.environ.get("CUSRL_RECORD_THRESHOLD_BYTES", 128 << 20))
         self._pack = None
         self._pack_hot = None
         self._hot_fields: set[str] = set()
         self._hot_dirty = False
-        self._pack_valid = False
+        self._record_clean: dict[str, int] = {}
+        self._through = None  # (pack, storage layout) -> write-through arguments of the steady-state push
         # bumped whenever a storage tensor or the packed record is (re)allocated: captured hipGraphs bake those
         # addresses in and compare this number before replaying (template/graphs.py)
         self.layout_version = 0
+        self._storage_epoch = 0
+        self._pack_key = None
 
     # ------------------------------------------------------------------ bookkeeping
     def get_parallelism(self) -> int:
@@ -208,9 +220,10 @@ class Buffer(MutableMapping):
         self._derived.clear()
         self._push_plan = None
         self._pack = None
-        self._pack_valid = False
+        self._record_clean.clear()
+        self._through = None
         self._hot_dirty = bool(self._hot_fields)  # the field names stay known; their leaves are re-resolved
-        self.layout_version += 1
+        self._storage_changed()
 
     def reset_cursor(self):
         self.cursor = 0
@@ -231,17 +244,23 @@ class Buffer(MutableMapping):
         return key in self.schema
 
     def __getitem__(self, key):
-        # hands out the storage tensors themselves: in-place edits by hooks are visible (advantage.py:102)
+        # hands out the storage tensors themselves: in-place edits by hooks are visible (advantage.py:102) — also to the
+        # per-slot record, through the tensors' version counters (no matter when the edit happens)
         self._derived.pop(key, None)
-        self._pack_valid = False
         return reconstruct_nested(self.storage, self.schema[key])
 
     def get(self, key, default=None):
         if (schema := self.schema.get(key)) is None:
             return default
         self._derived.pop(key, None)
-        self._pack_valid = False
         return reconstruct_nested(self.storage, schema)
+
+    def _touch(self, name: str):
+        """A writer that torch's version counters cannot see (a raw kernel) is about to write field ``name``."""
+        schema = self.schema.get(name)
+        if schema is not None and self._record_clean:
+            for _, key in iterate_nested(schema):
+                self._record_clean.pop(key, None)
 
     def __setitem__(self, name, data):
         """Register or overwrite a whole field; every leaf must be ``[capacity, parallelism, ...]``."""
@@ -249,14 +268,14 @@ class Buffer(MutableMapping):
             return
         self._check_schema(name, data)
         self._derived.pop(name, None)
-        self._pack_valid = False
+        self._touch(name)
         for key, value in iterate_nested(data, name):
             value = self._as_tensor(value)
             self._validate_field_shape(key, value.shape)
             storage = self.storage.get(key)
             if storage is None:
                 storage = self.storage[key] = torch.zeros_like(value, device=self.device)
-                self.layout_version += 1
+                self._storage_changed()
             if storage.data_ptr() != value.data_ptr():
                 storage.copy_(value)
 
@@ -268,8 +287,9 @@ class Buffer(MutableMapping):
         del self.schema[name]
         self._derived.pop(name, None)
         self._pack = None
-        self._pack_valid = False
-        self.layout_version += 1
+        self._record_clean.clear()
+        self._through = None
+        self._storage_changed()
 
     # ------------------------------------------------------------------ extensions used by the HIP hooks
     def field(self, name: str, like: torch.Tensor) -> torch.Tensor:
@@ -280,9 +300,9 @@ class Buffer(MutableMapping):
             self._validate_field_shape(name, like.shape)
             storage = self.storage[name] = torch.empty_like(like, device=self.device)
             self.schema[name] = name
-            self.layout_version += 1
+            self._storage_changed()
         self._derived.pop(name, None)
-        self._pack_valid = False
+        self._record_clean.pop(name, None)
         return storage
 
     def set_derived(self, name: str, value: Any):
@@ -307,13 +327,14 @@ class Buffer(MutableMapping):
                 continue
             self._check_schema(name, nested_value)
             self._derived.pop(name, None)
+            self._touch(name)
             for key, value in iterate_nested(nested_value, name):
                 value = self._as_tensor(value)
                 storage = self.storage.get(key)
                 if storage is None:
                     self._validate_step_shape(key, value.shape)
                     storage = self.storage[key] = value.new_zeros(self.capacity, *value.shape)
-                    self.layout_version += 1
+                    self._storage_changed()
                 elif value.shape != storage.shape[1:]:
                     raise ValueError(
                         f"Shape mismatch for field '{key}': expected {tuple(storage.shape[1:])}, got {tuple(value.shape)}"
@@ -330,7 +351,6 @@ class Buffer(MutableMapping):
         self._build_push_plan(data)
 
     def _advance(self):
-        self._pack_valid = False
         self.cursor += 1
         if self.cursor == self.capacity:
             self.full = True
@@ -342,7 +362,7 @@ class Buffer(MutableMapping):
         self._push_plan = None
         if len(self.storage) > _native_max_fields():
             return
-        names, absent, nested_sizes, specs, storages = [], [], [], [], []
+        names, absent, nested_sizes, specs, storages, keys = [], [], [], [], [], []
         for name, nested_value in data.items():
             names.append(name)
             if nested_value is None:
@@ -356,16 +376,19 @@ class Buffer(MutableMapping):
                 path = tuple(int(part) if part.isdigit() else part for part in key.split(".")[1:])
                 specs.append((name, path, value.shape, value.dtype))
                 storages.append((self.storage[key], value.shape))
+                keys.append(key)
         table = ops.make_push_table(storages)
         fields = [table[i] for i in range(len(specs))]  # ctypes views of the array slots: `.src` writes go straight in
         leaves = tuple((name, path, shape, dtype, field) for (name, path, shape, dtype), field in zip(specs, fields))
-        self._push_plan = (tuple(names), tuple(absent), tuple(nested_sizes), leaves, table, tuple(self.storage.items()))
+        self._push_plan = (tuple(names), tuple(absent), tuple(nested_sizes), leaves, table, tuple(self.storage.items()),
+                           tuple(keys))
+        self._through = None
 
     def _fast_push(self, data: Mapping[str, Any]) -> bool:
         plan = getattr(self, "_push_plan", None)
         if plan is None:
             return False
-        names, absent, nested_sizes, leaves, table, storage_refs = plan
+        names, absent, nested_sizes, leaves, table, storage_refs, keys = plan
         if tuple(data) != names:
             return False
         for name in absent:
@@ -393,9 +416,28 @@ class Buffer(MutableMapping):
         if self._derived:
             for name in names:
                 self._derived.pop(name, None)
-        ops.push_table(table, len(leaves), self.cursor, self.parallelism)
+        ops.push_table(table, len(leaves), self.cursor, self.parallelism, self._push_through(keys))
         self._advance()
         return True
+
+    def _push_through(self, keys):
+        """Write-through arguments of the steady-state push and the record bookkeeping of one push: the wide leaves of
+        the current record are stored into it by the push kernel itself (they stay current — the pack at update time then
+        only moves the narrow leaves); every other pushed leaf stops being mirrored."""
+        pack, clean = self._pack, self._record_clean
+        if pack is None:
+            return None
+        cached = self._through
+        if cached is None or cached[0] is not pack or cached[1] is not keys:
+            offsets = pack.through_offsets(keys)
+            kept = frozenset(key for key, offset in zip(keys, offsets) if offset >= 0) if offsets is not None else frozenset()
+            cached = self._through = (pack, keys, None if offsets is None else (pack.record, pack.record_bytes, offsets), kept)
+        if clean:
+            kept = cached[3]
+            for key in keys:
+                if key not in kept:
+                    clean.pop(key, None)
+        return cached[2]
 
     def replay_push(self):
         """Host bookkeeping of a steady-state :meth:`push` whose launch was replayed from a hipGraph (the cursor the
@@ -406,12 +448,12 @@ class Buffer(MutableMapping):
         if self._derived:
             for name in plan[0]:
                 self._derived.pop(name, None)
+        self._push_through(plan[6])  # the same record bookkeeping as the push that was captured
         self._advance()
 
     # ------------------------------------------------------------------ a7/a8: sampling
     def sample(self, sampler: Callable[[str, torch.Tensor], torch.Tensor]) -> dict[str, Any]:
         """Generic per-leaf callback form of the reference (buffer.py:153-162)."""
-        self._pack_valid = False  # the callback sees (and may keep or edit) the storage tensors themselves
         batch = {key: sampler(key, tensor) for key, tensor in self.storage.items()}
         return reconstruct_nested(batch, self.schema)
 
@@ -435,22 +477,49 @@ class Buffer(MutableMapping):
                 hot = tuple(key for name in self.schema if name in self._hot_fields for _, key in iterate_nested(self.schema[name]))
             if hot != self._pack_hot:
                 self._pack_hot = hot
-                self._pack_valid = False
-        if self._pack_valid:
-            return
+                self._record_clean.clear()
         if not self.pack_narrow_leaves or self.device.type != "cuda":
             self._pack = None
             return
-        names = ops.RecordPack.plan(self.storage, self._pack_hot)
-        if not names:
-            self._pack = None
+        pack = self._pack
+        key = self._pack_plan_key()
+        if key != self._pack_key:  # leaves were (re)allocated or the plan changed: plan again
+            self._pack_key = key
+            names = ops.RecordPack.plan(self.storage, self._pack_hot)
+            packed_bytes = sum(ops._row_bytes(self.storage[name], 2) for name in names) * self.capacity * self.parallelism
+            if not names or packed_bytes < self.record_threshold_bytes:
+                if pack is not None:
+                    self.layout_version += 1
+                self._pack = None
+                self._record_clean.clear()
+                return
+            wanted = tuple((name, self.storage[name].data_ptr(), ops._row_bytes(self.storage[name], 2)) for name in names)
+            if pack is None or set(pack.key) != set(wanted):
+                pack = self._pack = ops.RecordPack({name: self.storage[name] for name in names})
+                self._record_clean.clear()
+                self._through = None
+                self.layout_version += 1
+        if pack is None:
             return
-        key = tuple((name, self.storage[name].data_ptr(), ops._row_bytes(self.storage[name], 2)) for name in names)
-        if self._pack is None or set(self._pack.key) != set(key):
-            self._pack = ops.RecordPack({name: self.storage[name] for name in names})
-            self.layout_version += 1
-        self._pack.build()
-        self._pack_valid = True
+        clean, storage = self._record_clean, self.storage
+        stale = [name for name in pack.leaves if clean.get(name) != storage[name]._version]
+        if stale:
+            pack.build(None if len(stale) == len(pack.leaves) else stale)
+            for name in stale:
+                clean[name] = storage[name]._version
+
+    def _pack_plan_key(self):
+        return (self._pack_hot, self.record_threshold_bytes, self._storage_epoch)
+
+    def _storage_changed(self):
+        """A storage tensor was allocated or dropped: captured graphs bake addresses (layout_version), the record plan
+        depends on the set of leaves (_storage_epoch)."""
+        self.layout_version += 1
+        self._storage_epoch += 1
+
+    def _mirrored(self, pack, key: str) -> bool:
+        """Does the record hold leaf ``key`` as it is right now?"""
+        return key in pack.offsets and self._record_clean.get(key) == self.storage[key]._version
 
     def gather(self, indices: torch.Tensor, temporal: bool = False, fields: Sequence[str] | None = None,
                lead_shape: tuple[int, ...] | None = None) -> dict[str, Any]:
@@ -463,8 +532,8 @@ class Buffer(MutableMapping):
         else:
             schema = {name: self.schema[name] for name in fields}
             keys = [key for name in fields for _, key in iterate_nested(self.schema[name])]
-        pack = self._pack if (self._pack_valid and self._pack is not None) else None
-        packed = [key for key in keys if pack is not None and key in pack.offsets]
+        pack = self._pack
+        packed = [key for key in keys if pack is not None and self._mirrored(pack, key)]
         plain = [key for key in keys if key not in packed] if packed else keys
         if packed and len(plain) <= _native_max_fields():
             outputs, packed_outputs = ops.gather_rows_packed(

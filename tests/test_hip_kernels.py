@@ -239,6 +239,8 @@ def test_buffer_gathers_through_the_record_and_lazily(ops):
 
     T, N = 6, 32
     buffer = Buffer(T, N, device=DEV)
+    assert buffer.record_threshold_bytes == 128 << 20
+    buffer.record_threshold_bytes = 0  # this tiny buffer would gather plainly: force the record
     torch.manual_seed(3)
     for _ in range(T):
         buffer.push({"observation": torch.randn(N, 48, device=DEV), "action_dist": {"mean": torch.randn(N, 12, device=DEV),
@@ -276,6 +278,103 @@ def test_buffer_gathers_through_the_record_and_lazily(ops):
     perm = torch.randperm(T * N, device=DEV)
     assert type(full) is dict and torch.equal(full["action_dist"]["std"], buffer["action_dist"]["std"].flatten(0, 1)[perm])
     assert torch.equal(full["done"], buffer["done"].flatten(0, 1)[perm])
+
+
+def _filled_buffer(T, N, threshold=0):
+    from cusrl_amd.template.buffer import Buffer
+
+    buffer = Buffer(T, N, device=DEV)
+    buffer.record_threshold_bytes = threshold
+    torch.manual_seed(5)
+    for _ in range(T):
+        buffer.push(_step(N))
+    return buffer
+
+
+def _step(N):
+    return {"observation": torch.randn(N, 48, device=DEV), "action": torch.randn(N, 12, device=DEV),
+            "action_logp": torch.randn(N, 1, device=DEV), "reward": torch.randn(N, 1, device=DEV),
+            "done": torch.rand(N, 1, device=DEV) < 0.2}
+
+
+def test_push_writes_the_wide_leaves_through_into_the_record(ops):
+    """Once the record's layout is known, ``push`` stores the wide leaves (observation 192 B, action 48 B) into their record
+    slots from the registers that already hold them (cusrl_buffer_push_through): after a full rollout the record mirrors them
+    without any pack, ``prepare_sampling`` only moves the narrow leaves, and the gather returns exactly the leaves' rows."""
+    from cusrl_amd import _native
+
+    T, N = 8, 256
+    buffer = _filled_buffer(T, N)
+    buffer["advantage"] = torch.randn(T, N, 1, device=DEV)
+    for _ in range(T):  # (a new field re-plans the steady-state append once)
+        buffer.push(_step(N))
+    hot = {"observation", "action", "action_logp", "advantage", "done"}
+    buffer.prepare_sampling(hot)
+    pack = buffer._pack
+    assert pack is not None and set(pack.leaves) == hot and pack.record_bytes == 256
+    counts, observer = _native.launch_counts, ops.LaunchObserver(only={"cusrl_pack_rows"})
+    through_before, plain_before = counts.get("cusrl_buffer_push_through", 0), counts.get("cusrl_buffer_push", 0)
+    for _ in range(T):  # the next rollout overwrites every row
+        buffer.push(_step(N))
+    assert counts["cusrl_buffer_push_through"] - through_before == T and counts.get("cusrl_buffer_push", 0) == plain_before
+    # the wide leaves are still mirrored, the pushed narrow ones are not; `advantage` was not pushed at all
+    assert buffer._mirrored(pack, "observation") and buffer._mirrored(pack, "action") and buffer._mirrored(pack, "advantage")
+    assert not buffer._mirrored(pack, "action_logp") and not buffer._mirrored(pack, "done")
+    record = pack.record.view(T * N, 256)
+    assert torch.equal(record[:, :192].contiguous().view(torch.float32).view(T, N, 48), buffer.storage["observation"])
+    assert torch.equal(record[:, 192:240].contiguous().view(torch.float32).view(T, N, 12), buffer.storage["action"])
+    ops.set_launch_observer(observer)
+    try:
+        buffer.prepare_sampling(hot)
+    finally:
+        ops.set_launch_observer(None)
+    (_, _, moved), = observer.records["cusrl_pack_rows"]
+    assert moved == T * N * 2 * (4 + 1)  # action_logp + done only: 5 of the 253 bytes per slot, read + written
+    assert buffer._pack is pack and all(buffer._mirrored(pack, key) for key in hot)
+    indices = torch.randperm(T * N, device=DEV)[: T * N // 2]
+    packed_before = counts.get("cusrl_gather_rows_packed", 0)
+    batch = buffer.gather(indices, fields=sorted(hot))
+    assert counts["cusrl_gather_rows_packed"] == packed_before + 1
+    for key in hot:
+        assert torch.equal(batch[key], buffer.storage[key].flatten(0, 1)[indices]), key
+
+
+def test_an_alias_edited_after_the_pack_is_never_read_stale(ops):
+    """``buffer[key]`` hands out the storage tensor itself (buffer.py:119-122); a hook may keep it and edit it whenever it
+    likes.  The record notices through the tensor's version counter: the next gather reads that leaf from its storage,
+    the next ``prepare_sampling`` re-packs exactly that leaf."""
+    from cusrl_amd import _native
+
+    T, N = 4, 128
+    buffer = _filled_buffer(T, N)
+    hot = {"observation", "action_logp", "reward", "done"}
+    buffer.prepare_sampling(hot)
+    pack = buffer._pack
+    kept = buffer["reward"]  # an alias taken BEFORE ...
+    buffer.prepare_sampling(hot)
+    assert all(buffer._mirrored(pack, key) for key in hot)  # ... reading is not a write
+    kept.mul_(3.0)  # ... and edited AFTER the record was built
+    assert not buffer._mirrored(pack, "reward") and buffer._mirrored(pack, "observation")
+    indices = torch.randperm(T * N, device=DEV)
+    batch = buffer.gather(indices, fields=sorted(hot))
+    assert torch.equal(batch["reward"], buffer.storage["reward"].flatten(0, 1)[indices])  # the edited values
+    observer = ops.LaunchObserver(only={"cusrl_pack_rows"})
+    ops.set_launch_observer(observer)
+    try:
+        buffer.prepare_sampling(hot)
+    finally:
+        ops.set_launch_observer(None)
+    (_, _, moved), = observer.records["cusrl_pack_rows"]
+    assert moved == T * N * 2 * 4 and buffer._mirrored(pack, "reward")  # the one stale leaf, nothing else
+    # this package's own in-place kernels announce themselves the same way
+    ops.normalize_(buffer["reward"], torch.zeros(1, device=DEV), torch.ones(1, device=DEV))
+    assert not buffer._mirrored(pack, "reward")
+    # ... and a buffer small enough for the caches does not build a record at all
+    small = _filled_buffer(T, N, threshold=128 << 20)
+    small.prepare_sampling(hot)
+    before = _native.launch_counts.get("cusrl_gather_rows", 0)
+    small.gather(indices, fields=sorted(hot))
+    assert small._pack is None and _native.launch_counts["cusrl_gather_rows"] == before + 1
 
 
 # ------------------------------------------------------------------------------------------------ a3 next_value
