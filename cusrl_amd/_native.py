@@ -50,6 +50,7 @@ _SIGNATURES = {
     "cusrl_flag_blocks": (c_int64, [c_int64]),
     "cusrl_compact_flags": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P]),
     "cusrl_scatter_rows": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
+    "cusrl_splice_rows": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, _P]),
     "cusrl_gae": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_double, c_double, c_double, _P]),
     "cusrl_gae_num_partials": (c_int64, [c_int64, c_int64, c_int64]),
     "cusrl_col_stats": (c_int, [_P, c_int64, c_int64, _P, _P]),
@@ -71,7 +72,7 @@ _SIGNATURES = {
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
     "cusrl_ppo_loss_std_partial_rows": (c_int64, [c_int64]),
     "cusrl_ppo_loss_blocks": (c_int64, [c_int64, c_int64]),
-    "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
+    "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, c_int64, _P, _P]),
     "cusrl_categorical_sample_logp": (c_int, [_P] * 4 + [c_int64, c_int64, _P]),
     "cusrl_gru_gates_fwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, _P]),
     "cusrl_gru_gates_bwd": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P]),

@@ -563,6 +563,46 @@ __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(const char *__rest
         *reinterpret_cast<V *>(dst + dst_row[it] * row_bytes + col[it] * int64_t(sizeof(V))) = regs[it];
 }
 
+// The act input of the next env step in ONE pass (cusrl/template/environment.py:365-379 `update_observation_and_state`
+// + the copy into the act step's static input): dst[n] = src[n] for every env that did not finish, and
+// dst[indices[k]] = init[k] for k < *count — the finished envs, in the order the step epilogue listed them.  `done` and
+// (indices, count) describe the same set (cusrl_step_epilogue writes both), so every destination row has one writer.
+template <typename V>
+__global__ __launch_bounds__(kBlock) void splice_rows_kernel(const char *__restrict__ src, const char *__restrict__ init,
+                                                             const int64_t *__restrict__ indices,
+                                                             const int32_t *__restrict__ count_dev,
+                                                             const uint8_t *__restrict__ done, char *__restrict__ dst,
+                                                             int64_t N, int lpr, int64_t row_bytes) {
+    const int64_t ops = N * lpr;
+    const int64_t resets = min(N, int64_t(*count_dev)) * lpr;
+    const int64_t op0 = int64_t(blockIdx.x) * kGatherOpsPerBlock + threadIdx.x;
+    int64_t row[kGatherItems], col[kGatherItems];
+    V kept[kGatherItems], fresh[kGatherItems];
+    int64_t target[kGatherItems];
+    bool finished[kGatherItems];
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it) {
+        const int64_t op = min(op0 + int64_t(it) * kBlock, ops - 1);  // clamped, unpredicated loads (see gather_unit)
+        row[it] = lpr == 1 ? op : op / lpr;
+        col[it] = op - row[it] * lpr;
+    }
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it) {
+        finished[it] = done[row[it]] != 0;
+        target[it] = indices[row[it]];  // only meaningful below `resets`; the index buffer always holds valid env ids
+        kept[it] = *reinterpret_cast<const V *>(src + row[it] * row_bytes + col[it] * int64_t(sizeof(V)));
+        fresh[it] = *reinterpret_cast<const V *>(init + row[it] * row_bytes + col[it] * int64_t(sizeof(V)));
+    }
+#pragma unroll
+    for (int it = 0; it < kGatherItems; ++it) {
+        const int64_t op = op0 + int64_t(it) * kBlock;
+        if (op < ops && !finished[it])
+            *reinterpret_cast<V *>(dst + row[it] * row_bytes + col[it] * int64_t(sizeof(V))) = kept[it];
+        if (op < resets)
+            *reinterpret_cast<V *>(dst + target[it] * row_bytes + col[it] * int64_t(sizeof(V))) = fresh[it];
+    }
+}
+
 // Flat slot list of random temporal windows (cusrl/sampler/random_sampler.py:95-109): window b covers `L` consecutive
 // steps of env[b] from logical step start[b]; logical time 0 is physical row `cursor` once the ring is full.
 // out[t * B + b] = ((cursor + start[b] + t) % T) * N + env[b].
@@ -852,6 +892,34 @@ extern "C" int cusrl_compact_flags(const uint8_t *flags, int64_t n, int32_t *blo
 #define CUSRL_LAUNCH_SCATTER(V)                                                                                      \
     hipLaunchKernelGGL(scatter_rows_kernel<V>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream),           \
                        static_cast<const char *>(src), indices, static_cast<char *>(dst), K, lpr, row_bytes, count_dev)
+
+#define CUSRL_LAUNCH_SPLICE(V)                                                                                       \
+    hipLaunchKernelGGL(splice_rows_kernel<V>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream),           \
+                       static_cast<const char *>(src), static_cast<const char *>(init), indices, count_dev, done,    \
+                       static_cast<char *>(dst), N, lpr, row_bytes)
+
+extern "C" int cusrl_splice_rows(const void *src, const void *init, const int64_t *indices, const int32_t *count_dev,
+                                 const uint8_t *done, void *dst, int64_t N, int64_t row_bytes, void *stream) {
+    if (N == 0 || row_bytes == 0) return 0;
+    if (!src || !init || !indices || !count_dev || !done || !dst || N < 0 || row_bytes < 0) return CUSRL_E_INVALID;
+    int unit = 1;
+    for (int u : {16, 8, 4, 2})
+        if (row_bytes % u == 0 && aligned(src, u) && aligned(init, u) && aligned(dst, u)) {
+            unit = u;
+            break;
+        }
+    const int lpr = int(row_bytes / unit);
+    const int64_t blocks = ceil_div(N * lpr, kGatherOpsPerBlock);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    switch (unit) {
+        case 16: CUSRL_LAUNCH_SPLICE(uint4); break;
+        case 8: CUSRL_LAUNCH_SPLICE(uint2); break;
+        case 4: CUSRL_LAUNCH_SPLICE(uint32_t); break;
+        case 2: CUSRL_LAUNCH_SPLICE(uint16_t); break;
+        default: CUSRL_LAUNCH_SPLICE(uint8_t); break;
+    }
+    return launch_status();
+}
 
 extern "C" int cusrl_scatter_rows(const void *src, const int64_t *indices, void *dst, int64_t K, int64_t row_bytes,
                                   const int32_t *count_dev, void *stream) {

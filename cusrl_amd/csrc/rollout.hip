@@ -8,22 +8,29 @@ __device__ __forceinline__ float log_sqrt_2pi_r() { return 0.9189385332046727417
 
 // One lane per row for any A; rows are short (A = 12 -> 48 B) and the batch is one env step (N rows), so this is
 // latency-bound, not bandwidth-bound.  A % 4 == 0 rows are read as 16 B chunks.
+// `std_rows` = 1: std is the [A] vector a state-independent std repeats for every row (distribution.py:228-247); the kernel
+// broadcasts it and, with `std_out`, also writes the repeated [B, A] matrix the rollout buffer stores as a leaf — the
+// `repeat` launch of the acting path folded into this one.
 template <bool kVec4>
 __global__ __launch_bounds__(kBlock) void normal_sample_logp_kernel(const float *__restrict__ mean,
                                                                     const float *__restrict__ std,
                                                                     const float *__restrict__ eps,
                                                                     float *__restrict__ action,
-                                                                    float *__restrict__ logp, int64_t B, int A) {
+                                                                    float *__restrict__ logp, int64_t B, int A,
+                                                                    int std_is_vector, float *__restrict__ std_out) {
     const int64_t row = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (row >= B) return;
     float lp = 0.0f;
+    const int64_t std_row = std_is_vector ? 0 : row;
     if constexpr (kVec4) {
         const float4 *m4 = reinterpret_cast<const float4 *>(mean + row * A);
-        const float4 *s4 = reinterpret_cast<const float4 *>(std + row * A);
+        const float4 *s4 = reinterpret_cast<const float4 *>(std + std_row * A);
         const float4 *e4 = reinterpret_cast<const float4 *>(eps + row * A);
         float4 *a4 = reinterpret_cast<float4 *>(action + row * A);
+        float4 *so4 = std_out ? reinterpret_cast<float4 *>(std_out + row * A) : nullptr;
         for (int c = 0; c < A / 4; ++c) {
             const float4 m = m4[c], s = s4[c], e = e4[c];
+            if (so4) so4[c] = s;
             const float ms[4] = {m.x, m.y, m.z, m.w}, ss[4] = {s.x, s.y, s.z, s.w}, es[4] = {e.x, e.y, e.z, e.w};
             float as[4];
 #pragma unroll
@@ -37,10 +44,12 @@ __global__ __launch_bounds__(kBlock) void normal_sample_logp_kernel(const float 
     } else {
         for (int a = 0; a < A; ++a) {
             const int64_t i = row * A + a;
-            const float act = mean[i] + eps[i] * std[i];
+            const float sg = std[std_row * A + a];
+            const float act = mean[i] + eps[i] * sg;
             const float diff = act - mean[i];
             action[i] = act;
-            lp += -(diff * diff) / (2.0f * (std[i] * std[i])) - logf(std[i]) - log_sqrt_2pi_r();
+            if (std_out) std_out[i] = sg;
+            lp += -(diff * diff) / (2.0f * (sg * sg)) - logf(sg) - log_sqrt_2pi_r();
         }
     }
     logp[row] = lp;
@@ -253,20 +262,23 @@ extern "C" int cusrl_amp_style_reward(const float *logit, float *reward, float *
 }
 
 extern "C" int cusrl_normal_sample_logp(const float *mean, const float *std, const float *eps, float *action,
-                                        float *logp, int64_t B, int64_t A, void *stream) {
-    if (B < 0 || A <= 0) return CUSRL_E_INVALID;
+                                        float *logp, int64_t B, int64_t A, int64_t std_rows, float *std_out,
+                                        void *stream) {
+    if (B < 0 || A <= 0 || (std_rows != B && std_rows != 1)) return CUSRL_E_INVALID;
     if (B == 0) return 0;
     if (!mean || !std || !eps || !action || !logp) return CUSRL_E_INVALID;
     if (A > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     const int64_t blocks = ceil_div(B, kBlock);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
-    const bool vec4 = A % 4 == 0 && aligned(mean, 16) && aligned(std, 16) && aligned(eps, 16) && aligned(action, 16);
+    const int vector = std_rows == 1 && B != 1;
+    const bool vec4 = A % 4 == 0 && aligned(mean, 16) && aligned(std, 16) && aligned(eps, 16) && aligned(action, 16) &&
+                      (!std_out || aligned(std_out, 16));
     if (vec4)
         hipLaunchKernelGGL(normal_sample_logp_kernel<true>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream),
-                           mean, std, eps, action, logp, B, int(A));
+                           mean, std, eps, action, logp, B, int(A), vector, std_out);
     else
         hipLaunchKernelGGL(normal_sample_logp_kernel<false>, dim3(uint32_t(blocks)), dim3(kBlock), 0,
-                           as_stream(stream), mean, std, eps, action, logp, B, int(A));
+                           as_stream(stream), mean, std, eps, action, logp, B, int(A), vector, std_out);
     return launch_status();
 }
 

@@ -132,6 +132,15 @@ class _Normal(Distribution):
             from cusrl_amd import ops
 
             eps = torch.empty(mean.shape, dtype=mean.dtype, device=mean.device).normal_()
+            vector = getattr(dist_params["std"], "_cusrl_row_vector", None)
+            if vector is not None and vector.dtype == torch.float32 and mean.dim() == 2:
+                # a state-independent std arrives as a stride-0 view of its [A] vector (StddevVector.forward): the launch
+                # broadcasts it and writes the repeated [B, A] matrix the transition carries on to the rollout buffer
+                action, logp, repeated = ops.normal_sample_logp(mean, vector, eps, repeat_std=True)
+                dist_params["std"] = repeated
+                return action, logp
+            if not std.is_contiguous():  # (a view nobody resolved: the transition must carry a real [B, A] leaf)
+                std = dist_params["std"] = std.contiguous()
             return ops.normal_sample_logp(mean, std, eps)
         with disable_autocast(mean.device.type):
             # same draw as Normal.rsample(): mean + std * N(0, 1) from the global generator of mean's device
@@ -176,6 +185,7 @@ class StddevVector(nn.Module):
         super().__init__()
         self.bijector = make_bijector(bijector)
         self.param = nn.Parameter(torch.ones(output_dim) * self.bijector.inverse(_resolve_init_std(init_std)))
+        self.expand_when_acting = False  # set by _Normal.sample (the one caller that resolves the view in its launch)
 
     def forward(self, input: Tensor):
         with disable_autocast(input.device.type):
@@ -184,6 +194,13 @@ class StddevVector(nn.Module):
                 # launch, no [B, A] gradient for sum(0) to reduce); the fused PPO objective picks the vector up
                 # through `_cusrl_row_vector` and gets d_std as an [A] vector straight from its kernel
                 vector = self.bijector(self.param.float()).float()
+                expanded = vector.expand(*input.shape[:-1], -1)
+                expanded._cusrl_row_vector = vector
+                return expanded
+            if self.expand_when_acting and not torch.is_grad_enabled() and input.is_cuda and input.dim() == 2:
+                # acting on the GPU (the sampling launch of _Normal.sample_from_dist takes the vector and materialises
+                # the repeated matrix itself): the same stride-0 view, no repeat launch per env step
+                vector = self.bijector(self.param.detach().float()).float()
                 expanded = vector.expand(*input.shape[:-1], -1)
                 expanded._cusrl_row_vector = vector
                 return expanded
@@ -209,6 +226,17 @@ class NormalDist(_Normal):
 
     def forward(self, backbone_feat: Tensor, **kwargs):
         return {"mean": self.mean_head(backbone_feat), "std": self.std(backbone_feat)}
+
+    def sample(self, backbone_feat: Tensor, **kwargs):
+        if not (backbone_feat.is_cuda and not torch.is_grad_enabled()):
+            return super().sample(backbone_feat, **kwargs)
+        # acting on the GPU: the std stays a view of its vector until the sampling launch, which repeats it itself
+        self.std.expand_when_acting = True
+        try:
+            dist_params = self(backbone_feat, **kwargs)
+        finally:
+            self.std.expand_when_acting = False
+        return dist_params, self.sample_from_dist(dist_params)
 
 
 @dataclass(slots=True)

@@ -51,6 +51,7 @@ __all__ = [
     "rms_normalize",
     "scatter_rows",
     "set_launch_observer",
+    "splice_rows",
     "step_epilogue",
     "window_indices",
 ]
@@ -503,6 +504,28 @@ def assign_rows(dst: torch.Tensor, indices: torch.Tensor, src: torch.Tensor) -> 
     _modified_in_place(dst)
 
 
+def splice_rows(src: torch.Tensor, init: torch.Tensor, indices: torch.Tensor, count: torch.Tensor, done: torch.Tensor,
+                dst: torch.Tensor) -> torch.Tensor:
+    """``dst = src`` with the reset rows spliced in (``update_observation_and_state``, environment.py:365-379, fused with
+    the copy into the next act step's input): ``dst[n] = src[n]`` where ``done[n]`` is clear, ``dst[indices[k]] = init[k]``
+    for ``k < count`` (read on the device).  ``done`` and ``(indices, count)`` must come from the same step epilogue."""
+    for tensor, name in ((src, "src"), (init, "init"), (indices, "indices"), (count, "count"), (done, "done"), (dst, "dst")):
+        require_device(tensor, name)
+    N = src.shape[0]
+    if (src.dtype != dst.dtype or init.dtype != dst.dtype or src.shape != dst.shape or init.shape != dst.shape
+            or not (src.is_contiguous() and init.is_contiguous() and dst.is_contiguous())):
+        raise TypeError("splice_rows: src, init and dst must be contiguous tensors of one shape and dtype")
+    if indices.dtype != torch.int64 or indices.numel() < N or count.dtype != torch.int32 or count.numel() != 1 or done.numel() != N:
+        raise TypeError("splice_rows: indices int64[>= N], count int32[1], done [N] flags are required")
+    if dst.data_ptr() in (src.data_ptr(), init.data_ptr()):
+        raise ValueError("splice_rows: dst must not alias src or init")
+    done = _flag(done, "done")
+    check(_native.lib().cusrl_splice_rows(src.data_ptr(), init.data_ptr(), indices.data_ptr(), count.data_ptr(), done.data_ptr(),
+                                          dst.data_ptr(), N, _row_bytes(src, 1), _stream()), "cusrl_splice_rows")
+    _modified_in_place(dst)
+    return dst
+
+
 class HostCounter:
     """A pinned, device-mapped int32 the host polls for a kernel's result.
 
@@ -879,21 +902,28 @@ def ppo_loss_accepts_std_vector(action_dim: int) -> bool:
 
 
 # ------------------------------------------------------------------------------------------------ rollout side
-def normal_sample_logp(mean: torch.Tensor, std: torch.Tensor, eps: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+def normal_sample_logp(mean: torch.Tensor, std: torch.Tensor, eps: torch.Tensor, repeat_std: bool = False):
     """``action = mean + eps * std`` and ``log_prob(action).sum(-1, keepdim=True)`` in one launch
-    (cusrl/nn/module/distribution.py:198-205)."""
+    (cusrl/nn/module/distribution.py:198-205).  ``std`` may be the ``[A]`` vector a state-independent std repeats for every
+    row; with ``repeat_std`` the launch also writes that repeated ``[B, A]`` matrix (what ``param.repeat(B, 1)`` gives,
+    distribution.py:241-243) and returns it as a third value."""
     mean, std, eps = _f32(mean, "mean"), _f32(std, "std"), _f32(eps, "eps")
-    if std.shape != mean.shape or eps.shape != mean.shape:
-        raise ValueError("normal_sample_logp: shape mismatch")
     A = mean.shape[-1]
     B = mean.numel() // A
+    vector = std.dim() == 1 and std.numel() == A and B != 1
+    if (not vector and std.shape != mean.shape) or eps.shape != mean.shape:
+        raise ValueError("normal_sample_logp: shape mismatch")
     action = torch.empty_like(mean)
     logp = torch.empty(mean.shape[:-1] + (1,), dtype=torch.float32, device=mean.device)
+    repeated = torch.empty_like(mean) if (repeat_std and vector) else None
     _observed(
         "cusrl_normal_sample_logp",
-        lambda: B * (16 * A + 4),
-        lambda: _native.lib().cusrl_normal_sample_logp(mean.data_ptr(), std.data_ptr(), eps.data_ptr(), action.data_ptr(), logp.data_ptr(), B, A, _stream()),
+        lambda: B * ((12 if vector else 16) * A + 4 + (4 * A if repeated is not None else 0)),
+        lambda: _native.lib().cusrl_normal_sample_logp(mean.data_ptr(), std.data_ptr(), eps.data_ptr(), action.data_ptr(), logp.data_ptr(),
+                                                       B, A, 1 if vector else B, None if repeated is None else repeated.data_ptr(), _stream()),
     )
+    if repeat_std:
+        return action, logp, (repeated if repeated is not None else std)
     return action, logp
 
 

@@ -449,10 +449,21 @@ class GraphedRolloutStep:
         stats.track_fused(reward, terminated, truncated, self.done, self.indices, self.count)
         self.ready = agent.step(next_observation, reward, terminated, truncated, next_state, **{**info, "done": self.done})
         init_observation, init_state, _ = env.reset_static(self.indices, self.count)
-        trainer._splice_static(next_observation, next_state, self.indices, self.count, init_observation, init_state)
-        act.static_observation.copy_(next_observation)
+        # the next act input = the env's next observation with the reset rows spliced in, one launch (the host-driven
+        # loop does the same in two: the in-place row scatter of Trainer._splice_static, then GraphedAct's copy)
+        self._advance_input(act.static_observation, next_observation, init_observation)
         if act.static_state is not None:
-            act.static_state.copy_(next_state)
+            self._advance_input(act.static_state, next_state, init_state)
+
+    def _advance_input(self, static, following, init):
+        from cusrl_amd import ops
+
+        if (following.dtype == static.dtype and init.dtype == static.dtype and following.shape == static.shape
+                and init.shape == static.shape and following.is_contiguous() and init.is_contiguous()):
+            ops.splice_rows(following, init, self.indices, self.count, self.done, static)
+        else:  # layouts the fused launch does not take: scatter in place, then copy
+            ops.scatter_rows(init, self.indices, following.unsqueeze(0), self.count)
+            static.copy_(following)
 
     def _replay_host_effects(self) -> bool:
         """The Python-side effects of one step that a replay does not perform."""

@@ -29,6 +29,7 @@ class SyntheticEnvironment(Environment):
         # every step / reset is shape-static device work from torch's generator: the trainer may drive it without
         # host synchronisation and replay whole env steps from hipGraphs (template/environment.py `capturable`)
         self.capturable = bool(capturable) and self.device.type == "cuda"
+        self._flag_probs = torch.tensor([terminate_prob, truncate_prob], dtype=torch.float32, device=self.device).view(2, 1, 1)
 
     def _randn(self, rows: int, cols: int | None):
         return None if cols is None else torch.randn(rows, cols, device=self.device)
@@ -44,15 +45,17 @@ class SyntheticEnvironment(Environment):
     def step(self, action):
         assert isinstance(action, torch.Tensor) and action.shape == (self.num_instances, self.action_dim)
         n = self.num_instances
-        flags = torch.rand(2, n, 1, device=self.device)
+        # both flag vectors from one draw and ONE comparison against the [2, 1, 1] probabilities (the same float32
+        # thresholds a Python scalar would be rounded to): [0] = terminated, [1] = truncated, each a contiguous [n, 1]
+        flags = torch.rand(2, n, 1, device=self.device) < self._flag_probs
         # with autoreset=True a finished instance restarts from a fresh N(0, 1) observation — which the i.i.d.
         # next observation below already is, so no masked overwrite is needed
         return (
             self._randn(n, self.observation_dim),
             self._randn(n, self.state_dim),
             self._randn(n, self.spec.reward_dim),
-            flags[0] < self.terminate_prob,
-            flags[1] < self.truncate_prob,
+            flags[0],
+            flags[1],
             {},
         )
 

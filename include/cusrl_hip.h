@@ -87,6 +87,15 @@ int cusrl_compact_flags(const uint8_t *flags, int64_t n, int32_t *block_counts, 
 int cusrl_scatter_rows(const void *src, const int64_t *indices, void *dst, int64_t K, int64_t row_bytes,
                        const int32_t *count_dev, void *stream);
 
+/* ---- the next act input of a vectorised rollout — cusrl/template/environment.py:365-379 (`update_observation_and_state`:
+ * `last_observation[indices] = init_observation`) fused with the copy into the act step's input buffer ----
+ * dst[n] = src[n] for every env n with done[n] == 0, and dst[indices[k]] = init[k] for k < min(N, *count_dev): `done`
+ * [N] and (indices, count_dev) must describe the same set of finished envs (cusrl_step_epilogue emits both), src / init
+ * / dst are [N, row_bytes] with dst distinct from src and init; the count is read by the kernel (device or pinned host
+ * memory), so a captured env step needs no host read to reset its finished envs. */
+int cusrl_splice_rows(const void *src, const void *init, const int64_t *indices, const int32_t *count_dev,
+                      const uint8_t *done, void *dst, int64_t N, int64_t row_bytes, void *stream);
+
 /* ---- a4  GAE(lambda) + return — cusrl/hook/on_policy/gae.py:8-20, 85-110 ----
  * delta = (r + nv*gamma) - v;  A[T-1] = delta;  A[t] = delta[t] + ((done[t] ? 0 : gamma*lamda) * A[t+1])
  * (separate multiply and add, bit-exact with the reference);  ret = value + A, or value + A' where A' is the
@@ -247,9 +256,12 @@ int cusrl_rnn_cell_bwd(float *d_pre, const float *out, const float *d_out, float
 /* ---- rollout-side: sampling and episode statistics ----
  * Normal sample + log-prob of the sample in one pass — cusrl/nn/module/distribution.py:198-205 (`rsample`, then
  * `log_prob(sample).sum(-1, keepdim)`): action = mean + eps * std with eps ~ N(0,1) supplied by the caller (drawn
- * from torch's generator so the random stream is the reference's); logp[B] as in cusrl_ppo_loss_fwd_bwd. */
+ * from torch's generator so the random stream is the reference's); logp[B] as in cusrl_ppo_loss_fwd_bwd.
+ * std_rows = B: std [B,A]; std_rows = 1: std is the [A] vector a state-independent std repeats for every row
+ * (distribution.py:228-247, `param.repeat(B, 1)`) — broadcast inside the kernel, and std_out [B,A] (optional) receives
+ * the repeated matrix the rollout buffer stores as a leaf, so the acting path needs no `repeat` launch. */
 int cusrl_normal_sample_logp(const float *mean, const float *std, const float *eps, float *action, float *logp,
-                             int64_t B, int64_t A, void *stream);
+                             int64_t B, int64_t A, int64_t std_rows, float *std_out, void *stream);
 
 /* One-hot categorical sample + its log-prob in one pass — cusrl/nn/module/distribution.py:332-366
  * (`OneHotCategorical(logits).sample()`, `log_prob(sample)`): idx = argmax_j softmax(logits)_j / noise_j with

@@ -133,6 +133,24 @@ def bench_size(N, T=24, obs=48, act=12, mbs=4, only=None, iters=None):
     hot_pack = ops.RecordPack({"observation": leaves[0], "action": leaves[3], "logp": leaves[4], "advantage": leaves[12],
                                "return": leaves[13], "done": done})
     rows.measure("pack hot record (once per update)", hot_pack.build, S * (hot_pack.used_bytes + hot_pack.record_bytes))
+    # round 3: push writes the wide leaves (observation, action) through into the record, the per-update pack only moves
+    # the narrow ones (13 of the 253 bytes per slot)
+    rows.measure("pack the narrow leaves of the hot record (once per update, wide leaves pushed through)",
+                 lambda: hot_pack.build(["logp", "advantage", "return", "done"]), S * 2 * 13)
+    through_keys = ["observation", "mean", "std", "action", "logp", "value", "next_observation", "reward", "terminated", "truncated", "done"]
+    through_pack = ops.RecordPack({"observation": storage["observation"], "action": storage["action"], "logp": storage["logp"],
+                                   "done": storage["done"]})
+    offsets = through_pack.through_offsets(through_keys)
+    table = ops.make_push_table([(storage[k], step[k].shape) for k in through_keys])
+    for i, k in enumerate(through_keys):
+        table[i].src = step[k].data_ptr()
+
+    def push_through():
+        ops.push_table(table, len(through_keys), cursor[0], N, (through_pack.record, through_pack.record_bytes, offsets))
+        cursor[0] = (cursor[0] + 1) % T
+
+    rows.measure("push with write-through (1 step, 11 leaves + observation / action into the record)", push_through,
+                 push_bytes + N * 4 * (obs + act))
     rows.measure(f"gather hot leaves from the 256 B hot record (B={B})",
                  lambda: ops.gather_rows_packed([], hot_pack, list(hot_pack.leaves), idx, T, N), B * (2 * hot_pack.used_bytes + 8))
     rows.measure(f"gather all leaves via record (B={B})",

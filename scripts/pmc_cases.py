@@ -15,6 +15,11 @@ Product cases at config 2 (4096 envs x 24 steps, minibatch of 24 576 slots; work
   gather_minibatch_all_leaves   the reference's semantics: all 14 leaves (9 through the record)
   gather_minibatch_all_plain    all 14 leaves without the record (the round-1 kernel's access pattern)
   pack_rows                     building the record (once per update)
+  gather_minibatch_hot_plain    (round 3) what the captured train step launches at config 2 now: the six leaves a PPO step
+                                reads, gathered plainly — the 25 MB of sampled leaves sit in L2 + Infinity Cache
+Loss kernel at 1 048 576 envs (minibatch of 6 291 456 rows x 12 actions; round 3, cusrl::ppo_loss_rowgroup_kernel):
+  loss_std_vector_1m            the preset's form: std handed over as its [12] vector (180 algorithmic bytes per row)
+  loss_std_matrix_1m            std as a [B, 12] matrix (276 bytes per row)
 """
 import json
 import sys
@@ -96,6 +101,24 @@ def main(out_dir):
         "gather_kernel", wide_blocks(all_plain) + record_blocks(pack), all_bytes)
     plain_blocks = wide_blocks(all_plain) + 6 * blocks_plain(B, 4, 4) + 3 * (-(-((B + 3) // 4) // KBLOCK))
     run("gather_minibatch_all_plain", lambda: ops.gather_rows(list(leaves.values()), perm, T, N), "gather_kernel", plain_blocks, all_bytes)
+    hot6 = ["observation", "action", "logp", "advantage", "return", "done"]
+    hot6_blocks = (wide_blocks(["observation", "action"]) + 3 * blocks_plain(B, 4, 4) + (-(-((B + 3) // 4) // KBLOCK)))
+    run("gather_minibatch_hot_plain", lambda: ops.gather_rows([leaves[k] for k in hot6], perm, T, N), "gather_kernel", hot6_blocks,
+        B * (2 * 253 + 8))
+    del leaves, pack, hot_pack
+    torch.cuda.empty_cache()
+
+    # ---- the fused objective at roofline scale
+    Bl, A = (1 << 20) * 24 // 4, 12
+    a = dict(advantage=f(Bl, 1), old_logp=f(Bl, 1) - 12, action=f(Bl, A), mean=f(Bl, A), std=torch.rand(Bl, A, device=DEV) + 0.5,
+             ret=f(Bl, 1), curr_value=f(Bl, 1), old_value=f(Bl, 1))
+    kw = dict(clip=0.2, value_clip=None, w_sur=1.0, w_val=0.5, w_ent=0.01)
+    loss_blocks = -(-Bl // 252)  # 21 rows x 4 waves x 3 rounds per block at A = 12
+    matrix_bytes = Bl * (8 + 3 * 4 * A + 8 + 2 * 4 * A + 4 + 16)
+    v = dict(a, std=torch.rand(A, device=DEV) + 0.5)
+    run("loss_std_vector_1m", lambda: ops.ppo_loss_fwd_bwd(*v.values(), **kw), "ppo_loss_rowgroup_kernel", loss_blocks,
+        matrix_bytes - Bl * 8 * A)
+    run("loss_std_matrix_1m", lambda: ops.ppo_loss_fwd_bwd(*a.values(), **kw), "ppo_loss_rowgroup_kernel", loss_blocks, matrix_bytes)
     Path(out_dir).mkdir(parents=True, exist_ok=True)
     Path(out_dir, "cases.json").write_text(json.dumps(cases, indent=1))
 

@@ -24,7 +24,7 @@ def per_launch(path, cases):
     with open(path) as fh:
         rows = sorted(csv.DictReader(fh), key=lambda row: int(row["Dispatch_Id"]))
     for row in rows:
-        for kernel in ("gather_kernel", "push_kernel", "pack_rows_kernel"):
+        for kernel in ("gather_kernel", "push_kernel", "pack_rows_kernel", "ppo_loss_rowgroup_kernel"):
             if kernel in row["Kernel_Name"]:
                 by_kernel.setdefault(kernel, []).append(row)
     sums = {}
@@ -32,6 +32,39 @@ def per_launch(path, cases):
         mine = by_kernel.get(case["kernel"], [])[case["first_ordinal"]: case["first_ordinal"] + case["ordinals"]]
         sums[name] = [float(row["Counter_Value"]) for row in mine if int(row["Grid_Size"]) == case["grid_threads"]]
     return {name: (sum(v) / len(v) if v else None) for name, v in sums.items()}, {name: len(v) for name, v in sums.items()}
+
+
+def sq_counters(path, cases):
+    """{case: {counter: average per launch}} + the ratios that say where a wave's time goes.  SQ_WAVE_CYCLES, SQ_WAIT_ANY
+    and SQ_ACTIVE_INST_* count quad-cycles summed over waves (MI355X_MICROARCH.md): ratios between them are unit-free."""
+    by_kernel = {}
+    with open(path) as fh:
+        rows = sorted(csv.DictReader(fh), key=lambda row: int(row["Dispatch_Id"]))
+    dispatches = {}  # dispatch id -> (kernel, grid, {counter: value})
+    for row in rows:
+        for kernel in ("gather_kernel", "push_kernel", "pack_rows_kernel", "ppo_loss_rowgroup_kernel"):
+            if kernel in row["Kernel_Name"]:
+                entry = dispatches.setdefault(int(row["Dispatch_Id"]), (kernel, int(row["Grid_Size"]), {}))
+                entry[2][row["Counter_Name"]] = float(row["Counter_Value"])
+    for dispatch in sorted(dispatches):
+        kernel, grid, counters = dispatches[dispatch]
+        by_kernel.setdefault(kernel, []).append((grid, counters))
+    out = {}
+    for name, case in cases.items():
+        mine = by_kernel.get(case["kernel"], [])[case["first_ordinal"]: case["first_ordinal"] + case["ordinals"]]
+        mine = [counters for grid, counters in mine if grid == case["grid_threads"]]
+        if not mine:
+            continue
+        average = {key: sum(c.get(key, 0.0) for c in mine) / len(mine) for key in mine[0]}
+        wave = average.get("SQ_WAVE_CYCLES") or 0.0
+        if wave:
+            average["valu_issue_share_of_wave_cycles"] = round(average.get("SQ_ACTIVE_INST_VALU", 0.0) / wave, 4)
+            average["lds_issue_share_of_wave_cycles"] = round(average.get("SQ_ACTIVE_INST_LDS", 0.0) / wave, 4)
+            average["waiting_share_of_wave_cycles"] = round(average.get("SQ_WAIT_ANY", 0.0) / wave, 4)
+        if average.get("SQ_LDS_IDX_ACTIVE"):
+            average["lds_bank_conflict_share_of_lds_cycles"] = round(average.get("SQ_LDS_BANK_CONFLICT", 0.0) / average["SQ_LDS_IDX_ACTIVE"], 4)
+        out[name] = average
+    return out
 
 
 def main(directory, out_path):
@@ -58,7 +91,8 @@ def main(directory, out_path):
     # the read counter tallies each memory-side request at 64 B: a streaming 128-byte request counts half (factor 2);
     # a random row shorter than a request is ONE request (raw ~64 B per 4- or 32-byte row), so for the row part of a
     # gather raw x 2 is an UPPER bound (request = 128 B) and raw x 1 a LOWER bound (request = 64 B)
-    for name in ("gather_minibatch_hot_record", "pack_hot_record", "gather_minibatch_hot_leaves", "gather_minibatch_all_leaves", "gather_minibatch_all_plain", "pack_rows"):
+    for name in ("gather_minibatch_hot_record", "pack_hot_record", "gather_minibatch_hot_leaves", "gather_minibatch_all_leaves", "gather_minibatch_all_plain", "pack_rows",
+                 "gather_minibatch_hot_plain", "loss_std_vector_1m", "loss_std_matrix_1m"):
         entry = out["cases"].get(name)
         if entry and entry["fetch_raw"] is not None and entry["write_raw"] is not None:
             lo, hi = entry["fetch_raw"] + entry["write_raw"], 2 * entry["fetch_raw"] + entry["write_raw"]
@@ -66,6 +100,10 @@ def main(directory, out_path):
             entry["hbm_traffic_bytes"] = hi
             entry["traffic_over_algorithmic_bracket"] = [round(lo / entry["algorithmic_bytes"], 3), round(hi / entry["algorithmic_bytes"], 3)]
             out[name] = entry
+    sq_path = directory / "SQ_counters.csv"
+    if sq_path.exists():  # round 3: per-launch SQ counters of the same cases (one row per counter per dispatch)
+        out["sq"] = sq_counters(sq_path, cases)
+    out["ppo_loss_hip_sha256_16"] = hashlib.sha256((ROOT / "cusrl_amd" / "csrc" / "ppo_loss.hip").read_bytes()).hexdigest()[:16]
     out["buffer_hip_sha256_16"] = hashlib.sha256((ROOT / "cusrl_amd" / "csrc" / "buffer.hip").read_bytes()).hexdigest()[:16]
     try:
         out["commit"] = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "worktree"

@@ -101,6 +101,32 @@ def test_static_reset_rows_reach_only_the_finished_envs_in_order(cusrl):
     assert torch.equal(observation, expect_obs)
 
 
+def test_splice_rows_is_the_reset_scatter_plus_the_copy(cusrl):
+    """``cusrl_splice_rows`` (what a captured step runs instead of scatter + copy): every dtype width, rows of any size,
+    no finished env, every env finished."""
+    from cusrl_amd import ops
+
+    generator = torch.Generator(device=DEV).manual_seed(3)
+    for N, shape, dtype in ((4096, (48,), torch.float32), (257, (5,), torch.float32), (64, (3,), torch.uint8), (1000, (6,), torch.float16),
+                            (33, (2, 4), torch.float64)):
+        for rate in (0.1, 0.0, 1.0):
+            src = (torch.rand((N,) + shape, device=DEV, generator=generator) * 100).to(dtype)
+            init = (torch.rand((N,) + shape, device=DEV, generator=generator) * 100 + 200).to(dtype)
+            done = torch.rand(N, 1, device=DEV, generator=generator) < rate
+            finished = done.squeeze(-1).nonzero().squeeze(-1)
+            indices = torch.zeros(N, dtype=torch.int64, device=DEV)
+            indices[: finished.numel()] = finished
+            indices[finished.numel():] = torch.randint(0, N, (N - finished.numel(),), device=DEV, generator=generator)  # stale ids
+            count = torch.tensor([finished.numel()], dtype=torch.int32, device=DEV)
+            dst = torch.full_like(src, 7)
+            ops.splice_rows(src, init, indices, count, done, dst)
+            expect = src.clone()
+            expect[finished] = init[: finished.numel()]
+            assert torch.equal(dst, expect), (N, shape, dtype, rate)
+    with pytest.raises(ValueError, match="alias"):
+        ops.splice_rows(src, init, indices, count, done, src)
+
+
 def test_a_user_hook_with_per_step_python_state_keeps_the_loop_host_driven(cusrl):
     """A hook from outside the package that overrides ``post_step`` may keep Python state per step: the captured step is
     only taken when it opts in (``rollout_capture_safe``)."""
