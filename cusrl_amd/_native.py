@@ -93,7 +93,8 @@ _SIGNATURES = {
     "cusrl_narrow_linear_supported": (c_int, [c_int64, c_int64]),
     "cusrl_clip_grad_norm": (c_int, [_P, c_int64, c_float, _P, _P, _P]),
     "cusrl_clip_grad_norm_num_partials": (c_int64, [c_int64]),
-    "cusrl_assemble_gradients": (c_int, [POINTER(GradPiece), c_int64, _P, _P]),
+    "cusrl_assemble_gradients": (c_int, [POINTER(GradPiece), c_int64, _P, _P, _P]),
+    "cusrl_assemble_gradients_blocks": (c_int64, [POINTER(GradPiece), c_int64]),
     "cusrl_grad_sumsq": (c_int, [_P, c_int64, _P, _P]),
     "cusrl_adam_step": (c_int, [_P] * 6 + [c_int64, c_double, c_double, c_double, c_double, c_int, c_int, _P, c_int64, c_float, _P, _P, _P]),
     "cusrl_masked_col_stats": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, _P]),

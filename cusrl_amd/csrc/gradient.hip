@@ -7,7 +7,8 @@
 
 namespace cusrl {
 
-constexpr int kNormMaxBlocks = 64;           // partials fit one wave's lanes in the second kernel
+constexpr int kNormMaxBlocks = 64;           // blocks of the stand-alone squared-sum pass
+constexpr int kMaxClipPartials = 1 << 16;    // partial rows a consumer (scale pass / Adam step) walks with one wave
 constexpr int kNormFloatsPerBlock = 256 * 16;  // 4 float4 per thread
 
 __global__ __launch_bounds__(kBlock) void sumsq_partials_kernel(const float *__restrict__ g, int64_t n,
@@ -32,8 +33,9 @@ __global__ __launch_bounds__(kBlock) void clip_scale_kernel(float *__restrict__ 
                                                             const double *__restrict__ partials, int num_partials,
                                                             float max_norm, float *__restrict__ norm_out) {
     __shared__ float coef_shared;
-    if (threadIdx.x < kWave) {  // wave 0: fixed-order sum of <= 64 partials
-        double p = int(threadIdx.x) < num_partials ? partials[threadIdx.x] : 0.0;
+    if (threadIdx.x < kWave) {  // wave 0: fixed-order sum of the partials
+        double p = 0.0;
+        for (int i = threadIdx.x; i < num_partials; i += kWave) p += partials[i];
         p = wave_sum(p);
         if (threadIdx.x == 0) {
             const float norm = float(sqrt(p));
@@ -102,8 +104,9 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float *__restrict__ p
     __shared__ float shared[4];  // clip coefficient, step size, sqrt(bias_correction2), new step count
     if (threadIdx.x < kWave) {
         float coef = 1.0f;
-        if (clip_partials) {  // uniform branch
-            double p = int(threadIdx.x) < a.num_clip_partials ? clip_partials[threadIdx.x] : 0.0;
+        if (clip_partials) {  // uniform branch; the partials of cusrl_grad_sumsq (<= 64) or of the gradient assembly
+            double p = 0.0;
+            for (int i = threadIdx.x; i < a.num_clip_partials; i += kWave) p += clip_partials[i];
             p = wave_sum(p);
             const float norm = float(sqrt(p));
             if (a.max_norm >= 0.0f) {
@@ -179,7 +182,7 @@ extern "C" int cusrl_adam_step(float *param, const float *grad, float *exp_avg, 
                                void *stream) {
     using namespace cusrl;
     if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !step || !lr || !ticket) return CUSRL_E_INVALID;
-    if (clip_partials && (num_clip_partials < 1 || num_clip_partials > kNormMaxBlocks)) return CUSRL_E_INVALID;
+    if (clip_partials && (num_clip_partials < 1 || num_clip_partials > kMaxClipPartials)) return CUSRL_E_INVALID;
     if (!aligned(param, 16) || !aligned(grad, 16) || !aligned(exp_avg, 16) || !aligned(exp_avg_sq, 16))
         return CUSRL_E_UNSUPPORTED;
     AdamParams a{beta1, beta2, float(eps), float(weight_decay), max_norm, decoupled_weight_decay, maximize,
@@ -213,7 +216,13 @@ constexpr int kAssemblePerBlock = kBlock * 4;  // elements of one piece per bloc
 constexpr int kAssembleWideCols = 16;          // elements per block of a WIDE piece: 16 columns x 16 slab groups
 constexpr int kAssembleWideSplits = 16;        // more slabs than this -> wide
 
-__global__ __launch_bounds__(kBlock) void assemble_gradients_kernel(const GradTable tab, float *__restrict__ flat) {
+// sumsq (optional): partial row blockIdx.x + sumsq_base receives the sum of squares of the elements this block wrote —
+// the squared gradient norm the clipping needs, taken while the values are in registers (one launch fewer per optimizer
+// step whenever nothing — no cross-rank reduction — changes the gradients between assembly and clipping).
+__global__ __launch_bounds__(kBlock) void assemble_gradients_kernel(const GradTable tab, float *__restrict__ flat,
+                                                                    double *__restrict__ sumsq, int sumsq_base) {
+    __shared__ double sq_scratch[kWavesPerBlock];
+    double sq = 0.0;
     const int blk = blockIdx.x;
     int f = 0;
 #pragma unroll
@@ -244,6 +253,11 @@ __global__ __launch_bounds__(kBlock) void assemble_gradients_kernel(const GradTa
 #pragma unroll
             for (int k = 1; k < kGroups; ++k) sum += red[k * kAssembleWideCols + c];
             flat[piece.offset + e] = sum;
+            sq = double(sum * sum);
+        }
+        if (sumsq) {  // uniform
+            const double total_sq = block_sum(sq, sq_scratch);
+            if (threadIdx.x == 0) sumsq[sumsq_base + blk] = total_sq;
         }
         return;
     }
@@ -261,14 +275,35 @@ __global__ __launch_bounds__(kBlock) void assemble_gradients_kernel(const GradTa
         }
         for (; s < piece.splits; ++s) total += src[int64_t(s) * stride + e];
         flat[piece.offset + e] = total;
+        sq += double(total * total);
+    }
+    if (sumsq) {  // uniform
+        const double total_sq = block_sum(sq, sq_scratch);
+        if (threadIdx.x == 0) sumsq[sumsq_base + blk] = total_sq;
     }
 }
 
 }  // namespace cusrl
 
-extern "C" int cusrl_assemble_gradients(const cusrl_grad_piece_t *pieces, int64_t num_pieces, float *flat, void *stream) {
+static int64_t assemble_blocks(const cusrl_grad_piece_t &p) {
+    return cusrl::ceil_div(p.numel, p.splits > cusrl::kAssembleWideSplits ? cusrl::kAssembleWideCols : cusrl::kAssemblePerBlock);
+}
+
+extern "C" int64_t cusrl_assemble_gradients_blocks(const cusrl_grad_piece_t *pieces, int64_t num_pieces) {
+    if (num_pieces < 0 || (num_pieces > 0 && !pieces)) return -1;
+    int64_t blocks = 0;
+    for (int64_t i = 0; i < num_pieces; ++i) {
+        if (pieces[i].numel < 0 || pieces[i].splits < 0) return -1;
+        blocks += assemble_blocks(pieces[i]);
+    }
+    return blocks;
+}
+
+extern "C" int cusrl_assemble_gradients(const cusrl_grad_piece_t *pieces, int64_t num_pieces, float *flat,
+                                        double *sumsq_partials, void *stream) {
     using namespace cusrl;
     if (num_pieces < 0 || (num_pieces > 0 && (!pieces || !flat))) return CUSRL_E_INVALID;
+    int64_t sumsq_base = 0;
     for (int64_t first = 0; first < num_pieces; first += CUSRL_MAX_FIELDS) {
         GradTable tab;
         tab.n = int32_t(num_pieces - first < CUSRL_MAX_FIELDS ? num_pieces - first : CUSRL_MAX_FIELDS);
@@ -286,8 +321,10 @@ extern "C" int cusrl_assemble_gradients(const cusrl_grad_piece_t *pieces, int64_
         }
         tab.block_start[tab.n] = int32_t(blocks);
         if (blocks == 0) continue;
-        assemble_gradients_kernel<<<uint32_t(blocks), kBlock, 0, as_stream(stream)>>>(tab, flat);
+        if (sumsq_base + blocks > kMaxClipPartials && sumsq_partials) return CUSRL_E_UNSUPPORTED;
+        assemble_gradients_kernel<<<uint32_t(blocks), kBlock, 0, as_stream(stream)>>>(tab, flat, sumsq_partials, int(sumsq_base));
         if (int rc = launch_status()) return rc;
+        sumsq_base += blocks;
     }
     return 0;
 }

@@ -1202,11 +1202,12 @@ class DeferredColumns:
         return rows[:, self.column : self.column + self.numel].sum(0)
 
 
-def assemble_gradients(pieces: Sequence[tuple], flat: torch.Tensor):
+def assemble_gradients(pieces: Sequence[tuple], flat: torch.Tensor, want_sumsq: bool = False):
     """Fill the flat gradient buffer in one launch.  ``pieces`` = ``(src, offset, numel, splits)`` per parameter:
     ``src [splits, numel]`` slabs are summed into ``flat[offset : offset + numel]``; ``splits = 1`` copies a plain
     gradient, ``src = None`` / ``splits = 0`` writes zeros; a :class:`DeferredColumns` ``src`` is reduced over its
-    partial rows (``splits`` is taken from it)."""
+    partial rows (``splits`` is taken from it).  ``want_sumsq``: also return the blocks' partial sums of squares of what
+    they wrote (fp64) — the squared gradient norm :func:`adam_step` turns into the clipping coefficient."""
     flat = _f32(flat, "flat")
     table = (_native.GradPiece * max(len(pieces), 1))()
     keep = []
@@ -1228,7 +1229,15 @@ def assemble_gradients(pieces: Sequence[tuple], flat: torch.Tensor):
             keep.append(src)
             slot.src, slot.splits = src.data_ptr(), splits
         slot.offset, slot.numel = offset, numel
-    check(_native.lib().cusrl_assemble_gradients(table, len(pieces), flat.data_ptr(), _stream()), "cusrl_assemble_gradients")
+    lib = _native.lib()
+    sumsq = None
+    if want_sumsq:
+        blocks = int(lib.cusrl_assemble_gradients_blocks(table, len(pieces)))
+        if 0 < blocks <= 1 << 16:
+            sumsq = torch.empty(blocks, dtype=torch.float64, device=flat.device)
+    check(lib.cusrl_assemble_gradients(table, len(pieces), flat.data_ptr(), None if sumsq is None else sumsq.data_ptr(), _stream()),
+          "cusrl_assemble_gradients")
+    return sumsq
 
 
 def grad_sumsq(flat_grad: torch.Tensor) -> torch.Tensor:

@@ -353,6 +353,8 @@ class FlatGradients:
         self.buffer = torch.zeros(total, dtype=torch.float32, device=device)
         self.views = []
         self.absent: list[int] = []
+        self._sumsq: torch.Tensor | None = None
+        self._sumsq_version = -1
         for p, offset in zip(self.params, self.offsets):
             if p.dtype != torch.float32:
                 raise TypeError("FlatGradients expects fp32 master parameters")
@@ -400,7 +402,16 @@ class FlatGradients:
                 pieces.append((None, offset, n, 0))
         if split_slabs:
             raise RuntimeError("split weight gradients were produced for tensors that are not optimizer parameters")
-        ops.assemble_gradients(pieces, self.buffer)
+        # single process: nothing changes the gradients between here and the clipping, so the assembly also leaves the
+        # partial sums of squares the clipping coefficient needs (with several ranks the all-reduce comes in between)
+        self._sumsq = ops.assemble_gradients(pieces, self.buffer, want_sumsq=not configure_distributed())
+        self._sumsq_version = self.buffer._version
+
+    def take_sumsq(self) -> torch.Tensor | None:
+        """The squared-norm partials the last :meth:`assemble` produced, if the gradients are still what it wrote (any
+        in-place edit through a ``.grad`` view moves the buffer's version counter)."""
+        sumsq, self._sumsq = self._sumsq, None
+        return sumsq if sumsq is not None and self.buffer._version == self._sumsq_version else None
 
 
 def reduce_gradients(optimizer: torch.optim.Optimizer, flat: FlatGradients | None = None):
@@ -408,6 +419,7 @@ def reduce_gradients(optimizer: torch.optim.Optimizer, flat: FlatGradients | Non
     if not configure_distributed():
         return
     if flat is not None and flat.intact():
+        flat._sumsq = None  # the averaged gradients have another norm
         reduce_mean_(flat.buffer)
         return
     params = [p for group in optimizer.param_groups for p in group["params"] if p.grad is not None]

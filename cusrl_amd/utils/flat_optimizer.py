@@ -98,7 +98,10 @@ class FlatAdam:
         """Take over gradient clipping: launches only the squared-norm partials now; the coefficient is applied by
         the next :meth:`step`.  Returns the device scalar that will hold the pre-clip norm after that step."""
         norm = torch.empty(1, dtype=torch.float32, device=self.lr.device)  # one per step: metrics keep a reference
-        self._pending_clip = (ops.grad_sumsq(self.gradients.buffer), max_norm, norm)
+        partials = self.gradients.take_sumsq()  # left behind by the gradient assembly when nothing touched them since
+        if partials is None:
+            partials = ops.grad_sumsq(self.gradients.buffer)
+        self._pending_clip = (partials, max_norm, norm)
         return norm[0]
 
     def discard_pending_clip(self):

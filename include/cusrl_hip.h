@@ -351,7 +351,11 @@ int64_t cusrl_clip_grad_norm_num_partials(int64_t n);
  * [S, out, in] partial products here instead of running one sum(0) each; the column-sum kernels (bias gradients,
  * cusrl_relu_bwd_colsum / cusrl_narrow_linear_bwd called without their output pointer) leave their per-block partial
  * rows here instead of running a finalize launch each (a column window of a wider partial row is addressed through
- * `src` + `row_stride`).  One launch per 24 pieces.  Fixed order. */
+ * `src` + `row_stride`).  One launch per 24 pieces.  Fixed order.
+ * sumsq_partials (optional): double[cusrl_assemble_gradients_blocks(pieces, num_pieces)] — every block also stores the sum
+ * of squares of the gradient elements it wrote; summed, that is the squared gradient norm of clip_grad_norm_
+ * (gradient_clipping.py:74) and cusrl_adam_step takes the rows as its clip_partials, so a single-process optimizer step
+ * needs no separate squared-sum pass (with several ranks the all-reduce changes the gradients in between). */
 typedef struct {
     const void *src;
     int64_t offset;     /* element offset of the parameter's slot in `flat` */
@@ -359,7 +363,9 @@ typedef struct {
     int64_t splits;
     int64_t row_stride; /* elements between consecutive slabs; 0 = numel (densely stacked slabs) */
 } cusrl_grad_piece_t;
-int cusrl_assemble_gradients(const cusrl_grad_piece_t *pieces, int64_t num_pieces, float *flat, void *stream);
+int cusrl_assemble_gradients(const cusrl_grad_piece_t *pieces, int64_t num_pieces, float *flat, double *sumsq_partials,
+                             void *stream);
+int64_t cusrl_assemble_gradients_blocks(const cusrl_grad_piece_t *pieces, int64_t num_pieces);
 
 /* Block partials of sum(grad^2) only (the first half of cusrl_clip_grad_norm): the caller hands them to
  * cusrl_adam_step, which applies the clipping coefficient while it streams the gradient. */

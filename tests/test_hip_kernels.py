@@ -971,10 +971,21 @@ def test_assemble_gradients_sums_slabs_into_slots(ops):
             total = total + src[r]
         expect[offset : offset + n] = total
         offset += n
-    ops.assemble_gradients(pieces, flat)
+    sumsq = ops.assemble_gradients(pieces, flat, want_sumsq=True)
     got = host(flat)
     assert np.isnan(got[offset:]).all()  # nothing written past the last slot
     np.testing.assert_array_equal(got[:offset], expect[:offset])
+    # the blocks' partial sums of squares of what they wrote = the squared gradient norm the clipping needs; handed to the
+    # Adam step as its clip partials they give the coefficient of clip_grad_norm_ (gradient_clipping.py:74)
+    assert sumsq.dtype == torch.float64 and sumsq.numel() > 64
+    np.testing.assert_allclose(float(sumsq.sum()), float((expect[:offset].astype(np.float64) ** 2).sum()), rtol=1e-12)
+    n = offset - offset % 4
+    param, m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step, lr, ticket = torch.zeros(1, device=DEV), torch.full((1,), 0.1, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    norm = torch.zeros(1, device=DEV)
+    ops.adam_step(param, flat[:n].contiguous(), m, v, step, lr, ticket, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                  decoupled=False, clip_partials=sumsq, max_norm=1.0, norm_out=norm)
+    np.testing.assert_allclose(norm.item(), np.sqrt((expect[:offset].astype(np.float64) ** 2).sum()), rtol=1e-6)
 
 
 @pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 4, 2), (257, 32, 1), (2, 8, 1), (5000, 16, 1), (999, 20, 1),

@@ -464,8 +464,8 @@ def test_flat_gradient_assembly_builds_one_piece_per_parameter(monkeypatch):
     flat = FlatGradients(torch.optim.SGD(params, lr=0.1))
     captured = {}
 
-    def fake_assemble(pieces, buffer):  # numpy restatement of cusrl_assemble_gradients
-        captured["pieces"] = pieces
+    def fake_assemble(pieces, buffer, want_sumsq=False):  # numpy restatement of cusrl_assemble_gradients
+        captured["pieces"], captured["want_sumsq"] = pieces, want_sumsq
         for src, offset, numel, splits in pieces:
             if isinstance(src, ops.DeferredColumns):
                 buffer[offset : offset + numel] = src.materialize()
@@ -485,6 +485,7 @@ def test_flat_gradient_assembly_builds_one_piece_per_parameter(monkeypatch):
     flat.buffer.fill_(float("nan"))
     flat.assemble([plain, None, None, None, twice_grad], sink)
     assert not sink and len(captured["pieces"]) == 5
+    assert captured["want_sumsq"] and flat.take_sumsq() is None  # single process: asked for; the stand-in returned none
     want = torch.cat([plain.reshape(-1), slabs.sum(0), rows[:, 4:8].sum(0), torch.zeros(6), twice_grad + twice_slabs.sum(0)])
     torch.testing.assert_close(flat.packed(), want)
     assert [piece[3] for piece in captured["pieces"]] == [1, 7, 9, 0, 1]
