@@ -978,7 +978,7 @@ def test_assemble_gradients_sums_slabs_into_slots(ops):
     # the blocks' partial sums of squares of what they wrote = the squared gradient norm the clipping needs; handed to the
     # Adam step as its clip partials they give the coefficient of clip_grad_norm_ (gradient_clipping.py:74)
     assert sumsq.dtype == torch.float64 and sumsq.numel() > 64
-    np.testing.assert_allclose(float(sumsq.sum()), float((expect[:offset].astype(np.float64) ** 2).sum()), rtol=1e-12)
+    np.testing.assert_allclose(float(sumsq.sum()), float((expect[:offset].astype(np.float64) ** 2).sum()), rtol=1e-6)  # fp32 squares
     n = offset - offset % 4
     param, m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     step, lr, ticket = torch.zeros(1, device=DEV), torch.full((1,), 0.1, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
