@@ -1,4 +1,4 @@
-from cusrl_amd.hook.control import ModuleInitialization
+from cusrl_amd.hook.control import EmptyCudaCache, ModuleInitialization
 from cusrl_amd.hook.auxiliary import AdversarialMotionPrior, RandomNetworkDistillation
 from cusrl_amd.hook.mdp import ObservationNormalization, RewardShaping
 from cusrl_amd.hook.on_policy import (
@@ -25,6 +25,7 @@ __all__ = [
     "RewardShaping",
     "AdvantageNormalization",
     "AdvantageReduction",
+    "EmptyCudaCache",
     "EntropyLoss",
     "GeneralizedAdvantageEstimation",
     "GradientClipping",

@@ -722,12 +722,21 @@ class DeferredLoss:
 
     MAX_BLOCKS = 256  # beyond this the per-row read-modify-write and the host-side sum stop being negligible
 
+    def sums(self) -> torch.Tensor | None:
+        """The five running sums as a device tensor (no host read) and a reset of the rows; None if nothing ran."""
+        if not self.armed or self.weights is None:
+            return None
+        total = self.rows[: self.blocks].sum(0)
+        self.rows.zero_()
+        return total
+
     def drain(self, replays: int) -> dict[str, tuple[float, int]] | None:
         """``{metric: (sum over replays of the per-step mean, samples per step)}`` and a reset of the rows."""
-        if not self.armed or replays <= 0 or self.weights is None:
+        if replays <= 0 or (total := self.sums()) is None:
             return None
-        sums = self.rows[: self.blocks].sum(0).tolist()
-        self.rows.zero_()
+        return self.metrics(total.tolist())
+
+    def metrics(self, sums: Sequence[float]) -> dict[str, tuple[float, int]]:
         w_val, w_sur, w_ent = self.weights
         B, D = self.B, self.D
         return {
@@ -1049,6 +1058,9 @@ def step_epilogue(reward, terminated, truncated, done_out, episode_rew, episode_
     N, D = reward.shape
     if terminated.numel() != N or truncated.numel() != N or done_out.numel() != N or indices_out.numel() < N:
         raise ValueError("step_epilogue: inconsistent sizes")
+    if episode_rew.shape != (N, D) or episode_len.numel() != N or ring_rew.shape[-1] != D or step_reward_sum.numel() != D:
+        raise ValueError(f"step_epilogue: the reward is [{N}, {D}] but the accumulators were built for "
+                         f"{tuple(episode_rew.shape)} (an env returning another channel count than its spec says?)")
     _observed(
         "cusrl_step_epilogue",
         lambda: N * (12 * D + 11),

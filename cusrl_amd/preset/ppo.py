@@ -60,6 +60,7 @@ def ppo_hook_suite(
         hooks.OnPolicyStatistics(sampler=AutoMiniBatchSampler()),
         (hooks.AdaptiveLRSchedule(desired_kl_divergence, max_kl_divergence=max_kl_divergence)
          if desired_kl_divergence is not None else None),
+        hooks.EmptyCudaCache() if empty_cuda_cache else None,
     ]
     return [h for h in suite if h is not None]
 
@@ -100,6 +101,9 @@ class PpoAgentFactory(AgentFactory):
     max_kl_divergence: float | None = None
     optimizer_kwargs: dict[str, Any] = field(default_factory=dict)
     """Extra torch.optim.Adam kwargs (extension), e.g. ``{"fused": True}`` for the single-kernel Adam."""
+    empty_cuda_cache: bool = False
+    """Release the allocator's cached blocks after every update (``hooks.EmptyCudaCache``; the reference has this field on
+    the recurrent factory only, preset/ppo.py:243, where it defaults to True)."""
 
     def to_underlying(self) -> ActorCriticFactory:
         def backbone(dims):
@@ -131,6 +135,7 @@ class PpoAgentFactory(AgentFactory):
                 grad_clip_groups=self.grad_clip_groups,
                 desired_kl_divergence=self.desired_kl_divergence,
                 max_kl_divergence=self.max_kl_divergence,
+                empty_cuda_cache=self.empty_cuda_cache,
             ),
             name=self.name,
             device=self.device,
@@ -152,6 +157,7 @@ class RecurrentPpoAgentFactory(PpoAgentFactory):
     actor_hidden_size: int = 256
     critic_num_layers: int = 2
     critic_hidden_size: int = 256
+    empty_cuda_cache: bool = True  # preset/ppo.py:243
 
     def to_underlying(self) -> ActorCriticFactory:
         underlying = super().to_underlying()

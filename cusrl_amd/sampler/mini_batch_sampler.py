@@ -110,6 +110,9 @@ class MiniBatchSampler(Sampler):
                     side.wait_stream(main)  # `spare` was last read by the epoch before this one
                     with torch.cuda.stream(side):
                         torch.randperm(num_samples, device=perm_device, out=spare)
+                    # should the consumer abandon this generator mid-epoch (an exception, a hook stopping early), `spare`
+                    # goes back to the main stream's allocator pool while the side stream may still be writing it
+                    spare.record_stream(side)
                     pending = True
             elif self.shuffle and epoch > 0:
                 torch.randperm(num_samples, device=perm_device, out=epoch_indices)

@@ -37,6 +37,14 @@ class _RandomBase(Sampler):
         drawn = torch.randint(high, (self.batch_size,), device=device)
         return drawn if device == buffer.device else drawn.to(buffer.device, non_blocking=True)
 
+    def _prepare(self, buffer: Buffer, rows_per_batch: int):
+        """The per-slot record only pays when a pass samples about as many rows as the buffer holds: refreshing it costs
+        a pass over every leaf that changed since the last one — after a single ``push`` that is the whole narrow part of
+        the buffer, far more than a replay-style consumer (push a step, sample a small batch) reads.  Below that the
+        gather simply reads the leaves (anything the record still mirrors is used as it is)."""
+        if self.num_batches * rows_per_batch >= buffer.capacity * buffer.get_parallelism():
+            buffer.prepare_sampling(self.hot_fields if self.lazy else None)
+
     def _batch(self, buffer: Buffer, slots: torch.Tensor, lead_shape: tuple[int, ...] | None):
         if self.lazy:
             return buffer.gather_lazy(slots, False, self.hot_fields, lead_shape=lead_shape)
@@ -48,7 +56,7 @@ class RandomSampler(_RandomBase):
 
     def __call__(self, buffer: Buffer):
         num_samples = (buffer.capacity if buffer.full else buffer.cursor) * buffer.get_parallelism()
-        buffer.prepare_sampling(self.hot_fields if self.lazy else None)
+        self._prepare(buffer, self.batch_size)
         previous = None
         for batch_index in range(self.num_batches):
             metadata = {"batch_index": batch_index, "total_batches": self.num_batches, "temporal": False}
@@ -81,7 +89,7 @@ class TemporalRandomSampler(_RandomBase):
         if sequence_len == 0:
             raise RuntimeError("TemporalRandomSampler can sample only from a non-empty buffer")
         num_starts = valid_sequence_len - sequence_len + 1  # starts live in logical time (oldest valid step = 0)
-        buffer.prepare_sampling(self.hot_fields if self.lazy else None)
+        self._prepare(buffer, self.batch_size * sequence_len)
         previous = None
         for batch_index in range(self.num_batches):
             metadata = {"batch_index": batch_index, "total_batches": self.num_batches, "temporal": True}

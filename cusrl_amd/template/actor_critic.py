@@ -133,6 +133,7 @@ class ActorCritic(Agent):
         self.optimizer = build_optimizer(optimizer_factory, self.named_parameters())
         self._graphed_act = None
         self._graphed_steps: dict[tuple, Any] = {}
+        self._metadata_reads: set[str] = set()  # metadata keys hooks read inside captured steps (graphs.TrackedMetadata)
         if self.compile:
             # `compile=True` = hipGraph replay of the act step and of every minibatch step (template/graphs.py)
             if self.device.type != "cuda":
@@ -264,11 +265,16 @@ class ActorCritic(Agent):
             if graphed:
                 for metadata, indices in self.sampler.iter_indices(self.buffer):
                     key = (metadata["mini_batch_index"], metadata["temporal"], indices.numel())
+                    if self._metadata_reads:  # a hook looks at these: steps whose values differ are different captures
+                        key += tuple((name, metadata.get(name)) for name in sorted(self._metadata_reads)
+                                     if name not in ("mini_batch_index", "temporal"))
                     if (step := self._graphed_steps.get(key)) is None:
                         step = self._graphed_steps[key] = GraphedTrainStep(self, key[0], key[1])
                     step.run(metadata, indices)
+                deferred: list = []
                 for step in self._graphed_steps.values():
-                    step.flush_metrics()
+                    step.flush_metrics(deferred)
+                GraphedTrainStep.resolve_deferred(deferred)  # the loss sums of every step: one host read
             else:
                 for metadata, batch in self.sampler(self.buffer):  # a7/a8
                     self._train_step(metadata, batch)

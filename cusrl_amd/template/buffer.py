@@ -138,12 +138,32 @@ class LazyBatch(dict):
         self[key] = default
         return default
 
+    def update(self, *args, **kwargs):
+        # through __setitem__: a field the consumer overwrites must leave `_pending`, or a later whole-batch access
+        # (iteration, **batch, copy) would fetch the buffer's rows over the consumer's value
+        for key, value in dict(*args, **kwargs).items():
+            self[key] = value
+
+    def __ior__(self, other):
+        self.update(other)
+        return self
+
+    def __or__(self, other):
+        merged = self.copy()
+        merged.update(other)
+        return merged
+
+    def __ror__(self, other):
+        merged = dict(other)
+        merged.update(self.copy())
+        return merged
+
     def __iter__(self):
         self._fetch_all()
         return dict.__iter__(self)
 
     def __len__(self):
-        return dict.__len__(self) + len(self._pending)
+        return dict.__len__(self) + sum(1 for key in self._pending if not dict.__contains__(self, key))
 
     def keys(self):
         self._fetch_all()

@@ -1,20 +1,34 @@
-"""hipGraph capture of the two launch-bound inner loops (what ``compile=True`` means in cusrl_amd).
+"""hipGraph capture of the launch-bound loops (what ``compile=True`` means in cusrl_amd).
 
 The reference offers ``compile=True`` = ``torch.compile`` of actor / critic / hook objective
-(cusrl/template/actor_critic.py:217-220, hook.py:396-399).  On MI355X the inner loops are not FLOP-bound but
-launch-bound — one minibatch step is ≈ 75 kernels of a few µs each, one ``act`` ≈ 26 — so instead of a tracing
-compiler the same knob captures them into HIP graphs and replays them:
+(cusrl/template/actor_critic.py:217-220, hook.py:396-399).  On MI355X these loops are chains of dependent launches of
+a few µs each (a dependent kernel costs ≥ 1.5 µs from a graph, several times that when Python issues it), so instead of a
+tracing compiler the same knob captures them into HIP graphs and replays them:
 
-* :class:`GraphedTrainStep` — one per minibatch slot ``j``: graph A = gather of every buffer leaf (HIP kernel) →
-  critic / actor forward → fused PPO objective (HIP kernel) → zero flat gradients → backward; then the gradient
-  all-reduce runs EAGERLY between the graphs (RCCL stays outside capture); graph B = clipping → Adam → metric taps.
-* :class:`GraphedAct` — ``pre_act`` hooks → ``actor.explore`` (sampling included: torch's graph-safe Philox state)
-  → ``post_act`` hooks (critic value).
+* :class:`GraphedRolloutStep` — one per buffer cursor: a WHOLE env step of a capturable env — ``pre_act`` hooks →
+  ``actor.explore`` → ``post_act`` hooks → ``env.step`` → fused step epilogue (done flag, episode statistics, ordered
+  finished-env ids + device-side count) → ``post_step`` hooks → buffer push → fixed-shape resets spliced by that count →
+  the next act input.  No host read on the path: the trainer issues the rollout's replays back to back.
+* :class:`GraphedAct` — ``pre_act`` → ``actor.explore`` (sampling included: torch's graph-safe Philox state) →
+  ``post_act`` for envs that are not capturable (the env step then stays host-driven).
+* :class:`GraphedTrainStep` — one per minibatch slot (and per value of every ``metadata`` key a hook reads,
+  :class:`TrackedMetadata`): gather of the fields the step's hooks read (``LazyBatch``; plain leaves while the buffer is
+  cache-resident, the per-slot record beyond) → critic forward on a second stream ‖ actor forward → fused PPO objective
+  WITHOUT its finalize launch (loss values as running block sums, ``ops.DeferredLoss``) → backward (critic's on its own
+  branch) → one-launch gradient assembly (+ the squared-norm partials of the clip) → gradient all-reduce → Adam.
+  One process, or RCCL through the C ABI (``cusrl_allreduce_mean`` enqueued on the step's stream — the default route of
+  an RCCL job): ONE graph; torch.distributed's collectives (gloo, or the fallback route): two graphs with the eager
+  all-reduce between them.
+* :class:`GraphedRegion` — the shape-static parts of ``agent.update()`` outside the minibatch loop (critic pass +
+  ``next_value`` + compaction, the truncated-slot bootstrap per power-of-two bucket, the statistics pass).
 
 Protocol per graph: first use runs eagerly on the capture stream (warm-up of rocBLAS workspaces and allocator,
-and it IS the real step), second use captures and replays, later uses replay.  Hooks must be capture-safe: no host
-synchronisation and no Python side effects other than ``agent.record`` inside the captured phases — true for every
-stock hook.  Anything else keeps ``compile=False`` (eager), which is the default.
+and it IS the real step), second use captures and replays, later uses replay; a graph is only replayed while the
+host-side values it froze (``capture_signature``: hook mutables, inference / deterministic flags; buffer layout) still
+hold.  Hooks must be capture-safe: no host synchronisation and no Python side effects other than ``agent.record``
+inside the captured phases — true for every stock hook; a hook that needs more declares the phase eager
+(``Hook.eager_phases``), repeats its host half in ``Hook.on_replay``, or — for user hooks overriding ``post_step`` —
+simply does not opt in (``rollout_capture_safe``).  ``compile=False`` (the default) runs everything eagerly.
 """
 
 from __future__ import annotations
@@ -53,6 +67,55 @@ def capture_signature(agent) -> tuple:
     for hook in agent.hook:
         parts.append((hook.name, hook._active, tuple((name, _freeze(getattr(hook, name, None))) for name in sorted(hook._mutable))))
     return tuple(parts)
+
+
+class TrackedMetadata(dict):
+    """The ``metadata`` dict a captured minibatch step hands to the hooks: reads are recorded in ``reads`` (a set the
+    agent owns).  A captured step freezes whatever Python did with a value it read — a hook branching on
+    ``metadata["epoch_index"]`` would silently keep the capture-time branch on every replay — so ``ActorCritic.update``
+    makes every key that was ever read part of the key its step graphs are looked up under: a step whose read values
+    differ gets (and replays) its own capture."""
+
+    __slots__ = ("reads",)
+
+    def __init__(self, data, reads: set):
+        super().__init__(data)
+        self.reads = reads
+
+    def __getitem__(self, key):
+        self.reads.add(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self.reads.add(key)
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        self.reads.add(key)
+        return dict.__contains__(self, key)
+
+    def _all(self):
+        self.reads.update(dict.keys(self))
+
+    def __iter__(self):
+        self._all()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._all()
+        return dict.keys(self)
+
+    def values(self):
+        self._all()
+        return dict.values(self)
+
+    def items(self):
+        self._all()
+        return dict.items(self)
+
+    def copy(self):
+        self._all()
+        return dict(self)
 
 
 def collective_phases(agent) -> set[str]:
@@ -218,7 +281,7 @@ class GraphedTrainStep:
             self.static_indices = torch.empty_like(indices)
             self.state = 0
         self.static_indices.copy_(indices)
-        self.metadata = dict(metadata)
+        self.metadata = TrackedMetadata(metadata, agent._metadata_reads)
         # the captured gather reads the per-slot record: keep it current (flag check); once the warm-up has learned which
         # fields the step reads, the record holds exactly those (two memory lines per sampled slot)
         agent.buffer.prepare_sampling(self.hot_fields)
@@ -257,13 +320,29 @@ class GraphedTrainStep:
         reduce_gradients(agent.optimizer, agent.flat_gradients)
         self.optimize.replay()
 
-    def flush_metrics(self):
+    def flush_metrics(self, deferred: list | None = None):
+        """Fold what the replays accumulated on the device into the agent's metrics.  ``deferred`` (a list the caller
+        resolves with :meth:`resolve_deferred`): the loss sums are only ENQUEUED here, so that all steps of an update
+        share one host read."""
         replays = self.forward_backward.replays
         self.forward_backward.flush_metrics()
         self.optimize.flush_metrics()
-        if self.deferred_loss is not None and (drained := self.deferred_loss.drain(replays)) is not None:
-            for name, (total, count) in drained.items():  # total = sum over the replays of the step's mean
-                self.agent.metrics.add_resolved(name, total * count, count * replays)
+        if self.deferred_loss is None or replays <= 0 or (sums := self.deferred_loss.sums()) is None:
+            return
+        if deferred is None:
+            self._record_deferred(sums.tolist(), replays)
+        else:
+            deferred.append((self, sums, replays))
+
+    def _record_deferred(self, sums, replays: int):
+        for name, (total, count) in self.deferred_loss.metrics(sums).items():  # total = sum over the replays of the step's mean
+            self.agent.metrics.add_resolved(name, total * count, count * replays)
+
+    @staticmethod
+    def resolve_deferred(deferred: list):
+        if deferred:
+            for (step, _, replays), sums in zip(deferred, torch.stack([entry[1] for entry in deferred]).tolist()):
+                step._record_deferred(sums, replays)
 
 
 class GraphedRegion:

@@ -358,7 +358,8 @@ class Trainer:
         return (isinstance(reward, torch.Tensor) and isinstance(terminated, torch.Tensor) and isinstance(truncated, torch.Tensor)
                 and reward.device == stats.device and terminated.device == stats.device and truncated.device == stats.device
                 and reward.dtype == torch.float32 and terminated.dtype == torch.bool and truncated.dtype == torch.bool
-                and reward.dim() == 2 and terminated.shape == (stats.num_envs, 1) and truncated.shape == terminated.shape
+                and reward.shape == (stats.num_envs, stats.reward_dim)  # the kernel indexes the [N, D] accumulators with it
+                and terminated.shape == (stats.num_envs, 1) and truncated.shape == terminated.shape
                 and reward.is_contiguous() and terminated.is_contiguous() and truncated.is_contiguous()
                 and stats.num_envs <= limit and "done" not in info)
 

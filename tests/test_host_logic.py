@@ -542,6 +542,47 @@ def test_lazy_batch_is_a_dict_that_gathers_on_first_access():
         pass
     else:
         raise AssertionError
+    # update() / |= / | go through __setitem__: an overwritten pending field must never be re-fetched over the user's value
+    sixth = LazyBatch(buffer, None, False, hot)
+    calls = len(buffer.calls)
+    sixth.update(action_dist="mine", extra=3)
+    sixth |= {"observation": "also mine"}
+    assert "action_dist" not in sixth._pending and len(sixth) == 5 and len(buffer.calls) == calls
+    everything = dict(sixth.items())                                       # whole-batch access: nothing left to fetch over them
+    assert everything["action_dist"] == "mine" and everything["observation"] == "also mine" and everything["extra"] == 3
+    assert len(buffer.calls) == calls
+    merged = sixth | {"reward": "override"}
+    assert type(merged) is dict and merged["reward"] == "override" and sixth["reward"][0] == "reward"
+
+
+def test_replayed_steps_repeat_their_host_side_effects():
+    """What a hipGraph replay of an env step leaves to Python (template/graphs.py GraphedRolloutStep): the buffer cursor
+    (``Buffer.replay_push``), the hooks' host halves (``Hook.on_replay``) and the update cadence (``ActorCritic.replay_step``)
+    — exercised on CPU objects, no launch involved."""
+    from cusrl_amd.hook.on_policy.value import ValueComputation
+    from cusrl_amd.template.buffer import Buffer
+
+    buffer = Buffer(3, 2, device="cpu")
+    with pytest.raises(RuntimeError, match="no steady-state append"):
+        buffer.replay_push()
+    buffer._push_plan = (("reward",), (), (), (), None, (), ("reward",))  # as a steady-state plan would leave it
+    buffer.set_derived("reward", "by-product")
+    for expect_cursor, expect_full in ((1, False), (2, False), (0, True)):
+        buffer.replay_push()
+        assert buffer.cursor == expect_cursor and buffer.full == expect_full
+    assert buffer.take_derived("reward") is None
+    hook = ValueComputation()
+    hook.agent = SimpleNamespace(critic=SimpleNamespace(is_recurrent=False), inference_mode=False, device=torch.device("cpu"),
+                                 hook=[hook])
+    hook.defer_value = True
+    hook.on_replay("act")
+    assert not hook._value_pending
+    hook.on_replay("step")
+    assert hook._value_pending                                              # pre_update must run the deferred critic pass
+    hook.defer_value = False
+    hook._value_pending = False
+    hook.on_replay("step")
+    assert not hook._value_pending
 
 
 def test_tuned_gemm_selection_file_is_well_formed_and_inert_without_a_gpu():
