@@ -69,15 +69,17 @@ def pmc_traffic(envs_per_gpu):
     cusrl_amd/csrc/buffer.hip recorded next to the numbers); otherwise null."""
     import hashlib
 
-    path = ROOT / "profiles" / "r02" / "pmc_summary.json"
+    path = ROOT / "profiles" / "r03" / "pmc_summary.json"
     if envs_per_gpu != NUM_ENVS or not path.exists():
         return None, None
     summary = json.loads(path.read_text())
     source = hashlib.sha256((ROOT / "cusrl_amd" / "csrc" / "buffer.hip").read_bytes()).hexdigest()[:16]
-    entry = summary.get("gather_minibatch_hot_record")
+    entry = summary.get("gather_minibatch_hot_plain")  # the six leaves a PPO step reads, gathered plainly (round 3)
     if not entry or summary.get("buffer_hip_sha256_16") != source:
         return None, None
-    return entry["hbm_traffic_bytes"], f"quoted: rocprofv3 PMC passes of this kernel source ({summary.get('commit', '?')}), profiles/r02/pmc_summary.json"
+    return entry["hbm_traffic_bytes"], (f"quoted: rocprofv3 PMC passes of this kernel source ({summary.get('commit', '?')}), "
+                                        "profiles/r03/pmc_summary.json; the 25 MB of sampled leaves are L2 / Infinity-Cache "
+                                        "resident, the memory-side counters include the cache's hits")
 
 
 def graph_time(fn, launches=10, replays=20):
@@ -221,8 +223,11 @@ def run_gpu(args, rank, world):
 
         wanted = {"gae + return + stats": "gae", "ppo loss fwd+bwd, std vector": "ppo_loss_std_vector",
                   "ppo loss fwd+bwd (": "ppo_loss_std_matrix", "gather hot leaves via record": "gather_narrow_record_plus_leaves",
-                  "gather hot leaves from the 256 B hot record": "gather_hot_record"}
-        for name, (us, nbytes) in kernel_bench.bench_size(1 << 20, only=("gae + return", "ppo loss", "gather hot"), iters=10).items():
+                  "gather hot leaves from the 256 B hot record": "gather_hot_record",
+                  "pack the narrow leaves of the hot record": "pack_narrow_leaves_of_hot_record",
+                  "pack hot record": "pack_whole_hot_record", "push with write-through": "push_with_write_through"}
+        for name, (us, nbytes) in kernel_bench.bench_size(1 << 20, only=("gae + return", "ppo loss", "gather hot", "pack the narrow",
+                                                                        "pack hot", "push with write"), iters=10).items():
             for prefix, key in wanted.items():
                 if name.startswith(prefix):
                     scale[key] = {"avg_us": round(us, 1), "bytes_per_launch": int(nbytes),
@@ -275,7 +280,7 @@ def run_gpu(args, rank, world):
                       f"Infinity Cache, Buffer.record_threshold_bytes), {dominant['row_bytes']} B/slot read + written + 8 B index",
             "timing": "graph-timed: hipGraph of 10 identical launches x 20 replays between one HIP-event pair, right after "
                       "the timed region, on the graph's stream (the in-step launch cannot be bracketed from the host); "
-                      "rocprofv3 per-grid averages of the same command: profiles/r02/",
+                      "rocprofv3 per-grid averages of the same command: profiles/r03/",
             "achieved": dominant["achieved_GBps"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -60,6 +60,19 @@ def main():
     horizon = trainer.agent.num_steps_per_update
     observation, state, _ = env.reset()
     print(f"== {args.config}: {env.num_instances} envs x {horizon} steps, compile={args.compile}", flush=True)
+    # where an iteration goes: agent.update() bracketed by a synchronised host clock (the rollout is the rest)
+    update_time = [0.0]
+    original_update = trainer.agent.update
+
+    def timed_update():
+        torch.cuda.synchronize()
+        start = time.perf_counter()
+        result = original_update()
+        torch.cuda.synchronize()
+        update_time[0] = time.perf_counter() - start
+        return result
+
+    trainer.agent.update = timed_update
     for i in range(args.iterations):
         before = dict(_native.launch_counts)
         torch.cuda.synchronize()
@@ -70,7 +83,7 @@ def main():
         dt = time.perf_counter() - t0
         info = trainer.last_info
         launches = sum(v - before.get(k, 0) for k, v in _native.launch_counts.items())
-        print(f"iteration {i}: {dt * 1e3:8.2f} ms  {env.num_instances * horizon / dt / 1e6:6.3f} M env-steps/s  "
+        print(f"iteration {i}: {dt * 1e3:8.2f} ms (update {update_time[0] * 1e3:7.2f})  {env.num_instances * horizon / dt / 1e6:6.3f} M env-steps/s  "
               f"value_loss={info['Agent/value_loss']:.4f} kl={info['Agent/kl_divergence']:.2e} "
               f"hip_entry_calls={launches} mem={torch.cuda.max_memory_allocated() / 2**30:.2f} GiB", flush=True)
     census = {k: v for k, v in sorted(_native.launch_counts.items())}
