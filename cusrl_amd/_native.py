@@ -72,7 +72,7 @@ _SIGNATURES = {
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
     "cusrl_ppo_loss_std_partial_rows": (c_int64, [c_int64]),
     "cusrl_ppo_loss_blocks": (c_int64, [c_int64, c_int64]),
-    "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, c_int64, _P, _P]),
+    "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, c_int64, _P, _P, _P, _P]),
     "cusrl_categorical_sample_logp": (c_int, [_P] * 4 + [c_int64, c_int64, _P]),
     "cusrl_gru_gates_fwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, _P]),
     "cusrl_gru_gates_bwd": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P]),

@@ -17,7 +17,12 @@ __global__ __launch_bounds__(kBlock) void normal_sample_logp_kernel(const float 
                                                                     const float *__restrict__ eps,
                                                                     float *__restrict__ action,
                                                                     float *__restrict__ logp, int64_t B, int A,
-                                                                    int std_is_vector, float *__restrict__ std_out) {
+                                                                    int std_is_vector, float *__restrict__ std_out,
+                                                                    const float *__restrict__ mean_bias,
+                                                                    float *__restrict__ mean_out) {
+    // mean_bias (optional, [A]): `mean` is the policy head's product WITHOUT its bias; the bias is added here and the
+    // finished mean goes to mean_out [B, A] — for a 12-column head the library adds the bias by broadcasting it into the
+    // output with a copy launch before the GEMM, which costs more than the GEMM itself.
     const int64_t row = int64_t(blockIdx.x) * kBlock + threadIdx.x;
     if (row >= B) return;
     float lp = 0.0f;
@@ -28,8 +33,16 @@ __global__ __launch_bounds__(kBlock) void normal_sample_logp_kernel(const float 
         const float4 *e4 = reinterpret_cast<const float4 *>(eps + row * A);
         float4 *a4 = reinterpret_cast<float4 *>(action + row * A);
         float4 *so4 = std_out ? reinterpret_cast<float4 *>(std_out + row * A) : nullptr;
+        const float4 *b4 = reinterpret_cast<const float4 *>(mean_bias);
+        float4 *mo4 = reinterpret_cast<float4 *>(mean_out + (mean_out ? row * A : 0));
         for (int c = 0; c < A / 4; ++c) {
-            const float4 m = m4[c], s = s4[c], e = e4[c];
+            float4 m = m4[c];
+            const float4 s = s4[c], e = e4[c];
+            if (mean_bias) {
+                const float4 b = b4[c];
+                m.x += b.x, m.y += b.y, m.z += b.z, m.w += b.w;
+                mo4[c] = m;
+            }
             if (so4) so4[c] = s;
             const float ms[4] = {m.x, m.y, m.z, m.w}, ss[4] = {s.x, s.y, s.z, s.w}, es[4] = {e.x, e.y, e.z, e.w};
             float as[4];
@@ -45,8 +58,10 @@ __global__ __launch_bounds__(kBlock) void normal_sample_logp_kernel(const float 
         for (int a = 0; a < A; ++a) {
             const int64_t i = row * A + a;
             const float sg = std[std_row * A + a];
-            const float act = mean[i] + eps[i] * sg;
-            const float diff = act - mean[i];
+            const float mu = mean_bias ? mean[i] + mean_bias[a] : mean[i];
+            if (mean_bias) mean_out[i] = mu;
+            const float act = mu + eps[i] * sg;
+            const float diff = act - mu;
             action[i] = act;
             if (std_out) std_out[i] = sg;
             lp += -(diff * diff) / (2.0f * (sg * sg)) - logf(sg) - log_sqrt_2pi_r();
@@ -263,22 +278,22 @@ extern "C" int cusrl_amp_style_reward(const float *logit, float *reward, float *
 
 extern "C" int cusrl_normal_sample_logp(const float *mean, const float *std, const float *eps, float *action,
                                         float *logp, int64_t B, int64_t A, int64_t std_rows, float *std_out,
-                                        void *stream) {
+                                        const float *mean_bias, float *mean_out, void *stream) {
     if (B < 0 || A <= 0 || (std_rows != B && std_rows != 1)) return CUSRL_E_INVALID;
     if (B == 0) return 0;
-    if (!mean || !std || !eps || !action || !logp) return CUSRL_E_INVALID;
+    if (!mean || !std || !eps || !action || !logp || (mean_bias != nullptr) != (mean_out != nullptr)) return CUSRL_E_INVALID;
     if (A > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     const int64_t blocks = ceil_div(B, kBlock);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     const int vector = std_rows == 1 && B != 1;
     const bool vec4 = A % 4 == 0 && aligned(mean, 16) && aligned(std, 16) && aligned(eps, 16) && aligned(action, 16) &&
-                      (!std_out || aligned(std_out, 16));
+                      (!std_out || aligned(std_out, 16)) && (!mean_bias || (aligned(mean_bias, 16) && aligned(mean_out, 16)));
     if (vec4)
         hipLaunchKernelGGL(normal_sample_logp_kernel<true>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream),
-                           mean, std, eps, action, logp, B, int(A), vector, std_out);
+                           mean, std, eps, action, logp, B, int(A), vector, std_out, mean_bias, mean_out);
     else
         hipLaunchKernelGGL(normal_sample_logp_kernel<false>, dim3(uint32_t(blocks)), dim3(kBlock), 0,
-                           as_stream(stream), mean, std, eps, action, logp, B, int(A), vector, std_out);
+                           as_stream(stream), mean, std, eps, action, logp, B, int(A), vector, std_out, mean_bias, mean_out);
     return launch_status();
 }
 

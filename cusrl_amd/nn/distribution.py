@@ -233,6 +233,22 @@ class NormalDist(_Normal):
         # acting on the GPU: the std stays a view of its vector until the sampling launch, which repeats it itself
         self.std.expand_when_acting = True
         try:
+            head = self.mean_head
+            vector = None
+            if (head.bias is not None and backbone_feat.dim() == 2 and backbone_feat.dtype == torch.float32
+                    and head.weight.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")):
+                std = self.std(backbone_feat)
+                vector = getattr(std, "_cusrl_row_vector", None)
+            if vector is not None and vector.dtype == torch.float32:
+                # ONE launch behind the head's bias-free GEMM: + bias, action = mean + eps * std, log-prob, and the two
+                # [B, A] leaves the transition carries (finished mean, repeated std) — instead of a bias-broadcast copy
+                # launch in front of the GEMM, a repeat launch for the std and the sampling launch
+                from cusrl_amd import ops
+
+                raw = torch.mm(backbone_feat, head.weight.t())
+                eps = torch.empty(raw.shape, dtype=raw.dtype, device=raw.device).normal_()
+                action, logp, repeated, mean = ops.normal_sample_logp(raw, vector, eps, repeat_std=True, mean_bias=head.bias)
+                return {"mean": mean, "std": repeated}, (action, logp)
             dist_params = self(backbone_feat, **kwargs)
         finally:
             self.std.expand_when_acting = False

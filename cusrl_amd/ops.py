@@ -911,11 +911,13 @@ def ppo_loss_accepts_std_vector(action_dim: int) -> bool:
 
 
 # ------------------------------------------------------------------------------------------------ rollout side
-def normal_sample_logp(mean: torch.Tensor, std: torch.Tensor, eps: torch.Tensor, repeat_std: bool = False):
+def normal_sample_logp(mean: torch.Tensor, std: torch.Tensor, eps: torch.Tensor, repeat_std: bool = False,
+                       mean_bias: torch.Tensor | None = None):
     """``action = mean + eps * std`` and ``log_prob(action).sum(-1, keepdim=True)`` in one launch
     (cusrl/nn/module/distribution.py:198-205).  ``std`` may be the ``[A]`` vector a state-independent std repeats for every
     row; with ``repeat_std`` the launch also writes that repeated ``[B, A]`` matrix (what ``param.repeat(B, 1)`` gives,
-    distribution.py:241-243) and returns it as a third value."""
+    distribution.py:241-243) and returns it as a third value.  ``mean_bias`` ([A]): ``mean`` is the head's product without
+    its bias; the launch adds it and returns the finished mean as the last value."""
     mean, std, eps = _f32(mean, "mean"), _f32(std, "std"), _f32(eps, "eps")
     A = mean.shape[-1]
     B = mean.numel() // A
@@ -925,15 +927,26 @@ def normal_sample_logp(mean: torch.Tensor, std: torch.Tensor, eps: torch.Tensor,
     action = torch.empty_like(mean)
     logp = torch.empty(mean.shape[:-1] + (1,), dtype=torch.float32, device=mean.device)
     repeated = torch.empty_like(mean) if (repeat_std and vector) else None
+    finished = None
+    if mean_bias is not None:
+        mean_bias = _f32(mean_bias, "mean_bias")
+        if mean_bias.numel() != A:
+            raise ValueError("normal_sample_logp: one bias per action dim is required")
+        finished = torch.empty_like(mean)
     _observed(
         "cusrl_normal_sample_logp",
-        lambda: B * ((12 if vector else 16) * A + 4 + (4 * A if repeated is not None else 0)),
+        lambda: B * ((12 if vector else 16) * A + 4 + (4 * A if repeated is not None else 0) + (4 * A if finished is not None else 0)),
         lambda: _native.lib().cusrl_normal_sample_logp(mean.data_ptr(), std.data_ptr(), eps.data_ptr(), action.data_ptr(), logp.data_ptr(),
-                                                       B, A, 1 if vector else B, None if repeated is None else repeated.data_ptr(), _stream()),
+                                                       B, A, 1 if vector else B, None if repeated is None else repeated.data_ptr(),
+                                                       None if finished is None else mean_bias.data_ptr(),
+                                                       None if finished is None else finished.data_ptr(), _stream()),
     )
+    result = (action, logp)
     if repeat_std:
-        return action, logp, (repeated if repeated is not None else std)
-    return action, logp
+        result += (repeated if repeated is not None else std,)
+    if finished is not None:
+        result += (finished,)
+    return result
 
 
 def categorical_sample_logp(logits: torch.Tensor, noise: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:

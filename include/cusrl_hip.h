@@ -259,9 +259,13 @@ int cusrl_rnn_cell_bwd(float *d_pre, const float *out, const float *d_out, float
  * from torch's generator so the random stream is the reference's); logp[B] as in cusrl_ppo_loss_fwd_bwd.
  * std_rows = B: std [B,A]; std_rows = 1: std is the [A] vector a state-independent std repeats for every row
  * (distribution.py:228-247, `param.repeat(B, 1)`) — broadcast inside the kernel, and std_out [B,A] (optional) receives
- * the repeated matrix the rollout buffer stores as a leaf, so the acting path needs no `repeat` launch. */
+ * the repeated matrix the rollout buffer stores as a leaf, so the acting path needs no `repeat` launch.
+ * mean_bias [A] + mean_out [B,A] (both or neither): `mean` is the policy head's product WITHOUT its bias
+ * (`latent @ W^T`, distribution.py:195-197 `mean_head`); the bias is added here and the finished mean written to
+ * mean_out — the library adds a 12-column bias by broadcasting it into the output with a copy launch before the GEMM. */
 int cusrl_normal_sample_logp(const float *mean, const float *std, const float *eps, float *action, float *logp,
-                             int64_t B, int64_t A, int64_t std_rows, float *std_out, void *stream);
+                             int64_t B, int64_t A, int64_t std_rows, float *std_out, const float *mean_bias,
+                             float *mean_out, void *stream);
 
 /* One-hot categorical sample + its log-prob in one pass — cusrl/nn/module/distribution.py:332-366
  * (`OneHotCategorical(logits).sample()`, `log_prob(sample)`): idx = argmax_j softmax(logits)_j / noise_j with

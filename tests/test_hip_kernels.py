@@ -664,6 +664,18 @@ def test_normal_sample_logp_vs_oracle(ops, B, A):
     ref_logp, _ = oracle.normal_logp_entropy(expect, mean, std)
     np.testing.assert_allclose(host(logp), ref_logp, rtol=1e-5, atol=1e-5)
     assert logp.shape == (B, 1)
+    # the acting path's form: std as the [A] vector every row repeats (the launch also emits the repeated matrix the
+    # rollout buffer stores) and the policy head's bias added to a bias-free product (the finished mean is emitted too):
+    # the same numbers as the plain form on the materialised operands, bit for bit
+    vector = std[0].copy()
+    bias = rng.standard_normal(A).astype(np.float32)
+    raw = (mean - bias).astype(np.float32)
+    action_v, logp_v, repeated, finished = ops.normal_sample_logp(dev(raw), dev(vector), dev(eps), repeat_std=True, mean_bias=dev(bias))
+    if B > 1:
+        assert np.array_equal(host(repeated), np.repeat(vector[None], B, 0))
+    assert np.array_equal(host(finished), raw + bias)
+    plain_action, plain_logp = ops.normal_sample_logp(dev(raw + bias), dev(np.repeat(vector[None], B, 0)), dev(eps))
+    assert torch.equal(action_v, plain_action) and torch.equal(logp_v, plain_logp)
 
 
 @pytest.mark.parametrize("B,A", [(8, 3), (4096, 12), (1000, 32), (777, 33), (300, 200), (1, 1)])
