@@ -921,7 +921,7 @@ def normal_sample_logp(mean: torch.Tensor, std: torch.Tensor, eps: torch.Tensor,
     mean, std, eps = _f32(mean, "mean"), _f32(std, "std"), _f32(eps, "eps")
     A = mean.shape[-1]
     B = mean.numel() // A
-    vector = std.dim() == 1 and std.numel() == A and B != 1
+    vector = std.dim() == 1 and std.numel() == A
     if (not vector and std.shape != mean.shape) or eps.shape != mean.shape:
         raise ValueError("normal_sample_logp: shape mismatch")
     action = torch.empty_like(mean)

@@ -671,8 +671,7 @@ def test_normal_sample_logp_vs_oracle(ops, B, A):
     bias = rng.standard_normal(A).astype(np.float32)
     raw = (mean - bias).astype(np.float32)
     action_v, logp_v, repeated, finished = ops.normal_sample_logp(dev(raw), dev(vector), dev(eps), repeat_std=True, mean_bias=dev(bias))
-    if B > 1:
-        assert np.array_equal(host(repeated), np.repeat(vector[None], B, 0))
+    assert np.array_equal(host(repeated), np.repeat(vector[None], B, 0))
     assert np.array_equal(host(finished), raw + bias)
     plain_action, plain_logp = ops.normal_sample_logp(dev(raw + bias), dev(np.repeat(vector[None], B, 0)), dev(eps))
     assert torch.equal(action_v, plain_action) and torch.equal(logp_v, plain_logp)
