@@ -52,6 +52,9 @@ def main():
     parser.add_argument("--envs", type=int, default=None)
     parser.add_argument("--iterations", type=int, default=6)
     parser.add_argument("--compile", action="store_true")
+    parser.add_argument("--phases", action="store_true",
+                        help="also print agent.update()'s share (two device synchronisations per iteration: the host can no "
+                             "longer run ahead of the device, small configs read ~1 ms slower)")
     args = parser.parse_args()
     cusrl.config.set_device("cuda:0")
     cusrl.set_global_seed(42)
@@ -72,7 +75,8 @@ def main():
         update_time[0] = time.perf_counter() - start
         return result
 
-    trainer.agent.update = timed_update
+    if args.phases:
+        trainer.agent.update = timed_update
     for i in range(args.iterations):
         before = dict(_native.launch_counts)
         torch.cuda.synchronize()
@@ -83,7 +87,8 @@ def main():
         dt = time.perf_counter() - t0
         info = trainer.last_info
         launches = sum(v - before.get(k, 0) for k, v in _native.launch_counts.items())
-        print(f"iteration {i}: {dt * 1e3:8.2f} ms (update {update_time[0] * 1e3:7.2f})  {env.num_instances * horizon / dt / 1e6:6.3f} M env-steps/s  "
+        share = f" (update {update_time[0] * 1e3:7.2f})" if args.phases else ""
+        print(f"iteration {i}: {dt * 1e3:8.2f} ms{share}  {env.num_instances * horizon / dt / 1e6:6.3f} M env-steps/s  "
               f"value_loss={info['Agent/value_loss']:.4f} kl={info['Agent/kl_divergence']:.2e} "
               f"hip_entry_calls={launches} mem={torch.cuda.max_memory_allocated() / 2**30:.2f} GiB", flush=True)
     census = {k: v for k, v in sorted(_native.launch_counts.items())}
