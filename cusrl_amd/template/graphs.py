@@ -34,6 +34,7 @@ simply does not opt in (``rollout_capture_safe``).  ``compile=False`` (the defau
 from __future__ import annotations
 
 import gc
+import os
 from typing import Any
 
 import torch
@@ -153,7 +154,7 @@ class _Capture:
         self.accumulator: torch.Tensor | None = None
         self.replays = 0
 
-    MAX_TAPS = 64
+    MAX_TAPS = 256  # (a whole-rollout graph taps every env step's metrics)
 
     def capture(self, fn, stream: torch.cuda.Stream, pool=None):
         tap = MetricTap()
@@ -493,6 +494,10 @@ class GraphedRolloutStep:
         self.static_observation: torch.Tensor | None = None
         self.static_state: torch.Tensor | None = None
         self.replays = 0
+        # ... and, once every step of a rollout has its graph, the WHOLE rollout as one graph (run_rollout)
+        self.rollouts: dict[tuple, dict] = {}
+        self.rollout_replays = 0
+        self.whole_rollouts = os.environ.get("CUSRL_WHOLE_ROLLOUT_GRAPH", "1") != "0"
 
     # ------------------------------------------------------------------ eligibility
     def supported(self, observation, state) -> bool:
@@ -561,6 +566,7 @@ class GraphedRolloutStep:
             self.flush_metrics()
             for entry in self.steps.values():
                 entry["state"] = min(entry["state"], 1)
+            self.rollouts.clear()
             self.signature = signature
 
     def run(self, observation, state):
@@ -605,8 +611,71 @@ class GraphedRolloutStep:
         entry["capture"].replay()
         return act.static_observation, act.static_state, self.ready
 
+    # ------------------------------------------------------------------ the whole rollout as ONE graph
+    def _rollout_length(self) -> int | None:
+        """T when this rollout is exactly one pass over the buffer — starts at cursor 0 with a fresh step counter, the
+        update comes after ``capacity`` steps, no hook decides ``should_update`` itself — and every one of its steps
+        already replays from its own graph under the current signature (so every body is warm); else None."""
+        agent, trainer = self.agent, self.trainer
+        buffer = agent.buffer
+        T = buffer.capacity
+        if not self.whole_rollouts or buffer.cursor != 0 or agent.step_index != 0 or agent.num_steps_per_update != T:
+            return None
+        from cusrl_amd.template.hook import Hook
+
+        if any(hook._active and type(hook).should_update is not Hook.should_update for hook in agent.hook):
+            return None
+        parity = trainer.stats._parity
+        for t in range(T):
+            entry = self.steps.get((t, parity ^ (t & 1)))
+            if entry is None or entry["state"] != 2:
+                return None
+        return T
+
+    def _rollout_body(self, steps: int):
+        for _ in range(steps):
+            self._body()
+
+    def run_rollout(self, observation, state):
+        """The whole rollout from one replay — the T step bodies captured back to back into ONE graph: one launch, one
+        pair of generator-state fills and no replay boundaries instead of T of each.  Returns ``(observation, state)`` for
+        the next rollout, or None when the conditions of :meth:`_rollout_length` do not hold (the caller then steps)."""
+        steps = self._rollout_length()
+        if steps is None:
+            return None
+        agent, trainer = self.agent, self.trainer
+        act = agent._graphed_act
+        if observation is not act.static_observation:
+            act.static_observation.copy_(observation)
+            if state is not None:
+                act.static_state.copy_(state)
+        key = (trainer.stats._parity, steps)
+        entry = self.rollouts.get(key)
+        if entry is None:
+            # capture: the bodies' host effects (cursor, counters, hooks' host halves) happen here, once, for this very
+            # rollout; the replay right behind the capture performs its device work
+            entry = self.rollouts[key] = {"capture": _Capture(agent), "transition": None}
+            entry["capture"].capture(lambda: self._rollout_body(steps), self.stream, pool=agent._graph_pool)
+            entry["transition"] = dict(agent.transition)
+            entry["capture"].replay()
+            ready = self.ready
+        else:
+            entry["capture"].replay()
+            agent.transition.clear()
+            agent.transition.update(entry["transition"])
+            ready = False
+            for _ in range(steps):
+                agent.hook.on_replay("act")
+                ready = self._replay_host_effects()
+            self.rollout_replays += 1
+        if not ready:
+            raise RuntimeError("a whole-rollout graph ended without the agent asking for an update")
+        return act.static_observation, act.static_state
+
     def flush_metrics(self):
         for entry in self.steps.values():
+            entry["capture"].flush_metrics()
+        for entry in self.rollouts.values():
             entry["capture"].flush_metrics()
 
     @property

@@ -240,10 +240,13 @@ class Trainer:
         timer = self.timer
         graphed.begin()
         with timer.record("rollout"):
-            while True:
+            whole = graphed.run_rollout(observation, state)  # one graph for all steps once every step is captured
+            while whole is None:
                 observation, state, ready = graphed.run(observation, state)
                 if ready:
                     break
+            if whole is not None:
+                observation, state = whole
         graphed.flush_metrics()
         return observation, state
 

@@ -59,10 +59,11 @@ def test_captured_rollout_is_bit_identical_to_the_host_driven_loop(cusrl, kind):
     captured = _run(cusrl, kind, capture=True, T=T)
     graphed = captured._graphed_rollout
     assert graphed is not None and graphed.captured == T, (graphed and graphed.captured)
-    # iteration 0 host-driven, 1 eager bodies, 2 captures (+ the replay behind each), 3.. pure replays
-    assert graphed.replays == T * 3
-    # ... and a replayed step issues no C call at all: the push entry point was only called in iterations 0-2
-    assert _native.launch_counts["cusrl_buffer_push"] - pushes_before == T * 3
+    # iteration 0 host-driven, 1 eager step bodies, 2 one capture per step (+ the replay behind each), 3 the whole rollout
+    # captured as ONE graph (every step was warm), 4-5 one replay per rollout
+    assert graphed.replays == 0 and len(graphed.rollouts) == 1 and graphed.rollout_replays == 2
+    # ... and a replay issues no C call at all: the push entry point was only called in iterations 0-3
+    assert _native.launch_counts["cusrl_buffer_push"] - pushes_before == T * 4
     a, b = host.agent, captured.agent
     assert set(a.buffer.storage) == set(b.buffer.storage)
     for key in a.buffer.storage:
@@ -79,6 +80,26 @@ def test_captured_rollout_is_bit_identical_to_the_host_driven_loop(cusrl, kind):
             continue
         assert captured.last_info[key] == pytest.approx(value, rel=1e-6, abs=1e-7), key
     assert captured.last_info["Perf/environment_time"] > 0 and captured.last_info["Perf/agent_time"] > 0
+
+
+def test_per_step_graphs_alone_are_bit_identical_too(cusrl):
+    """The same comparison with the whole-rollout graph switched off (what runs when a rollout is not exactly one pass over
+    the buffer, or a hook decides ``should_update`` itself): T replays per rollout."""
+    T = 8
+    host = _run(cusrl, "continuous", capture=False, T=T)
+    import os
+
+    os.environ["CUSRL_WHOLE_ROLLOUT_GRAPH"] = "0"
+    try:
+        captured = _run(cusrl, "continuous", capture=True, T=T)
+    finally:
+        del os.environ["CUSRL_WHOLE_ROLLOUT_GRAPH"]
+    graphed = captured._graphed_rollout
+    assert graphed.captured == T and graphed.replays == T * 3 and not graphed.rollouts
+    for key in host.agent.buffer.storage:
+        assert torch.equal(host.agent.buffer.storage[key], captured.agent.buffer.storage[key]), key
+    for p, q in zip(host.agent.parameters(), captured.agent.parameters()):
+        assert torch.equal(p, q)
 
 
 def test_static_reset_rows_reach_only_the_finished_envs_in_order(cusrl):
@@ -151,7 +172,7 @@ def test_a_user_hook_with_per_step_python_state_keeps_the_loop_host_driven(cusrl
         trainer.run_training_loop()
         graphed = trainer._graphed_rollout
         if expect_capture:
-            assert graphed is not None and graphed.captured == 4 and graphed.replays == 4  # iteration 3 only
+            assert graphed is not None and graphed.captured == 4 and len(graphed.rollouts) == 1  # iteration 3: whole rollout
         else:
             assert graphed is None or graphed.captured == 0
             assert len(seen) == 4 * 4
