@@ -69,6 +69,12 @@ class MiniBatchSampler(Sampler):
         # prefetch (extension, default): a device permutation for the next epoch is drawn on a second stream while the
         # current epoch's minibatches run (same generator stream of values; see iter_indices)
         self.prefetch = prefetch and os.environ.get("CUSRL_PREFETCH_PERMUTATIONS", "1") != "0"
+        # Device permutations are drawn into PERSISTENT index buffers (two, alternating when drawing ahead): every
+        # minibatch's index slice then lives at an address that repeats from update to update, and a captured minibatch
+        # step can read it in place instead of through a copy into a static buffer (`persistent_indices`, template/graphs.py).
+        # Same generator calls, same values: `randperm(n, out=buffer)` is what `randperm(n, device=...)` runs on a fresh tensor.
+        self._index_buffers: dict[tuple, list[torch.Tensor]] = {}
+        self.persistent_indices = False
 
     def iter_indices(self, buffer: Buffer):
         """Yield ``(metadata, device index slice)`` per minibatch — the permutation logic of ``__call__`` without
@@ -80,7 +86,16 @@ class MiniBatchSampler(Sampler):
         buffer.prepare_sampling(self.hot_fields if self.lazy else None)
         perm_device = self.permutation_device or buffer.device
         staged = perm_device != buffer.device
-        epoch_indices = torch.randperm(num_samples, device=perm_device)
+        persistent = not staged and perm_device.type == "cuda" and not torch.cuda.is_current_stream_capturing()
+        self.persistent_indices = persistent
+        if persistent:
+            pair = self._index_buffers.get((num_samples, perm_device))
+            if pair is None:
+                pair = self._index_buffers[(num_samples, perm_device)] = [
+                    torch.empty(num_samples, dtype=torch.int64, device=perm_device) for _ in range(2)]
+            epoch_indices = torch.randperm(num_samples, device=perm_device, out=pair[0])
+        else:
+            epoch_indices = torch.randperm(num_samples, device=perm_device)
         device_indices = epoch_indices.to(buffer.device, non_blocking=True) if staged else epoch_indices
         # A device permutation is a dozen launches (keys, radix / merge sort, de-duplication: ~60 us of device time) in
         # front of an epoch whose minibatch steps are device-bound.  The permutation of epoch e + 1 depends on nothing
@@ -93,7 +108,7 @@ class MiniBatchSampler(Sampler):
                  and not torch.cuda.is_current_stream_capturing())
         if ahead:
             side = _prefetch_stream(buffer.device)
-            spare, pending = torch.empty_like(epoch_indices), False
+            spare, pending = (pair[1] if persistent else torch.empty_like(epoch_indices)), False
         for epoch in range(self.num_epochs):
             count = self.num_mini_batches if isinstance(self.num_mini_batches, int) else self.num_mini_batches[epoch]
             if count > num_samples:
@@ -166,6 +181,12 @@ class AutoMiniBatchSampler(Sampler):
         self.lazy = lazy
         self.prefetch = prefetch
         self.hot_fields: set[str] = set()
+        self._index_buffers: dict[tuple, list[torch.Tensor]] = {}
+        self._last: MiniBatchSampler | None = None
+
+    @property
+    def persistent_indices(self) -> bool:
+        return self._last is not None and self._last.persistent_indices
 
     def _dispatch(self, buffer: Buffer) -> MiniBatchSampler:
         temporal = any(key.split(".")[0].endswith("memory") for key in buffer)
@@ -173,6 +194,8 @@ class AutoMiniBatchSampler(Sampler):
         sampler = cls(self.num_epochs, self.num_mini_batches, self.shuffle, permutation_device=self.permutation_device,
                       lazy=self.lazy, prefetch=self.prefetch)
         sampler.hot_fields = self.hot_fields  # the per-call sampler objects share what earlier passes learned
+        sampler._index_buffers = self._index_buffers  # ... and the persistent index buffers
+        self._last = sampler
         return sampler
 
     def __call__(self, buffer: Buffer):

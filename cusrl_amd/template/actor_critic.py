@@ -264,13 +264,16 @@ class ActorCritic(Agent):
                 graphed = "objective" not in eager_phases(self)  # a hook's collective / host read-back stays out of capture
             if graphed:
                 for metadata, indices in self.sampler.iter_indices(self.buffer):
-                    key = (metadata["mini_batch_index"], metadata["temporal"], indices.numel())
+                    # index slices at addresses that repeat from update to update (the sampler's persistent buffers) are
+                    # read in place by the captured step: one capture per address, no copy into a static buffer
+                    in_place = getattr(self.sampler, "persistent_indices", False)
+                    key = (metadata["mini_batch_index"], metadata["temporal"], indices.numel(), indices.data_ptr() if in_place else 0)
                     if self._metadata_reads:  # a hook looks at these: steps whose values differ are different captures
                         key += tuple((name, metadata.get(name)) for name in sorted(self._metadata_reads)
                                      if name not in ("mini_batch_index", "temporal"))
                     if (step := self._graphed_steps.get(key)) is None:
                         step = self._graphed_steps[key] = GraphedTrainStep(self, key[0], key[1])
-                    step.run(metadata, indices)
+                    step.run(metadata, indices, in_place)
                 deferred: list = []
                 for step in self._graphed_steps.values():
                     step.flush_metrics(deferred)

@@ -274,14 +274,21 @@ class GraphedTrainStep:
             agent.record(**objectives)
         agent.hook.post_objective(self.metadata, batch)
 
-    def run(self, metadata: dict[str, Any], indices: torch.Tensor):
+    def run(self, metadata: dict[str, Any], indices: torch.Tensor, in_place: bool = False):
+        """``in_place``: ``indices`` lives at an address the caller keys this step on (a slice of the sampler's persistent
+        index buffers): the capture reads it where it is; otherwise it is copied into the step's static buffer."""
         from cusrl_amd.utils.distributed import reduce_gradients
 
         agent = self.agent
-        if self.static_indices is None or self.static_indices.shape != indices.shape:
-            self.static_indices = torch.empty_like(indices)
-            self.state = 0
-        self.static_indices.copy_(indices)
+        if in_place:
+            if self.static_indices is None or self.static_indices.data_ptr() != indices.data_ptr() or self.static_indices.shape != indices.shape:
+                self.static_indices = indices
+                self.state = 0
+        else:
+            if self.static_indices is None or self.static_indices.shape != indices.shape:
+                self.static_indices = torch.empty_like(indices)
+                self.state = 0
+            self.static_indices.copy_(indices)
         self.metadata = TrackedMetadata(metadata, agent._metadata_reads)
         # the captured gather reads the per-slot record: keep it current (flag check); once the warm-up has learned which
         # fields the step reads, the record holds exactly those (two memory lines per sampled slot)
