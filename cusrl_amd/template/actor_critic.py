@@ -149,6 +149,9 @@ class ActorCritic(Agent):
             self.concurrent_critic = os.environ.get("CUSRL_CONCURRENT_CRITIC", "1") != "0"
             # captured minibatch steps run the fused objective without its one-block finalize launch (ops.DeferredLoss)
             self.defer_loss_finalize = os.environ.get("CUSRL_DEFER_LOSS_FINALIZE", "1") != "0"
+            # opt-in: measured 0.1 ms per iteration SLOWER than the 4 us copy into a static index buffer (config 2, A/B on one
+            # box) — two index-buffer addresses per slot double the number of step graphs and their activation pools
+            self.index_slices_in_place = os.environ.get("CUSRL_INPLACE_INDICES", "0") != "0"
             self._graphed_act = GraphedAct(self)
         self.flat_gradients: FlatGradients | None = None
         self._unit_grad: torch.Tensor | None = None
@@ -264,9 +267,9 @@ class ActorCritic(Agent):
                 graphed = "objective" not in eager_phases(self)  # a hook's collective / host read-back stays out of capture
             if graphed:
                 for metadata, indices in self.sampler.iter_indices(self.buffer):
-                    # index slices at addresses that repeat from update to update (the sampler's persistent buffers) are
-                    # read in place by the captured step: one capture per address, no copy into a static buffer
-                    in_place = getattr(self.sampler, "persistent_indices", False)
+                    # (opt-in) index slices at addresses that repeat from update to update — the sampler's persistent
+                    # buffers — read in place by the captured step: one capture per address, no copy into a static buffer
+                    in_place = self.index_slices_in_place and getattr(self.sampler, "persistent_indices", False)
                     key = (metadata["mini_batch_index"], metadata["temporal"], indices.numel(), indices.data_ptr() if in_place else 0)
                     if self._metadata_reads:  # a hook looks at these: steps whose values differ are different captures
                         key += tuple((name, metadata.get(name)) for name in sorted(self._metadata_reads)
