@@ -8,7 +8,7 @@ tracing compiler the same knob captures them into HIP graphs and replays them:
 * :class:`GraphedRolloutStep` — one per buffer cursor: a WHOLE env step of a capturable env — ``pre_act`` hooks →
   ``actor.explore`` → ``post_act`` hooks → ``env.step`` → fused step epilogue (done flag, episode statistics, ordered
   finished-env ids + device-side count) → ``post_step`` hooks → buffer push → fixed-shape resets spliced by that count →
-  the next act input.  No host read on the path: the trainer issues the rollout's replays back to back.
+  the next act input.  No host read on the path; once every step is captured, the whole rollout is ONE graph.
 * :class:`GraphedAct` — ``pre_act`` → ``actor.explore`` (sampling included: torch's graph-safe Philox state) →
   ``post_act`` for envs that are not capturable (the env step then stays host-driven).
 * :class:`GraphedTrainStep` — one per minibatch slot (and per value of every ``metadata`` key a hook reads,
@@ -475,11 +475,15 @@ class GraphedRolloutStep:
         env.reset_static(ids, count) -> cusrl_scatter_rows(count)   (reset rows spliced in by a device-side count)
         the spliced observation -> the act input of the next step
 
-    Nothing on this path is read by the host: the trainer issues 24 replays back to back and the update's graphs behind
+    Nothing on this path is read by the host: the trainer issues the replays back to back and the update's graphs behind
     them, the device never waits for Python.  One graph per (buffer cursor, statistics parity) — both are baked into
     kernel arguments — captured under the usual protocol (first use eager on the capture stream, second use capture,
     later uses replay; re-capture when the host-side signature changes).  What a replay skips on the HOST is replayed
     explicitly: the agent's step counter, the buffer cursor, the statistics counters, ``Hook.on_replay("step")``.
+    Once every step of a rollout replays from its own graph, the T bodies are captured once more back to back as ONE
+    graph (:meth:`run_rollout`): one launch and one pair of generator-state fills per rollout instead of T (a replayed
+    graph costs the device >= 1.5 us per dependent node AND per replay boundary); the per-step graphs stay as the path
+    for rollouts that are not exactly one pass over the buffer.
 
     Requirements (checked by :meth:`supported`): ``compile=True`` agent with a capturable act step, an env with
     ``capturable = True`` and no autoreset, device-resident episode statistics, fp32 rewards / bool flags of the shapes
