@@ -602,3 +602,59 @@ def test_tuned_gemm_selection_file_is_well_formed_and_inert_without_a_gpu():
     assert all(row[0].split("_")[0] in ("GemmTunableOp", "GemmAndBiasTunableOp", "GemmStridedBatchedTunableOp") for row in entries)
     if not torch.cuda.is_available():
         assert tuning.enable_tuned_gemms() is False
+
+
+def test_tracked_metadata_records_what_hooks_read():
+    """graphs.TrackedMetadata: the metadata dict of a captured minibatch step remembers which keys were read, so that
+    ActorCritic.update can key its step captures on their values (no stale capture-time branch)."""
+    from cusrl_amd.template.graphs import TrackedMetadata
+
+    reads: set[str] = set()
+    metadata = TrackedMetadata({"epoch_index": 2, "mini_batch_index": 1, "temporal": False, "total_epochs": 5}, reads)
+    assert not reads and len(metadata) == 4 and not reads           # constructing and sizing it reads nothing
+    assert metadata["epoch_index"] == 2 and metadata.get("missing", 7) == 7 and "temporal" in metadata
+    assert reads == {"epoch_index", "missing", "temporal"}
+    assert dict(metadata.items())["total_epochs"] == 5 and reads >= {"total_epochs", "mini_batch_index"}
+    other: set[str] = set()
+    assert sorted(TrackedMetadata({"a": 1, "b": 2}, other)) == ["a", "b"] and other == {"a", "b"}   # iteration reads all
+
+
+def test_empty_cuda_cache_hook_and_preset_fields():
+    """hook.EmptyCudaCache (cusrl/hook/control/empty_cuda_cache.py:8-13) and where the presets put it (preset/ppo.py:35,64,243)."""
+    with pytest.raises(ValueError, match="min_reserved_fraction"):
+        cusrl.hook.EmptyCudaCache(min_reserved_fraction=1.5)
+    hook = cusrl.hook.EmptyCudaCache()
+    hook.agent = SimpleNamespace(device=torch.device("cpu"))
+    hook.post_update()                                                # no GPU in this process: a no-op, like the reference
+    assert hook.releases == 0 and hook.name == "empty_cuda_cache"
+    names = lambda hooks: [h.name for h in hooks]  # noqa: E731
+    assert names(cusrl.preset.ppo_hook_suite(empty_cuda_cache=True))[-1] == "empty_cuda_cache"
+    assert "empty_cuda_cache" not in names(cusrl.preset.ppo_hook_suite())
+    assert names(cusrl.preset.RecurrentPpoAgentFactory(rnn_type="GRU").to_underlying().hooks)[-1] == "empty_cuda_cache"
+    assert "empty_cuda_cache" not in names(cusrl.preset.RecurrentPpoAgentFactory(empty_cuda_cache=False).to_underlying().hooks)
+    assert "empty_cuda_cache" not in names(cusrl.preset.PpoAgentFactory().to_underlying().hooks)
+
+
+def test_capturable_environment_protocol_defaults():
+    """template/environment.py: an env is not capturable unless it says so, and the fixed-shape reset is its own to write;
+    the synthetic env only advertises the protocol on a GPU."""
+    from cusrl_amd.template.environment import Environment
+
+    class Plain(Environment):
+        def reset(self, *, indices=None, randomize_episode_progress=False):
+            return torch.zeros(self.num_instances, self.observation_dim), None, {}
+
+        def step(self, action):
+            raise NotImplementedError
+
+    env = Plain(3, 2, num_instances=4)
+    assert env.capturable is False
+    with pytest.raises(NotImplementedError, match="capturable reset protocol"):
+        env.reset_static(torch.zeros(4, dtype=torch.int64), torch.zeros(1, dtype=torch.int32))
+    synthetic = cusrl.testing.SyntheticEnvironment(4, 3, 2, device="cpu")
+    assert synthetic.capturable is False                              # device-side protocol: CPU envs keep the reference loop
+    observation, state, _ = synthetic.reset_static(torch.zeros(4, dtype=torch.int64), torch.zeros(1, dtype=torch.int32))
+    assert observation.shape == (4, 3) and state is None
+    _, _, reward, terminated, truncated, _ = synthetic.step(torch.zeros(4, 2))
+    assert reward.shape == (4, 1) and terminated.dtype == torch.bool and terminated.shape == truncated.shape == (4, 1)
+    assert terminated.is_contiguous() and truncated.is_contiguous()
