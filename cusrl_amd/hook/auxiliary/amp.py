@@ -35,7 +35,6 @@ class GradientPenaltyLoss(nn.Module):
 
 class AdversarialMotionPrior(Hook):
     objective_draws_random = True  # torch.randint for the discriminator batch
-    objective_branch = True
 
     def __init__(self, discriminator_factory, dataset_source=None, state_indices=None, batch_size: int | None = 512,
                  reward_scale: float = 1.0, loss_weight: float = 1.0, grad_penalty_weight: float = 5.0):

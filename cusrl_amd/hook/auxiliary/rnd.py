@@ -17,8 +17,6 @@ __all__ = ["RandomNetworkDistillation"]
 
 
 class RandomNetworkDistillation(Hook):
-    objective_branch = True
-
     def __init__(self, module_factory, output_dim: int, reward_scale: float, state_indices=None):
         super().__init__()
         self.output_dim = output_dim

@@ -152,9 +152,6 @@ class ActorCritic(Agent):
             # opt-in: measured 0.1 ms per iteration SLOWER than the 4 us copy into a static index buffer (config 2, A/B on one
             # box) — two index-buffer addresses per slot double the number of step graphs and their activation pools
             self.index_slices_in_place = os.environ.get("CUSRL_INPLACE_INDICES", "0") != "0"
-            # auxiliary objectives (Hook.objective_branch: RND, AMP) as branches of the captured minibatch step
-            self._aux_streams: dict[str, torch.cuda.Stream] | None = (
-                {} if os.environ.get("CUSRL_AUX_BRANCHES", "1") != "0" else None)
             self._graphed_act = GraphedAct(self)
         self.flat_gradients: FlatGradients | None = None
         self._unit_grad: torch.Tensor | None = None
@@ -237,12 +234,6 @@ class ActorCritic(Agent):
         self.actor.reset_memory(self.actor_memory, transition["done"])
         ready = super().step(next_observation, reward, terminated, truncated, next_state, **kwargs)
         return ready and self.hook.should_update(transition)
-
-    def _aux_stream(self, name: str) -> "torch.cuda.Stream":
-        stream = self._aux_streams.get(name)
-        if stream is None:
-            stream = self._aux_streams[name] = torch.cuda.Stream(device=self.device)
-        return stream
 
     def replay_step(self) -> bool:
         """Host half of :meth:`step` for an env step whose device work was replayed from a hipGraph

@@ -53,9 +53,6 @@ class Hook(Generic[AgentT]):
     # per step, no host read-back), so a whole env step may be replayed from a hipGraph (template/graphs.py
     # GraphedRolloutStep).  Stock hooks qualify; a user-defined hook that overrides either method sets this to opt in.
     rollout_capture_safe: bool = False
-    # Extension: this hook's objective reads the batch and its own modules only (nothing another hook's objective writes),
-    # so inside a captured minibatch step it may run as a branch of its own (HookComposite.objective).
-    objective_branch: bool = False
 
     def __init__(self, training_only: bool = False):
         self._modules: dict[str, nn.Module | None] = {}
@@ -307,34 +304,12 @@ class HookComposite(Hook):
 
         context = FusedPpoObjective.arm(self, batch)
         objectives = Objectives()
-        # Inside a captured minibatch step, hooks that declare `objective_branch` (auxiliary objectives that share nothing
-        # with the policy terms until the gradient assembly: RND, AMP) are evaluated on a stream of their own: their
-        # forward — and, since autograd replays a node on the stream its forward ran on, their backward — become further
-        # branches of the step graph.  A captured chain costs the device >= 1.5 us per dependent node, so chains side by
-        # side are the only way such a step gets shorter without changing the models.
-        branching = getattr(self.agent, "_aux_streams", None) is not None and torch.cuda.is_current_stream_capturing()
-        joined = []
         try:
             for hook in self.active_hooks():
-                if branching and hook.objective_branch:
-                    main = torch.cuda.current_stream()
-                    stream = self.agent._aux_stream(hook.name)
-                    stream.wait_stream(main)  # the gather (and anything earlier hooks put into the batch) ran on `main`
-                    with torch.cuda.stream(stream):
-                        terms = hook.objective(metadata, batch)
-                    if terms is not None:
-                        for term in terms.values():
-                            if isinstance(term, torch.Tensor):
-                                term.record_stream(main)
-                    joined.append(stream)
-                else:
-                    terms = hook.objective(metadata, batch)
-                if terms is not None:
+                if (terms := hook.objective(metadata, batch)) is not None:
                     objectives.update(terms)
             if context is not None:
                 context.resolve(objectives, batch)
-            for stream in joined:
-                torch.cuda.current_stream().wait_stream(stream)
         finally:
             FusedPpoObjective.disarm(self)
         return objectives or None
