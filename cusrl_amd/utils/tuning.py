@@ -21,12 +21,14 @@ _state: dict[str, bool | None] = {"enabled": None}
 
 
 def enable_tuned_gemms(path: str | os.PathLike | None = None) -> bool:
-    """Idempotent; returns whether a selection file is active.  ``CUSRL_TUNED_GEMMS=0`` leaves torch untouched."""
+    """Idempotent; returns whether a selection file is active.  ``CUSRL_TUNED_GEMMS=0`` leaves torch untouched,
+    ``CUSRL_TUNED_GEMMS=<file>`` loads another selection (A/B runs of a re-tuned file)."""
     if _state["enabled"] is not None and path is None:
         return bool(_state["enabled"])
     active = False
-    file = Path(path) if path is not None else TUNED_GEMMS_FILE
-    if os.environ.get("CUSRL_TUNED_GEMMS", "1") != "0" and torch.cuda.is_available() and file.exists():
+    choice = os.environ.get("CUSRL_TUNED_GEMMS", "1")
+    file = Path(path) if path is not None else (TUNED_GEMMS_FILE if choice in ("0", "1") else Path(choice))
+    if choice != "0" and torch.cuda.is_available() and file.exists():
         import torch.cuda.tunable as tunable
 
         if not tunable.tuning_is_enabled() or not tunable.is_enabled():  # a user's own TunableOp session is left alone
