@@ -46,11 +46,18 @@ def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--envs", type=int, default=4096)
     parser.add_argument("--top", type=int, default=60)
+    parser.add_argument("--config", default=None, help="a BASELINE config of scripts/run_config.py instead of the ppo preset")
     args = parser.parse_args()
     cusrl.config.set_device("cuda:0")
     cusrl.set_global_seed(42)
-    env = cusrl.testing.SyntheticEnvironment(args.envs, 48, 12, device="cuda:0")
-    factory = cusrl.preset.PpoAgentFactory(optimizer_kwargs={"capturable": True, "fused": True})
+    if args.config:
+        sys.path.insert(0, str(Path(__file__).resolve().parent))
+        import run_config
+
+        env, factory = run_config.build(args.config, None, False)
+    else:
+        env = cusrl.testing.SyntheticEnvironment(args.envs, 48, 12, device="cuda:0")
+        factory = cusrl.preset.PpoAgentFactory(optimizer_kwargs={"capturable": True, "fused": True})
     trainer = cusrl.Trainer(env, factory, num_iterations=10**9, verbose=False)
     observation, state, _ = env.reset()
     for _ in range(2):

@@ -658,3 +658,42 @@ def test_capturable_environment_protocol_defaults():
     _, _, reward, terminated, truncated, _ = synthetic.step(torch.zeros(4, 2))
     assert reward.shape == (4, 1) and terminated.dtype == torch.bool and terminated.shape == truncated.shape == (4, 1)
     assert terminated.is_contiguous() and truncated.is_contiguous()
+
+
+@pytest.mark.parametrize("hidden", [[32, 16], [24], [16, 16, 8]])
+def test_amp_closed_form_objective_matches_the_autograd_double_backward(hidden):
+    """AdversarialMotionPrior.objective (cusrl/hook/auxiliary/amp.py:135-154; gradient penalty cusrl/nn/layer/loss.py:
+    10-56): for a Linear / ReLU discriminator both terms and every parameter gradient in closed form equal the autograd
+    evaluation (create_graph double backward) to float64 rounding, for one, two and three hidden layers and non-unit
+    upstream gradients; any other discriminator keeps the autograd path."""
+    from types import SimpleNamespace
+
+    import cusrl_amd as cusrl
+    from cusrl_amd.hook.auxiliary.amp import AdversarialMotionPrior
+
+    def make(factory):
+        hook = AdversarialMotionPrior(factory, dataset_source=torch.randn(1000, 12, dtype=torch.float64), batch_size=None,
+                                      loss_weight=0.7, grad_penalty_weight=5.0)
+        hook.agent = SimpleNamespace(device=torch.device("cpu"), to_tensor=torch.as_tensor, environment_spec=None)
+        hook.register_module = lambda name, module: setattr(hook, name, module)
+        hook.init()
+        hook.discriminator.double()
+        return hook
+
+    torch.manual_seed(0)
+    hook = make(cusrl.Mlp.Factory(hidden_dims=hidden))
+    assert hook._relu_stack() is not None
+    batch = {"agent_transition": torch.randn(64, 12, dtype=torch.float64), "expert_transition": torch.randn(64, 12, dtype=torch.float64)}
+    results = {}
+    for closed in (True, False):
+        hook.closed_form_objective = closed
+        hook.discriminator.zero_grad()
+        terms = hook.objective({}, {name: value.clone() for name, value in batch.items()})
+        assert list(terms) == ["amp_discrimination_loss", "amp_grad_penalty_loss"]
+        (terms["amp_discrimination_loss"] * 1.3 + terms["amp_grad_penalty_loss"] * 0.9).backward()
+        results[closed] = [t.detach().clone() for t in terms.values()] + [p.grad.clone() for p in hook.discriminator.parameters()]
+    for got, want in zip(results[True], results[False]):
+        assert (got - want).abs().max().item() <= 1e-12 * max(want.abs().max().item(), 1e-30)
+    # a discriminator the closed form does not cover keeps the autograd path
+    assert make(cusrl.Mlp.Factory(hidden_dims=hidden, activation_fn="Tanh"))._relu_stack() is None
+    assert make(cusrl.Mlp.Factory(hidden_dims=hidden, dropout=0.1))._relu_stack() is None
