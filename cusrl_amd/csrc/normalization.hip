@@ -53,28 +53,46 @@ __global__ __launch_bounds__(kBlock) void masked_col_stats_kernel(const float *_
     }
 }
 
+// One block folds the P block partials: the C + 1 columns (C channels + the row count) are spread over the whole block,
+// kBlock / (C + 1) lanes per column each taking every G-th partial, so the serial chain is P / G fp64 loads long instead
+// of P (P = 24 .. 256; as a single loop per channel this launch was 15 us inside every captured env step).
 __global__ __launch_bounds__(kBlock) void masked_stats_finalize_kernel(const double *__restrict__ partials, int P, int C,
                                                                        float *__restrict__ mean, float *__restrict__ var,
                                                                        double *__restrict__ count) {
-    double n = 0.0;
-    for (int p = 0; p < P; ++p) n += partials[(int64_t(p) * (C + 1) + C) * 2];
-    for (int c = threadIdx.x; c < C; c += kBlock) {
-        double s = 0.0, q = 0.0;
-        for (int p = 0; p < P; ++p) {
-            s += partials[(int64_t(p) * (C + 1) + c) * 2 + 0];
-            q += partials[(int64_t(p) * (C + 1) + c) * 2 + 1];
+    __shared__ double folded[kBlock][2];
+    const int columns = C + 1;            // C < kBlock (checked by the entry point)
+    const int groups = kBlock / columns;  // >= 1
+    const int column = threadIdx.x % columns, group = threadIdx.x / columns;
+    double s = 0.0, q = 0.0;
+    if (group < groups) {
+        for (int p = group; p < P; p += groups) {
+            const double2 v = reinterpret_cast<const double2 *>(partials)[int64_t(p) * columns + column];
+            s += v.x;
+            q += v.y;
+        }
+    }
+    folded[threadIdx.x][0] = s;
+    folded[threadIdx.x][1] = q;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        double n = 0.0;
+        s = q = 0.0;
+        for (int g = 0; g < groups; ++g) {
+            s += folded[g * columns + threadIdx.x][0];
+            q += folded[g * columns + threadIdx.x][1];
+            n += folded[g * columns + C][0];
         }
         if (n > 0.0) {
             const double m = s / n;
             const double v = q / n - m * m;  // population variance (correction = 0)
-            mean[c] = float(m);
-            var[c] = float(v < 0.0 ? 0.0 : v);
+            mean[threadIdx.x] = float(m);
+            var[threadIdx.x] = float(v < 0.0 ? 0.0 : v);
         } else {
-            mean[c] = 0.0f;
-            var[c] = 1.0f;
+            mean[threadIdx.x] = 0.0f;
+            var[threadIdx.x] = 1.0f;
         }
+        if (threadIdx.x == 0) *count = n;
     }
-    if (threadIdx.x == 0) *count = n;
 }
 
 __global__ __launch_bounds__(kBlock) void rms_merge_kernel(float *__restrict__ mean, float *__restrict__ var,

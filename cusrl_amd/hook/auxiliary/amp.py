@@ -56,7 +56,7 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
     and every weight gradient is produced once: ~40 launches instead of ~80 per minibatch step, the same arithmetic."""
 
     @staticmethod
-    def forward(ctx, agent, expert, target, loss_weight, penalty_weight, *parameters):
+    def forward(ctx, agent, expert, target, ones, loss_weight, penalty_weight, *parameters):
         weights, biases = parameters[0::2], parameters[1::2]
         rows = expert.shape[0]
         hidden = [torch.cat((agent, expert))]
@@ -72,7 +72,7 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
         input_gradient = units[0] @ weights[0]
         flat = input_gradient.reshape(-1)
         penalty = torch.dot(flat, flat) / rows
-        ctx.save_for_backward(logit, target, input_gradient, *hidden, *units, *weights)
+        ctx.save_for_backward(logit, target, ones, input_gradient, *hidden, *units, *weights)
         ctx.layers, ctx.rows = len(weights), rows
         ctx.loss_weight, ctx.penalty_weight = loss_weight, penalty_weight
         return discrimination * loss_weight, penalty * (penalty_weight * loss_weight)
@@ -81,7 +81,7 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_discrimination, grad_penalty):
         layers, rows = ctx.layers, ctx.rows
-        logit, target, input_gradient, *saved = ctx.saved_tensors
+        logit, target, ones, input_gradient, *saved = ctx.saved_tensors  # ones: [1, 2N], column sums as GEMMs
         hidden, units, weights = saved[:layers], saved[layers:2 * layers - 1], saved[2 * layers - 1:]
         # --- penalty: d/dW_k of mean || u_1 W_1 ||^2, the masks being constants
         d_input = input_gradient * (grad_penalty * (2.0 * ctx.penalty_weight * ctx.loss_weight / rows))
@@ -91,17 +91,17 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
             d_pre = _masked(d_units, hidden[k][rows:], 0)  # through m_k, to v_k = u_{k+1} W_{k+1}
             penalty_grads.append(units[k].t() @ d_pre)
             d_units = d_pre @ weights[k].t()
-        penalty_grads.append(_masked(d_units, hidden[layers - 1][rows:], 0).sum(0, keepdim=True))
+        penalty_grads.append(ones[:, :rows] @ _masked(d_units, hidden[layers - 1][rows:], 0))
         # --- discrimination: an ordinary MLP backward over the joint batch, the penalty's share added by the GEMM
         d_out = (torch.sigmoid(logit) - target) * (grad_discrimination * (ctx.loss_weight / logit.shape[0]))
         gradients: list[Tensor] = []
         for k in range(layers - 1, -1, -1):
-            gradients.append(d_out.sum(0))
+            gradients.append((ones @ d_out).reshape(-1))
             gradients.append(torch.addmm(penalty_grads[k], d_out.t(), hidden[k]))
             if k:
                 d_out = _masked(d_out @ weights[k], hidden[k], 0)
         gradients.reverse()  # weight_1, bias_1, weight_2, ...
-        return (None, None, None, None, None, *gradients)
+        return (None, None, None, None, None, None, *gradients)
 
 
 class AdversarialMotionPrior(Hook):
@@ -122,6 +122,7 @@ class AdversarialMotionPrior(Hook):
             self.register_mutable(name)
         self.dataset: Tensor | None = None
         self._targets: Tensor | None = None
+        self._ones: Tensor | None = None
 
     def init(self):
         source = self.dataset_source
@@ -188,10 +189,13 @@ class AdversarialMotionPrior(Hook):
         parameters = self._relu_stack() if self.closed_form_objective else None
         if parameters is not None and all(p.dtype == agent_transition.dtype for p in parameters):
             rows = agent_transition.size(0)
-            if self._targets is None or self._targets.size(0) != 2 * rows or self._targets.device != agent_transition.device:
+            if (self._targets is None or self._targets.size(0) != 2 * rows or self._targets.device != agent_transition.device
+                    or self._targets.dtype != agent_transition.dtype):
                 self._targets = torch.cat((agent_transition.new_zeros(rows, 1), agent_transition.new_ones(rows, 1)))
+                self._ones = agent_transition.new_ones(1, 2 * rows)
             discrimination, penalty = _ReluDiscriminatorObjective.apply(
-                agent_transition, expert_transition, self._targets, self.loss_weight, self.grad_penalty_weight, *parameters)
+                agent_transition, expert_transition, self._targets, self._ones, self.loss_weight, self.grad_penalty_weight,
+                *parameters)
             return {"amp_discrimination_loss": discrimination, "amp_grad_penalty_loss": penalty}
         expert_transition.requires_grad_(True)
         from cusrl_amd.nn.module import double_differentiable
