@@ -30,6 +30,16 @@ from cusrl_amd import ops
 __all__ = ["gru_forward", "gru_supported", "lstm_forward", "rnn_forward"]
 
 
+def _gemm_rows(n: int, B: int) -> int:
+    """Row count of a time step's recurrent GEMM: the ``n`` running sequences rounded up to a multiple of 256 (at most
+    the batch).  The extra rows belong to ended sequences — their state is frozen and finite, the gate pass ignores their
+    projections, and in the backward pass their gate gradients are zeros — so the products over them change nothing; the
+    point is that the GEMM shapes no longer depend on where episodes happened to end, which lets the measured kernel
+    selection (cusrl_amd/tuned_gemms_gfx950.csv) cover them: rocBLAS's default choice for ``[~5000, 256] x [256, 768]`` runs
+    at half the speed of its best kernel."""
+    return min(B, (n + 255) // 256 * 256)
+
+
 class _GruLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, h0: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor | None, b_hh: Tensor | None,
@@ -48,7 +58,8 @@ class _GruLayer(torch.autograd.Function):
             if n == 0:
                 break
             gh_t = gh[t if keep else 0]
-            torch.mm(h[:n], w_hh_t, out=gh_t[:n])
+            rows = _gemm_rows(n, B)
+            torch.mm(h[:rows], w_hh_t, out=gh_t[:rows])
             ops.gru_gates_forward(gi[t, :n], gh_t[:n], b_hh, h[:n], out[t, :n], lengths, t)
         if keep:
             ctx.save_for_backward(x, h0, w_ih, w_hh, b_hh, lengths, out)
@@ -80,7 +91,8 @@ class _GruLayer(torch.autograd.Function):
             h_prev = h0 if t == 0 else out[t - 1]
             if in_kernel_tails and n > 0:
                 ops.gru_gates_backward(gi[t], gh[t], b_hh, h_prev, None if d_out is None else d_out[t], dh, lengths, t)
-                dh[:n].addmm_(gh[t, :n], w_hh)  # + d_gh_t @ W_hh
+                rows = _gemm_rows(n, B)
+                dh[:rows].addmm_(gh[t, :rows], w_hh)  # + d_gh_t @ W_hh (zero rows for the ended sequences)
                 continue
             if n < B:  # ended sequences: no gate gradients (their rows still hold the forward's projections)
                 gi[t, n:].zero_()

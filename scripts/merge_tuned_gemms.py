@@ -6,7 +6,7 @@
 Entries already shipped win unless --replace is given (the headline's selection stays the one its numbers were measured
 with); the validator lines must agree (same PyTorch / ROCm / hipBLASLt / rocBLAS), and shapes with a data-dependent row count — the eager
 truncated-state bootstrap, the packed / per-time-step row counts of the recurrent update — are dropped: kept are row
-counts that are a multiple of 4096 (envs, envs x steps, minibatches) or a multiple of 8 up to 512 (the toy config, the
+counts that are a multiple of 256 (envs, envs x steps, minibatches, the bucketed recurrent steps) or a multiple of 8 up to 512 (the toy config, the
 AMP discriminator batch, the weight-gradient slabs)."""
 import argparse
 import re
@@ -41,7 +41,7 @@ def main():
     added = replaced = dropped = 0
     for key, rest in fresh.items():
         rows = int(re.match(r"[a-z]+_(\d+)_(\d+)_(\d+)", key[1]).group(2))
-        if rows % 4096 and (rows % 8 or rows > 512):
+        if rows % 256 and (rows % 8 or rows > 512):
             dropped += 1
             continue
         if key in shipped and not args.replace:
