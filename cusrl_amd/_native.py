@@ -61,6 +61,7 @@ _SIGNATURES = {
     "cusrl_merge_mean_var": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
     "cusrl_gather_rows": (c_int, [POINTER(Field), c_int, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_pack_rows": (c_int, [POINTER(PackedField), c_int, _P, c_int64, c_int64, _P]),
+    "cusrl_pack_rows_owned": (c_int, [POINTER(PackedField), c_int, _P, c_int64, c_int64, c_int, c_int, _P]),
     "cusrl_gather_rows_packed": (c_int, [POINTER(Field), c_int, _P, c_int64, POINTER(PackedField), c_int, _P, c_int64, c_int64,
                                          c_int64, c_int, _P]),
     "cusrl_window_indices": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int64, _P]),

@@ -350,11 +350,33 @@ class RecordPack:
                 storage = self.leaves[name]
                 slot.ptr, slot.offset, slot.width = storage.data_ptr(), self.offsets[name], _row_bytes(storage, 2)
             count, moved = len(chosen), sum(_row_bytes(self.leaves[name], 2) for name in chosen)
+        owned = self._owned_chunks(None if names is None else set(names))
+        if owned is not None:
+            _observed(
+                "cusrl_pack_rows_owned",
+                lambda: self.rows * 2 * moved,
+                lambda: _native.lib().cusrl_pack_rows_owned(table, count, self.record.data_ptr(), self.record_bytes, self.rows,
+                                                            owned[0], owned[1], _stream()),
+            )
+            return
         _observed(
             "cusrl_pack_rows",
             lambda: self.rows * 2 * moved,
             lambda: _native.lib().cusrl_pack_rows(table, count, self.record.data_ptr(), self.record_bytes, self.rows, _stream()),
         )
+
+    def _owned_chunks(self, names: set[str] | None) -> tuple[int, int] | None:
+        """``(first chunk, chunks)`` when the narrow leaves of this record occupy at most two 16-byte chunks of their own
+        (the layout puts them behind the wide leaves, which end on a chunk boundary) and the call writes ALL of them: the
+        kernel may then store those chunks whole.  A partial repack must leave the other narrow leaves' bytes alone."""
+        narrow = [name for name, storage in self.leaves.items() if _row_bytes(storage, 2) < 16]
+        if not narrow or (names is not None and not all(name in names for name in narrow)):
+            return None
+        start = min(self.offsets[name] for name in narrow)
+        if start % 16:
+            return None
+        chunks = -(-(self.used_bytes - start) // 16)
+        return (start // 16, chunks) if chunks <= 2 else None
 
     def through_offsets(self, leaves: Sequence[str]):
         """int32 array for ``cusrl_buffer_push_through``: the record offset of every pushed leaf that can be written

@@ -155,6 +155,13 @@ typedef struct {
 } cusrl_packed_field_t;
 int cusrl_pack_rows(const cusrl_packed_field_t *fields, int n_fields, void *record, int64_t record_bytes,
                     int64_t rows, void *stream);
+/* cusrl_pack_rows where the caller owns `owned_chunks` (1 or 2) whole 16-byte chunks of every record, starting at chunk
+ * `owned_first_chunk`: every narrow field of the call lies inside them and nothing else lives there (no other leaf of
+ * the record, no wide field).  The narrow fields then leave as ONE 16-byte store per chunk instead of one 1-4 byte store
+ * per field (bytes of the owned chunks no field covers become zero).  The update-time leaves of the `ppo` hot record
+ * (action_logp, advantage, return, done: 13 bytes in the record's last chunk) are the case it is there for. */
+int cusrl_pack_rows_owned(const cusrl_packed_field_t *fields, int n_fields, void *record, int64_t record_bytes,
+                          int64_t rows, int32_t owned_first_chunk, int32_t owned_chunks, void *stream);
 int cusrl_gather_rows_packed(const cusrl_field_t *fields, int n_fields, const void *record, int64_t record_bytes,
                              const cusrl_packed_field_t *packed, int n_packed, const int64_t *indices, int64_t B,
                              int64_t T, int64_t N, int temporal, void *stream);

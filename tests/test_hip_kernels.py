@@ -206,6 +206,67 @@ def test_hot_record_with_wide_leaves_bit_exact(ops, T, N, B):
     assert ops.RecordPack.plan({**storages, "odd": dev(other)}, hot=list(storages) + ["odd"]) == ["action_logp", "advantage", "return", "done"]
 
 
+def test_pack_with_owned_chunks_equals_the_field_by_field_pack(ops):
+    """cusrl_pack_rows_owned (the narrow leaves leave as one 16-byte store per owned chunk) against cusrl_pack_rows on the
+    same table: identical records wherever a field lives, zero in the owned chunks' padding, wide leaves untouched; a
+    partial repack (one stale leaf) must take the field-by-field form and leave its neighbours' bytes alone."""
+    from cusrl_amd import _native
+
+    rng = np.random.default_rng(11)
+    T, N = 5, 1031
+    leaves = {
+        "observation": rng.standard_normal((T, N, 48)).astype(np.float32),
+        "action": rng.standard_normal((T, N, 12)).astype(np.float32),
+        "action_logp": rng.standard_normal((T, N, 1)).astype(np.float32),
+        "advantage": rng.standard_normal((T, N, 1)).astype(np.float32),
+        "return": rng.standard_normal((T, N, 1)).astype(np.float32),
+        "done": rng.random((T, N, 1)) < 0.3,
+    }
+    storages = {k: dev(v) for k, v in leaves.items()}
+    pack = ops.RecordPack(storages)
+    assert pack._owned_chunks(None) == (15, 1) and pack._owned_chunks({"advantage", "return"}) is None
+    assert pack._owned_chunks({"action_logp", "advantage", "return", "done", "observation"}) == (15, 1)
+    pack.record.fill_(0xAB)
+    before = dict(_native.launch_counts)
+    pack.build()
+    assert _native.launch_counts["cusrl_pack_rows_owned"] == before.get("cusrl_pack_rows_owned", 0) + 1
+    owned = host(pack.record).copy()
+    pack.record.fill_(0xAB)
+    lib = _native.lib()
+    assert lib.cusrl_pack_rows(pack._table, len(pack.leaves), pack.record.data_ptr(), 256, T * N, None) == 0
+    plain = host(pack.record).copy()
+    assert np.array_equal(owned[:, :253], plain[:, :253])
+    assert not owned[:, 253:].any() and (plain[:, 253:] == 0xAB).all()  # padding: zero when the chunk is owned
+    # a stale single leaf: the other narrow bytes of the chunk stay
+    storages["advantage"].mul_(2.0)
+    before = dict(_native.launch_counts)
+    pack.build(["advantage"])
+    assert _native.launch_counts["cusrl_pack_rows"] == before.get("cusrl_pack_rows", 0) + 1
+    again = host(pack.record)
+    assert np.array_equal(again[:, 244:248].copy().view(np.float32).reshape(-1), (leaves["advantage"] * 2.0).reshape(-1))
+    assert np.array_equal(again[:, 240:244], plain[:, 240:244]) and np.array_equal(again[:, 248:253], plain[:, 248:253])
+    # two owned chunks: the `ppo` buffer's nine narrow leaves (27 -> 32 B)
+    narrow = _narrow_leaves(rng, T, N, ["f32"] * 6 + ["bool"] * 3)
+    small = ops.RecordPack({k: dev(v) for k, v in narrow.items()})
+    assert small._owned_chunks(None) == (0, 2)
+    small.record.fill_(0xCD)
+    small.build()
+    image = host(small.record)
+    for name, offset in small.offsets.items():
+        width = narrow[name].dtype.itemsize
+        assert np.array_equal(image[:, offset:offset + width].copy().view(narrow[name].dtype).reshape(-1), narrow[name].reshape(-1)), name
+    assert not image[:, 27:].any()
+    # argument errors, straight through ctypes: a narrow field outside the owned chunk, a wide field over it, bad counts
+    table = pack._table
+    rec = pack.record.data_ptr()
+    assert lib.cusrl_pack_rows_owned(table, len(pack.leaves), rec, 256, T * N, 14, 1, None) == -1
+    assert lib.cusrl_pack_rows_owned(table, len(pack.leaves), rec, 256, T * N, 15, 0, None) == -1
+    assert lib.cusrl_pack_rows_owned(table, len(pack.leaves), rec, 256, T * N, 15, 3, None) == -1
+    assert lib.cusrl_pack_rows_owned(table, len(pack.leaves), rec, 256, T * N, 15, 2, None) == -1   # chunk 16 is past the record
+    assert lib.cusrl_pack_rows_owned(table, len(pack.leaves), rec, 256, T * N, 14, 2, None) == -1   # `action` ends in chunk 14
+    torch.cuda.synchronize()
+
+
 def test_packed_gather_argument_errors(ops):
     """Negative return codes of the two entry points, straight through ctypes."""
     from cusrl_amd import _native
