@@ -10,6 +10,7 @@ way, the three ``random_rows_*`` cases read a known number of distinct rows far 
 import csv
 import hashlib
 import json
+import os
 import subprocess
 import sys
 from pathlib import Path
@@ -106,7 +107,9 @@ def main(directory, out_path):
     out["ppo_loss_hip_sha256_16"] = hashlib.sha256((ROOT / "cusrl_amd" / "csrc" / "ppo_loss.hip").read_bytes()).hexdigest()[:16]
     out["buffer_hip_sha256_16"] = hashlib.sha256((ROOT / "cusrl_amd" / "csrc" / "buffer.hip").read_bytes()).hexdigest()[:16]
     try:
-        out["commit"] = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "worktree"
+        out["commit"] = (os.environ.get("CUSRL_COMMIT")  # the GPU box gets a snapshot without .git: the caller passes the hash
+                         or subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+                         or "worktree")
     except OSError:
         out["commit"] = "worktree"
     Path(out_path).write_text(json.dumps(out, indent=1))
