@@ -113,8 +113,30 @@ class RcclComm:
 
     @classmethod
     def from_process_group(cls) -> "RcclComm":
-        payload = [cls.unique_id() if CONFIG.rank == 0 else None]
-        torch.distributed.broadcast_object_list(payload, src=0)
+        """Collective.  ``ncclCommInitRank`` blocks until every rank has joined, so nothing may make ONE rank leave before
+        it: local preconditions (the library found RCCL, rank 0 could draw an id) are agreed on over the existing process
+        group first, and only a unanimous yes proceeds to the collective creation."""
+        from cusrl_amd import _native
+
+        problem = ""
+        try:
+            if not _native.lib().cusrl_comm_available():
+                problem = "RCCL is not available to libcusrl_hip.so: " + _native.lib().cusrl_comm_last_error().decode()
+        except Exception as error:
+            problem = f"{type(error).__name__}: {error}"
+        payload: list = [None]
+        if CONFIG.rank == 0 and not problem:
+            try:
+                payload[0] = cls.unique_id()
+            except Exception as error:
+                problem = f"{type(error).__name__}: {error}"
+        torch.distributed.broadcast_object_list(payload, src=0)  # None when rank 0 could not draw an id
+        if payload[0] is None and not problem:
+            problem = "rank 0 could not draw a communicator id"
+        ready = torch.tensor([1.0 if problem else 0.0], device=CONFIG.device)
+        torch.distributed.all_reduce(ready, op=torch.distributed.ReduceOp.MAX)
+        if ready.item() > 0:
+            raise _native.NativeError(problem or "another rank cannot create its communicator")
         return cls(CONFIG.world_size, CONFIG.rank, payload[0])
 
     def _stream(self) -> int:

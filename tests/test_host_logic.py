@@ -697,3 +697,50 @@ def test_amp_closed_form_objective_matches_the_autograd_double_backward(hidden):
     # a discriminator the closed form does not cover keeps the autograd path
     assert make(cusrl.Mlp.Factory(hidden_dims=hidden, activation_fn="Tanh"))._relu_stack() is None
     assert make(cusrl.Mlp.Factory(hidden_dims=hidden, dropout=0.1))._relu_stack() is None
+
+
+def test_merge_of_tuned_gemm_selections_keeps_shipped_entries_and_drops_data_dependent_shapes(tmp_path, monkeypatch):
+    """scripts/merge_tuned_gemms.py: shipped entries win unless --replace, validator lines must agree, and shapes whose
+    row count depends on the data (not a multiple of 256, nor a multiple of 8 up to 512) never reach the shipped file."""
+    import importlib.util
+    import sys as _sys
+
+    spec = importlib.util.spec_from_file_location("merge_tuned_gemms", ROOT / "scripts" / "merge_tuned_gemms.py")
+    merge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(merge)
+    validators = "Validator,PT_VERSION,2.10.0\nValidator,HIP_VERSION,700\n"
+    shipped = tmp_path / "shipped.csv"
+    shipped.write_text(validators + "GemmTunableOp_float_NN,nn_1_4096_128_ld_1_128_1,Gemm_Rocblas_1,0.01\n")
+    fresh = tmp_path / "fresh.csv"
+    fresh.write_text(validators
+                     + "GemmTunableOp_float_NN,nn_1_4096_128_ld_1_128_1,Gemm_Rocblas_2,0.02\n"      # already shipped
+                     + "GemmTunableOp_float_TN,tn_768_5504_256_ld_256_256_768,Gemm_Rocblas_3,0.02\n"  # 5504 = 21.5 x 256: dropped
+                     + "GemmTunableOp_float_TN,tn_768_5632_256_ld_256_256_768,Gemm_Rocblas_4,0.02\n"  # 22 x 256: kept
+                     + "GemmAndBiasTunableOp_float_TN,tn_256_512_12_ld_12_12_256,Default,0.01\n"      # the AMP batch: kept
+                     + "GemmAndBiasTunableOp_float_TN,tn_256_983_48_ld_48_48_256,Default,0.01\n")     # truncated-env count: dropped
+    monkeypatch.setattr(merge, "SHIPPED", shipped)
+    monkeypatch.setattr(_sys, "argv", ["merge_tuned_gemms.py", str(fresh)])
+    merge.main()
+    lines = shipped.read_text().splitlines()
+    assert lines[:2] == validators.splitlines()
+    entries = {tuple(line.split(",")[:2]): line.split(",")[2] for line in lines[2:]}
+    assert entries == {("GemmTunableOp_float_NN", "nn_1_4096_128_ld_1_128_1"): "Gemm_Rocblas_1",
+                       ("GemmTunableOp_float_TN", "tn_768_5632_256_ld_256_256_768"): "Gemm_Rocblas_4",
+                       ("GemmAndBiasTunableOp_float_TN", "tn_256_512_12_ld_12_12_256"): "Default"}
+    monkeypatch.setattr(_sys, "argv", ["merge_tuned_gemms.py", str(fresh), "--replace"])
+    merge.main()
+    assert "Gemm_Rocblas_2" in shipped.read_text()
+    other = tmp_path / "other.csv"
+    other.write_text("Validator,PT_VERSION,2.11.0\nValidator,HIP_VERSION,700\n")
+    monkeypatch.setattr(_sys, "argv", ["merge_tuned_gemms.py", str(other)])
+    with pytest.raises(SystemExit):
+        merge.main()
+
+
+def test_recurrent_step_gemm_rows_are_bucketed_to_256_and_capped_by_the_batch():
+    """nn/gru.py::_gemm_rows — the per-time-step recurrent GEMM covers the running sequences rounded up to a multiple of
+    256 (never more than the batch), so its shape does not depend on where episodes ended."""
+    from cusrl_amd.nn.gru import _gemm_rows
+
+    assert [_gemm_rows(n, 5536) for n in (1, 255, 256, 257, 4100, 5376, 5377, 5536)] == [256, 256, 256, 512, 4352, 5376, 5536, 5536]
+    assert _gemm_rows(7, 7) == 7 and _gemm_rows(100, 100) == 100
