@@ -168,8 +168,14 @@ class _Capture:
         gc.collect()
         gc_was_enabled = gc.isenabled()
         gc.disable()
+        # In a multi-process job other threads of this process are alive during the capture — torch.distributed's
+        # watchdog polling events, RCCL's proxy threads — and in the default "global" mode any of their HIP calls that is
+        # not capture-safe invalidates OUR capture.  The capturing thread's own discipline is what matters here.
+        from cusrl_amd.utils import distributed
+
+        mode = "thread_local" if distributed.enabled() else "global"
         try:
-            with torch.cuda.graph(graph, stream=stream, pool=pool):
+            with torch.cuda.graph(graph, stream=stream, pool=pool, capture_error_mode=mode):
                 result = fn()
                 if tap.values:
                     if len(tap.values) > self.MAX_TAPS:
