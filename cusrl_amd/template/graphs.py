@@ -173,7 +173,7 @@ class _Capture:
         # not capture-safe invalidates OUR capture.  The capturing thread's own discipline is what matters here.
         from cusrl_amd.utils import distributed
 
-        mode = "thread_local" if distributed.enabled() else "global"
+        mode = os.environ.get("CUSRL_CAPTURE_ERROR_MODE") or ("thread_local" if distributed.enabled() else "global")
         try:
             with torch.cuda.graph(graph, stream=stream, pool=pool, capture_error_mode=mode):
                 result = fn()
