@@ -207,12 +207,18 @@ def native_comm() -> RcclComm | None:
                 problem = "cusrl_allreduce_mean disagrees with torch.distributed.all_reduce"
         except Exception as error:  # creation / first collective failed on this rank
             problem = f"{type(error).__name__}: {error}"
+        leak = False
+        if not problem:
+            # what the route exists for is the all-reduce INSIDE a hipGraph: capture and replay one now, so that a stack
+            # on which RCCL cannot be captured falls back here instead of failing in the first captured minibatch step
+            problem = _probe_captured_allreduce(comm)
+            leak = bool(problem)  # a communicator whose capture went wrong is abandoned, not destroyed (destroy may block)
         # every rank must take the same route: agree over the process group
         verdict = torch.tensor([1.0 if problem else 0.0], device=CONFIG.device)
         torch.distributed.all_reduce(verdict, op=torch.distributed.ReduceOp.MAX)
         if verdict.item() > 0:
             _native_comm_failed = problem or "another rank could not create its communicator"
-            if comm is not None:
+            if comm is not None and not leak:
                 comm.close()
             print(f"\033[1;33mcusrl_amd: C-ABI RCCL communicator unavailable on rank {CONFIG.rank} ({_native_comm_failed}); "
                   "falling back to torch.distributed collectives (eager all-reduce between two graphs per step)\033[0m",
@@ -220,6 +226,29 @@ def native_comm() -> RcclComm | None:
         else:
             _native_comm = comm
     return _native_comm
+
+
+def _probe_captured_allreduce(comm: RcclComm) -> str:
+    """Capture a 64-float ``cusrl_allreduce_mean`` into a hipGraph on a side stream, replay it once and compare with the
+    closed-form mean over the ranks; returns '' or what went wrong.  Collective: every rank runs it at the same point."""
+    try:
+        device, world = comm.device, comm.world_size
+        base = torch.arange(64, dtype=torch.float32, device=device)
+        probe = base * (CONFIG.rank + 1)
+        expect = base * ((world + 1) / 2)  # mean over ranks of (rank + 1)
+        stream = torch.cuda.Stream(device=device)
+        stream.wait_stream(torch.cuda.current_stream(device))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            comm.allreduce_mean_(probe)
+        torch.cuda.current_stream(device).wait_stream(stream)
+        graph.replay()
+        torch.cuda.synchronize(device)
+        if not torch.allclose(probe, expect, rtol=1e-6, atol=0):
+            return "a captured cusrl_allreduce_mean replayed a wrong result"
+    except Exception as error:
+        return f"cusrl_allreduce_mean inside a hipGraph: {type(error).__name__}: {error}"
+    return ""
 
 
 def collective_route() -> str:
