@@ -26,6 +26,7 @@ from cusrl_amd.template.buffer import Buffer, Sampler
 from cusrl_amd.template.environment import EnvironmentSpec
 from cusrl_amd.template.hook import Hook, HookComposite
 from cusrl_amd.template.optimizer import OptimizerFactory, build_optimizer
+from cusrl_amd.utils.config import CONFIG
 from cusrl_amd.utils.distributed import FlatGradients, broadcast_parameters, reduce_gradients
 
 __all__ = ["ActorCritic", "ActorCriticFactory", "HookList"]
@@ -124,7 +125,7 @@ class ActorCritic(Agent):
         self.actor_memory = None
         self.hook.init()
 
-        if self.device.type == "cuda":
+        if self.device.type == "cuda" and CONFIG.tuned_gemms:
             from cusrl_amd.utils.tuning import enable_tuned_gemms
 
             enable_tuned_gemms()  # measured rocBLAS / hipBLASLt kernel choice for this workload's GEMM shapes

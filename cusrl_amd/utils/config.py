@@ -38,6 +38,11 @@ class _Config:
         # collectives).  CUSRL_NATIVE_COLLECTIVES=0 (or CONFIG.native_collectives = False before the agent is built)
         # forces the torch.distributed route: eager all-reduce between two graphs per minibatch step.
         self.native_collectives = env.get("CUSRL_NATIVE_COLLECTIVES", "1") != "0"
+        # Building an agent on a GPU loads the measured rocBLAS / hipBLASLt kernel selection through PyTorch TunableOp
+        # (utils/tuning.py) — a PROCESS-WIDE setting: other torch code in the process gets the same kernel choice for
+        # the GEMM shapes listed in the file.  CONFIG.tuned_gemms = False before the first agent is built (or
+        # CUSRL_TUNED_GEMMS=0) leaves torch untouched.
+        self.tuned_gemms = env.get("CUSRL_TUNED_GEMMS", "1") != "0"
 
     @property
     def device(self) -> torch.device:

@@ -602,6 +602,11 @@ def test_tuned_gemm_selection_file_is_well_formed_and_inert_without_a_gpu():
     assert all(row[0].split("_")[0] in ("GemmTunableOp", "GemmAndBiasTunableOp", "GemmStridedBatchedTunableOp") for row in entries)
     if not torch.cuda.is_available():
         assert tuning.enable_tuned_gemms() is False
+    # the programmatic opt-out the agent consults (a process-wide TunableOp setting must be refusable)
+    from cusrl_amd.template import actor_critic
+
+    assert actor_critic.CONFIG is cusrl.config  # `cusrl.config.tuned_gemms = False` before building an agent
+    assert actor_critic.CONFIG.tuned_gemms is (os.environ.get("CUSRL_TUNED_GEMMS", "1") != "0")
 
 
 def test_tracked_metadata_records_what_hooks_read():
