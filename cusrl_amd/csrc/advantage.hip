@@ -5,6 +5,8 @@
 // file built with -ffp-contract=off) in exactly the reference's association order, which makes advantage and
 // return BIT-EXACT with cusrl/hook/on_policy/gae.py:8-20.  Statistics accumulate in fp64 with a fixed
 // (launch-shape-determined) summation order, so results are run-to-run deterministic.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace cusrl {
@@ -103,9 +105,45 @@ __device__ __forceinline__ typename Vec<VEC>::type pack(const float (&in)[VEC]) 
     }
 }
 
-// BLK = threads per block: 256 at scale; 64 (one wave) for small rollouts, where the launch is pure latency and spreading
-// the few columns over 4x more CUs — with the whole horizon requested in ONE load round (TC >= T) — is what counts.
-template <int VEC, int TC, bool kTwoLambdas, int BLK = kBlock>
+// Cache policy of the scan's streams (round 4, profiles/r04/gae_policy.md).  Every input element is read exactly once and
+// every output element written exactly once; beyond the 256 MB Infinity Cache a default-policy launch spends its time
+// evicting the predecessor's dirty lines to make room for lines nobody will touch again (measured: 0.40 of the roofline
+// behind 1 GiB of fresh writes, 0.64 in a hot loop).  Non-temporal loads / stores stream past the caches.
+//   kNtLoad   reward / value / next_value / done are loaded non-temporally
+//   kNtAdv    advantage is stored non-temporally (NOT set when the normalisation pass reads it right back)
+//   kNtRet    return is stored non-temporally (its next reader is a random minibatch gather, many launches later)
+constexpr int kNtLoad = 1, kNtAdv = 2, kNtRet = 4;
+
+typedef float native_float4 __attribute__((ext_vector_type(4)));
+
+template <int VEC, bool NT>
+__device__ __forceinline__ typename Vec<VEC>::type load_stream(const float *p) {
+    if constexpr (!NT) {
+        return *reinterpret_cast<const typename Vec<VEC>::type *>(p);
+    } else if constexpr (VEC == 4) {
+        const native_float4 v = __builtin_nontemporal_load(reinterpret_cast<const native_float4 *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return __builtin_nontemporal_load(p);
+    }
+}
+
+template <int VEC, bool NT>
+__device__ __forceinline__ void store_stream(float *p, const typename Vec<VEC>::type &v) {
+    if constexpr (!NT) {
+        *reinterpret_cast<typename Vec<VEC>::type *>(p) = v;
+    } else if constexpr (VEC == 4) {
+        const native_float4 n = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(n, reinterpret_cast<native_float4 *>(p));
+    } else {
+        __builtin_nontemporal_store(v, p);
+    }
+}
+
+// BLK = threads per block: 128 at scale (finer blocks desynchronise the load and store phases of the one resident wave of
+// blocks: +8 % at 4 M envs); 64 (one wave) for small rollouts, where the launch is pure latency and spreading the few
+// columns over 4x more CUs — with the whole horizon requested in ONE load round (TC >= T) — is what counts.
+template <int VEC, int TC, bool kTwoLambdas, int BLK = kBlock, int POLICY = 0>
 __global__ __launch_bounds__(BLK) void gae_kernel(const float *__restrict__ reward, const float *__restrict__ value,
                                                      const float *__restrict__ next_value,
                                                      const uint8_t *__restrict__ done, float *__restrict__ advantage,
@@ -132,10 +170,13 @@ __global__ __launch_bounds__(BLK) void gae_kernel(const float *__restrict__ rewa
                 const int t = t_hi - 1 - k;
                 if (t >= 0) {
                     const int64_t off = int64_t(t) * C + col;
-                    r[k] = *reinterpret_cast<const V *>(reward + off);
-                    v[k] = *reinterpret_cast<const V *>(value + off);
-                    nv[k] = *reinterpret_cast<const V *>(next_value + off);
-                    if constexpr (VEC == 4)
+                    constexpr bool nt = (POLICY & kNtLoad) != 0;
+                    r[k] = load_stream<VEC, nt>(reward + off);
+                    v[k] = load_stream<VEC, nt>(value + off);
+                    nv[k] = load_stream<VEC, nt>(next_value + off);
+                    if constexpr (VEC == 4 && nt)
+                        dn[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(done + int64_t(t) * N + env));
+                    else if constexpr (VEC == 4)
                         dn[k] = *reinterpret_cast<const uint32_t *>(done + int64_t(t) * N + env);
                     else
                         dn[k] = done[int64_t(t) * N + env];
@@ -172,8 +213,8 @@ __global__ __launch_bounds__(BLK) void gae_kernel(const float *__restrict__ rewa
                         sumsq += double(a) * double(a);
                     }
                     const int64_t off = int64_t(t) * C + col;
-                    *reinterpret_cast<V *>(advantage + off) = pack<VEC>(aa);
-                    *reinterpret_cast<V *>(ret + off) = pack<VEC>(rt);
+                    store_stream<VEC, (POLICY & kNtAdv) != 0>(advantage + off, pack<VEC>(aa));
+                    store_stream<VEC, (POLICY & kNtRet) != 0>(ret + off, pack<VEC>(rt));
                 }
             }
         }
@@ -435,6 +476,61 @@ static bool gae_vec4(const float *reward, const float *value, const float *next_
            aligned(advantage, 16) && aligned(ret, 16) && aligned(done, 4);
 }
 
+// ---- launch shape of the at-scale scan (measured: profiles/r04/gae_policy.md)
+static int env_int(const char *name, int fallback) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : fallback;
+}
+// Cache policy by footprint.  While the six streams (21 B/slot) fit the 256 MB Infinity Cache the default policy is the
+// fastest; beyond it the inputs and `return` stream past the caches, and `advantage` — which the normalisation pass reads
+// right back — stays cached while it fits half of the Infinity Cache, else it streams too.
+// CUSRL_GAE_POLICY = 0 | 5 | 7 forces one of the three instantiated policies (A/B measurements, scripts/pmc_r04_cases.py).
+static int gae_policy(int64_t slots) {
+    const int forced = env_int("CUSRL_GAE_POLICY", -1);
+    if (forced == 0 || forced == (kNtLoad | kNtRet) || forced == (kNtLoad | kNtAdv | kNtRet)) return forced;
+    if (slots * 21 < (int64_t(256) << 20)) return 0;
+    return slots * 4 <= (int64_t(128) << 20) ? (kNtLoad | kNtRet) : (kNtLoad | kNtAdv | kNtRet);
+}
+// 256-thread blocks while ONE resident wave of blocks covers the columns (<= 5 blocks per CU at ~100 VGPRs); beyond
+// that 128-thread blocks backfill at a finer grain (+8 % at 4 M envs).  CUSRL_GAE_BLOCK = 128 | 256 forces one.
+static int gae_block(int64_t columns) {
+    const int forced = env_int("CUSRL_GAE_BLOCK", 0);
+    if (forced == 128 || forced == 256) return forced;
+    return ceil_div(columns / 4, 256) <= 5 * 256 ? 256 : 128;
+}
+
+template <int POLICY, int BLK, bool TWO>
+static void launch_gae_one(uint32_t blocks, hipStream_t s, const float *reward, const float *value, const float *next_value,
+                           const uint8_t *done, float *advantage, float *ret, double *partials, int T, int64_t N, int D,
+                           float g, float c_adv, float c_val) {
+    hipLaunchKernelGGL((gae_kernel<4, 6, TWO, BLK, POLICY>), dim3(blocks), dim3(BLK), 0, s, reward, value, next_value, done,
+                       advantage, ret, partials, T, N, D, g, c_adv, c_val);
+}
+
+template <int POLICY>
+static void launch_gae_policy(int blk, bool two, uint32_t blocks, hipStream_t s, const float *reward, const float *value,
+                              const float *next_value, const uint8_t *done, float *advantage, float *ret, double *partials,
+                              int T, int64_t N, int D, float g, float c_adv, float c_val) {
+#define CUSRL_GAE_ARGS blocks, s, reward, value, next_value, done, advantage, ret, partials, T, N, D, g, c_adv, c_val
+    if (blk == 256)
+        two ? launch_gae_one<POLICY, 256, true>(CUSRL_GAE_ARGS) : launch_gae_one<POLICY, 256, false>(CUSRL_GAE_ARGS);
+    else
+        two ? launch_gae_one<POLICY, 128, true>(CUSRL_GAE_ARGS) : launch_gae_one<POLICY, 128, false>(CUSRL_GAE_ARGS);
+#undef CUSRL_GAE_ARGS
+}
+
+static void launch_gae_scaled(int policy, int blk, bool two, uint32_t blocks, hipStream_t s, const float *reward,
+                              const float *value, const float *next_value, const uint8_t *done, float *advantage, float *ret,
+                              double *partials, int T, int64_t N, int D, float g, float c_adv, float c_val) {
+#define CUSRL_GAE_ARGS blk, two, blocks, s, reward, value, next_value, done, advantage, ret, partials, T, N, D, g, c_adv, c_val
+    switch (policy) {
+        case 0: launch_gae_policy<0>(CUSRL_GAE_ARGS); break;
+        case kNtLoad | kNtRet: launch_gae_policy<kNtLoad | kNtRet>(CUSRL_GAE_ARGS); break;
+        default: launch_gae_policy<kNtLoad | kNtAdv | kNtRet>(CUSRL_GAE_ARGS); break;
+    }
+#undef CUSRL_GAE_ARGS
+}
+
 extern "C" int64_t cusrl_gae_num_partials(int64_t T, int64_t N, int64_t D) {
     (void)T;
     if (N <= 0 || D <= 0) return 0;
@@ -458,7 +554,9 @@ extern "C" int cusrl_gae(const float *reward, const float *value, const float *n
     // 4 columns per lane only when that still fills the chip (>= 256 blocks); small rollouts (config 2: 4096 envs)
     // are latency-bound and want every lane they can get
     if (gae_vec4(reward, value, next_value, done, advantage, ret, N, D) && C >= int64_t(4) * kBlock * 256) {
-        const int64_t blocks = ceil_div(C / 4, kBlock);
+        const int policy = gae_policy(T * C);
+        const int blk = gae_block(C);
+        const int64_t blocks = ceil_div(C / 4, blk);
         // the host sizes `stat_partials` with cusrl_gae_num_partials (>= blocks); unused rows are zeroed
         if (stat_partials) {
             const int64_t rows = cusrl_gae_num_partials(T, N, D);
@@ -467,12 +565,8 @@ extern "C" int cusrl_gae(const float *reward, const float *value, const float *n
                                                   sizeof(double) * size_t((rows - blocks) * D * 2), s))
                     return int(e);
         }
-        if (two)
-            hipLaunchKernelGGL((gae_kernel<4, 6, true>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, reward, value,
-                               next_value, done, advantage, ret, stat_partials, int(T), N, int(D), g, c_adv, c_val);
-        else
-            hipLaunchKernelGGL((gae_kernel<4, 6, false>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, reward, value,
-                               next_value, done, advantage, ret, stat_partials, int(T), N, int(D), g, c_adv, c_val);
+        launch_gae_scaled(policy, blk, two, uint32_t(blocks), s, reward, value, next_value, done, advantage, ret,
+                          stat_partials, int(T), N, int(D), g, c_adv, c_val);
     } else if (C <= 65536 && T <= 32) {
         // small rollouts (config 2: 4096 columns x 24 steps): one-wave blocks on 4x more CUs, the whole horizon in ONE
         // load round (32 steps x 4 streams in flight per lane) — the launch is one memory latency + the scan
