@@ -10,8 +10,9 @@ per rank (weak scaling), gradients and advantage statistics are all-reduced over
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline       — dominant hot-path kernel = the minibatch gather that replays inside every captured train step (20 per
                    iteration): algorithmic bytes of exactly that launch / its graph-timed duration vs 8 TB/s HBM
-  roofline_scale — GAE, the PPO objective (std-vector form the preset runs) and the gather at 1 048 576 envs, where a
-                   bandwidth roofline can physically be approached (config 2 moves 1-13 MB per launch out of L2 / MALL)
+                   roofline.at_scale — GAE, the PPO objective (std-vector form the preset runs), push, next_value,
+                   normalise and the record gather at 1 048 576 envs, where a bandwidth roofline can physically be
+                   approached (config 2 moves 1-13 MB per launch out of L2 / MALL)
   kernels        — the same accounting for every HIP kernel of the path at this workload's sizes
   cpu_baseline   — oracle/torch_ppo.py (reference-equivalent torch CPU path) timed on this box's host cores
 
@@ -222,17 +223,15 @@ def run_gpu(args, rank, world):
         import kernel_bench
 
         wanted = {"gae + return + stats": "gae", "ppo loss fwd+bwd, std vector": "ppo_loss_std_vector",
-                  "ppo loss fwd+bwd (": "ppo_loss_std_matrix", "gather hot leaves via record": "gather_narrow_record_plus_leaves",
-                  "gather hot leaves from the 256 B hot record": "gather_hot_record",
-                  "pack the narrow leaves of the hot record": "pack_narrow_leaves_of_hot_record",
-                  "pack hot record": "pack_whole_hot_record", "push with write-through": "push_with_write_through"}
-        for name, (us, nbytes) in kernel_bench.bench_size(1 << 20, only=("gae + return", "ppo loss", "gather hot", "pack the narrow",
-                                                                        "pack hot", "push with write"), iters=10).items():
+                  "ppo loss fwd+bwd (": "ppo_loss_std_matrix", "push (1 step": "push", "next_value": "next_value",
+                  "normalize": "normalize", "gather hot leaves from the 256 B hot record": "gather_hot_record"}
+        for name, (us, nbytes) in kernel_bench.bench_size(1 << 20, only=("gae + return", "ppo loss", "push (1 step", "next_value",
+                                                                        "normalize", "gather hot leaves from"), iters=10).items():
             for prefix, key in wanted.items():
                 if name.startswith(prefix):
                     scale[key] = {"avg_us": round(us, 1), "bytes_per_launch": int(nbytes),
                                   "achieved_GBps": round(nbytes / us / 1e3, 1),
-                                  "frac_of_hbm_peak": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+                                  "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
         torch.cuda.empty_cache()
 
     steps_per_iteration = args.envs_per_gpu * HORIZON * world
@@ -280,7 +279,7 @@ def run_gpu(args, rank, world):
                       f"Infinity Cache, Buffer.record_threshold_bytes), {dominant['row_bytes']} B/slot read + written + 8 B index",
             "timing": "graph-timed: hipGraph of 10 identical launches x 20 replays between one HIP-event pair, right after "
                       "the timed region, on the graph's stream (the in-step launch cannot be bracketed from the host); "
-                      "rocprofv3 per-grid averages of the same command: profiles/r03/",
+                      "rocprofv3 per-grid averages of the same command: profiles/r04/",
             "achieved": dominant["achieved_GBps"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -292,8 +291,11 @@ def run_gpu(args, rank, world):
             "launches_per_iteration": 20,
             "note": "GAE stages its (reward, value, next_value, done) tuple in registers, not LDS: every element is used "
                     "once by the lane that loaded it (DESIGN.md section 3)",
+            # the north-star criterion (GAE + loss >= 40 % of the HBM roofline) where a roofline can physically be shown:
+            # the same C-ABI launches at 1 048 576 envs x 24 steps, algorithmic bytes / graph-timed duration / 8 TB/s
+            "at_scale": {"envs": 1 << 20, "timing": "hipGraph of 10 launches between one HIP-event pair (scripts/kernel_bench.py)",
+                         "counters": "profiles/r04/pmc/pmc_summary.json", **scale},
         },
-        "roofline_scale": {"envs": 1 << 20, "timing": "graph-timed (scripts/kernel_bench.py)", **scale},
         "kernels": kernels,
     }
     trainer.environment.close()

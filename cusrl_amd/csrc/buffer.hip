@@ -2,6 +2,8 @@
 // compaction and row scatter (a3 support).  All kernels are HBM-bound byte movers: 16 B per lane where
 // alignment allows, every leaf of a transition handled by ONE launch through a by-value leaf table
 // (no device-side table upload, no per-leaf launches).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace cusrl {
@@ -38,6 +40,29 @@ __device__ __forceinline__ int find_leaf(const Table &tab, int blk) {
     return f;
 }
 
+typedef uint32_t native_u4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 stream_load16(const char *p) {
+    if constexpr (NT) {
+        const native_u4 v = __builtin_nontemporal_load(reinterpret_cast<const native_u4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return *reinterpret_cast<const uint4 *>(p);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void stream_store16(char *p, const uint4 &v) {
+    if constexpr (NT) {
+        const native_u4 n = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(n, reinterpret_cast<native_u4 *>(p));
+    } else {
+        *reinterpret_cast<uint4 *>(p) = v;
+    }
+}
+
+// POLICY: bit 0 = non-temporal loads of the step's tensors, bit 1 = non-temporal stores into the buffer's slabs (chosen by
+// the step's footprint, see push_fields).
+template <int POLICY>
 __global__ __launch_bounds__(kBlock) void push_kernel(const PushTable tab) {
     const int blk = blockIdx.x;
     const int f = find_leaf(tab, blk);
@@ -53,10 +78,10 @@ __global__ __launch_bounds__(kBlock) void push_kernel(const PushTable tab) {
         const int64_t o1 = o0 + int64_t(kBlock) * 16;
         uint4 r0, r1;
         const bool p0 = o0 < end, p1 = o1 < end;
-        if (p0) r0 = *reinterpret_cast<const uint4 *>(src + o0);
-        if (p1) r1 = *reinterpret_cast<const uint4 *>(src + o1);
-        if (p0) *reinterpret_cast<uint4 *>(dst + o0) = r0;
-        if (p1) *reinterpret_cast<uint4 *>(dst + o1) = r1;
+        if (p0) r0 = stream_load16<(POLICY & 1) != 0>(src + o0);
+        if (p1) r1 = stream_load16<(POLICY & 1) != 0>(src + o1);
+        if (p0) stream_store16<(POLICY & 2) != 0>(dst + o0, r0);
+        if (p1) stream_store16<(POLICY & 2) != 0>(dst + o1, r1);
         if (leaf.dst2) {  // uniform per block: the same 16 bytes, once more, at the row's place inside its record
             const uint32_t rb = leaf.row_bytes;  // a multiple of 16, so a 16-byte lane-op never straddles two rows
             if (p0) {
@@ -663,8 +688,10 @@ static int push_fields(const cusrl_field_t *fields, int n_fields, int64_t cursor
     PushTable tab;
     int32_t blocks = 0;
     int n = 0;
+    int64_t step_bytes = 0;
     for (int i = 0; i < n_fields; ++i) {
         const int64_t bytes = N * fields[i].row_bytes;
+        step_bytes += bytes > 0 ? bytes : 0;
         if (fields[i].row_bytes < 0 || (bytes > 0 && (!fields[i].src || !fields[i].dst))) return CUSRL_E_INVALID;
         const int32_t offset = record_offset ? record_offset[i] : -1;
         if (offset >= 0) {
@@ -690,7 +717,14 @@ static int push_fields(const cusrl_field_t *fields, int n_fields, int64_t cursor
     if (n == 0) return 0;
     for (int i = n; i <= CUSRL_MAX_FIELDS; ++i) tab.block_start[i] = blocks;
     tab.n = n;
-    hipLaunchKernelGGL(push_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream), tab);
+    // a step whose read + written bytes do not fit the 256 MB Infinity Cache streams past the caches (0.72 -> 0.79 of the
+    // roofline at 1 M envs, profiles/r04/push_policy.txt); CUSRL_PUSH_POLICY = 0 | 3 forces one form (A/B measurements)
+    const char *forced = getenv("CUSRL_PUSH_POLICY");
+    const bool streaming = forced && *forced ? atoi(forced) == 3 : 2 * step_bytes >= (int64_t(256) << 20);
+    if (streaming)
+        hipLaunchKernelGGL(push_kernel<3>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), tab);
+    else
+        hipLaunchKernelGGL(push_kernel<0>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), tab);
     return launch_status();
 }
 
