@@ -87,6 +87,11 @@ _SIGNATURES = {
     "cusrl_policy_stats": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P, _P, _P]),
     "cusrl_policy_stats_num_partials": (c_int64, [c_int64]),
     "cusrl_categorical_policy_stats": (c_int, [_P] * 5 + [c_int64, c_int64, c_int64, _P, _P, _P]),
+    "cusrl_policy_terms_fwd": (c_int, [_P, _P, c_int64, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P]),
+    "cusrl_policy_terms_bwd": (c_int, [_P, _P, c_int64] + [_P] * 6 + [c_int64, c_int64, _P, _P, _P, _P]),
+    "cusrl_policy_terms_std_partial_rows": (c_int64, [c_int64]),
+    "cusrl_categorical_terms_fwd": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P]),
+    "cusrl_categorical_terms_bwd": (c_int, [_P] * 7 + [c_int64, c_int64, _P, _P]),
     "cusrl_relu_bwd_colsum": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
     "cusrl_colsum_num_partials": (c_int64, [c_int64, c_int64]),
     "cusrl_narrow_linear_bwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, c_int, _P]),

@@ -22,7 +22,9 @@ class OnPolicyPreparation(Hook):
             batch["kl_divergence"] = actor.compute_kl_div(batch["action_dist"], action_dist)
         if (fused := FusedPpoObjective.current(self)) is not None:
             # logp / entropy / ratios (and their gradients) come out of the fused kernel at resolve time
-            fused.add_policy(action_dist, batch["action"], batch["action_logp"])
+            # (split mode — further objective hooks present: add_policy also leaves them in the batch right now, as
+            # differentiable tensors from one cusrl_policy_terms_fwd launch)
+            fused.add_policy(action_dist, batch["action"], batch["action_logp"], batch)
             return None
         action_logp = actor.compute_logp(action_dist, batch["action"])
         logp_ratio = action_logp - batch["action_logp"]

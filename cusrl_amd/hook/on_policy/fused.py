@@ -9,8 +9,16 @@ Here the four hooks keep their names, constructors and outputs, but when the com
 they only *register* their term with a per-step :class:`FusedPpoObjective`; once the last hook has run, one
 ``cusrl_ppo_loss_fwd_bwd`` launch produces the three weighted losses, the per-sample log-prob / entropy /
 ratios the other hooks and metrics read, AND d(loss)/d(mean, std, value) — autograd then continues from the
-actor / critic heads.  Any non-stock composition (custom hooks that define ``objective``, non-Gaussian policies,
-multi-channel advantages reaching the surrogate) disables fusion and runs hook by hook with the same formulas.
+actor / critic heads.
+
+A composition that contains the stock four plus FURTHER hooks defining ``objective`` ("split" mode, round 4) keeps the
+one launch for the stock terms and additionally publishes the policy terms the reference's ``OnPolicyPreparation`` leaves
+in the batch — ``curr_action_logp``, ``curr_entropy``, ``action_logp_ratio``, ``action_prob_ratio`` — as DIFFERENTIABLE
+tensors right when that hook runs, from one more HIP launch (``cusrl_policy_terms_fwd``; its backward,
+``cusrl_policy_terms_bwd``, is only launched if some hook's loss actually reaches them).  A hook that REPLACES one of these
+batch entries takes the stock term reading it (surrogate / entropy) out of the fused launch: that term is then evaluated
+from the replaced tensor with the reference's formula.  Only compositions without the stock four in order, non-Gaussian /
+non-categorical policies and CPU agents run hook by hook.
 """
 
 from __future__ import annotations
@@ -109,6 +117,46 @@ class _FusedCategoricalPpoFunction(torch.autograd.Function):
         return (d_logits.view(ctx.shapes[0]), d_value.view(ctx.shapes[1]), *([None] * 12))
 
 
+class _PolicyTermsFunction(torch.autograd.Function):
+    """(logp, entropy, logp_ratio, prob_ratio) of a Gaussian policy: one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, mean, std, action, old_logp):
+        outs = ops.policy_terms_fwd(mean, std, action, old_logp)
+        ctx.save_for_backward(mean, std, action, outs[3])
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_logp, g_entropy, g_logp_ratio, g_ratio):
+        if g_logp is None and g_entropy is None and g_logp_ratio is None and g_ratio is None:
+            return None, None, None, None
+        mean, std, action, ratio = ctx.saved_tensors
+        d_mean, d_std = ops.policy_terms_bwd(mean, std, action, ratio, g_logp, g_entropy, g_logp_ratio, g_ratio)
+        return d_mean, d_std, None, None
+
+
+class _CategoricalTermsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, action, old_logp):
+        outs = ops.categorical_terms_fwd(logits, action, old_logp)
+        ctx.save_for_backward(logits, action, outs[3])
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_logp, g_entropy, g_logp_ratio, g_ratio):
+        if g_logp is None and g_entropy is None and g_logp_ratio is None and g_ratio is None:
+            return None, None, None
+        logits, action, ratio = ctx.saved_tensors
+        return ops.categorical_terms_bwd(logits, action, ratio, g_logp, g_entropy, g_logp_ratio, g_ratio), None, None
+
+
+_TERM_KEYS = ("curr_action_logp", "curr_entropy", "action_logp_ratio", "action_prob_ratio")
+
+
 def _overrides(hook, method: str) -> bool:
     from cusrl_amd.template.hook import Hook
 
@@ -118,9 +166,13 @@ def _overrides(hook, method: str) -> bool:
 class FusedPpoObjective:
     """Collects the terms of one minibatch step; ``resolve`` turns them into real tensors."""
 
-    def __init__(self, unit_grad: bool, owner=None):
+    def __init__(self, unit_grad: bool, owner=None, split: bool = False):
         self.unit_grad = unit_grad
         self.owner = owner  # the GraphedTrainStep this objective is evaluated for, if any (deferred loss finalize)
+        # further hooks define `objective`: the policy terms are published as differentiable tensors when
+        # OnPolicyPreparation runs (self.terms), the stock terms still share the one fused launch
+        self.split = split
+        self.terms: dict[str, torch.Tensor] = {}
         self.value: tuple | None = None
         self.policy: tuple | None = None
         self.surrogate: tuple | None = None
@@ -130,8 +182,15 @@ class FusedPpoObjective:
     # ------------------------------------------------------------------ arming
     @staticmethod
     def eligible(composite) -> bool:
-        """Stock PPO composition only: exactly one each of the four term hooks (exact types, in the reference's
-        order), a Gaussian policy, and no other active hook that defines ``objective``."""
+        """Exactly the stock composition (one launch, nothing else): see :meth:`mode`."""
+        return FusedPpoObjective.mode(composite) == "fused"
+
+    @staticmethod
+    def mode(composite) -> str | None:
+        """``"fused"``: exactly one each of the four term hooks (exact types, in the reference's order), a Gaussian or
+        one-hot categorical policy on a GPU, and no other active hook that defines ``objective``;  ``"split"``: the same
+        with further ``objective`` hooks (they get differentiable policy terms from ``cusrl_policy_terms_fwd``);
+        ``None``: the hooks evaluate their terms one by one."""
         from cusrl_amd.hook.auxiliary import AdversarialMotionPrior, RandomNetworkDistillation
         from cusrl_amd.hook.mdp.observation import ObservationNormalization
         from cusrl_amd.hook.on_policy.advantage import AdvantageNormalization, AdvantageReduction
@@ -145,20 +204,22 @@ class FusedPpoObjective:
         distribution = getattr(getattr(agent, "actor", None), "distribution", None)
         supported = getattr(distribution, "is_normal", False) or getattr(distribution, "is_categorical", False)
         if not supported or agent.device.type != "cuda":
-            return False
+            return None
         terms = (ValueLoss, OnPolicyPreparation, PpoSurrogateLoss, EntropyLoss)
         # hooks whose objective neither reads nor differentiates the policy terms: they keep fusion available
         passive = (GeneralizedAdvantageEstimation, AdvantageNormalization, AdvantageReduction, ObservationNormalization,
                    RandomNetworkDistillation, AdversarialMotionPrior, MiniBatchWiseLRSchedule)
-        order = []
+        order, extra = [], False
         for hook in composite:
             if not hook.active:
                 continue
             if type(hook) in terms:
                 order.append(type(hook))
             elif _overrides(hook, "objective") and type(hook) not in passive:
-                return False
-        return tuple(order) == terms
+                extra = True
+        if tuple(order) != terms:
+            return None
+        return "split" if extra else "fused"
 
     @classmethod
     def arm(cls, composite, batch) -> "FusedPpoObjective | None":
@@ -170,10 +231,11 @@ class FusedPpoObjective:
         key = tuple(hook.active for hook in composite)
         cached = getattr(composite, "_fusion_cache", None)
         if cached is None or cached[0] != key:
-            cached = composite._fusion_cache = (key, cls.eligible(composite))
-        if not cached[1]:
+            cached = composite._fusion_cache = (key, cls.mode(composite))
+        if cached[1] is None:
             return None
-        context = cls(unit_grad=not agent.grad_scaler_enabled, owner=getattr(agent, "_deferred_loss_owner", None))
+        context = cls(unit_grad=not agent.grad_scaler_enabled, owner=getattr(agent, "_deferred_loss_owner", None),
+                      split=cached[1] == "split")
         agent._fused_objective = context
         return context
 
@@ -194,8 +256,38 @@ class FusedPpoObjective:
         """A term was produced on another stream: the loss launch waits for it."""
         self.pending_streams.append(stream)
 
-    def add_policy(self, action_dist, action, old_logp):
+    def add_policy(self, action_dist, action, old_logp, batch=None):
         self.policy = (action_dist, action, old_logp)
+        if not self.split or batch is None:
+            return
+        # what common.py:38-41 leaves in the batch, differentiable, for the further objective hooks of this composition
+        if "logits" in action_dist:
+            outs = _CategoricalTermsFunction.apply(action_dist["logits"].float(), action, old_logp)
+        else:
+            outs = _PolicyTermsFunction.apply(action_dist["mean"].float(), self._std_operand(action_dist["std"]), action, old_logp)
+        self.terms = dict(zip(_TERM_KEYS, outs))
+        batch.update(self.terms)
+
+    @staticmethod
+    def _std_operand(std):
+        """The ``[A]`` vector a state-independent std is a broadcast view of (autograd continues from the vector), else
+        the matrix itself."""
+        row_vector = getattr(std, "_cusrl_row_vector", None)
+        if row_vector is not None and std.dim() >= 2 and std.stride(-2) == 0 and row_vector.numel() <= 64:
+            return row_vector.float()
+        return std.float()
+
+    def owns(self, batch, *keys: str) -> bool:
+        """True while the batch entries a stock term reads are still the tensors this objective published (fused mode: they
+        do not exist yet — nothing can have replaced them)."""
+        return all(batch.get(key) is self.terms.get(key) for key in keys) if self.split else True
+
+    def drop_surrogate(self):
+        """A further hook replaced ``action_prob_ratio``: PpoSurrogateLoss evaluates its term from the batch itself."""
+        self.surrogate = (None, 0.2, 0.0)
+
+    def drop_entropy(self):
+        self.entropy = 0.0
 
     def add_surrogate(self, advantage, clip_ratio: float, weight: float):
         self.surrogate = (advantage, clip_ratio, weight)
@@ -212,6 +304,8 @@ class FusedPpoObjective:
         curr_value, old_value, ret, w_val, value_clip = self.value
         action_dist, action, old_logp = self.policy
         advantage, clip, w_sur = self.surrogate
+        if advantage is None:  # surrogate term dropped (split mode): zero weight, any [B, 1] tensor serves as operand
+            advantage = torch.zeros_like(old_logp)
         for stream in self.pending_streams:
             torch.cuda.current_stream().wait_stream(stream)
         self.pending_streams.clear()
@@ -222,7 +316,7 @@ class FusedPpoObjective:
                 logits, curr_value, advantage, old_logp, action, ret, old_value,
                 clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad, deferred,
             )
-            self._publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio, deferred)
+            self._publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio, deferred, self)
             return
         std = action_dist["std"]
         row_vector = getattr(std, "_cusrl_row_vector", None)
@@ -234,7 +328,7 @@ class FusedPpoObjective:
             mean, std, curr_value, advantage, old_logp, action, ret, old_value,
             clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad, deferred,
         )
-        self._publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio, deferred)
+        self._publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio, deferred, self)
 
     def _deferred(self, device, A: int, D: int, B: int, categorical: bool, std):
         """The :class:`ops.DeferredLoss` of the captured minibatch step this objective belongs to, or None.  Taken only
@@ -257,25 +351,32 @@ class FusedPpoObjective:
         return current
 
     @staticmethod
-    def _publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio, deferred=None):
-        batch["curr_action_logp"] = logp
-        batch["curr_entropy"] = entropy
-        batch["action_logp_ratio"] = logp_ratio
-        batch["action_prob_ratio"] = ratio
+    def _publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio, deferred=None, context=None):
+        split = context is not None and context.split
+        if not split:  # (split mode: the batch already holds these, differentiable, since OnPolicyPreparation ran)
+            batch["curr_action_logp"] = logp
+            batch["curr_entropy"] = entropy
+            batch["action_logp_ratio"] = logp_ratio
+            batch["action_prob_ratio"] = ratio
+        dropped = set()
+        if split and context.surrogate[0] is None:
+            dropped.add("surrogate_loss")
+        if split and context.entropy == 0.0 and "entropy_loss" in objectives and objectives["entropy_loss"] is not None:
+            dropped.add("entropy_loss")
+        fused_keys = tuple(k for k in ("value_loss", "surrogate_loss", "entropy_loss") if k not in dropped)
         objectives.total = total
-        objectives.fused_keys = ("value_loss", "surrogate_loss", "entropy_loss")
+        objectives.fused_keys = fused_keys
         if deferred is not None:
             # captured step without a finalize launch: the loss values exist as running block sums (ops.DeferredLoss),
             # read once per update by GraphedTrainStep.flush_metrics; agent.record skips the None entries
             batch["_fused_metrics"] = {"deferred": True}
-            objectives["value_loss"] = objectives["surrogate_loss"] = objectives["entropy_loss"] = None
+            for key in fused_keys:
+                objectives[key] = None
             return
         value_loss, surrogate_loss, entropy_loss, mean_abs_ratio, mean_entropy, mean_value, _ = losses.unbind(0)
         # the means the hooks record after every minibatch, already reduced by the kernel (no extra launches)
         rows = advantage.numel()
         batch["_fused_metrics"] = {"ratio": (mean_abs_ratio, rows), "entropy": (mean_entropy, rows), "value": (mean_value, rows)}
-        objectives["value_loss"] = value_loss
-        objectives["surrogate_loss"] = surrogate_loss
-        objectives["entropy_loss"] = entropy_loss
-        objectives.total = total
-        objectives.fused_keys = ("value_loss", "surrogate_loss", "entropy_loss")
+        for key, value in (("value_loss", value_loss), ("surrogate_loss", surrogate_loss), ("entropy_loss", entropy_loss)):
+            if key in fused_keys:
+                objectives[key] = value

@@ -38,7 +38,9 @@ class PpoSurrogateLoss(Hook):
         if advantage.size(-1) != 1:
             raise ValueError(f"Expected advantage to have shape [..., 1], got {advantage.shape}")
         if (fused := FusedPpoObjective.current(self)) is not None:
-            return fused.add_surrogate(advantage, self.clip_ratio, self.weight)
+            if fused.owns(batch, "action_prob_ratio"):
+                return fused.add_surrogate(advantage, self.clip_ratio, self.weight)
+            fused.drop_surrogate()  # a further hook replaced the ratio: this term is evaluated from what it left
         loss = _ppo_surrogate_loss(advantage, batch["action_prob_ratio"], self.clip_ratio)
         return {"surrogate_loss": loss * self.weight}
 
@@ -53,5 +55,7 @@ class EntropyLoss(Hook):
 
     def objective(self, metadata, batch):
         if (fused := FusedPpoObjective.current(self)) is not None:
-            return fused.add_entropy(self.weight)
+            if fused.owns(batch, "curr_entropy"):
+                return fused.add_entropy(self.weight)
+            fused.drop_entropy()
         return {"entropy_loss": -batch["curr_entropy"].mean() * self.weight}

@@ -209,7 +209,8 @@ class ValueLoss(Hook):
         state = get_first(batch, "state", "observation")
         memory, done = batch.get("critic_memory"), batch["done"]
         fused = FusedPpoObjective.current(self)
-        branch = getattr(self.agent, "_critic_stream", None) if fused is not None else None
+        # (split mode: a further hook may read `curr_value` on the main stream right behind this one — no second stream)
+        branch = getattr(self.agent, "_critic_stream", None) if fused is not None and not fused.split else None
         if branch is not None:
             # inside a minibatch step that is (being) captured: the critic's forward — and, because autograd replays
             # every node on the stream its forward ran on, its backward — goes to a second stream.  The two networks

@@ -40,6 +40,10 @@ __all__ = [
     "rnn_cell_forward",
     "rnn_cell_backward",
     "normalize_",
+    "policy_terms_fwd",
+    "policy_terms_bwd",
+    "categorical_terms_fwd",
+    "categorical_terms_bwd",
     "normalize_from_partials_",
     "ppo_loss_categorical_fwd_bwd",
     "ppo_loss_fwd_bwd",
@@ -1105,6 +1109,84 @@ def step_epilogue(reward, terminated, truncated, done_out, episode_rew, episode_
             indices_out.data_ptr(), count_out.data_ptr(), N, D, ring_len.numel(), int(parity), _stream(),
         ),
     )
+
+
+# ------------------------------------------------------------------------------------------------ differentiable policy terms
+def policy_terms_fwd(mean: torch.Tensor, std: torch.Tensor, action: torch.Tensor, old_logp: torch.Tensor):
+    """``(logp, entropy, logp_ratio, prob_ratio)``, each ``[..., 1]``, of a Gaussian policy in ONE launch
+    (common.py:29-43, distribution.py:207-213).  ``std`` is ``[..., A]`` like ``mean`` or ONE ``[A]`` vector."""
+    mean, std, action, old_logp = _f32(mean, "mean"), _f32(std, "std"), _f32(action, "action"), _f32(old_logp, "old_logp")
+    A = mean.shape[-1]
+    B = mean.numel() // max(A, 1)
+    std_rows = 1 if std.dim() == 1 else B
+    if action.numel() != B * A or old_logp.numel() != B or std.numel() != std_rows * A:
+        raise ValueError("policy_terms: inconsistent shapes")
+    outs = [torch.empty(mean.shape[:-1] + (1,), dtype=torch.float32, device=mean.device) for _ in range(4)]
+    _observed("cusrl_policy_terms_fwd", lambda: B * (12 * A + 20),
+              lambda: _native.lib().cusrl_policy_terms_fwd(mean.data_ptr(), std.data_ptr(), std_rows, action.data_ptr(),
+                                                           old_logp.data_ptr(), B, A, *(o.data_ptr() for o in outs), _stream()))
+    return tuple(outs)
+
+
+def _optional_rows(tensor, rows: int, name: str):
+    if tensor is None:
+        return None
+    tensor = _f32(tensor, name)
+    if tensor.numel() != rows:
+        raise ValueError(f"policy_terms backward: '{name}' has {tensor.numel()} elements, expected {rows}")
+    return tensor
+
+
+def policy_terms_bwd(mean, std, action, ratio, g_logp, g_entropy, g_logp_ratio, g_ratio):
+    """``(d_mean, d_std)`` from the gradients wrt the four outputs of :func:`policy_terms_fwd` (any may be None):
+    one launch (+ the one-block column-sum finalize for a std vector)."""
+    mean, std, action = _f32(mean, "mean"), _f32(std, "std"), _f32(action, "action")
+    A = mean.shape[-1]
+    B = mean.numel() // max(A, 1)
+    std_rows = 1 if std.dim() == 1 else B
+    grads = [_optional_rows(g, B, n) for g, n in ((g_logp, "g_logp"), (g_entropy, "g_entropy"), (g_logp_ratio, "g_logp_ratio"),
+                                                   (g_ratio, "g_ratio"))]
+    ratio = _optional_rows(ratio, B, "ratio")
+    d_mean, d_std = torch.empty_like(mean), torch.empty_like(std)
+    lib = _native.lib()
+    vector = std_rows == 1 and B != 1
+    partials = (torch.empty((max(int(lib.cusrl_policy_terms_std_partial_rows(B)), 1), A), dtype=torch.float32, device=mean.device)
+                if vector else None)
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    _observed("cusrl_policy_terms_bwd", lambda: B * (20 * A + 20),
+              lambda: lib.cusrl_policy_terms_bwd(mean.data_ptr(), std.data_ptr(), std_rows, action.data_ptr(), ptr(ratio),
+                                                 *(ptr(g) for g in grads), B, A, d_mean.data_ptr(), d_std.data_ptr(),
+                                                 ptr(partials), _stream()))
+    return d_mean, d_std
+
+
+def categorical_terms_fwd(logits: torch.Tensor, action: torch.Tensor, old_logp: torch.Tensor):
+    """The same four terms for a one-hot categorical policy (distribution.py:354-362)."""
+    logits, action, old_logp = _f32(logits, "logits"), _f32(action, "action"), _f32(old_logp, "old_logp")
+    A = logits.shape[-1]
+    B = logits.numel() // max(A, 1)
+    if action.numel() != B * A or old_logp.numel() != B:
+        raise ValueError("categorical_terms: inconsistent shapes")
+    outs = [torch.empty(logits.shape[:-1] + (1,), dtype=torch.float32, device=logits.device) for _ in range(4)]
+    _observed("cusrl_categorical_terms_fwd", lambda: B * (8 * A + 20),
+              lambda: _native.lib().cusrl_categorical_terms_fwd(logits.data_ptr(), action.data_ptr(), old_logp.data_ptr(), B, A,
+                                                                *(o.data_ptr() for o in outs), _stream()))
+    return tuple(outs)
+
+
+def categorical_terms_bwd(logits, action, ratio, g_logp, g_entropy, g_logp_ratio, g_ratio):
+    logits, action = _f32(logits, "logits"), _f32(action, "action")
+    A = logits.shape[-1]
+    B = logits.numel() // max(A, 1)
+    grads = [_optional_rows(g, B, n) for g, n in ((g_logp, "g_logp"), (g_entropy, "g_entropy"), (g_logp_ratio, "g_logp_ratio"),
+                                                   (g_ratio, "g_ratio"))]
+    ratio = _optional_rows(ratio, B, "ratio")
+    d_logits = torch.empty_like(logits)
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    _observed("cusrl_categorical_terms_bwd", lambda: B * (12 * A + 20),
+              lambda: _native.lib().cusrl_categorical_terms_bwd(logits.data_ptr(), action.data_ptr(), ptr(ratio),
+                                                                *(ptr(g) for g in grads), B, A, d_logits.data_ptr(), _stream()))
+    return d_logits
 
 
 # ------------------------------------------------------------------------------------------------ policy statistics

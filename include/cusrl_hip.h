@@ -323,6 +323,29 @@ int cusrl_categorical_policy_stats(const float *old_logits, const float *new_log
                                    const float *old_logp, const float *advantage, int64_t B, int64_t A, int64_t D,
                                    double *partials, float *out, void *stream);
 
+/* ---- differentiable policy terms — OnPolicyPreparation.objective, cusrl/hook/on_policy/common.py:29-43 ----
+ * logp = sum_a log N(action | mean, std) (cusrl/nn/module/distribution.py:207-209), entropy (distribution.py:211-213),
+ * logp_ratio = logp - old_logp, ratio = exp(logp_ratio); outputs [B].  The stock `ppo` composition gets these (and their
+ * gradients) from cusrl_ppo_loss_fwd_bwd; this pair serves compositions in which a further hook defines `objective` and
+ * may read or differentiate them (one launch forward, one backward instead of the reference's ~15 torch ops + autograd).
+ * std: [B, A] (std_rows = B) or ONE [A] vector shared by all rows (std_rows = 1).
+ * Backward: g_* = gradients wrt the four outputs, each [B] or NULL; `ratio` = the forward's output (needed with g_ratio).
+ * d_mean [B, A]; d_std [B, A], or [A] for a std vector (column sums in fixed order through d_std_partials:
+ * float[cusrl_policy_terms_std_partial_rows(B)][A], A <= 64). */
+int cusrl_policy_terms_fwd(const float *mean, const float *std, int64_t std_rows, const float *action,
+                           const float *old_logp, int64_t B, int64_t A, float *logp_out, float *entropy_out,
+                           float *logp_ratio_out, float *ratio_out, void *stream);
+int cusrl_policy_terms_bwd(const float *mean, const float *std, int64_t std_rows, const float *action, const float *ratio,
+                           const float *g_logp, const float *g_entropy, const float *g_logp_ratio, const float *g_ratio,
+                           int64_t B, int64_t A, float *d_mean, float *d_std, float *d_std_partials, void *stream);
+int64_t cusrl_policy_terms_std_partial_rows(int64_t B);
+/* The same pair for one-hot categorical policies (distribution.py:354-362): logits / one-hot action [B, A]. */
+int cusrl_categorical_terms_fwd(const float *logits, const float *action, const float *old_logp, int64_t B, int64_t A,
+                                float *logp_out, float *entropy_out, float *logp_ratio_out, float *ratio_out, void *stream);
+int cusrl_categorical_terms_bwd(const float *logits, const float *action, const float *ratio, const float *g_logp,
+                                const float *g_entropy, const float *g_logp_ratio, const float *g_ratio, int64_t B,
+                                int64_t A, float *d_logits, void *stream);
+
 /* ---- MLP backward epilogues (callers of the path: torch.nn.Linear / ReLU backward of the actor-critic) ----
  * Bias gradient = column sums of grad [rows, H]; with `output` != NULL the ReLU backward mask is applied first
  * (grad_in = grad * (output > 0), written to grad_in) and the column sums are taken of the masked gradient, i.e.

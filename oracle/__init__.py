@@ -354,6 +354,60 @@ def ppo_loss_f64(advantage, old_logp, action, mean, std, ret, curr_value, old_va
     )
 
 
+def policy_terms_f64(mean, std, action, old_logp, g_logp=None, g_entropy=None, g_logp_ratio=None, g_ratio=None):
+    """What OnPolicyPreparation.objective leaves in the batch (cusrl/hook/on_policy/common.py:29-43) for a Normal policy —
+    ``logp`` / ``entropy`` as sums over the action dims of torch.distributions.Normal.log_prob / entropy
+    (cusrl/nn/module/distribution.py:207-213), ``logp_ratio = logp - old_logp``, ``ratio = exp(logp_ratio)`` — evaluated in
+    float64, and (given gradients wrt those four [B] outputs, None = no gradient) the vector-Jacobian products wrt ``mean`` and
+    ``std`` that autograd forms through the same ops.  ``std`` may be the [A] vector (``d_std`` is then its [A] gradient)."""
+    f = lambda x: np.asarray(x, np.float64)  # noqa: E731
+    x, mu, sg, old = f(action), f(mean), f(std), f(old_logp).reshape(-1)
+    vector = sg.ndim == 1
+    sgb = np.broadcast_to(sg, mu.shape)
+    diff = x - mu
+    logp = (-(diff * diff) / (2.0 * sgb * sgb) - np.log(sgb) - np.log(np.sqrt(2.0 * np.pi))).sum(-1)
+    entropy = (0.5 + 0.5 * np.log(2.0 * np.pi) + np.log(sgb)).sum(-1)
+    lr = logp - old
+    ratio = np.exp(lr)
+    out = dict(logp=logp[:, None], entropy=entropy[:, None], logp_ratio=lr[:, None], ratio=ratio[:, None])
+    if g_logp is None and g_entropy is None and g_logp_ratio is None and g_ratio is None:
+        return out
+    zero = np.zeros_like(logp)
+    g = lambda v: zero if v is None else f(v).reshape(-1)  # noqa: E731
+    G = g(g_logp) + g(g_logp_ratio) + g(g_ratio) * ratio
+    var = sgb * sgb
+    out["d_mean"] = G[:, None] * (diff / var)
+    d_std = G[:, None] * ((diff * diff) / (var * sgb) - 1.0 / sgb) + g(g_entropy)[:, None] / sgb
+    out["d_std"] = d_std.sum(0) if vector else d_std
+    return out
+
+
+def categorical_terms_f64(logits, action, old_logp, g_logp=None, g_entropy=None, g_logp_ratio=None, g_ratio=None):
+    """The same four terms for a one-hot categorical policy (distribution.py:354-362: OneHotCategorical.log_prob / entropy;
+    ``log p`` clamped to the smallest finite float32 like torch.distributions.Categorical.entropy) and their VJP wrt logits."""
+    f = lambda x: np.asarray(x, np.float64)  # noqa: E731
+    z, onehot, old = f(logits), f(action), f(old_logp).reshape(-1)
+    taken = onehot.argmax(-1)
+    norm = np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1, keepdims=True)) + z.max(-1, keepdims=True)
+    lp = np.maximum(z - norm, np.float64(np.finfo(np.float32).min))
+    p = np.exp(lp)
+    entropy = -(p * lp).sum(-1)
+    rows = np.arange(z.shape[0])
+    logp = (z - norm)[rows, taken]
+    lr = logp - old
+    ratio = np.exp(lr)
+    out = dict(logp=logp[:, None], entropy=entropy[:, None], logp_ratio=lr[:, None], ratio=ratio[:, None])
+    if g_logp is None and g_entropy is None and g_logp_ratio is None and g_ratio is None:
+        return out
+    zero = np.zeros_like(logp)
+    g = lambda v: zero if v is None else f(v).reshape(-1)  # noqa: E731
+    G = g(g_logp) + g(g_logp_ratio) + g(g_ratio) * ratio
+    hot = np.zeros_like(z)
+    hot[rows, taken] = 1.0
+    out["d_logits"] = G[:, None] * (hot - p) - g(g_entropy)[:, None] * p * (lp + entropy[:, None])
+    return out
+
+
 def gradient_error(candidate, reference) -> float:
     """max |candidate - reference| / max |reference|: the error of a gradient TENSOR in units of its largest entry (what
     the optimizer step sees), robust against elements that cancel to ~0 where an element-wise relative error is meaningless."""

@@ -566,6 +566,96 @@ def test_ppo_loss_vs_reference_goldens(ops, golden, gradient_parity):
             gradient_parity(f"loss_golden.{name}[{i}]", host(out[name]), g[p + name], 1e-5)
 
 
+def test_policy_terms_forward_vs_reference_goldens(ops, golden):
+    """cusrl_policy_terms_fwd against what the reference's OnPolicyPreparation left in the batch (common.py:29-43)."""
+    g = golden("losses")
+    for i in cases(g):
+        p = f"c{i}_"
+        logp, entropy, lr, ratio = ops.policy_terms_fwd(dev(g[p + "mean"]), dev(g[p + "std"]), dev(g[p + "action"]), dev(g[p + "old_logp"]))
+        np.testing.assert_allclose(host(logp), g[p + "logp"], rtol=1e-5, atol=1e-5)  # 1e-5 rel fp32
+        np.testing.assert_allclose(host(entropy), g[p + "entropy"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(host(lr), g[p + "logp_ratio"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(host(ratio), g[p + "ratio"], rtol=2e-5)
+
+
+@pytest.mark.parametrize("B,A", [(1, 4), (7, 3), (257, 12), (70001, 12), (4096, 64)])
+@pytest.mark.parametrize("vector", [False, True])
+@pytest.mark.parametrize("wanted", [(1, 1, 1, 1), (0, 0, 0, 1), (0, 1, 0, 0), (1, 0, 1, 0)])
+def test_policy_terms_vs_oracle(ops, B, A, vector, wanted, gradient_parity):
+    """Forward and vector-Jacobian product of the policy-terms op against the float64 restatement; any subset of the four
+    outputs may carry a gradient (the others arrive as NULL)."""
+    rng = np.random.default_rng(B * 31 + A)
+    mean, action = rng.standard_normal((B, A), np.float32), rng.standard_normal((B, A), np.float32)
+    std = (rng.random(A if vector else (B, A), np.float32) + 0.5).astype(np.float32)
+    # the behaviour policy's log-prob: near the current one, like in an update (ratios around 1, not denormals)
+    old_logp = (oracle.policy_terms_f64(mean, std, action, np.zeros((B, 1)))["logp"] + 0.3 * rng.standard_normal((B, 1))).astype(np.float32)
+    grads = [rng.standard_normal(B).astype(np.float32) if w else None for w in wanted]
+    ref = oracle.policy_terms_f64(mean, std, action, old_logp, *grads)
+    logp, entropy, lr, ratio = ops.policy_terms_fwd(dev(mean), dev(std), dev(action), dev(old_logp))
+    np.testing.assert_allclose(host(logp), ref["logp"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(entropy), ref["entropy"], rtol=1e-5, atol=1e-6)
+    noise = 1e-6 * float(np.abs(ref["logp"]).max())  # a difference of two |logp| ~ A numbers: absolute noise ~ ulp(|logp|)
+    np.testing.assert_allclose(host(lr), ref["logp_ratio"], rtol=1e-5, atol=1e-5 + noise)
+    np.testing.assert_allclose(host(ratio), ref["ratio"], rtol=2e-5 + noise)  # exp() turns that absolute noise into relative
+    d_mean, d_std = ops.policy_terms_bwd(dev(mean), dev(std), dev(action), ratio, *(None if g is None else dev(g) for g in grads))
+    gradient_parity(f"policy_terms.d_mean[{B},{A},{vector},{wanted}]", host(d_mean), ref["d_mean"], 1e-5)
+    gradient_parity(f"policy_terms.d_std[{B},{A},{vector},{wanted}]", host(d_std), ref["d_std"], 1e-5)
+
+
+def test_policy_terms_autograd_function_matches_torch_distributions(ops):
+    """The op as autograd sees it (hook/on_policy/fused.py) against torch.distributions.Normal differentiated by autograd."""
+    from cusrl_amd.hook.on_policy.fused import _PolicyTermsFunction
+
+    torch.manual_seed(3)
+    B, A = 513, 12
+    mean = torch.randn(B, A, device=DEV, requires_grad=True)
+    std = (torch.rand(A, device=DEV) + 0.5).requires_grad_()
+    action, old_logp = torch.randn(B, A, device=DEV), torch.randn(B, 1, device=DEV) - A
+    weights = [torch.randn(B, 1, device=DEV) for _ in range(4)]
+    outs = _PolicyTermsFunction.apply(mean, std, action, old_logp)
+    sum((o * w).sum() for o, w in zip(outs, weights)).backward()
+    got = (mean.grad.double().cpu(), std.grad.double().cpu())
+    m64, s64 = mean.detach().double().cpu().requires_grad_(), std.detach().double().cpu().requires_grad_()
+    dist = torch.distributions.Normal(m64, s64.expand(B, A))
+    logp = dist.log_prob(action.double().cpu()).sum(-1, keepdim=True)
+    lr = logp - old_logp.double().cpu()
+    ref = (logp, dist.entropy().sum(-1, keepdim=True), lr, lr.exp())
+    sum((o * w.double().cpu()).sum() for o, w in zip(ref, weights)).backward()
+    for name, a, b in (("d_mean", got[0], m64.grad), ("d_std", got[1], s64.grad)):
+        assert oracle.gradient_error(a.numpy(), b.numpy()) <= 1e-5, name
+
+
+@pytest.mark.parametrize("B,A", [(1, 3), (300, 3), (5000, 17)])
+@pytest.mark.parametrize("wanted", [(1, 1, 1, 1), (0, 0, 0, 1), (0, 1, 0, 0)])
+def test_categorical_terms_vs_oracle(ops, B, A, wanted, gradient_parity):
+    rng = np.random.default_rng(B + A)
+    logits = rng.standard_normal((B, A), np.float32) * 2
+    if B > 1:
+        logits[1, 0] = -np.inf  # a masked action: p = 0, contributes nothing, gets zero gradient
+    taken = rng.integers(1, A, B)
+    action = np.eye(A, dtype=np.float32)[taken]
+    old_logp = (rng.standard_normal(B).astype(np.float32) - 1).reshape(B, 1)
+    grads = [rng.standard_normal(B).astype(np.float32) if w else None for w in wanted]
+    ref = oracle.categorical_terms_f64(logits, action, old_logp, *grads)
+    logp, entropy, lr, ratio = ops.categorical_terms_fwd(dev(logits), dev(action), dev(old_logp))
+    np.testing.assert_allclose(host(logp), ref["logp"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(entropy), ref["entropy"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(ratio), ref["ratio"], rtol=2e-5)
+    d_logits = ops.categorical_terms_bwd(dev(logits), dev(action), ratio, *(None if g is None else dev(g) for g in grads))
+    assert np.isfinite(host(d_logits)).all()
+    gradient_parity(f"categorical_terms.d_logits[{B},{A},{wanted}]", host(d_logits), ref["d_logits"], 1e-5)
+
+
+def test_categorical_terms_forward_vs_reference_goldens(ops, golden):
+    g = golden("categorical_losses")
+    for i in cases(g):
+        p = f"c{i}_"
+        logp, entropy, lr, ratio = ops.categorical_terms_fwd(dev(g[p + "logits"]), dev(g[p + "action"]), dev(g[p + "old_logp"]))
+        np.testing.assert_allclose(host(logp), g[p + "logp"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(host(entropy), g[p + "entropy"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(host(ratio), g[p + "ratio"], rtol=2e-5)
+
+
 def test_categorical_ppo_loss_vs_reference_goldens(ops, golden, gradient_parity):
     """cusrl_ppo_loss_categorical_fwd_bwd vs the reference's OneHotCategoricalDist + PPO hooks (losses, autograd grads)."""
     g = golden("categorical_losses")

@@ -340,3 +340,44 @@ def test_categorical_draw_restatement_is_the_exponential_race():
     freq = np.bincount(draws, minlength=4) / draws.size
     expect = np.exp(row) / np.exp(row).sum()
     np.testing.assert_allclose(freq, expect, atol=4e-3)
+
+
+def test_policy_terms_restatement_vs_reference(golden):
+    """oracle.policy_terms_f64 / categorical_terms_f64 against the reference: the four batch entries OnPolicyPreparation
+    leaves (recorded in losses.npz / categorical_losses.npz), and their vector-Jacobian products — fed the gradients the PPO
+    objective sends into `ratio` and `entropy`, they must reproduce the reference's recorded autograd gradients d_mean / d_std /
+    d_logits (1e-5 of the tensor's largest entry)."""
+    g = golden("losses")
+    for i in range(int(g["num_cases"])):
+        p = f"c{i}_"
+        clip, vclip, w_sur, w_val, w_ent = g[p + "params"]
+        B = g[p + "mean"].shape[0]
+        adv, ratio = g[p + "advantage"].astype(np.float64).reshape(-1), g[p + "ratio"].astype(np.float64).reshape(-1)
+        lo, hi = np.float64(np.float32(1.0 - clip)), np.float64(np.float32(1.0 + clip))
+        s1, s2 = adv * ratio, adv * np.clip(ratio, lo, hi)
+        inside = (ratio >= lo) & (ratio <= hi)
+        d_ratio = np.where(s1 < s2, adv, np.where(s1 > s2, np.where(inside, adv, 0.0), 0.5 * adv + np.where(inside, 0.5 * adv, 0.0)))
+        out = oracle.policy_terms_f64(g[p + "mean"], g[p + "std"], g[p + "action"], g[p + "old_logp"],
+                                      g_ratio=(-w_sur / B) * d_ratio, g_entropy=np.full(B, -w_ent / B))
+        np.testing.assert_allclose(out["logp"], g[p + "logp"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out["entropy"], g[p + "entropy"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out["logp_ratio"], g[p + "logp_ratio"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out["ratio"], g[p + "ratio"], rtol=2e-5)
+        assert oracle.gradient_error(out["d_mean"], g[p + "d_mean"]) <= 1e-5
+        assert oracle.gradient_error(out["d_std"], g[p + "d_std"]) <= 1e-5
+    g = golden("categorical_losses")
+    for i in range(int(g["num_cases"])):
+        p = f"c{i}_"
+        clip, vclip, w_sur, w_val, w_ent = g[p + "params"]
+        B = g[p + "logits"].shape[0]
+        adv, ratio = g[p + "advantage"].astype(np.float64).reshape(-1), g[p + "ratio"].astype(np.float64).reshape(-1)
+        lo, hi = np.float64(np.float32(1.0 - clip)), np.float64(np.float32(1.0 + clip))
+        s1, s2 = adv * ratio, adv * np.clip(ratio, lo, hi)
+        inside = (ratio >= lo) & (ratio <= hi)
+        d_ratio = np.where(s1 < s2, adv, np.where(s1 > s2, np.where(inside, adv, 0.0), 0.5 * adv + np.where(inside, 0.5 * adv, 0.0)))
+        out = oracle.categorical_terms_f64(g[p + "logits"], g[p + "action"], g[p + "old_logp"],
+                                           g_ratio=(-w_sur / B) * d_ratio, g_entropy=np.full(B, -w_ent / B))
+        np.testing.assert_allclose(out["logp"], g[p + "logp"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out["entropy"], g[p + "entropy"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out["ratio"], g[p + "ratio"], rtol=2e-5)
+        assert oracle.gradient_error(out["d_logits"], g[p + "d_logits"]) <= 1e-5
