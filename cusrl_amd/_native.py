@@ -109,6 +109,16 @@ _SIGNATURES = {
     "cusrl_rms_normalize": (c_int, [_P, _P, _P, c_float, _P, c_int64, c_int64, _P]),
     "cusrl_rnd_reward": (c_int, [_P, _P, _P, _P, c_float, c_int64, c_int64, _P]),
     "cusrl_amp_style_reward": (c_int, [_P, _P, _P, c_float, c_int64, _P]),
+    "cusrl_amp_style_reward_mean": (c_int, [_P, _P, _P, c_float, c_int64, _P, _P]),
+    "cusrl_amp_prepare": (c_int, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, c_float, c_double,
+                                  c_float, _P, _P, _P, _P]),
+    "cusrl_amp_prepare_max_elements": (c_int64, []),
+    "cusrl_amp_prepare_workspace": (c_int64, [c_int64, c_int64]),
+    "cusrl_reward_shaping": (c_int, [_P, c_float, c_float, c_float, c_float, c_int, c_int, c_int64, _P]),
+    "cusrl_mse_loss_fwd_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P]),
+    "cusrl_mse_loss_num_partials": (c_int64, [c_int64]),
+    "cusrl_sumsq_fwd_bwd": (c_int, [_P, c_int64, c_double, c_double, _P, _P, _P, _P]),
+    "cusrl_bce_pair_fwd_bwd": (c_int, [_P, c_int64, c_float, _P, _P, _P]),
     "cusrl_comm_available": (c_int, []),
     "cusrl_comm_last_error": (c_char_p, []),
     "cusrl_comm_unique_id": (c_int, [_P]),

@@ -55,27 +55,48 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
     pass, expert pass, penalty) whose weight gradients it then adds up.  Here the two passes share one ``[2N, .]`` batch
     and every weight gradient is produced once: ~40 launches instead of ~80 per minibatch step, the same arithmetic."""
 
+    # set by the hook around ``apply``: the two outputs are differentiated with unit gradients (no GradScaler, the flat
+    # gradient path), so the backward uses the forward kernels' gradients as they are instead of rescaling them
+    unit_grad_hint = False
+
     @staticmethod
     def forward(ctx, agent, expert, target, ones, loss_weight, penalty_weight, *parameters):
+        """``expert is None``: ``agent`` already is the joint ``[2N, C]`` batch (agent rows first), e.g. filled by ONE row
+        gather of both buffer leaves."""
         weights, biases = parameters[0::2], parameters[1::2]
-        rows = expert.shape[0]
-        hidden = [torch.cat((agent, expert))]
+        rows = agent.shape[0] // 2 if expert is None else expert.shape[0]
+        hidden = [agent if expert is None else torch.cat((agent, expert))]
         for weight, bias in zip(weights[:-1], biases[:-1]):
             hidden.append(_hidden(hidden[-1], weight, bias))
         logit = torch.addmm(biases[-1], hidden[-1], weights[-1].t())
-        discrimination = nn.functional.binary_cross_entropy_with_logits(logit, target)
+        on_device = logit.is_cuda and logit.dtype == torch.float32
+        if on_device:
+            # loss AND d loss / d logit of the joint batch from ONE launch (log_sigmoid / mul / add / mean forward and
+            # sigmoid / sub / mul backward as torch ops: ~10 launches over 1024 logits)
+            from cusrl_amd import ops
+
+            discrimination, d_logit = ops.bce_pair_fwd_bwd(logit, loss_weight)
+        else:
+            discrimination, d_logit = nn.functional.binary_cross_entropy_with_logits(logit, target) * loss_weight, None
         # d logit / d expert, layer by layer from the output: u_k = m_k * (u_{k+1} W_{k+1})
         units = [_masked(weights[-1].expand(rows, -1), hidden[-1][rows:], 0)]
         for weight, activation in zip(reversed(weights[1:-1]), reversed(hidden[1:-1])):
             units.append(_masked(units[-1] @ weight, activation[rows:], 0))
         units.reverse()  # units[k - 1] = u_k
         input_gradient = units[0] @ weights[0]
-        flat = input_gradient.reshape(-1)
-        penalty = torch.dot(flat, flat) / rows
-        ctx.save_for_backward(logit, target, ones, input_gradient, *hidden, *units, *weights)
+        if on_device:
+            # penalty = mean_n ||g_n||^2 and what it sends back, 2 g / rows — both with their weights — from one pass
+            penalty, d_input = ops.sumsq_fwd_bwd(input_gradient, penalty_weight * loss_weight / rows,
+                                                 2.0 * penalty_weight * loss_weight / rows)
+            ctx.save_for_backward(d_logit, target, ones, d_input, *hidden, *units, *weights)
+        else:
+            flat = input_gradient.reshape(-1)
+            penalty = torch.dot(flat, flat) / rows * (penalty_weight * loss_weight)
+            ctx.save_for_backward(logit, target, ones, input_gradient, *hidden, *units, *weights)
+        ctx.on_device, ctx.unit_grad = on_device, _ReluDiscriminatorObjective.unit_grad_hint
         ctx.layers, ctx.rows = len(weights), rows
         ctx.loss_weight, ctx.penalty_weight = loss_weight, penalty_weight
-        return discrimination * loss_weight, penalty * (penalty_weight * loss_weight)
+        return discrimination, penalty
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -84,7 +105,10 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
         logit, target, ones, input_gradient, *saved = ctx.saved_tensors  # ones: [1, 2N], column sums as GEMMs
         hidden, units, weights = saved[:layers], saved[layers:2 * layers - 1], saved[2 * layers - 1:]
         # --- penalty: d/dW_k of mean || u_1 W_1 ||^2, the masks being constants
-        d_input = input_gradient * (grad_penalty * (2.0 * ctx.penalty_weight * ctx.loss_weight / rows))
+        if ctx.on_device:  # `input_gradient` already is 2 g pw lw / rows, `logit` already d loss / d logit (forward kernels)
+            d_input = input_gradient if ctx.unit_grad else input_gradient * grad_penalty
+        else:
+            d_input = input_gradient * (grad_penalty * (2.0 * ctx.penalty_weight * ctx.loss_weight / rows))
         penalty_grads = [units[0].t() @ d_input]
         d_units = d_input @ weights[0].t()
         for k in range(1, layers - 1):
@@ -93,7 +117,10 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
             d_units = d_pre @ weights[k].t()
         penalty_grads.append(ones[:, :rows] @ _masked(d_units, hidden[layers - 1][rows:], 0))
         # --- discrimination: an ordinary MLP backward over the joint batch, the penalty's share added by the GEMM
-        d_out = (torch.sigmoid(logit) - target) * (grad_discrimination * (ctx.loss_weight / logit.shape[0]))
+        if ctx.on_device:
+            d_out = logit if ctx.unit_grad else logit * grad_discrimination
+        else:
+            d_out = (torch.sigmoid(logit) - target) * (grad_discrimination * (ctx.loss_weight / logit.shape[0]))
         gradients: list[Tensor] = []
         for k in range(layers - 1, -1, -1):
             gradients.append((ones @ d_out).reshape(-1))
@@ -123,6 +150,7 @@ class AdversarialMotionPrior(Hook):
         self.dataset: Tensor | None = None
         self._targets: Tensor | None = None
         self._ones: Tensor | None = None
+        self._columns: tuple | None = None  # (state width, prefix width | None, int32 device column vector | None)
 
     def init(self):
         source = self.dataset_source
@@ -148,21 +176,75 @@ class AdversarialMotionPrior(Hook):
     def collective_phases(self):
         return ("step",)  # transition_rms.update synchronises across ranks on every env step (amp.py:123-124)
 
+    def _selected_columns(self, width: int, device):
+        """``state_indices`` as what the one-launch preparation takes: a prefix width, or an int32 device column vector."""
+        cached = self._columns
+        if cached is None or cached[0] != width:
+            picked = torch.arange(width)[self.state_indices].reshape(-1)
+            prefix = picked.numel() if torch.equal(picked, torch.arange(picked.numel())) else None
+            cached = self._columns = (width, prefix, None if prefix is not None else picked.to(device=device, dtype=torch.int32))
+        return cached[1], cached[2]
+
+    def _prepare_fused(self, transition, agent_raw):
+        """``state[idx] || next_state[idx]`` + ``dataset[randint]`` + both statistics updates + both normalisations as ONE
+        launch (``cusrl_amp_prepare``), or None when a condition of the fused form does not hold (grouped / excluded
+        statistics channels, several ranks synchronising every update, layouts it does not take) — the caller then issues
+        the same steps as separate HIP launches."""
+        from cusrl_amd import ops
+        from cusrl_amd.utils import distributed
+
+        rms = self.transition_rms
+        if not rms.mean.is_cuda or rms.groups or rms.excluded_indices is not None or distributed.enabled():
+            return None
+        kwargs = {}
+        if agent_raw is not None:
+            if not (agent_raw.is_cuda and agent_raw.dim() == 2 and agent_raw.dtype == torch.float32):
+                return None
+            rows, channels = agent_raw.shape
+            kwargs["agent_raw"] = agent_raw
+        else:
+            state = get_first(transition, "state", "observation")
+            next_state = get_first(transition, "next_state", "next_observation")
+            if not (state.is_cuda and state.dim() == 2 and state.dtype == torch.float32 and state.shape == next_state.shape
+                    and next_state.dtype == torch.float32):
+                return None
+            prefix, columns = self._selected_columns(state.shape[1], state.device)
+            rows, channels = state.shape[0], 2 * (prefix if prefix is not None else columns.numel())
+            kwargs.update(state=state, next_state=next_state, columns=columns, width=prefix)
+        if channels != self.transition_dim or not ops.amp_prepare_supported(rows, channels):
+            return None
+        stock_sampler = ("_sample_demonstration" not in self.__dict__
+                         and type(self)._sample_demonstration is AdversarialMotionPrior._sample_demonstration)
+        if self.dataset is not None and stock_sampler:
+            if not (self.dataset.is_cuda and self.dataset.dtype == torch.float32 and self.dataset.dim() == 2):
+                return None
+            # the reference's draw (amp.py:161), so the random stream stays the reference's
+            kwargs.update(dataset=self.dataset, indices=torch.randint(self.dataset.size(0), (rows,), device=self.agent.device))
+        else:
+            kwargs["expert_raw"] = self._sample_demonstration(rows).float()
+        return ops.amp_prepare(rms, **kwargs)
+
     @torch.no_grad()
     def post_step(self, transition):
         agent_transition = transition.pop("amp_obs", None)
-        if agent_transition is None:
-            if self.state_indices is None:
-                raise ValueError("AMP observations were not provided, and 'state_indices' is not set")
-            state = get_first(transition, "state", "observation")[..., self.state_indices]
-            next_state = get_first(transition, "next_state", "next_observation")[..., self.state_indices]
-            agent_transition = torch.cat([state, next_state], dim=-1)
-        expert_transition = self._sample_demonstration(agent_transition.size(0))
-        self.transition_rms.update(agent_transition)
-        self.transition_rms.update(expert_transition)
-        agent_transition = self.transition_rms.normalize(agent_transition)
+        if agent_transition is None and self.state_indices is None:
+            raise ValueError("AMP observations were not provided, and 'state_indices' is not set")
+        prepared = self._prepare_fused(transition, agent_transition) if transition["reward"].is_cuda else None
+        if prepared is not None:
+            agent_transition, expert_transition = prepared
+            self.transition_rms._is_synchronized = True
+        else:
+            if agent_transition is None:
+                state = get_first(transition, "state", "observation")[..., self.state_indices]
+                next_state = get_first(transition, "next_state", "next_observation")[..., self.state_indices]
+                agent_transition = torch.cat([state, next_state], dim=-1)
+            expert_transition = self._sample_demonstration(agent_transition.size(0))
+            self.transition_rms.update(agent_transition)
+            self.transition_rms.update(expert_transition)
+            agent_transition = self.transition_rms.normalize(agent_transition)
+            expert_transition = self.transition_rms.normalize(expert_transition)
         transition["agent_transition"] = agent_transition
-        transition["expert_transition"] = self.transition_rms.normalize(expert_transition)
+        transition["expert_transition"] = expert_transition
         logit = self.discriminator(agent_transition)
         reward = transition["reward"]
         if reward.is_cuda:
@@ -171,6 +253,12 @@ class AdversarialMotionPrior(Hook):
             from cusrl_amd import ops
 
             if reward.is_contiguous() and reward.shape == logit.shape and reward.dtype == torch.float32:
+                # bonus, reward update and the mean the metric records: one launch
+                metrics = getattr(self.agent, "metrics", None)
+                if hasattr(metrics, "record_reduced"):
+                    style_reward, mean = ops.amp_style_reward_mean_(reward, logit, self.reward_scale)
+                    metrics.record_reduced("amp_reward", mean[0], style_reward.numel())
+                    return
                 style_reward = ops.amp_style_reward_(reward, logit, self.reward_scale)
             else:
                 style_reward = ops.amp_style_reward_(torch.zeros_like(logit, dtype=torch.float32), logit.float(), self.reward_scale)
@@ -183,19 +271,38 @@ class AdversarialMotionPrior(Hook):
     def objective(self, metadata, batch):
         agent_transition = batch["agent_transition"].flatten(0, -2)
         expert_transition = batch["expert_transition"].flatten(0, -2)
+        parameters = self._relu_stack() if self.closed_form_objective else None
+        closed_form = parameters is not None and all(p.dtype == agent_transition.dtype for p in parameters)
+        joint = None
         if self.batch_size is not None:
             indices = torch.randint(agent_transition.size(0), (self.batch_size,), device=self.agent.device)
-            agent_transition, expert_transition = agent_transition[indices], expert_transition[indices]
-        parameters = self._relu_stack() if self.closed_form_objective else None
-        if parameters is not None and all(p.dtype == agent_transition.dtype for p in parameters):
+            if (agent_transition.is_cuda and agent_transition.is_contiguous() and expert_transition.is_contiguous()
+                    and agent_transition.dtype == torch.float32 and expert_transition.dtype == torch.float32):
+                # both subsamples with ONE launch of the row-gather kernel — and, for the closed-form objective, straight into
+                # the joint [2N, C] batch it evaluates (no index kernels, no cat)
+                from cusrl_amd import ops
+
+                pool, rows, width = agent_transition.size(0), self.batch_size, agent_transition.size(-1)
+                joint = torch.empty((2 * rows, width), dtype=torch.float32, device=agent_transition.device)
+                ops.gather_rows([agent_transition.view(1, pool, width), expert_transition.view(1, pool, width)], indices, 1, pool,
+                                out=[joint[:rows], joint[rows:]])
+                agent_transition, expert_transition = joint[:rows], joint[rows:]
+            else:
+                agent_transition, expert_transition = agent_transition[indices], expert_transition[indices]
+        if closed_form:
             rows = agent_transition.size(0)
             if (self._targets is None or self._targets.size(0) != 2 * rows or self._targets.device != agent_transition.device
                     or self._targets.dtype != agent_transition.dtype):
                 self._targets = torch.cat((agent_transition.new_zeros(rows, 1), agent_transition.new_ones(rows, 1)))
                 self._ones = agent_transition.new_ones(1, 2 * rows)
-            discrimination, penalty = _ReluDiscriminatorObjective.apply(
-                agent_transition, expert_transition, self._targets, self._ones, self.loss_weight, self.grad_penalty_weight,
-                *parameters)
+            _ReluDiscriminatorObjective.unit_grad_hint = (not getattr(self.agent, "grad_scaler_enabled", False)
+                                                          and getattr(self.agent, "flat_gradients", None) is not None)
+            try:
+                discrimination, penalty = _ReluDiscriminatorObjective.apply(
+                    agent_transition if joint is None else joint, expert_transition if joint is None else None, self._targets,
+                    self._ones, self.loss_weight, self.grad_penalty_weight, *parameters)
+            finally:
+                _ReluDiscriminatorObjective.unit_grad_hint = False
             return {"amp_discrimination_loss": discrimination, "amp_grad_penalty_loss": penalty}
         expert_transition.requires_grad_(True)
         from cusrl_amd.nn.module import double_differentiable

@@ -16,6 +16,28 @@ from cusrl_amd.utils.misc import get_first
 __all__ = ["RandomNetworkDistillation"]
 
 
+class _MseLossFunction(torch.autograd.Function):
+    """``nn.MSELoss()(prediction, target)`` with the target constant: loss AND d loss / d prediction from one pass
+    (``cusrl_mse_loss_fwd_bwd``) instead of sub / square / mean forward and fill / mse_backward behind it."""
+
+    @staticmethod
+    def forward(ctx, prediction, target, unit_grad):
+        from cusrl_amd import ops
+
+        loss, grad = ops.mse_loss_fwd_bwd(prediction, target)
+        ctx.save_for_backward(grad)
+        ctx.unit_grad, ctx.shape = unit_grad, prediction.shape
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss):
+        (grad,) = ctx.saved_tensors
+        if not ctx.unit_grad:  # GradScaler, or a caller that rescales the loss
+            grad = grad * grad_loss
+        return grad.view(ctx.shape), None, None
+
+
 class RandomNetworkDistillation(Hook):
     def __init__(self, module_factory, output_dim: int, reward_scale: float, state_indices=None):
         super().__init__()
@@ -61,4 +83,11 @@ class RandomNetworkDistillation(Hook):
 
     def objective(self, metadata, batch):
         next_state = get_first(batch, "next_state", "next_observation")[..., self.state_indices]
-        return {"rnd_loss": self.criterion(self.predictor(next_state), self.target(next_state))}
+        prediction, target = self.predictor(next_state), self.target(next_state)
+        criterion = self.criterion
+        if (prediction.is_cuda and type(criterion) is nn.MSELoss and criterion.reduction == "mean"
+                and prediction.dtype == torch.float32 and target.dtype == torch.float32 and not target.requires_grad):
+            # forward + backward of the squared error in one HIP pass; a user-supplied criterion keeps torch's ops
+            unit = not getattr(self.agent, "grad_scaler_enabled", False) and getattr(self.agent, "flat_gradients", None) is not None
+            return {"rnd_loss": _MseLossFunction.apply(prediction, target, unit)}
+        return {"rnd_loss": criterion(prediction, target)}

@@ -21,7 +21,14 @@ __all__ = [
     "LaunchObserver",
     "RecordPack",
     "adv_stats_finalize",
+    "amp_prepare",
+    "amp_prepare_supported",
     "amp_style_reward_",
+    "amp_style_reward_mean_",
+    "mse_loss_fwd_bwd",
+    "sumsq_fwd_bwd",
+    "bce_pair_fwd_bwd",
+    "reward_shaping_",
     "buffer_push",
     "col_stats",
     "compact_flags",
@@ -200,17 +207,26 @@ def push_table(table, count: int, cursor: int, parallelism: int, through: tuple 
 
 
 # ------------------------------------------------------------------------------------------------ a7 / a8
+def _row_elems(storage: torch.Tensor) -> int:
+    n = 1
+    for d in storage.shape[2:]:
+        n *= d
+    return n
+
+
 def gather_rows(
     storages: Sequence[torch.Tensor],
     indices: torch.Tensor,
     capacity: int,
     parallelism: int,
     temporal: bool = False,
+    out: Sequence[torch.Tensor] | None = None,
 ) -> list[torch.Tensor]:
     """Minibatch gather of every leaf in one launch.
 
     ``storage.flatten(0, 1)[indices]`` (cusrl/sampler/mini_batch_sampler.py:87-89) or ``storage[:, indices]``
-    (``:113-114``) for each ``[T, N, ...]`` leaf.
+    (``:113-114``) for each ``[T, N, ...]`` leaf.  ``out``: contiguous destinations the caller owns (e.g. two halves of
+    one joint batch), one per leaf.
     """
     require_device(indices, "indices")
     if indices.dtype != torch.int64:
@@ -219,7 +235,13 @@ def gather_rows(
         indices = indices.contiguous()
     batch = indices.numel()
     lead = (capacity, batch) if temporal else (batch,)
-    outputs = [torch.empty(lead + tuple(s.shape[2:]), dtype=s.dtype, device=s.device) for s in storages]
+    if out is None:
+        outputs = [torch.empty(lead + tuple(s.shape[2:]), dtype=s.dtype, device=s.device) for s in storages]
+    else:
+        outputs = list(out)
+        for dst, src in zip(outputs, storages):
+            if not dst.is_contiguous() or dst.dtype != src.dtype or dst.numel() != batch * (capacity if temporal else 1) * _row_elems(src):
+                raise ValueError("gather_rows: an 'out' tensor does not match its leaf (contiguous, same dtype, batch rows)")
     if batch == 0:
         return outputs
     lib = _native.lib()
@@ -1485,3 +1507,119 @@ def amp_style_reward_(reward: torch.Tensor, logit: torch.Tensor, scale: float) -
                                                logit.numel(), _stream()), "cusrl_amp_style_reward")
     _modified_in_place(reward)
     return bonus
+
+
+def amp_style_reward_mean_(reward: torch.Tensor, logit: torch.Tensor, scale: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """:func:`amp_style_reward_` + the mean of the bonus (what ``agent.record(amp_reward=...)`` reduces) from ONE launch;
+    returns ``(bonus, mean[1])``.  Falls back to the two-launch form beyond the single-workgroup size."""
+    logit = _f32(logit, "logit")
+    require_device(reward, "reward")
+    if reward.dtype != torch.float32 or not reward.is_contiguous() or reward.numel() != logit.numel():
+        raise TypeError("amp_style_reward_mean_: reward must be a contiguous float32 tensor matching the logits")
+    if logit.numel() > (1 << 20):
+        bonus = amp_style_reward_(reward, logit, scale)
+        return bonus, bonus.mean().reshape(1)
+    bonus = torch.empty_like(reward)
+    mean = torch.empty(1, dtype=torch.float32, device=reward.device)
+    check(_native.lib().cusrl_amp_style_reward_mean(logit.data_ptr(), reward.data_ptr(), bonus.data_ptr(), float(scale),
+                                                    logit.numel(), mean.data_ptr(), _stream()), "cusrl_amp_style_reward_mean")
+    _modified_in_place(reward)
+    return bonus, mean
+
+
+def amp_prepare_supported(rows: int, channels: int) -> bool:
+    return 0 < channels <= 128 and 0 < rows * channels <= int(_native.lib().cusrl_amp_prepare_max_elements())
+
+
+def amp_prepare(rms, *, state=None, next_state=None, columns=None, width: int | None = None, agent_raw=None, dataset=None,
+                indices=None, expert_raw=None) -> tuple[torch.Tensor, torch.Tensor]:
+    """AMP's ``post_step`` up to the discriminator (amp.py:112-128) as ONE C-ABI call (two launches): assemble ``state[cols] || next_state[cols]``
+    (or take ``agent_raw``), fetch ``dataset[indices]`` (or take ``expert_raw``), update ``rms`` (a RunningMeanStd) with the
+    agent rows, then the expert rows, normalise both.  ``columns``: int32 device vector of the selected state columns, or
+    None with ``width`` = K for the first K columns.  Returns ``(agent_transition, expert_transition)``, ``[N, C]`` each."""
+    if agent_raw is not None:
+        agent_raw = _f32(agent_raw, "agent_raw")
+        N, C = agent_raw.shape
+        K = C // 2
+    else:
+        state, next_state = _f32(state, "state"), _f32(next_state, "next_state")
+        if state.dim() != 2 or state.shape != next_state.shape:
+            raise ValueError("amp_prepare: state / next_state must be [N, S] tensors of one shape")
+        N = state.shape[0]
+        K = int(columns.numel()) if columns is not None else int(width)
+        C = 2 * K
+        if columns is not None and (columns.dtype != torch.int32 or not columns.is_cuda):
+            raise TypeError("amp_prepare: 'columns' must be an int32 device vector")
+    if expert_raw is not None:
+        expert_raw = _f32(expert_raw, "expert_raw")
+        if tuple(expert_raw.shape) != (N, C):
+            raise ValueError("amp_prepare: expert rows do not match the agent rows")
+    else:
+        dataset = _f32(dataset, "dataset")
+        if indices.dtype != torch.int64 or indices.numel() != N or dataset.shape[-1] != C:
+            raise ValueError("amp_prepare: need one int64 dataset index per agent row and rows of the transition's width")
+        indices = indices.contiguous()
+    dev = rms.mean.device
+    agent_out = torch.empty((N, C), dtype=torch.float32, device=dev)
+    expert_out = torch.empty((N, C), dtype=torch.float32, device=dev)
+    workspace = torch.empty(max(int(_native.lib().cusrl_amp_prepare_workspace(N, C)), 1), dtype=torch.float64, device=dev)
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    check(_native.lib().cusrl_amp_prepare(
+        ptr(state), ptr(next_state), 0 if state is None else state.shape[1], ptr(columns), K, ptr(agent_raw), ptr(dataset),
+        ptr(indices), ptr(expert_raw), N, C, rms.mean.data_ptr(), rms.var.data_ptr(), rms.std.data_ptr(), rms._count.data_ptr(),
+        float(rms.epsilon), -1.0 if rms.max_count is None else float(rms.max_count), -1.0 if rms.clamp is None else float(rms.clamp),
+        agent_out.data_ptr(), expert_out.data_ptr(), workspace.data_ptr(), _stream()), "cusrl_amp_prepare")
+    return agent_out, expert_out
+
+
+def reward_shaping_(reward: torch.Tensor, scale: float, shift: float, lower: float | None, upper: float | None) -> torch.Tensor:
+    """``reward.mul_(scale).add_(shift).clamp_(lower, upper)`` (reward.py:43-47) in place, one launch."""
+    require_device(reward, "reward")
+    if reward.dtype != torch.float32 or not reward.is_contiguous():
+        raise TypeError("reward_shaping_: expected a contiguous float32 tensor")
+    check(_native.lib().cusrl_reward_shaping(reward.data_ptr(), float(scale), float(shift), 0.0 if lower is None else float(lower),
+                                             0.0 if upper is None else float(upper), int(lower is not None), int(upper is not None),
+                                             reward.numel(), _stream()), "cusrl_reward_shaping")
+    _modified_in_place(reward)
+    return reward
+
+
+def mse_loss_fwd_bwd(prediction: torch.Tensor, target: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """``(mean((prediction - target)^2), d loss / d prediction)`` from one pass (+ a one-block finalize)."""
+    prediction, target = _f32(prediction, "prediction"), _f32(target, "target")
+    if prediction.shape != target.shape or prediction.numel() == 0:
+        raise ValueError("mse_loss_fwd_bwd: shapes differ or are empty")
+    lib = _native.lib()
+    n = prediction.numel()
+    loss = torch.empty((), dtype=torch.float32, device=prediction.device)
+    grad = torch.empty_like(prediction)
+    partials = torch.empty(max(int(lib.cusrl_mse_loss_num_partials(n)), 1), dtype=torch.float64, device=prediction.device)
+    check(lib.cusrl_mse_loss_fwd_bwd(prediction.data_ptr(), target.data_ptr(), n, loss.data_ptr(), grad.data_ptr(),
+                                     partials.data_ptr(), _stream()), "cusrl_mse_loss_fwd_bwd")
+    return loss, grad
+
+
+def sumsq_fwd_bwd(x: torch.Tensor, loss_scale: float, grad_scale: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """``(loss_scale * sum(x^2), grad_scale * x)`` from one pass (AMP's gradient penalty and what it sends back)."""
+    x = _f32(x, "x")
+    lib = _native.lib()
+    n = x.numel()
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    grad = torch.empty_like(x)
+    partials = torch.empty(max(int(lib.cusrl_mse_loss_num_partials(n)), 1), dtype=torch.float64, device=x.device)
+    check(lib.cusrl_sumsq_fwd_bwd(x.data_ptr(), n, float(loss_scale), float(grad_scale), loss.data_ptr(), grad.data_ptr(),
+                                  partials.data_ptr(), _stream()), "cusrl_sumsq_fwd_bwd")
+    return loss, grad
+
+
+def bce_pair_fwd_bwd(logit: torch.Tensor, weight: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """Discrimination loss of a joint ``[2N, 1]`` logit batch (agent rows first: target 0, expert rows: target 1) times
+    ``weight``, and its gradient wrt the logits — one launch."""
+    logit = _f32(logit, "logit")
+    if logit.numel() % 2:
+        raise ValueError("bce_pair_fwd_bwd: the joint batch holds as many expert as agent rows")
+    loss = torch.empty((), dtype=torch.float32, device=logit.device)
+    grad = torch.empty_like(logit)
+    check(_native.lib().cusrl_bce_pair_fwd_bwd(logit.data_ptr(), logit.numel() // 2, float(weight), loss.data_ptr(), grad.data_ptr(),
+                                               _stream()), "cusrl_bce_pair_fwd_bwd")
+    return loss, grad

@@ -297,19 +297,28 @@ class ActorCritic(Agent):
         elif not self.flat_gradients.intact():
             self.flat_gradients.attach()
 
-    def _backward(self, loss: torch.Tensor):
+    def _backward(self, loss):
         """Gradients of ``loss`` into ``p.grad``.  With the flat gradient buffer the per-parameter gradients — and the
         unsummed slabs of the split-batch weight-gradient GEMMs — are written into it by ONE kernel (no memset, no 13
         accumulate launches, no per-layer sum(0)); otherwise this is the
         reference's ``scaled_loss.backward()`` (actor_critic.py:311-312)."""
         flat = self.flat_gradients
+        roots = list(loss) if isinstance(loss, (list, tuple)) else [loss]  # several roots = the summands of the loss
+        if len(roots) > 1:  # a constant summand (a hook returning a plain number) changes no gradient
+            roots = [t for t in roots if isinstance(t, torch.Tensor) and t.requires_grad] or roots[:1]
         if flat is None:
-            self.grad_scaler.scale(loss).backward()
+            total = roots[0]
+            for term in roots[1:]:
+                total = total + term
+            self.grad_scaler.scale(total).backward()
             return
-        if self._unit_grad is None or self._unit_grad.dtype != loss.dtype:
-            self._unit_grad = torch.ones((), dtype=loss.dtype, device=loss.device)  # persistent: no ones_like per step
+        first = roots[0]
+        if self._unit_grad is None or self._unit_grad.dtype != first.dtype:
+            self._unit_grad = torch.ones((), dtype=first.dtype, device=first.device)  # persistent: no ones_like per step
+        units = [self._unit_grad if term.dtype == first.dtype else torch.ones((), dtype=term.dtype, device=term.device)
+                 for term in roots]
         with collect_split_weight_grads() as split_slabs:
-            grads = torch.autograd.grad(loss, flat.params, grad_outputs=self._unit_grad, allow_unused=True)
+            grads = torch.autograd.grad(roots, flat.params, grad_outputs=units, allow_unused=True)
         flat.assemble(grads, split_slabs)
 
     def _train_step(self, metadata: dict[str, Any], batch: dict[str, Any]):
@@ -319,7 +328,11 @@ class ActorCritic(Agent):
         with self.autocast():
             objectives = self.hook.objective(metadata, batch)  # a9-a13
         if objectives is not None:
-            loss = objectives.loss() if hasattr(objectives, "loss") else sum(objectives.values())
+            # with the flat gradient buffer the summands are differentiated as separate roots (no additions launched)
+            if hasattr(objectives, "terms") and self.flat_gradients is not None:
+                loss = objectives.terms()
+            else:
+                loss = objectives.loss() if hasattr(objectives, "loss") else sum(objectives.values())
             self._zero_grad()
             self._backward(loss)
             self.grad_scaler.unscale_(self.optimizer)

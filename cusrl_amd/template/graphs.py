@@ -263,7 +263,7 @@ class GraphedTrainStep:
             agent._critic_stream = None
             agent._deferred_loss_owner = None
         if objectives is not None:
-            loss = objectives.loss()
+            loss = objectives.terms() if agent.flat_gradients is not None else objectives.loss()
             agent._zero_grad()
             agent._backward(loss)
             agent.grad_scaler.unscale_(agent.optimizer)

@@ -43,6 +43,13 @@ class Objectives(dict):
                 loss = loss + value
         return loss
 
+    def terms(self) -> list[torch.Tensor]:
+        """The summands of :meth:`loss` as separate roots: differentiating them together with unit gradients gives the
+        gradient of the sum without launching the additions (one tiny kernel per auxiliary term and minibatch step)."""
+        if self.total is None:
+            return [value for value in self.values() if value is not None]
+        return [self.total] + [value for key, value in self.items() if key not in self.fused_keys and value is not None]
+
 
 class Hook(Generic[AgentT]):
     agent: AgentT

@@ -473,6 +473,51 @@ int cusrl_rnd_reward(const float *target, const float *prediction, float *reward
 /* AMP, cusrl/hook/auxiliary/amp.py:134-136: reward[i] += scale * -log(max(1 - 1/(1 + exp(-logit[i])), 1e-4));
  * bonus_out as above (`amp_reward`). */
 int cusrl_amp_style_reward(const float *logit, float *reward, float *bonus_out, float scale, int64_t rows, void *stream);
+/* The style reward together with the mean the metric `amp_reward` records (amp.py:134-136 + agent.record): one
+ * single-workgroup launch for rows <= 2^20 (an env step), instead of the reward launch + a reduction. mean_out: float[1]. */
+int cusrl_amp_style_reward_mean(const float *logit, float *reward, float *bonus_out, float scale, int64_t rows,
+                                float *mean_out, void *stream);
+
+/* ---- AdversarialMotionPrior.post_step up to the discriminator — cusrl/hook/auxiliary/amp.py:112-128 ----
+ * agent rows  = cat(state[n, columns], next_state[n, columns])  (columns: K int32 entries, NULL = 0..K-1; state rows are
+ *               `state_pitch` floats apart), or `agent_raw` [N, C] when the env provides `amp_obs` (state = NULL);
+ * expert rows = dataset[indices[n]] (indices: the int64 draws of torch.randint, so the random stream is the
+ *               reference's), or `expert_raw` [N, C] when a demonstration sampler provides them;
+ * then transition_rms.update(agent), transition_rms.update(expert) (population statistics, Chan merge with weights
+ * count : N, count capped at max_count if > 0 — the arithmetic of cusrl_masked_col_stats + cusrl_rms_merge) and both
+ * normalised + clamped (clamp <= 0: none) with the statistics after BOTH updates, into agent_out / expert_out [N, C].
+ * C = 2K <= 128, N * C <= cusrl_amp_prepare_max_elements(): TWO launches (assemble + block partial sums; merge +
+ * normalise, every block folding the <= 64 partial rows itself) instead of the reference's cat + index + 2 x
+ * var_mean/merge + 2 x normalise (~25 torch launches; 10 launches of the per-op kernels above).
+ * workspace: double[cusrl_amp_prepare_workspace(N, C)]. */
+int cusrl_amp_prepare(const float *state, const float *next_state, int64_t state_pitch, const int32_t *columns, int64_t K,
+                      const float *agent_raw, const float *dataset, const int64_t *indices, const float *expert_raw,
+                      int64_t N, int64_t C, float *mean, float *var, float *std, double *count, float eps,
+                      double max_count, float clamp, float *agent_out, float *expert_out, double *workspace, void *stream);
+int64_t cusrl_amp_prepare_max_elements(void);
+int64_t cusrl_amp_prepare_workspace(int64_t N, int64_t C);
+
+/* ---- RewardShaping.post_step — cusrl/hook/mdp/reward.py:43-47 ----
+ * reward = clamp(reward * scale + shift, lower, upper) in place (the product and the sum rounded separately like the two
+ * torch ops; has_lower / has_upper = 0: that bound is None). */
+int cusrl_reward_shaping(float *reward, float scale, float shift, float lower, float upper, int has_lower, int has_upper,
+                         int64_t n, void *stream);
+
+/* ---- nn.MSELoss(prediction, target) forward AND backward — RandomNetworkDistillation.objective, rnd.py:78-81 ----
+ * loss_out[0] = mean((prediction - target)^2) over n elements (fp64 block partials, fixed order),
+ * d_prediction = 2 (prediction - target) / n.  partials: double[cusrl_mse_loss_num_partials(n)]. */
+int cusrl_mse_loss_fwd_bwd(const float *prediction, const float *target, int64_t n, float *loss_out, float *d_prediction,
+                           double *partials, void *stream);
+int64_t cusrl_mse_loss_num_partials(int64_t n);
+/* loss_out[0] = loss_scale * sum(x^2), grad_out = grad_scale * x — the gradient penalty of AMP's discriminator objective
+ * (mean_n ||dD/dx_n||^2, cusrl/nn/layer/loss.py:10-56) and what it sends back into the input gradient; same workspace. */
+int cusrl_sumsq_fwd_bwd(const float *x, int64_t n, double loss_scale, double grad_scale, float *loss_out, float *grad_out,
+                        double *partials, void *stream);
+/* AMP's discrimination loss over the joint batch logit[2 * rows] (first half agent = target 0, second half expert =
+ * target 1): loss_out[0] = weight * mean BCE-with-logits = (BCE(D(agent), 0) + BCE(D(expert), 1)) / 2 * loss_weight
+ * (amp.py:143-147), d_logit = weight * (sigmoid(logit) - target) / (2 rows).  One launch instead of ~10 torch ops. */
+int cusrl_bce_pair_fwd_bwd(const float *logit, int64_t rows, float weight, float *loss_out, float *d_logit, void *stream);
+
 
 /* ---- a6 / a14  data-parallel exchange over RCCL / xGMI — cusrl/utils/distributed.py:58-63, 101-110, 145-183 ----
  * One process per GPU (cusrl/utils/config.py:31-44); a communicator spans all ranks of the job and binds to the

@@ -408,6 +408,72 @@ def categorical_terms_f64(logits, action, old_logp, g_logp=None, g_entropy=None,
     return out
 
 
+def reward_shaping(reward, scale=1.0, shift=0.0, lower=None, upper=None):
+    """RewardShaping.post_step (cusrl/hook/mdp/reward.py:43-47): ``reward.mul_(scale).add_(shift)`` — product and sum rounded
+    separately in fp32 — then ``clamp_(min, max)``; returns the new array."""
+    out = np.asarray(reward, np.float32) * np.float32(scale)
+    out = (out + np.float32(shift)).astype(np.float32)
+    if lower is not None:
+        out = np.where(out < np.float32(lower), np.float32(lower), out)
+    if upper is not None:
+        out = np.where(out > np.float32(upper), np.float32(upper), out)
+    return out.astype(np.float32)
+
+
+def running_mean_std_update(mean, var, count, batch, epsilon=1e-8, max_count=None):
+    """One ``RunningMeanStd.update(batch)`` (cusrl/nn/layer/rms.py:140-167 with cusrl/nn/utils/normalization.py:15-50,80-93):
+    population statistics of the batch rows, merged with weights count : rows; fp32 like the reference's tensors.
+    Returns ``(mean, var, std, count)``."""
+    batch = np.asarray(batch, np.float32).reshape(-1, np.shape(batch)[-1])
+    n = batch.shape[0]
+    if n == 0:
+        return mean, var, np.sqrt(var + np.float32(epsilon)), count
+    b64 = batch.astype(np.float64)
+    batch_mean = b64.mean(0).astype(np.float32)
+    batch_var = b64.var(0).astype(np.float32)  # torch.var_mean(correction=0)
+    w_sum = count + n
+    w_old, w_new = np.float32(count / w_sum), np.float32(n / w_sum)
+    delta = batch_mean - np.asarray(mean, np.float32)
+    new_mean = (mean + delta * w_new).astype(np.float32)
+    new_var = (var + ((batch_var - var) * w_new + delta * delta * np.float32((count / w_sum) * (n / w_sum)))).astype(np.float32)
+    total = count + n
+    if max_count is not None and total > max_count:
+        total = max_count
+    return new_mean, new_var, np.sqrt(new_var + np.float32(epsilon)).astype(np.float32), total
+
+
+def amp_prepare(state, next_state, columns, dataset, picks, mean, var, count, clamp=10.0, epsilon=1e-8, max_count=None):
+    """AdversarialMotionPrior.post_step up to the discriminator (cusrl/hook/auxiliary/amp.py:112-128):
+    ``agent = cat(state[:, columns], next_state[:, columns])``, ``expert = dataset[picks]``, ``rms.update(agent)``,
+    ``rms.update(expert)``, both normalised (``(x - mean) / std`` clamped to +-clamp, rms.py:198-203) with the statistics
+    after both updates.  Returns ``(agent, expert, mean, var, std, count)``."""
+    agent = np.concatenate([np.asarray(state, np.float32)[:, columns], np.asarray(next_state, np.float32)[:, columns]], -1)
+    expert = np.asarray(dataset, np.float32)[np.asarray(picks)]
+    mean, var, std, count = running_mean_std_update(np.asarray(mean, np.float32), np.asarray(var, np.float32), count, agent,
+                                                    epsilon, max_count)
+    mean, var, std, count = running_mean_std_update(mean, var, count, expert, epsilon, max_count)
+
+    def normalise(x):
+        out = ((x - mean) / std).astype(np.float32)
+        return out if clamp is None else np.clip(out, -np.float32(clamp), np.float32(clamp))
+
+    return normalise(agent), normalise(expert), mean, var, std, count
+
+
+def amp_style_reward(logit, scale):
+    """``reward_scale * -log(clamp(1 - 1 / (1 + exp(-logit)), min=1e-4))`` (amp.py:131) in fp32, the reference's op order."""
+    logit = np.asarray(logit, np.float32)
+    p = (np.float32(1) - np.float32(1) / (np.float32(1) + np.exp(-logit))).astype(np.float32)
+    return (np.float32(scale) * -np.log(np.maximum(p, np.float32(1e-4)))).astype(np.float32)
+
+
+def mse_loss(prediction, target):
+    """``nn.MSELoss()(prediction, target)`` (rnd.py:80) and its gradient wrt ``prediction`` in float64."""
+    p, t = np.asarray(prediction, np.float64), np.asarray(target, np.float64)
+    d = p - t
+    return float((d * d).mean()), 2.0 * d / d.size
+
+
 def gradient_error(candidate, reference) -> float:
     """max |candidate - reference| / max |reference|: the error of a gradient TENSOR in units of its largest entry (what
     the optimizer step sees), robust against elements that cancel to ~0 where an element-wise relative error is meaningless."""

@@ -129,3 +129,115 @@ def test_amp_preset(compile_):  # cusrl_test/hook/auxiliary/test_amp.py:9-18
     for key in ("Agent/amp_discrimination_loss", "Agent/amp_grad_penalty_loss", "Agent/amp_reward", "Agent/surrogate_loss"):
         assert np.isfinite(info[key]), key
     assert {"agent_transition", "expert_transition"} <= set(trainer.agent.buffer.storage)
+
+
+# ------------------------------------------------------------------------------------------------ round 4: one-launch forms
+def test_amp_prepare_restatement_reproduces_the_reference_hook(golden):
+    """oracle.amp_prepare / oracle.amp_style_reward against what the reference's AdversarialMotionPrior.post_step recorded
+    (aux_rewards.npz): normalised transitions, running statistics and shaped rewards of every step."""
+    import oracle
+
+    g = golden("aux_rewards")
+    dataset, columns = g["amp_dataset"], np.arange(1, 5)
+    mean, var, count = np.zeros(8, np.float32), np.ones(8, np.float32), 0
+    for t in range(int(g["amp_steps"])):
+        torch.manual_seed(100 + t)
+        picks = torch.randint(50, (7,)).numpy()
+        agent, expert, mean, var, std, count = oracle.amp_prepare(g[f"amp_obs_{t}"], g[f"amp_next_obs_{t}"], columns, dataset, picks,
+                                                                  mean, var, count)
+        np.testing.assert_allclose(agent, g[f"amp_agent_transition_{t}"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(expert, g[f"amp_expert_transition_{t}"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(mean, g[f"amp_rms_mean_{t}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(var, g[f"amp_rms_var_{t}"], rtol=1e-5, atol=1e-6)
+
+
+def test_reward_shaping_restatement_matches_the_reference_hook_formula():
+    import oracle
+
+    reward = torch.randn(5, 7, 1)
+    expect = reward.clone().mul_(1.7).add_(-0.3).clamp_(min=-1.0, max=None)
+    assert np.array_equal(oracle.reward_shaping(reward.numpy(), 1.7, -0.3, -1.0, None), expect.numpy())
+    expect = reward.clone().mul_(0.5).add_(0.25).clamp_(min=None, max=0.4)
+    assert np.array_equal(oracle.reward_shaping(reward.numpy(), 0.5, 0.25, None, 0.4), expect.numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,state_dim,columns", [(7, 10, slice(1, 5)), (4096, 48, slice(6)), (300, 16, [15, 2, 7])])
+def test_amp_prepare_kernel_vs_oracle(rows, state_dim, columns):
+    """cusrl_amp_prepare — assembly, dataset rows, two statistics updates, two normalisations in ONE launch — against the
+    numpy restatement over three consecutive steps (the running statistics carry over)."""
+    import oracle
+    from cusrl_amd import ops
+    from cusrl_amd.nn.rms import RunningMeanStd
+
+    dev = "cuda:0"
+    rng = np.random.default_rng(rows)
+    picked = np.arange(state_dim)[columns]
+    C = 2 * len(picked)
+    dataset = rng.standard_normal((1000, C)).astype(np.float32) * 3 + 1
+    rms = RunningMeanStd(C).to(dev)
+    mean, var, count = np.zeros(C, np.float32), np.ones(C, np.float32), 0
+    prefix = len(picked) if np.array_equal(picked, np.arange(len(picked))) else None
+    cols = None if prefix is not None else torch.as_tensor(picked, dtype=torch.int32, device=dev)
+    for step in range(3):
+        state, nxt = rng.standard_normal((rows, state_dim)).astype(np.float32), rng.standard_normal((rows, state_dim)).astype(np.float32)
+        picks = rng.integers(0, 1000, rows)
+        agent, expert = ops.amp_prepare(rms, state=torch.from_numpy(state).to(dev), next_state=torch.from_numpy(nxt).to(dev), columns=cols,
+                                        width=prefix, dataset=torch.from_numpy(dataset).to(dev), indices=torch.from_numpy(picks).to(dev))
+        ref_agent, ref_expert, mean, var, std, count = oracle.amp_prepare(state, nxt, picked, dataset, picks, mean, var, count)
+        np.testing.assert_allclose(agent.cpu().numpy(), ref_agent, rtol=1e-5, atol=2e-5)  # 1e-5 rel fp32
+        np.testing.assert_allclose(expert.cpu().numpy(), ref_expert, rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(rms.mean.cpu().numpy(), mean, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rms.var.cpu().numpy(), var, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rms.std.cpu().numpy(), std, rtol=1e-5, atol=1e-6)
+        assert rms.count == count
+
+
+@pytest.mark.gpu
+def test_reward_shaping_style_mean_and_mse_kernels_vs_oracle():
+    import oracle
+    from cusrl_amd import ops
+
+    dev = "cuda:0"
+    reward = torch.randn(4096, 1, device=dev)
+    for args in ((1.7, -0.3, -1.0, None), (0.5, 0.25, None, 0.4), (1.0, 0.0, -0.2, 0.2), (2.0, 1.0, None, None)):
+        got = ops.reward_shaping_(reward.clone(), *args)
+        assert np.array_equal(got.cpu().numpy(), oracle.reward_shaping(reward.cpu().numpy(), *args)), args  # bit-exact
+    hook = cusrl.hook.RewardShaping(scale=1.7, shift=-0.3, lower_bound=-1.0)
+    transition = {"reward": reward.clone()}
+    hook.post_step(transition)
+    assert np.array_equal(transition["reward"].cpu().numpy(), oracle.reward_shaping(reward.cpu().numpy(), 1.7, -0.3, -1.0, None))
+    logit = torch.randn(4096, 1, device=dev) * 6
+    base = torch.randn(4096, 1, device=dev)
+    target = base.clone()
+    bonus, mean = ops.amp_style_reward_mean_(target, logit, 2.0)
+    expect = oracle.amp_style_reward(logit.cpu().numpy(), 2.0)
+    np.testing.assert_allclose(bonus.cpu().numpy(), expect, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(target.cpu().numpy(), base.cpu().numpy() + expect, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(mean.item(), expect.astype(np.float64).mean(), rtol=1e-5)
+    for shape in ((24576, 16), (1000, 5), (3,)):
+        prediction, tgt = torch.randn(*shape, device=dev), torch.randn(*shape, device=dev)
+        loss, grad = ops.mse_loss_fwd_bwd(prediction, tgt)
+        ref_loss, ref_grad = oracle.mse_loss(prediction.cpu().numpy(), tgt.cpu().numpy())
+        np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-5)
+        np.testing.assert_allclose(grad.cpu().numpy(), ref_grad, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_bce_pair_and_sumsq_kernels_vs_torch_formulas():
+    from cusrl_amd import ops
+
+    dev = "cuda:0"
+    for rows in (1, 512, 5000):
+        logit = (torch.randn(2 * rows, 1, device=dev) * 4).requires_grad_()
+        target = torch.cat((torch.zeros(rows, 1, device=dev), torch.ones(rows, 1, device=dev)))
+        ref = torch.nn.functional.binary_cross_entropy_with_logits(logit.double(), target.double()) * 2.5
+        (ref_grad,) = torch.autograd.grad(ref, logit)
+        loss, grad = ops.bce_pair_fwd_bwd(logit.detach(), 2.5)
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)  # 1e-5 rel fp32
+        np.testing.assert_allclose(grad.cpu().numpy(), ref_grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    for shape in ((512, 12), (7,), (300000,)):
+        x = torch.randn(*shape, device=dev)
+        loss, grad = ops.sumsq_fwd_bwd(x, 0.3, 0.6)
+        np.testing.assert_allclose(loss.item(), 0.3 * x.double().square().sum().item(), rtol=1e-5)
+        np.testing.assert_allclose(grad.cpu().numpy(), (0.6 * x).cpu().numpy(), rtol=1e-6)

@@ -355,8 +355,12 @@ def test_config5_rnd_and_amp_together_4096_envs(cusrl):
     agent.hook.pre_update = pre_update
     with Launches() as launched:
         trainer.run_training_loop()
-    assert launched["cusrl_amp_style_reward"] == T and launched["cusrl_rnd_reward"] == 1
-    assert launched["cusrl_masked_col_stats"] >= 2 * T  # the AMP transition statistics (agent + expert rows per step)
+    # per env step: ONE launch for the transition assembly + dataset rows + both statistics updates + both normalisations,
+    # one for the style reward and its recorded mean, one for the reward shaping (scale 0.5); RND's bonus once per update
+    assert launched["cusrl_amp_prepare"] == T and launched["cusrl_amp_style_reward_mean"] == T
+    assert launched["cusrl_reward_shaping"] == T and launched["cusrl_rnd_reward"] == 1
+    assert launched["cusrl_mse_loss_fwd_bwd"] > 0  # RND's objective: squared error forward + backward in one pass
+    assert amp.transition_rms.count == 2 * N * T  # agent + expert rows of every step went into the running statistics
     assert {"agent_transition", "expert_transition"} <= set(agent.buffer.storage)
     assert agent.buffer["agent_transition"].shape == (T, N, 2 * k)
     # per-step: reward = extrinsic * 0.5 + style, style >= 0 bounded by -log(1e-4) * scale
