@@ -15,6 +15,8 @@
 // its state, emits zeros, and lets the state gradient pass through untouched — so the final state is the state at each
 // sequence's own last step (cusrl/nn/module/rnn.py:273-291 obtains that through a PackedSequence and a host read of the
 // lengths).  Streaming, HBM-bound: 36 B per state element forward, 64 B backward; 16-byte lanes when H % 4 == 0.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace cusrl {
@@ -150,6 +152,120 @@ __global__ __launch_bounds__(kBlock) void gru_gates_bwd_kernel(float *__restrict
     *reinterpret_cast<V *>(gh_row + H + j) = d_z;
     *reinterpret_cast<V *>(gh_row + 2 * H + j) = d_q;
     *reinterpret_cast<V *>(dh + b * H + j) = d_h;
+}
+
+// The same pass with the bias gradients folded in: a block owns kBiasRows consecutive rows, every thread keeps one column
+// chunk (kBlock % cols == 0) and sums what it writes — d_r, d_z, d_n, d_q — over its rows; the block's row groups are
+// folded through LDS and the block leaves ONE partial row [4H] = {sum d_r, sum d_z, sum d_n, sum d_q}.  The caller sums the
+// L x ceil(B / kBiasRows) partial rows once per layer: d b_ih = {r, z, n}, d b_hh = {r, z, q}.  Replaces two column-sum
+// passes over the [L * B, 3H] gradient arrays (config 4: 2 x 408 MB read again per layer at the HBM roofline, 14 ms per
+// iteration) by 2 x 17 MB of partial rows.  Fixed summation order (deterministic).
+constexpr int kBiasRowsDefault = 16;
+static int bias_rows() {
+    static const int rows = [] {
+        const char *v = getenv("CUSRL_GRU_BIAS_ROWS");
+        const int r = v && *v ? atoi(v) : kBiasRowsDefault;
+        return (r == 4 || r == 8 || r == 16 || r == 32) ? r : kBiasRowsDefault;
+    }();
+    return rows;
+}
+
+template <typename V>
+__global__ __launch_bounds__(kBlock) void gru_gates_bwd_bias_kernel(float *__restrict__ gi, float *__restrict__ gh,
+                                                                    const float *__restrict__ b_hh,
+                                                                    const float *__restrict__ h_prev,
+                                                                    const float *__restrict__ d_out, float *__restrict__ dh,
+                                                                    const int64_t *__restrict__ lengths, int64_t t,
+                                                                    int64_t B, int H, float *__restrict__ bias_partials,
+                                                                    int kBiasRows) {
+    constexpr int kW = sizeof(V) / sizeof(float);
+    const int cols = H / kW;              // divides kBlock (checked by the entry point)
+    const int groups = kBlock / cols;     // rows in flight per pass of the block
+    const int col = threadIdx.x % cols, group = threadIdx.x / cols;
+    const int j = col * kW;
+    const int64_t row0 = int64_t(blockIdx.x) * kBiasRows;
+    float acc[4][kW];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < kW; ++k) acc[g][k] = 0.0f;
+    V br, bz, bn;
+    if (b_hh) {
+        br = *reinterpret_cast<const V *>(b_hh + j), bz = *reinterpret_cast<const V *>(b_hh + H + j),
+        bn = *reinterpret_cast<const V *>(b_hh + 2 * H + j);
+    }
+    const float *pbr = reinterpret_cast<const float *>(&br), *pbz = reinterpret_cast<const float *>(&bz),
+                *pbn = reinterpret_cast<const float *>(&bn);
+    for (int r = group; r < kBiasRows; r += groups) {
+        const int64_t b = row0 + r;
+        if (b >= B) break;
+        float *gi_row = gi + b * 3 * H, *gh_row = gh + b * 3 * H;
+        const bool live = !lengths || t < lengths[b];
+        V d_r, d_z, d_n, d_q;
+        float *pdr = reinterpret_cast<float *>(&d_r), *pdz = reinterpret_cast<float *>(&d_z),
+              *pdn = reinterpret_cast<float *>(&d_n), *pdq = reinterpret_cast<float *>(&d_q);
+        if (!live) {  // ended sequence: no gate gradients, the state gradient passes through (dh stays as it is)
+#pragma unroll
+            for (int k = 0; k < kW; ++k) pdr[k] = pdz[k] = pdn[k] = pdq[k] = 0.0f;
+        } else {
+            const V gir = *reinterpret_cast<const V *>(gi_row + j), giz = *reinterpret_cast<const V *>(gi_row + H + j),
+                    gin = *reinterpret_cast<const V *>(gi_row + 2 * H + j);
+            const V ghr = *reinterpret_cast<const V *>(gh_row + j), ghz = *reinterpret_cast<const V *>(gh_row + H + j),
+                    ghn = *reinterpret_cast<const V *>(gh_row + 2 * H + j);
+            const V hp = *reinterpret_cast<const V *>(h_prev + b * H + j);
+            const V dhn = *reinterpret_cast<const V *>(dh + b * H + j);
+            V dout;
+            if (d_out) dout = *reinterpret_cast<const V *>(d_out + b * H + j);
+            const float *pgir = reinterpret_cast<const float *>(&gir), *pgiz = reinterpret_cast<const float *>(&giz),
+                        *pgin = reinterpret_cast<const float *>(&gin), *pghr = reinterpret_cast<const float *>(&ghr),
+                        *pghz = reinterpret_cast<const float *>(&ghz), *pghn = reinterpret_cast<const float *>(&ghn),
+                        *php = reinterpret_cast<const float *>(&hp), *pdhn = reinterpret_cast<const float *>(&dhn),
+                        *pdout = reinterpret_cast<const float *>(&dout);
+            V d_h;
+            float *pdh = reinterpret_cast<float *>(&d_h);
+#pragma unroll
+            for (int k = 0; k < kW; ++k) {
+                const GruGates g = gru_gates(pgir[k], pgiz[k], pgin[k], pghr[k], pghz[k], pghn[k], b_hh ? pbr[k] : 0.0f,
+                                             b_hh ? pbz[k] : 0.0f, b_hh ? pbn[k] : 0.0f);
+                const float dht = pdhn[k] + (d_out ? pdout[k] : 0.0f);
+                const float dn_pre = dht * (1.0f - g.z) * (1.0f - g.n * g.n);
+                pdn[k] = dn_pre;
+                pdq[k] = dn_pre * g.r;
+                pdr[k] = dn_pre * g.q * g.r * (1.0f - g.r);
+                pdz[k] = dht * (php[k] - g.n) * g.z * (1.0f - g.z);
+                pdh[k] = dht * g.z;
+                acc[0][k] += pdr[k], acc[1][k] += pdz[k], acc[2][k] += pdn[k], acc[3][k] += pdq[k];
+            }
+            *reinterpret_cast<V *>(dh + b * H + j) = d_h;
+        }
+        *reinterpret_cast<V *>(gi_row + j) = d_r;
+        *reinterpret_cast<V *>(gi_row + H + j) = d_z;
+        *reinterpret_cast<V *>(gi_row + 2 * H + j) = d_n;
+        *reinterpret_cast<V *>(gh_row + j) = d_r;
+        *reinterpret_cast<V *>(gh_row + H + j) = d_z;
+        *reinterpret_cast<V *>(gh_row + 2 * H + j) = d_q;
+    }
+    // fold the block's row groups (same column chunk: threads col, col + cols, ...), group 0 first
+    __shared__ float fold[kBlock][4 * kW];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < kW; ++k) fold[threadIdx.x][g * kW + k] = acc[g][k];
+    __syncthreads();
+    if (group == 0) {
+        float *out = bias_partials + int64_t(blockIdx.x) * 4 * H;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float total[kW];
+#pragma unroll
+            for (int k = 0; k < kW; ++k) total[k] = 0.0f;
+            for (int q = 0; q < groups; ++q)
+#pragma unroll
+                for (int k = 0; k < kW; ++k) total[k] += fold[q * cols + col][g * kW + k];
+#pragma unroll
+            for (int k = 0; k < kW; ++k) out[g * H + j + k] = total[k];
+        }
+    }
 }
 
 
@@ -386,6 +502,32 @@ extern "C" int cusrl_gru_gates_bwd(float *gi, float *gh, const float *b_hh, cons
     else
         hipLaunchKernelGGL(gru_gates_bwd_kernel<float>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), gi,
                            gh, b_hh, h_prev, d_out, dh, lengths, t, B, int(H));
+    return launch_status();
+}
+
+extern "C" int64_t cusrl_gru_bias_partial_rows(int64_t B) { return B <= 0 ? 0 : cusrl::ceil_div(B, cusrl::bias_rows()); }
+
+extern "C" int cusrl_gru_gates_bwd_bias(float *gi, float *gh, const float *b_hh, const float *h_prev, const float *d_out,
+                                        float *dh, const int64_t *lengths, int64_t t, int64_t B, int64_t H,
+                                        float *bias_partials, void *stream) {
+    using namespace cusrl;
+    if (B < 0 || H <= 0 || t < 0) return CUSRL_E_INVALID;
+    if (B == 0) return 0;
+    if (!gi || !gh || !h_prev || !dh || !bias_partials) return CUSRL_E_INVALID;
+    if (H > INT32_MAX / 3) return CUSRL_E_UNSUPPORTED;
+    const bool vec4 = gru_vec4(H, gi, gh, b_hh, h_prev, d_out, dh) && aligned(bias_partials, 16);
+    const int64_t cols = vec4 ? H / 4 : H;
+    if (cols > kBlock || kBlock % cols != 0) return CUSRL_E_UNSUPPORTED;  // the caller keeps the plain pass + column sums
+    const int rows_per_block = bias_rows();
+    if (kBlock / cols > rows_per_block) return CUSRL_E_UNSUPPORTED;  // narrow layers: more row groups than rows per block
+    const int64_t blocks = ceil_div(B, rows_per_block);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    if (vec4)
+        hipLaunchKernelGGL(gru_gates_bwd_bias_kernel<float4>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), gi,
+                           gh, b_hh, h_prev, d_out, dh, lengths, t, B, int(H), bias_partials, rows_per_block);
+    else
+        hipLaunchKernelGGL(gru_gates_bwd_bias_kernel<float>, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), gi,
+                           gh, b_hh, h_prev, d_out, dh, lengths, t, B, int(H), bias_partials, rows_per_block);
     return launch_status();
 }
 

@@ -50,7 +50,11 @@ class _GruLayer(torch.autograd.Function):
         gi = (torch.mm(flat, w_ih.t()) if b_ih is None else torch.addmm(b_ih, flat, w_ih.t())).view(L, B, 3 * H)
         keep = any(ctx.needs_input_grad[:6])
         gh = torch.empty((L if keep else 1, B, 3 * H), dtype=x.dtype, device=x.device)
-        out = _new_output(x, L, B, H, sizes)
+        # the outputs live behind one extra leading slab that holds h0: `states[:-1]` then IS the array of the states that
+        # entered every step — what the recurrent weight gradient pairs with d_gh — without a cat of 136 MB per layer
+        states = _new_output(x, L + 1, B, H, None if sizes is None else [B] + sizes)
+        states[0].copy_(h0)
+        out = states[1:]
         h = h0.clone(memory_format=torch.contiguous_format)
         w_hh_t = w_hh.t()
         for t in range(L):
@@ -63,7 +67,7 @@ class _GruLayer(torch.autograd.Function):
             ops.gru_gates_forward(gi[t, :n], gh_t[:n], b_hh, h[:n], out[t, :n], lengths, t)
         if keep:
             ctx.save_for_backward(x, h0, w_ih, w_hh, b_hh, lengths, out)
-            ctx.gi, ctx.gh, ctx.has_b_ih, ctx.sizes = gi, gh, b_ih is not None, sizes
+            ctx.gi, ctx.gh, ctx.has_b_ih, ctx.sizes, ctx.states = gi, gh, b_ih is not None, sizes, states
         return out, h
 
     @staticmethod
@@ -86,11 +90,24 @@ class _GruLayer(torch.autograd.Function):
         # gradients of the ended sequences itself (its `lengths` branch) — instead of two fill launches per step for the
         # tails (config 4: 3 840 of them per iteration, 6.8 % of the device time).
         in_kernel_tails = sizes is not None and lengths is not None
+        need = ctx.needs_input_grad
+        # bias gradients folded into the gate pass: every block leaves the column sums of the gate gradients it writes
+        # (ops.gru_gates_backward, `bias_partials`), summed ONCE per layer below — instead of two column-sum passes over the
+        # [L * B, 3H] gradient arrays (config 4: 14 ms per iteration of re-reading 408 MB arrays at the HBM roofline)
+        want_bias = (ctx.has_b_ih and need[4]) or (b_hh is not None and need[5])
+        bias_rows = ops.gru_bias_partial_rows(B)
+        bias_partials = None
+        if want_bias and ops.gru_bias_partials_supported(H, gi, gh, b_hh, h0, out, d_out, dh):
+            # partial rows no launch writes (row subsets of a length-sorted batch without device-side lengths, skipped
+            # steps) must read as zero
+            full = sizes is None or in_kernel_tails and sizes[-1] > 0
+            bias_partials = (torch.empty if full else torch.zeros)((L, bias_rows, 4 * H), dtype=x.dtype, device=x.device)
         for t in range(L - 1, -1, -1):
             n = B if sizes is None else sizes[t]
             h_prev = h0 if t == 0 else out[t - 1]
             if in_kernel_tails and n > 0:
-                ops.gru_gates_backward(gi[t], gh[t], b_hh, h_prev, None if d_out is None else d_out[t], dh, lengths, t)
+                ops.gru_gates_backward(gi[t], gh[t], b_hh, h_prev, None if d_out is None else d_out[t], dh, lengths, t,
+                                       None if bias_partials is None else bias_partials[t])
                 rows = _gemm_rows(n, B)
                 dh[:rows].addmm_(gh[t, :rows], w_hh)  # + d_gh_t @ W_hh (zero rows for the ended sequences)
                 continue
@@ -99,22 +116,31 @@ class _GruLayer(torch.autograd.Function):
                 gh[t, n:].zero_()
             if n == 0:
                 continue
+            partial = None if bias_partials is None else bias_partials[t, : ops.gru_bias_partial_rows(n)]
             ops.gru_gates_backward(gi[t, :n], gh[t, :n], b_hh, h_prev[:n], None if d_out is None else d_out[t, :n],
-                                   dh[:n], lengths, t)
+                                   dh[:n], lengths, t, partial)
             dh[:n].addmm_(gh[t, :n], w_hh)  # + d_gh_t @ W_hh
-        need = ctx.needs_input_grad
         d_x = d_w_ih = d_w_hh = d_b_ih = d_b_hh = None
         if need[0]:
             d_x = torch.mm(gi.view(L * B, 3 * H), w_ih).view(x.shape)
         if need[2]:
             d_w_ih = _sum_slabs(w_ih, torch.bmm(gi.transpose(1, 2), x)) if L > 1 else torch.mm(gi[0].t(), x[0])
         if need[3]:
-            h_prev = torch.cat([h0.unsqueeze(0), out[:-1]]) if L > 1 else h0.unsqueeze(0)
+            # slab t pairs d_gh[t] with the state that entered step t: h0 for t = 0, out[t - 1] after that = states[:-1]
+            h_prev = ctx.states[:-1]
+            ctx.states = None
             d_w_hh = _sum_slabs(w_hh, torch.bmm(gh.transpose(1, 2), h_prev)) if L > 1 else torch.mm(gh[0].t(), h_prev[0])
-        if ctx.has_b_ih and need[4]:
-            d_b_ih = _column_sums(gi.view(L * B, 3 * H))
-        if b_hh is not None and need[5]:
-            d_b_hh = _column_sums(gh.view(L * B, 3 * H))
+        if bias_partials is not None:
+            sums = _column_sums(bias_partials.view(L * bias_rows, 4 * H))  # {sum d_r, sum d_z, sum d_n, sum d_q}
+            if ctx.has_b_ih and need[4]:
+                d_b_ih = sums[: 3 * H]
+            if b_hh is not None and need[5]:
+                d_b_hh = torch.cat((sums[: 2 * H], sums[3 * H:]))
+        else:
+            if ctx.has_b_ih and need[4]:
+                d_b_ih = _column_sums(gi.view(L * B, 3 * H))
+            if b_hh is not None and need[5]:
+                d_b_hh = _column_sums(gh.view(L * B, 3 * H))
         return d_x, (dh if need[1] else None), d_w_ih, d_w_hh, d_b_ih, d_b_hh, None, None
 
 
@@ -293,10 +319,37 @@ class _LengthPlan:
         self.sizes: list[int] = running.sum(1).tolist()
 
     def sort(self, tensor: Tensor, dim: int) -> Tensor:
+        if _permutable(tensor, dim):
+            return _PermuteRows.apply(tensor, self.order, self.inverse)
         return tensor.index_select(dim, self.order)
 
     def unsort(self, tensor: Tensor, dim: int) -> Tensor:
+        if _permutable(tensor, dim):
+            return _PermuteRows.apply(tensor, self.inverse, self.order)
         return tensor.index_select(dim, self.inverse)
+
+
+def _permutable(tensor: Tensor, dim: int) -> bool:
+    return dim == 1 and tensor.dim() == 3 and tensor.is_cuda and tensor.dtype == torch.float32
+
+
+class _PermuteRows(torch.autograd.Function):
+    """``tensor[:, index]`` for a PERMUTATION ``index`` of the batch axis of a ``[L, B, C]`` tensor through the row-gather
+    kernel (``cusrl_gather_rows``, ``[:, idx]`` form); the backward of a permutation is the gather with its inverse — no
+    index_add.  (torch: a scatter/gather kernel forward and ``indexFuncLargeIndex`` backward, 12 ms per iteration of config 4.)"""
+
+    @staticmethod
+    def forward(ctx, tensor: Tensor, index: Tensor, inverse: Tensor):
+        ctx.save_for_backward(index, inverse)
+        tensor = tensor.contiguous()
+        return ops.gather_rows([tensor], index, tensor.shape[0], tensor.shape[1], temporal=True)[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad: Tensor):
+        index, inverse = ctx.saved_tensors
+        grad = grad.contiguous()
+        return ops.gather_rows([grad], inverse, grad.shape[0], grad.shape[1], temporal=True)[0], None, None
 
 
 def _plan(lengths: Tensor | None, input: Tensor) -> _LengthPlan | None:

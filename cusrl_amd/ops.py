@@ -1029,16 +1029,39 @@ def gru_gates_forward(gi: torch.Tensor, gh: torch.Tensor, b_hh: torch.Tensor | N
 
 
 def gru_gates_backward(gi: torch.Tensor, gh: torch.Tensor, b_hh: torch.Tensor | None, h_prev: torch.Tensor,
-                       d_out: torch.Tensor | None, dh: torch.Tensor, lengths: torch.Tensor | None, t: int) -> None:
+                       d_out: torch.Tensor | None, dh: torch.Tensor, lengths: torch.Tensor | None, t: int,
+                       bias_partials: torch.Tensor | None = None) -> None:
     """Backward of :func:`gru_gates_forward`, in place: ``gi`` / ``gh`` become their gradients, ``dh`` (the gradient that
-    arrived from step t + 1) becomes the direct-path gradient of ``h_prev`` (``cusrl_gru_gates_bwd``)."""
+    arrived from step t + 1) becomes the direct-path gradient of ``h_prev`` (``cusrl_gru_gates_bwd``).  With
+    ``bias_partials`` (``[gru_bias_partial_rows(B), 4H]``) every block of 16 rows also leaves the column sums of the gate
+    gradients it wrote — {d_r, d_z, d_n, d_q} — for the bias gradients (``cusrl_gru_gates_bwd_bias``)."""
     B, H = dh.shape
     if gi.shape != (B, 3 * H) or gh.shape != (B, 3 * H) or h_prev.shape != (B, H):
         raise ValueError("gru_gates_backward: shape mismatch")
+    if bias_partials is not None:
+        if bias_partials.shape != (gru_bias_partial_rows(B), 4 * H) or not bias_partials.is_contiguous():
+            raise ValueError("gru_gates_backward: 'bias_partials' must be a contiguous [ceil(B / 16), 4H] tensor")
+        check(_native.lib().cusrl_gru_gates_bwd_bias(gi.data_ptr(), gh.data_ptr(), None if b_hh is None else b_hh.data_ptr(),
+                                                     h_prev.data_ptr(), None if d_out is None else d_out.data_ptr(), dh.data_ptr(),
+                                                     None if lengths is None else lengths.data_ptr(), t, B, H,
+                                                     bias_partials.data_ptr(), _stream()), "cusrl_gru_gates_bwd_bias")
+        return
     check(_native.lib().cusrl_gru_gates_bwd(gi.data_ptr(), gh.data_ptr(), None if b_hh is None else b_hh.data_ptr(),
                                             h_prev.data_ptr(), None if d_out is None else d_out.data_ptr(), dh.data_ptr(),
                                             None if lengths is None else lengths.data_ptr(), t, B, H, _stream()),
           "cusrl_gru_gates_bwd")
+
+
+def gru_bias_partials_supported(H: int, *tensors: torch.Tensor) -> bool:
+    """Can :func:`gru_gates_backward` fold the bias gradients in (column chunks must tile a 256-thread block)?"""
+    vec4 = H % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in tensors)
+    cols = H // 4 if vec4 else H
+    rows_per_block = -(-4096 // max(gru_bias_partial_rows(4096), 1))
+    return 0 < cols <= 256 and 256 % cols == 0 and 256 // cols <= rows_per_block
+
+
+def gru_bias_partial_rows(B: int) -> int:
+    return int(_native.lib().cusrl_gru_bias_partial_rows(B))
 
 
 def lstm_gates_forward(gi: torch.Tensor, gh: torch.Tensor, b_hh: torch.Tensor | None, h: torch.Tensor, c: torch.Tensor,

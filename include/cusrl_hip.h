@@ -240,6 +240,13 @@ int cusrl_gru_gates_fwd(const float *gi, const float *gh, const float *b_hh, flo
                         const int64_t *lengths, int64_t t, int64_t B, int64_t H, void *stream);
 int cusrl_gru_gates_bwd(float *gi, float *gh, const float *b_hh, const float *h_prev, const float *d_out, float *dh,
                         const int64_t *lengths, int64_t t, int64_t B, int64_t H, void *stream);
+/* cusrl_gru_gates_bwd with the bias gradients folded in: every block of 16 rows also leaves the column sums of what it
+ * wrote, bias_partials[block][4H] = {sum d_r, sum d_z, sum d_n, sum d_q} (block = row / 16, cusrl_gru_bias_partial_rows(B)
+ * rows); summed over all blocks and steps, d b_ih = {r, z, n} and d b_hh = {r, z, q} — instead of two column-sum passes
+ * over the [L * B, 3H] gradient arrays.  Needs H / 4 (H for unaligned rows) to divide 256; CUSRL_E_UNSUPPORTED otherwise. */
+int cusrl_gru_gates_bwd_bias(float *gi, float *gh, const float *b_hh, const float *h_prev, const float *d_out, float *dh,
+                             const int64_t *lengths, int64_t t, int64_t B, int64_t H, float *bias_partials, void *stream);
+int64_t cusrl_gru_bias_partial_rows(int64_t B);
 
 /* The same for torch.nn.LSTM (gate order i, f, g, o), the default core of RecurrentPpoAgentFactory (cusrl/preset/ppo.py:189):
  *   pre = gi + gh + b_hh; c <- sigmoid(pre_f) * c + sigmoid(pre_i) * tanh(pre_g); h <- sigmoid(pre_o) * tanh(c); out = h.
