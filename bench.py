@@ -197,6 +197,22 @@ def run_gpu(args, rank, world):
     # the dominant kernel replays inside hipGraphs (20 launches per iteration) where it cannot be bracketed from the
     # host: time the identical launch stand-alone from a graph right after the timed region
     dominant = dominant_kernel(agent) if rank == 0 else None
+    # the gradient all-reduce of one optimizer step at this run's world size (a collective: EVERY rank times it), as the
+    # step issues it: the C-ABI call captured in a hipGraph, or torch.distributed's eager call between two graphs
+    allreduce_us = None
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and agent.flat_gradients is not None:
+        flat = agent.flat_gradients.buffer
+        scratch = torch.zeros_like(flat)
+        comm = cusrl.utils.distributed.native_comm()
+        if comm is not None:
+            allreduce_us = graph_time(lambda: comm.allreduce_mean_(scratch))
+        else:
+            torch.cuda.synchronize()
+            t_ar = time.perf_counter()
+            for _ in range(50):
+                torch.distributed.all_reduce(scratch)
+            torch.cuda.synchronize()
+            allreduce_us = (time.perf_counter() - t_ar) * 1e6 / 50
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -263,6 +279,10 @@ def run_gpu(args, rank, world):
             "backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend,
             "rccl_ranks": world if backend == "nccl" else 0,
             "collectives": cusrl.utils.distributed.collective_route(),
+            "gradient_allreduce": None if allreduce_us is None else {
+                "floats": int(agent.flat_gradients.buffer.numel()), "avg_us": round(allreduce_us, 2), "per_iteration": 20,
+                "timing": "hipGraph of 10 calls x 20 replays" if cusrl.utils.distributed.native_comm() is not None
+                          else "50 eager calls, host clock"},
             **({"share_gpu": True, "test_only": "all ranks drive cuda:0 over gloo: exercises the multi-rank path on one GPU, "
                                                 "NOT a scaling measurement"} if args.share_gpu else {}),
             "hipgraph": not args.eager,

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "libcusrl_hip.so"
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_FIELDS = 24
 MAX_PACKED = 16
 
@@ -126,6 +126,7 @@ _SIGNATURES = {
     "cusrl_comm_unique_id": (c_int, [_P]),
     "cusrl_comm_create": (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
     "cusrl_comm_destroy": (c_int, [_P]),
+    "cusrl_comm_abort": (c_int, [_P]),
     "cusrl_comm_world_size": (c_int, [_P]),
     "cusrl_allreduce_mean": (c_int, [_P, c_int64, _P, _P]),
     "cusrl_allgather": (c_int, [_P, _P, c_int64, _P, _P]),

@@ -34,6 +34,7 @@ struct Rccl {
     int (*GetUniqueId)(UniqueId *) = nullptr;
     int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommAbort)(Comm) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
@@ -54,7 +55,12 @@ bool resolve(void *handle, const char *name, F &slot) {
 void load_rccl() {
     const char *override_path = getenv("CUSRL_RCCL_LIBRARY");
     void *handle = nullptr;
-    if (override_path && *override_path) handle = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+    if (override_path && *override_path) {
+        // an explicit library is used or nothing is: silently loading another RCCL than the one the user named would hide
+        // exactly the misconfiguration the variable exists to test (the job then takes torch.distributed's collectives)
+        handle = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+        if (!handle) return;
+    }
     for (const char *name : {"librccl.so", "librccl.so.1"}) {
         if (!handle) handle = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);  // the instance PyTorch already loaded
     }
@@ -68,6 +74,7 @@ void load_rccl() {
            resolve(handle, "ncclCommDestroy", r.CommDestroy) && resolve(handle, "ncclAllReduce", r.AllReduce) &&
            resolve(handle, "ncclAllGather", r.AllGather) && resolve(handle, "ncclBroadcast", r.Broadcast) &&
            resolve(handle, "ncclGetErrorString", r.GetErrorString);
+    resolve(handle, "ncclCommAbort", r.CommAbort);  // optional: destroy is the fallback
 }
 
 const Rccl *rccl() {
@@ -121,6 +128,17 @@ extern "C" int cusrl_comm_destroy(cusrl_comm_t *comm) {
     const Rccl *r = rccl();
     if (!comm) return 0;
     int rc = r ? comm_status(r->CommDestroy(comm->comm)) : CUSRL_E_COMM;
+    delete comm;
+    return rc;
+}
+
+// Abandon a communicator whose collectives may never complete (a peer failed before enqueueing its half): ncclCommAbort
+// stops the communicator's in-flight kernels instead of waiting for them like ncclCommDestroy.
+extern "C" int cusrl_comm_abort(cusrl_comm_t *comm) {
+    const Rccl *r = rccl();
+    if (!comm) return 0;
+    int rc = CUSRL_E_COMM;
+    if (r) rc = comm_status(r->CommAbort ? r->CommAbort(comm->comm) : r->CommDestroy(comm->comm));
     delete comm;
     return rc;
 }

@@ -13,6 +13,7 @@ SURVEY.md §5), so the design goal is the fewest, copy-free collectives:
 
 from __future__ import annotations
 
+import os
 from collections.abc import Iterable
 from typing import Any, TypeVar
 
@@ -178,17 +179,97 @@ class RcclComm:
             self._lib.cusrl_comm_destroy(self._handle)
             self._handle = None
 
+    def abort(self):
+        """Abandon the communicator without waiting for collectives that may never complete (``cusrl_comm_abort``)."""
+        if getattr(self, "_handle", None):
+            self._lib.cusrl_comm_abort(self._handle)
+            self._handle = None
+
 
 _native_comm: RcclComm | None = None
 _native_comm_failed: str | None = None
 
 
+def _agree(problem: str, device) -> bool:
+    """Collective over the PROCESS GROUP (never over the communicator under test): True when no rank reported a problem.
+    Every rank calls this the same number of times in the same order, whatever happened to it locally."""
+    verdict = torch.tensor([1.0 if problem else 0.0], device=device)
+    torch.distributed.all_reduce(verdict, op=torch.distributed.ReduceOp.MAX)
+    return verdict.item() == 0
+
+
+def establish_native_comm(factory, device, rank: int, world: int):
+    """Create the C-ABI communicator and prove it, in stages every rank walks through TOGETHER — each stage ends in a
+    verdict all-reduce over the process group, and a rank that failed locally still issues every process-group collective of
+    the stage it is in, so that no two ranks are ever inside different collectives (the failure mode of an earlier version:
+    one rank raising in its probe skipped the reference all-reduce its peers were waiting in):
+
+      1. create      ``factory()`` (itself collective-safe: local preconditions agreed on before ncclCommInitRank)
+      2. eager probe a 64-float ``allreduce_mean_`` ENQUEUED ON A SIDE STREAM (a half-issued collective must not block the
+                     stream the process-group collectives synchronise with); verdict "every rank enqueued"; only then the
+                     side stream is joined and the result compared with the closed form; verdict "every rank agrees"
+      3. captured    the same all-reduce captured into a hipGraph and replayed once; verdict
+
+    Returns ``(comm, "")`` or ``(None, reason)`` — the same outcome on every rank.  A communicator that may have a
+    half-issued collective in flight is aborted (``cusrl_comm_abort``), never destroyed (destroy waits for its kernels).
+    ``CUSRL_COMM_FAULT = "<stage>:<rank>"`` injects a failure (tests of exactly this protocol)."""
+    fault_stage, _, fault_rank = os.environ.get("CUSRL_COMM_FAULT", "").partition(":")
+
+    def faulty(stage: str) -> bool:
+        return fault_stage == stage and fault_rank != "" and int(fault_rank) == rank
+
+    # ---- stage 1: creation
+    comm, problem = None, ""
+    try:
+        if faulty("create"):
+            raise RuntimeError("injected fault (CUSRL_COMM_FAULT)")
+        comm = factory()
+    except Exception as error:
+        problem = f"{type(error).__name__}: {error}"
+    if not _agree(problem, device):
+        if comm is not None:
+            comm.close()  # nothing was ever enqueued on it
+        return None, problem or "another rank could not create its communicator"
+    # ---- stage 2: one eager all-reduce, enqueued on a side stream
+    base = torch.arange(64, dtype=torch.float32, device=device)
+    probe, expect = base * (rank + 1), base * ((world + 1) / 2)  # mean over ranks of (rank + 1)
+    side = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+    try:
+        if faulty("probe"):
+            raise RuntimeError("injected fault (CUSRL_COMM_FAULT)")
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                comm.allreduce_mean_(probe)
+        else:
+            comm.allreduce_mean_(probe)
+    except Exception as error:
+        problem = f"{type(error).__name__}: {error}"
+    if not _agree(problem, device):  # some rank never enqueued its half: the others' kernels would wait forever
+        comm.abort()
+        return None, problem or "another rank could not enqueue the probe all-reduce"
+    if side is not None:
+        torch.cuda.current_stream(device).wait_stream(side)
+    getattr(comm, "complete", lambda: None)()  # (host-side communicators of the CPU tests perform the enqueued work here)
+    if not torch.allclose(probe, expect, rtol=1e-6, atol=0):
+        problem = "cusrl_allreduce_mean returned a wrong mean"
+    if not _agree(problem, device):
+        comm.close()
+        return None, problem or "another rank saw a wrong all-reduce result"
+    # ---- stage 3: what the route exists for — the all-reduce INSIDE a hipGraph
+    if device.type == "cuda":
+        problem = "injected fault (CUSRL_COMM_FAULT)" if faulty("capture") else _probe_captured_allreduce(comm)
+        if not _agree(problem, device):
+            comm.abort()  # a capture that went wrong on some rank leaves the others' replay waiting
+            return None, problem or "another rank could not capture the all-reduce"
+    return comm, ""
+
+
 def native_comm() -> RcclComm | None:
     """The process-wide C-ABI communicator — the default route of an RCCL job (``CONFIG.native_collectives``).  Created
     on first use, collectively: every rank must reach its first use together, which happens in ``broadcast_parameters``
-    at agent construction.  Creation is verified before anything depends on it: a small all-reduce through the new
-    communicator must reproduce torch.distributed's result on every rank; an error or a mismatch on ANY rank (agreed
-    through the process group) is logged once and the whole job uses torch.distributed's collectives instead.
+    at agent construction.  Creation is verified before anything depends on it (:func:`establish_native_comm`); a problem
+    on ANY rank is logged once and the whole job uses torch.distributed's collectives instead.
     ``None`` = collectives go through torch.distributed."""
     global _native_comm, _native_comm_failed
     if not (CONFIG.native_collectives and CONFIG.device.type == "cuda" and configure_distributed()):
@@ -196,30 +277,9 @@ def native_comm() -> RcclComm | None:
     if torch.distributed.get_backend() != torch.distributed.Backend.NCCL:
         return None
     if _native_comm is None and _native_comm_failed is None:
-        comm, problem = None, ""
-        try:
-            comm = RcclComm.from_process_group()
-            probe = torch.arange(64, dtype=torch.float32, device=CONFIG.device) * (CONFIG.rank + 1)
-            expect = probe.clone()
-            comm.allreduce_mean_(probe)
-            torch.distributed.all_reduce(expect, op=torch.distributed.ReduceOp.AVG)
-            if not torch.allclose(probe, expect, rtol=1e-6, atol=0):
-                problem = "cusrl_allreduce_mean disagrees with torch.distributed.all_reduce"
-        except Exception as error:  # creation / first collective failed on this rank
-            problem = f"{type(error).__name__}: {error}"
-        leak = False
-        if not problem:
-            # what the route exists for is the all-reduce INSIDE a hipGraph: capture and replay one now, so that a stack
-            # on which RCCL cannot be captured falls back here instead of failing in the first captured minibatch step
-            problem = _probe_captured_allreduce(comm)
-            leak = bool(problem)  # a communicator whose capture went wrong is abandoned, not destroyed (destroy may block)
-        # every rank must take the same route: agree over the process group
-        verdict = torch.tensor([1.0 if problem else 0.0], device=CONFIG.device)
-        torch.distributed.all_reduce(verdict, op=torch.distributed.ReduceOp.MAX)
-        if verdict.item() > 0:
-            _native_comm_failed = problem or "another rank could not create its communicator"
-            if comm is not None and not leak:
-                comm.close()
+        comm, problem = establish_native_comm(RcclComm.from_process_group, CONFIG.device, CONFIG.rank, CONFIG.world_size)
+        if comm is None:
+            _native_comm_failed = problem
             print(f"\033[1;33mcusrl_amd: C-ABI RCCL communicator unavailable on rank {CONFIG.rank} ({_native_comm_failed}); "
                   "falling back to torch.distributed collectives (eager all-reduce between two graphs per step)\033[0m",
                   flush=True)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CUSRL_ABI_VERSION 3
+#define CUSRL_ABI_VERSION 4
 #define CUSRL_MAX_FIELDS 24 /* leaves per push / gather launch; larger tables are split by the host */
 #define CUSRL_MAX_PACKED 16 /* 1-8 byte entries of the per-slot record (cusrl_pack_rows); wide fields count as leaves */
 #define CUSRL_MAX_RECORD_BYTES 1024
@@ -546,6 +546,9 @@ const char *cusrl_comm_last_error(void);
 int cusrl_comm_unique_id(void *id_out /* host, 128 bytes */);
 int cusrl_comm_create(const void *id /* host, 128 bytes */, int world_size, int rank, cusrl_comm_t **comm_out);
 int cusrl_comm_destroy(cusrl_comm_t *comm);
+/* Abandon a communicator whose enqueued collectives may never complete (a peer rank failed before issuing its half):
+ * ncclCommAbort — stops in-flight kernels instead of waiting for them — then frees the handle. */
+int cusrl_comm_abort(cusrl_comm_t *comm);
 int cusrl_comm_world_size(const cusrl_comm_t *comm);
 int cusrl_allreduce_mean(float *buffer, int64_t count, cusrl_comm_t *comm, void *stream);
 int cusrl_allgather(const void *input, void *output, int64_t bytes_per_rank, cusrl_comm_t *comm, void *stream);

@@ -74,6 +74,49 @@ def main(out_dir: str):
     rows = ScheduleProbe().run_mini_batch_wise(cusrl.hook.MiniBatchWiseLRSchedule(desired_kl_divergence=0.01),
                                                cusrl.hook.OnPolicyPreparation(), kls, 2)
     result["mini_batch_wise_lrs"] = rows[:, 0].tolist()
+    # start-up protocol of the C-ABI communicator (utils/distributed.py establish_native_comm) with a host-side stand-in
+    # for the communicator: every stage must end with the SAME outcome on both ranks and leave the process group's
+    # collective sequence aligned, whichever rank fails at whichever stage
+    class HostComm:
+        """Enqueue-then-complete like a stream-ordered RCCL call: `allreduce_mean_` only records the request."""
+
+        device, world_size = torch.device("cpu"), 2
+        closed = aborted = False
+
+        def __init__(self):
+            self.pending = []
+
+        def allreduce_mean_(self, tensor):
+            self.pending.append(tensor)
+
+        def complete(self):
+            for tensor in self.pending:
+                torch.distributed.all_reduce(tensor)
+                tensor.div_(2)
+            self.pending.clear()
+
+        def close(self):
+            self.closed = True
+
+        def abort(self):
+            self.aborted = True
+
+    outcomes = {}
+    for scenario in ("", "create:0", "create:1", "probe:0", "probe:1"):
+        os.environ["CUSRL_COMM_FAULT"] = scenario
+        created = []
+
+        def factory():
+            created.append(HostComm())
+            return created[-1]
+
+        comm, reason = distributed.establish_native_comm(factory, torch.device("cpu"), rank, 2)
+        check = torch.tensor([float(rank + 1)])
+        torch.distributed.all_reduce(check)  # the process group is still in step: 1 + 2
+        outcomes[scenario or "none"] = {"ok": comm is not None, "reason": reason, "in_step": check.item() == 3.0,
+                                        "closed": bool(created and created[-1].closed), "aborted": bool(created and created[-1].aborted)}
+    os.environ.pop("CUSRL_COMM_FAULT", None)
+    result["comm_protocol"] = outcomes
     distributed.barrier()
     Path(out_dir, f"rank{rank}.json").write_text(json.dumps(result))
 

@@ -85,3 +85,24 @@ def test_kl_driven_schedules_act_on_the_mean_kl_over_ranks(ranks):
                                                  cusrl_amd.hook.OnPolicyPreparation(), mean_kls, 2)
     np.testing.assert_allclose(ranks[0]["mini_batch_wise_lrs"], single[:, 0], rtol=1e-9)
     assert len(set(ranks[0]["threshold_lrs"])) > 1  # the sequence does move the learning rate
+
+
+def test_native_communicator_start_up_is_collective_safe_at_every_stage(ranks):
+    """establish_native_comm with a fault injected on one rank at one stage (CUSRL_COMM_FAULT): both ranks finish (no rank
+    is left inside a collective its peer never enters), report the same outcome, the faulty rank names the fault, a
+    communicator with a possibly half-issued collective is aborted (not destroyed), and the process group stays in step."""
+    for scenario in ("none", "create:0", "create:1", "probe:0", "probe:1"):
+        a, b = (r["comm_protocol"][scenario] for r in ranks)
+        assert a["ok"] == b["ok"] == (scenario == "none"), scenario
+        assert a["in_step"] and b["in_step"], scenario
+        if scenario == "none":
+            assert not (a["closed"] or a["aborted"] or b["closed"] or b["aborted"])
+            continue
+        stage, faulty = scenario.split(":")
+        reasons = [a["reason"], b["reason"]]
+        assert "injected fault" in reasons[int(faulty)] and reasons[1 - int(faulty)], scenario
+        for rank, outcome in enumerate((a, b)):
+            if stage == "create":  # the healthy rank created a communicator nothing was enqueued on: plain destroy
+                assert outcome["closed"] == (rank != int(faulty)) and not outcome["aborted"], scenario
+            else:  # the healthy rank's probe is enqueued and will never complete: abort, on every rank
+                assert outcome["aborted"] and not outcome["closed"], scenario

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _run(tmp_path, world: int, compile_: str, native: str, share_gpu: bool = False):
+def _run(tmp_path, world: int, compile_: str, native: str, share_gpu: bool = False, extra_env=None, want_output=False):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -29,9 +29,11 @@ def _run(tmp_path, world: int, compile_: str, native: str, share_gpu: bool = Fal
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if share_gpu:
         env["CUSRL_SHARE_GPU"] = "1"
+    env.update(extra_env or {})
     done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
-    return [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(world)]
+    results = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(world)]
+    return (results, done.stdout + done.stderr) if want_output else results
 
 
 @pytest.mark.parametrize("compile_,native", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
@@ -48,6 +50,31 @@ def test_ppo_preset_over_rccl_single_rank(tmp_path, compile_, native):
             assert result["single_graph"] and all(result["single_graph"])  # all-reduce captured inside the step graph
     elif compile_ == "1":
         assert result["single_graph"] and not any(result["single_graph"])  # eager all-reduce between two graphs
+
+
+@pytest.mark.parametrize("fault,needle", [
+    ({"CUSRL_RCCL_LIBRARY": "/nonexistent/librccl.so"}, "RCCL is not available"),  # the library the user named cannot be loaded
+    ({"CUSRL_COMM_FAULT": "probe:0"}, "injected fault"),    # the eager probe fails: communicator aborted, not destroyed
+    ({"CUSRL_COMM_FAULT": "capture:0"}, "injected fault"),  # RCCL "cannot be captured" on this stack
+])
+def test_c_abi_route_falls_back_to_torch_distributed_and_says_so(tmp_path, fault, needle):
+    """The default route of an RCCL job verifies itself at start-up (establish_native_comm); when a stage fails the job logs
+    the switch ONCE and trains through torch.distributed's collectives — eager all-reduce between two graphs per step."""
+    (result,), output = _run(tmp_path, 1, "1", "1", extra_env=fault, want_output=True)
+    assert not result["native"] and "torch.distributed rccl" in result["route"] and needle in result["route"]
+    assert output.count("C-ABI RCCL communicator unavailable") == 1 and needle in output
+    assert result["allreduce_calls"] <= 1  # at most the start-up probe went through the abandoned communicator
+    assert result["single_graph"] and not any(result["single_graph"])
+    for key in ("Agent/value_loss", "Agent/surrogate_loss", "Agent/entropy_loss", "Agent/kl_divergence"):
+        assert math.isfinite(result["info"][key]), key
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("fault", ["create:1", "probe:1", "capture:0"])
+def test_two_rccl_ranks_agree_on_the_fallback_when_one_rank_fails(tmp_path, fault):
+    ranks = _run(tmp_path, 2, "1", "1", extra_env={"CUSRL_COMM_FAULT": fault})
+    _assert_lockstep(ranks)
+    assert not any(r["native"] for r in ranks)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
