@@ -1357,6 +1357,8 @@ def clip_grad_norm_(flat_grad: torch.Tensor, max_norm: float | None) -> torch.Te
                                  partials.data_ptr(), norm.data_ptr(), _stream()),
         "cusrl_clip_grad_norm",
     )
+    if max_norm is not None:
+        _modified_in_place(flat_grad)  # scaled in place: stale squared-norm partials (FlatGradients.take_sumsq) must not survive
     return norm[0]
 
 

@@ -93,6 +93,10 @@ class MiniBatchSampler(Sampler):
             if pair is None:
                 pair = self._index_buffers[(num_samples, perm_device)] = [
                     torch.empty(num_samples, dtype=torch.int64, device=perm_device) for _ in range(2)]
+            elif self.prefetch:
+                # the buffers outlive a pass: should the previous pass have been abandoned mid-epoch (an exception, a consumer
+                # stopping early) a draw-ahead may still be writing one of them on the side stream — order this draw behind it
+                torch.cuda.current_stream(perm_device).wait_stream(_prefetch_stream(perm_device))
             epoch_indices = torch.randperm(num_samples, device=perm_device, out=pair[0])
         else:
             epoch_indices = torch.randperm(num_samples, device=perm_device)

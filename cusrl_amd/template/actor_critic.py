@@ -32,6 +32,22 @@ from cusrl_amd.utils.distributed import FlatGradients, broadcast_parameters, red
 __all__ = ["ActorCritic", "ActorCriticFactory", "HookList"]
 
 
+def _hashable(value):
+    """A metadata value as part of a step-graph key: hashable as it is, else its frozen form, else its repr."""
+    from cusrl_amd.template.graphs import _freeze
+
+    try:
+        hash(value)
+        return value
+    except TypeError:
+        frozen = _freeze(value)
+        try:
+            hash(frozen)
+            return frozen
+        except TypeError:
+            return repr(value)
+
+
 class HookList(list):
     """List of hooks with by-name attribute access (actor_critic.py:23-62)."""
 
@@ -134,6 +150,8 @@ class ActorCritic(Agent):
         self.optimizer = build_optimizer(optimizer_factory, self.named_parameters())
         self._graphed_act = None
         self._graphed_steps: dict[tuple, Any] = {}
+        self._graph_key_reads = 0
+        self._graph_budget_warned = False
         self._metadata_reads: set[str] = set()  # metadata keys hooks read inside captured steps (graphs.TrackedMetadata)
         if self.compile:
             # `compile=True` = hipGraph replay of the act step and of every minibatch step (template/graphs.py)
@@ -273,10 +291,24 @@ class ActorCritic(Agent):
                     in_place = self.index_slices_in_place and getattr(self.sampler, "persistent_indices", False)
                     key = (metadata["mini_batch_index"], metadata["temporal"], indices.numel(), indices.data_ptr() if in_place else 0)
                     if self._metadata_reads:  # a hook looks at these: steps whose values differ are different captures
-                        key += tuple((name, metadata.get(name)) for name in sorted(self._metadata_reads)
+                        key += tuple((name, _hashable(metadata.get(name))) for name in sorted(self._metadata_reads)
                                      if name not in ("mini_batch_index", "temporal"))
                     if (step := self._graphed_steps.get(key)) is None:
+                        if self._graph_key_reads != len(self._metadata_reads):
+                            # the set of metadata keys hooks read has grown: graphs keyed on the shorter signature can never
+                            # be looked up again — release them (and their static buffers) instead of flushing them forever
+                            self._graph_key_reads = len(self._metadata_reads)
+                            width = len(key)
+                            for stale in [k for k in self._graphed_steps if len(k) != width]:
+                                self._graphed_steps.pop(stale).flush_metrics()
                         step = self._graphed_steps[key] = GraphedTrainStep(self, key[0], key[1])
+                        budget = self.sampler.num_epochs * (self.sampler.num_mini_batches if isinstance(self.sampler.num_mini_batches, int)
+                                                            else max(self.sampler.num_mini_batches)) if hasattr(self.sampler, "num_epochs") else 0
+                        if budget and len(self._graphed_steps) > budget and not self._graph_budget_warned:
+                            self._graph_budget_warned = True
+                            self.warn(f"{len(self._graphed_steps)} minibatch-step graphs for {budget} steps per update: a hook reads "
+                                      f"metadata whose values keep changing ({sorted(self._metadata_reads)}); every distinct value is "
+                                      "its own capture")
                     step.run(metadata, indices, in_place)
                 deferred: list = []
                 for step in self._graphed_steps.values():

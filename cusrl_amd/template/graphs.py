@@ -643,10 +643,17 @@ class GraphedRolloutStep:
         if any(hook._active and type(hook).should_update is not Hook.should_update for hook in agent.hook):
             return None
         parity = trainer.stats._parity
+        taps = 0
         for t in range(T):
             entry = self.steps.get((t, parity ^ (t & 1)))
             if entry is None or entry["state"] != 2:
                 return None
+            taps += len(entry["capture"].tap_names)
+        if taps > _Capture.MAX_TAPS:
+            # one accumulator slot per recorded metric and env step: a rollout that taps more than the accumulator holds keeps
+            # its per-step graphs (finding out inside the capture would be too late: the bodies' host effects — buffer
+            # cursor, counters — cannot be undone)
+            return None
         return T
 
     def _rollout_body(self, steps: int):
