@@ -287,6 +287,7 @@ def run_gpu(args, rank, world):
                                                 "NOT a scaling measurement"} if args.share_gpu else {}),
             "hipgraph": not args.eager,
             "captured_env_steps": (trainer._graphed_rollout.captured if trainer._graphed_rollout is not None else 0),
+            "epoch_graph_updates": (agent._graphed_epochs.replays if getattr(agent, "_graphed_epochs", None) is not None else 0),
             "autoreset": args.autoreset,
             "host_thread_cpus": pinned,
         },

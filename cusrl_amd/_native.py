@@ -86,6 +86,7 @@ _SIGNATURES = {
     "cusrl_episode_stats": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_step_epilogue": (c_int, [_P] * 12 + [c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_step_epilogue_max_envs": (c_int64, []),
+    "cusrl_step_epilogue_push": (c_int, [_P] * 12 + [c_int64, c_int64, c_int64, c_int, POINTER(Field), c_int, c_int, c_int64, _P]),
     "cusrl_policy_stats": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P, _P, _P]),
     "cusrl_policy_stats_num_partials": (c_int64, [c_int64]),
     "cusrl_categorical_policy_stats": (c_int, [_P] * 5 + [c_int64, c_int64, c_int64, _P, _P, _P]),
@@ -116,6 +117,7 @@ _SIGNATURES = {
                                   c_float, _P, _P, _P, _P]),
     "cusrl_amp_prepare_max_elements": (c_int64, []),
     "cusrl_amp_prepare_workspace": (c_int64, [c_int64, c_int64]),
+    "cusrl_accumulate_scalars": (c_int, [POINTER(c_void_p), c_int, _P, _P]),
     "cusrl_reward_shaping": (c_int, [_P, c_float, c_float, c_float, c_float, c_int, c_int, c_int64, _P]),
     "cusrl_mse_loss_fwd_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P]),
     "cusrl_mse_loss_num_partials": (c_int64, [c_int64]),

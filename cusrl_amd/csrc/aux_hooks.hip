@@ -278,9 +278,34 @@ __global__ __launch_bounds__(kPrepThreads) void bce_pair_fwd_bwd_kernel(const fl
     }
 }
 
+// --------------------------------------------------------------------------------------------- metric taps of a captured step
+// accumulator[i] += *value[i] for up to 32 scalars whose addresses travel by value in the kernarg segment: what a captured
+// step does with the 0-d metrics its hooks record (torch: stack + add_, two launches per step).
+constexpr int kMaxTapScalars = 32;
+struct ScalarTable {
+    const float *value[kMaxTapScalars];
+};
+
+__global__ void accumulate_scalars_kernel(const ScalarTable table, int n, float *__restrict__ accumulator) {
+    const int i = threadIdx.x;
+    if (i < n) accumulator[i] += *table.value[i];
+}
+
 }  // namespace cusrl
 
 using namespace cusrl;
+
+extern "C" int cusrl_accumulate_scalars(const float *const *values, int n, float *accumulator, void *stream) {
+    if (n < 0 || n > kMaxTapScalars) return n < 0 ? CUSRL_E_INVALID : CUSRL_E_TOO_MANY;
+    if (n == 0) return 0;
+    if (!values || !accumulator) return CUSRL_E_INVALID;
+    ScalarTable table;
+    for (int i = 0; i < kMaxTapScalars; ++i) table.value[i] = i < n ? values[i] : nullptr;
+    for (int i = 0; i < n; ++i)
+        if (!table.value[i]) return CUSRL_E_INVALID;
+    hipLaunchKernelGGL(accumulate_scalars_kernel, dim3(1), dim3(kWave), 0, as_stream(stream), table, n, accumulator);
+    return launch_status();
+}
 
 extern "C" int cusrl_reward_shaping(float *reward, float scale, float shift, float lower, float upper, int has_lower,
                                     int has_upper, int64_t n, void *stream) {

@@ -1,6 +1,7 @@
 // Rollout-side kernels for gfx950: fused Normal sample + log-prob (a12, acting side) and one-launch episode
 // statistics (removes the per-step device->host sync of the reference trainer loop).
 #include "common.hpp"
+#include "push_body.hpp"
 
 namespace cusrl {
 
@@ -137,37 +138,37 @@ __global__ __launch_bounds__(kBlock) void categorical_sample_logp_kernel(const f
 constexpr int64_t kOrderedStatsMaxEnvs = 262144;
 
 template <bool kOrdered>
-__global__ __launch_bounds__(kBlock) void episode_stats_kernel(const float *__restrict__ reward,
-                                                               const uint8_t *__restrict__ done,
-                                                               const uint8_t *__restrict__ done_b,
-                                                               uint8_t *__restrict__ done_out,
-                                                               float *__restrict__ episode_rew,
-                                                               float *__restrict__ episode_len,
-                                                               float *__restrict__ ring_rew,
-                                                               float *__restrict__ ring_len,
-                                                               unsigned long long *__restrict__ num_episodes,
-                                                               double *__restrict__ step_reward_sum,
-                                                               int64_t *__restrict__ indices_out,
-                                                               int32_t *__restrict__ count_out, int64_t N, int D,
-                                                               int64_t R, int parity) {
+__device__ __forceinline__ void episode_stats_body(const int block, const int num_blocks, uint8_t *__restrict__ done_copy,
+                                                   const float *__restrict__ reward,
+                                                   const uint8_t *__restrict__ done,
+                                                   const uint8_t *__restrict__ done_b, uint8_t *__restrict__ done_out,
+                                                   float *__restrict__ episode_rew, float *__restrict__ episode_len,
+                                                   float *__restrict__ ring_rew, float *__restrict__ ring_len,
+                                                   unsigned long long *__restrict__ num_episodes,
+                                                   double *__restrict__ step_reward_sum,
+                                                   int64_t *__restrict__ indices_out, int32_t *__restrict__ count_out,
+                                                   int64_t N, int D, int64_t R, int parity) {
+    // `block` of `num_blocks`: the launch's block index (the plain launch) or the epilogue part of a fused launch;
+    // done_copy != NULL: the flag is ALSO stored there (the rollout buffer's `done` slab of this step)
     // `done_b` != NULL: the flag of env n is done[n] | done_b[n] (terminated | truncated, actor_critic.py:277), written
     // to done_out; indices_out / count_out != NULL: the finished envs in ascending order + their number
     // (environment.py:356-362 `get_done_indices`), the count with a system-scope store (may be pinned host memory).
     __shared__ double scratch[kWavesPerBlock];
     __shared__ int iscratch[kWavesPerBlock];
-    const int64_t n = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t n = int64_t(block) * kBlock + threadIdx.x;
     const bool active = n < N;
     bool finished = false;
     if (active) {
         finished = done[n] != 0 || (done_b && done_b[n] != 0);
         if (done_out) done_out[n] = finished ? 1 : 0;
+        if (done_copy) done_copy[n] = finished ? 1 : 0;
     }
     unsigned long long slot = 0;
     float len = 0.0f;
     if (active) len = episode_len[n] + 1.0f;
     if constexpr (kOrdered) {
         int earlier = 0;
-        const int64_t chunks = int64_t(blockIdx.x) * (kBlock / 16);  // 16-flag chunks in front of this block
+        const int64_t chunks = int64_t(block) * (kBlock / 16);  // 16-flag chunks in front of this block
         const bool vec = ((reinterpret_cast<uintptr_t>(done) | reinterpret_cast<uintptr_t>(done_b)) & 15) == 0;
         for (int64_t c = threadIdx.x; c < chunks; c += kBlock) {
             if (vec) {
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const float *__re
             slot = (base + (unsigned long long)(s_before + own_prefix)) % (unsigned long long)R;
             if (indices_out) indices_out[s_before + own_prefix] = n;
         }
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        if (block == num_blocks - 1 && threadIdx.x == 0) {
             num_episodes[parity ^ 1] = base + (unsigned long long)(s_before + own_total);
             if (count_out) __hip_atomic_store(count_out, s_before + own_total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -218,6 +219,50 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const float *__re
         if (threadIdx.x == 0) atomicAdd(step_reward_sum + d, block_total);
     }
     if (active) episode_len[n] = finished ? 0.0f : len;
+}
+
+
+template <bool kOrdered>
+__global__ __launch_bounds__(kBlock) void episode_stats_kernel(const float *__restrict__ reward,
+                                                               const uint8_t *__restrict__ done,
+                                                               const uint8_t *__restrict__ done_b,
+                                                               uint8_t *__restrict__ done_out,
+                                                               float *__restrict__ episode_rew,
+                                                               float *__restrict__ episode_len,
+                                                               float *__restrict__ ring_rew,
+                                                               float *__restrict__ ring_len,
+                                                               unsigned long long *__restrict__ num_episodes,
+                                                               double *__restrict__ step_reward_sum,
+                                                               int64_t *__restrict__ indices_out,
+                                                               int32_t *__restrict__ count_out, int64_t N, int D,
+                                                               int64_t R, int parity) {
+    episode_stats_body<kOrdered>(blockIdx.x, gridDim.x, nullptr, reward, done, done_b, done_out, episode_rew, episode_len,
+                                 ring_rew, ring_len, num_episodes, step_reward_sum, indices_out, count_out, N, D, R, parity);
+}
+
+// The step epilogue AND the buffer append of the same env step as ONE launch: the first `epilogue_blocks` blocks are the
+// epilogue (they also store the `done` flag straight into the buffer's slab, so that leaf needs no copy that would have to
+// wait for them), the remaining blocks are the push of every other leaf — no block of one part reads what the other writes.
+struct EpilogueArgs {
+    const float *reward;
+    const uint8_t *terminated, *truncated;
+    uint8_t *done_out, *done_slab;
+    float *episode_rew, *episode_len, *ring_rew, *ring_len;
+    unsigned long long *num_episodes;
+    double *step_reward_sum;
+    int64_t *indices_out;
+    int32_t *count_out;
+    int64_t N, R;
+    int D, parity, epilogue_blocks;
+};
+
+__global__ __launch_bounds__(kBlock) void step_epilogue_push_kernel(const EpilogueArgs e, const PushTable tab) {
+    if (int(blockIdx.x) < e.epilogue_blocks)
+        episode_stats_body<true>(blockIdx.x, e.epilogue_blocks, e.done_slab, e.reward, e.terminated, e.truncated, e.done_out,
+                                 e.episode_rew, e.episode_len, e.ring_rew, e.ring_len, e.num_episodes, e.step_reward_sum,
+                                 e.indices_out, e.count_out, e.N, e.D, e.R, e.parity);
+    else
+        push_body<0>(tab, int(blockIdx.x) - e.epilogue_blocks);
 }
 
 // ---- intrinsic-reward epilogues: one launch instead of sub / square / mean / mul / add_ (RND) or
@@ -342,6 +387,38 @@ extern "C" int cusrl_episode_stats(const float *reward, const uint8_t *done, flo
 }
 
 extern "C" int64_t cusrl_step_epilogue_max_envs(void) { return kOrderedStatsMaxEnvs; }
+
+extern "C" int cusrl_step_epilogue_push(const float *reward, const uint8_t *terminated, const uint8_t *truncated,
+                                        uint8_t *done_out, float *episode_rew, float *episode_len, float *ring_rew,
+                                        float *ring_len, uint64_t *num_episodes, double *step_reward_sum,
+                                        int64_t *indices_out, int32_t *count_out, int64_t N, int64_t D, int64_t R,
+                                        int parity, const cusrl_field_t *fields, int n_fields, int done_field,
+                                        int64_t cursor, void *stream) {
+    if (N <= 0 || D <= 0 || R <= 0 || (parity != 0 && parity != 1)) return CUSRL_E_INVALID;
+    if (!reward || !terminated || !truncated || !done_out || !episode_rew || !episode_len || !ring_rew || !ring_len ||
+        !num_episodes || !step_reward_sum || !indices_out || !count_out)
+        return CUSRL_E_INVALID;
+    if (D > INT32_MAX || N > kOrderedStatsMaxEnvs) return CUSRL_E_UNSUPPORTED;
+    if (!fields || done_field < 0 || done_field >= n_fields || fields[done_field].row_bytes != 1 || !fields[done_field].dst)
+        return CUSRL_E_INVALID;  // the `done` leaf: one flag byte per env, stored by the epilogue blocks themselves
+    PushTable tab;
+    int32_t push_blocks = 0;
+    int64_t step_bytes = 0;
+    if (int rc = build_push_table(fields, n_fields, cursor, N, nullptr, 0, nullptr, done_field, tab, push_blocks, step_bytes))
+        return rc;
+    EpilogueArgs e;
+    e.reward = reward, e.terminated = terminated, e.truncated = truncated, e.done_out = done_out;
+    e.done_slab = static_cast<uint8_t *>(fields[done_field].dst) + cursor * N;
+    e.episode_rew = episode_rew, e.episode_len = episode_len, e.ring_rew = ring_rew, e.ring_len = ring_len;
+    e.num_episodes = reinterpret_cast<unsigned long long *>(num_episodes);
+    e.step_reward_sum = step_reward_sum, e.indices_out = indices_out, e.count_out = count_out;
+    e.N = N, e.R = R, e.D = int(D), e.parity = parity;
+    e.epilogue_blocks = int(ceil_div(N, kBlock));
+    const int64_t blocks = int64_t(e.epilogue_blocks) + push_blocks;
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(step_epilogue_push_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), e, tab);
+    return launch_status();
+}
 
 extern "C" int cusrl_step_epilogue(const float *reward, const uint8_t *terminated, const uint8_t *truncated,
                                    uint8_t *done_out, float *episode_rew, float *episode_len, float *ring_rew,

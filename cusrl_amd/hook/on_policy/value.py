@@ -69,6 +69,10 @@ class ValueComputation(Hook):
         transition["next_critic_memory"] = next_memory
         self._critic_memory = next_memory
 
+    @property
+    def post_step_device_free(self) -> bool:
+        return self._deferred()  # deferred: post_step only sets a host flag
+
     def post_step(self, transition):
         if self._deferred():  # (post_act is replayed from a hipGraph under compile=True; this hook always runs)
             self._value_pending = True

@@ -1156,6 +1156,40 @@ def step_epilogue(reward, terminated, truncated, done_out, episode_rew, episode_
     )
 
 
+class PendingStepEpilogue:
+    """A step epilogue whose launch has been handed to the buffer push of the same env step (``cusrl_step_epilogue_push``:
+    ONE launch for both).  ``launch()`` issues it on its own — the push could not take it."""
+
+    __slots__ = ("args", "done_out")
+
+    def __init__(self, reward, terminated, truncated, done_out, episode_rew, episode_len, ring_rew, ring_len, num_episodes,
+                 step_reward_sum, indices_out, count_out, parity: int):
+        self.args = (reward, terminated, truncated, done_out, episode_rew, episode_len, ring_rew, ring_len, num_episodes,
+                     step_reward_sum, indices_out, count_out, parity)
+        self.done_out = done_out
+
+    def launch(self) -> None:
+        step_epilogue(*self.args)
+
+    def launch_with_push(self, table, count: int, done_field: int, cursor: int, parallelism: int) -> None:
+        (reward, terminated, truncated, done_out, episode_rew, episode_len, ring_rew, ring_len, num_episodes, step_reward_sum,
+         indices_out, count_out, parity) = self.args
+        reward = _f32(reward, "reward")
+        terminated, truncated = _flag(terminated, "terminated"), _flag(truncated, "truncated")
+        N, D = reward.shape
+        if terminated.numel() != N or truncated.numel() != N or done_out.numel() != N or indices_out.numel() < N or parallelism != N:
+            raise ValueError("step_epilogue_push: inconsistent sizes")
+        _observed(
+            "cusrl_step_epilogue_push",
+            lambda: N * (12 * D + 11) + sum(2 * parallelism * table[i].row_bytes for i in range(count)),
+            lambda: _native.lib().cusrl_step_epilogue_push(
+                reward.data_ptr(), terminated.data_ptr(), truncated.data_ptr(), done_out.data_ptr(), episode_rew.data_ptr(),
+                episode_len.data_ptr(), ring_rew.data_ptr(), ring_len.data_ptr(), num_episodes.data_ptr(), step_reward_sum.data_ptr(),
+                indices_out.data_ptr(), count_out.data_ptr(), N, D, ring_len.numel(), int(parity), table, count, done_field,
+                cursor, _stream()),
+        )
+
+
 # ------------------------------------------------------------------------------------------------ differentiable policy terms
 def policy_terms_fwd(mean: torch.Tensor, std: torch.Tensor, action: torch.Tensor, old_logp: torch.Tensor):
     """``(logp, entropy, logp_ratio, prob_ratio)``, each ``[..., 1]``, of a Gaussian policy in ONE launch
@@ -1648,3 +1682,17 @@ def bce_pair_fwd_bwd(logit: torch.Tensor, weight: float) -> tuple[torch.Tensor, 
     check(_native.lib().cusrl_bce_pair_fwd_bwd(logit.data_ptr(), logit.numel() // 2, float(weight), loss.data_ptr(), grad.data_ptr(),
                                                _stream()), "cusrl_bce_pair_fwd_bwd")
     return loss, grad
+
+
+def accumulate_scalars_(accumulator: torch.Tensor, values: Sequence[torch.Tensor]) -> None:
+    """``accumulator[i] += values[i]`` for 0-d fp32 device tensors — ONE launch per 32 values (pointer table by value)."""
+    import ctypes
+
+    if accumulator.dtype != torch.float32 or not accumulator.is_contiguous() or accumulator.numel() < len(values):
+        raise ValueError("accumulate_scalars_: need a contiguous float32 accumulator with one slot per value")
+    staged = [v if v.dtype == torch.float32 else v.float() for v in values]
+    for start in range(0, len(staged), 32):
+        chunk = staged[start:start + 32]
+        table = (ctypes.c_void_p * len(chunk))(*[require_device(v, "value").data_ptr() for v in chunk])
+        check(_native.lib().cusrl_accumulate_scalars(table, len(chunk), accumulator.data_ptr() + 4 * start, _stream()),
+              "cusrl_accumulate_scalars")

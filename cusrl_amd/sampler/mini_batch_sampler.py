@@ -147,6 +147,47 @@ class MiniBatchSampler(Sampler):
                 }
                 yield metadata, device_indices[j * size : (j + 1) * size]
 
+    def draw_epochs(self, buffer: Buffer):
+        """Every epoch's permutation drawn NOW, in epoch order, on the draw-ahead stream into one persistent ``[E, S]`` index
+        buffer: ``(permutations, [event per epoch], [(metadata, slice bounds)] per epoch)``, or None when a condition of
+        :meth:`iter_indices`'s draw-ahead does not hold (no shuffle, CPU-generator permutations, ``prefetch`` off because a
+        hook or a dropout layer draws random numbers inside the steps).  Same generator calls in the same order as the
+        epoch-by-epoch iteration.  For consumers that replay a whole epoch's minibatch steps from one hipGraph
+        (template/graphs.py GraphedEpochs): each slice lives at a fixed address, an epoch may start once its event fired."""
+        if not (buffer.full and buffer.cursor == 0):
+            raise RuntimeError("MiniBatchSampler requires a full buffer with cursor reset to 0")
+        perm_device = self.permutation_device or buffer.device
+        stock = type(self).iter_indices in (MiniBatchSampler.iter_indices,)  # a subclass that edits the iteration keeps it
+        if not (stock and self.prefetch and self.shuffle and perm_device == buffer.device and perm_device.type == "cuda"
+                and not torch.cuda.is_current_stream_capturing()):
+            return None
+        num_samples = self._get_num_samples(buffer)
+        buffer.prepare_sampling(self.hot_fields if self.lazy else None)
+        key = (num_samples, perm_device, "epochs", self.num_epochs)
+        slab = self._index_buffers.get(key)
+        if slab is None:
+            slab = self._index_buffers[key] = [torch.empty((self.num_epochs, num_samples), dtype=torch.int64, device=perm_device)]
+        permutations = slab[0]
+        main, side = torch.cuda.current_stream(perm_device), _prefetch_stream(perm_device)
+        side.wait_stream(main)  # the previous update's steps have read these rows
+        events, plan = [], []
+        with torch.cuda.stream(side):
+            for epoch in range(self.num_epochs):
+                torch.randperm(num_samples, device=perm_device, out=permutations[epoch])
+                event = torch.cuda.Event()
+                event.record(side)
+                events.append(event)
+        for epoch in range(self.num_epochs):
+            count = self.num_mini_batches if isinstance(self.num_mini_batches, int) else self.num_mini_batches[epoch]
+            if count > num_samples:
+                raise ValueError(f"'num_mini_batches' ({count}) cannot exceed the number of samples ({num_samples})")
+            size = num_samples // count
+            plan.append([({"epoch_index": epoch, "mini_batch_index": j, "total_epochs": self.num_epochs,
+                           "total_mini_batches": count, "temporal": self.temporal}, j * size, (j + 1) * size)
+                         for j in range(count)])
+        self.persistent_indices = True
+        return permutations, events, plan
+
     def __call__(self, buffer: Buffer):
         previous = None
         for metadata, indices in self.iter_indices(buffer):
@@ -191,6 +232,9 @@ class AutoMiniBatchSampler(Sampler):
     @property
     def persistent_indices(self) -> bool:
         return self._last is not None and self._last.persistent_indices
+
+    def draw_epochs(self, buffer: Buffer):
+        return self._dispatch(buffer).draw_epochs(buffer)
 
     def _dispatch(self, buffer: Buffer) -> MiniBatchSampler:
         temporal = any(key.split(".")[0].endswith("memory") for key in buffer)

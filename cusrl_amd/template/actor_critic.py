@@ -150,6 +150,7 @@ class ActorCritic(Agent):
         self.optimizer = build_optimizer(optimizer_factory, self.named_parameters())
         self._graphed_act = None
         self._graphed_steps: dict[tuple, Any] = {}
+        self._graphed_epochs = None
         self._graph_key_reads = 0
         self._graph_budget_warned = False
         self._metadata_reads: set[str] = set()  # metadata keys hooks read inside captured steps (graphs.TrackedMetadata)
@@ -285,34 +286,43 @@ class ActorCritic(Agent):
 
                 graphed = "objective" not in eager_phases(self)  # a hook's collective / host read-back stays out of capture
             if graphed:
-                for metadata, indices in self.sampler.iter_indices(self.buffer):
-                    # (opt-in) index slices at addresses that repeat from update to update — the sampler's persistent
-                    # buffers — read in place by the captured step: one capture per address, no copy into a static buffer
-                    in_place = self.index_slices_in_place and getattr(self.sampler, "persistent_indices", False)
-                    key = (metadata["mini_batch_index"], metadata["temporal"], indices.numel(), indices.data_ptr() if in_place else 0)
-                    if self._metadata_reads:  # a hook looks at these: steps whose values differ are different captures
-                        key += tuple((name, _hashable(metadata.get(name))) for name in sorted(self._metadata_reads)
-                                     if name not in ("mini_batch_index", "temporal"))
-                    if (step := self._graphed_steps.get(key)) is None:
-                        if self._graph_key_reads != len(self._metadata_reads):
-                            # the set of metadata keys hooks read has grown: graphs keyed on the shorter signature can never
-                            # be looked up again — release them (and their static buffers) instead of flushing them forever
-                            self._graph_key_reads = len(self._metadata_reads)
-                            width = len(key)
-                            for stale in [k for k in self._graphed_steps if len(k) != width]:
-                                self._graphed_steps.pop(stale).flush_metrics()
-                        step = self._graphed_steps[key] = GraphedTrainStep(self, key[0], key[1])
-                        budget = self.sampler.num_epochs * (self.sampler.num_mini_batches if isinstance(self.sampler.num_mini_batches, int)
-                                                            else max(self.sampler.num_mini_batches)) if hasattr(self.sampler, "num_epochs") else 0
-                        if budget and len(self._graphed_steps) > budget and not self._graph_budget_warned:
-                            self._graph_budget_warned = True
-                            self.warn(f"{len(self._graphed_steps)} minibatch-step graphs for {budget} steps per update: a hook reads "
-                                      f"metadata whose values keep changing ({sorted(self._metadata_reads)}); every distinct value is "
-                                      "its own capture")
-                    step.run(metadata, indices, in_place)
+                # every epoch's permutation drawn up front on the draw-ahead stream (same generator calls, same order):
+                # once every step replays from its own graph, a whole epoch's steps replay from ONE graph that reads its
+                # index slices in place (template/graphs.py GraphedEpochs); until then — and whenever a condition does
+                # not hold — the steps run graph by graph over the very same permutations
+                drawn = self.sampler.draw_epochs(self.buffer) if hasattr(self.sampler, "draw_epochs") else None
+                if drawn is not None and self._graphed_epochs is None:
+                    from cusrl_amd.template.graphs import GraphedEpochs
+
+                    self._graphed_epochs = GraphedEpochs(self)
+                if drawn is None or not self._graphed_epochs.run(drawn):
+                    for metadata, indices in (self._iter_drawn(drawn) if drawn is not None else self.sampler.iter_indices(self.buffer)):
+                        # (opt-in) index slices at addresses that repeat from update to update — the sampler's persistent
+                        # buffers — read in place by the captured step: one capture per address, no copy into a static buffer
+                        in_place = self.index_slices_in_place and getattr(self.sampler, "persistent_indices", False)
+                        key = self._step_key(metadata, indices.numel(), indices.data_ptr() if in_place else 0)
+                        if (step := self._graphed_steps.get(key)) is None:
+                            if self._graph_key_reads != len(self._metadata_reads):
+                                # the set of metadata keys hooks read has grown: graphs keyed on the shorter signature can
+                                # never be looked up again — release them (and their static buffers)
+                                self._graph_key_reads = len(self._metadata_reads)
+                                width = len(key)
+                                for stale in [k for k in self._graphed_steps if len(k) != width]:
+                                    self._graphed_steps.pop(stale).flush_metrics()
+                            step = self._graphed_steps[key] = GraphedTrainStep(self, key[0], key[1])
+                            budget = self.sampler.num_epochs * (self.sampler.num_mini_batches if isinstance(self.sampler.num_mini_batches, int)
+                                                                else max(self.sampler.num_mini_batches)) if hasattr(self.sampler, "num_epochs") else 0
+                            if budget and len(self._graphed_steps) > budget and not self._graph_budget_warned:
+                                self._graph_budget_warned = True
+                                self.warn(f"{len(self._graphed_steps)} minibatch-step graphs for {budget} steps per update: a hook reads "
+                                          f"metadata whose values keep changing ({sorted(self._metadata_reads)}); every distinct value is "
+                                          "its own capture")
+                        step.run(metadata, indices, in_place)
                 deferred: list = []
                 for step in self._graphed_steps.values():
                     step.flush_metrics(deferred)
+                if self._graphed_epochs is not None:
+                    self._graphed_epochs.flush_metrics()
                 GraphedTrainStep.resolve_deferred(deferred)  # the loss sums of every step: one host read
             else:
                 for metadata, batch in self.sampler(self.buffer):  # a7/a8
@@ -320,6 +330,26 @@ class ActorCritic(Agent):
         self.hook.post_update()
         self.hook.apply_schedule(self.iteration + 1)
         return super().update()
+
+    def _step_key(self, metadata, numel: int, address: int) -> tuple:
+        """Key of the captured minibatch step that serves ``metadata``: slot, sampling form, batch size, (in-place) index
+        address, and the value of every metadata key a hook ever read (steps whose values differ are different captures)."""
+        key = (metadata["mini_batch_index"], metadata["temporal"], numel, address)
+        if self._metadata_reads:
+            key += tuple((name, _hashable(metadata.get(name))) for name in sorted(self._metadata_reads)
+                         if name not in ("mini_batch_index", "temporal"))
+        return key
+
+    @staticmethod
+    def _iter_drawn(drawn):
+        """``(metadata, index slice)`` of every minibatch of permutations drawn by ``sampler.draw_epochs`` — each epoch after
+        its permutation's event."""
+        permutations, events, plan = drawn
+        main = torch.cuda.current_stream()
+        for epoch, row in enumerate(plan):
+            main.wait_event(events[epoch])
+            for metadata, lo, hi in row:
+                yield dict(metadata), permutations[epoch, lo:hi]
 
     def _zero_grad(self):
         if self.flat_optimizer is not None:

@@ -204,6 +204,7 @@ class Buffer(MutableMapping):
         # {sum, sumsq} partials the GAE kernel emits for the normalisation hook)
         self._derived: dict[str, Any] = {}
         self._push_plan = None
+        self.pending_epilogue = None  # ops.PendingStepEpilogue of the env step being appended (see push)
         # Leaves interleaved into one record per slot for the minibatch gather (ops.RecordPack), kept coherent LEAF BY LEAF:
         # `_record_clean[leaf]` is the leaf tensor's version counter at the moment the record mirrored it.  Any in-place
         # edit through torch — by whoever holds an alias handed out by `buffer[key]`, like the reference allows
@@ -339,8 +340,13 @@ class Buffer(MutableMapping):
         pushed dtype; ``None`` fields are skipped; after ``capacity`` pushes the buffer is ``full`` and the
         cursor wraps to 0 (buffer.py:124-151).
         """
-        if self._fast_push(data):
+        # a step epilogue the trainer handed over (ops.PendingStepEpilogue): issued WITH the steady-state append as one
+        # launch, or on its own in front of any other path — the append copies the `done` flag it produces
+        pending, self.pending_epilogue = self.pending_epilogue, None
+        if self._fast_push(data, pending):
             return
+        if pending is not None:
+            pending.launch()
         pairs = []
         for name, nested_value in data.items():
             if nested_value is None:
@@ -404,7 +410,7 @@ class Buffer(MutableMapping):
                            tuple(keys))
         self._through = None
 
-    def _fast_push(self, data: Mapping[str, Any]) -> bool:
+    def _fast_push(self, data: Mapping[str, Any], pending=None) -> bool:
         plan = getattr(self, "_push_plan", None)
         if plan is None:
             return False
@@ -436,7 +442,15 @@ class Buffer(MutableMapping):
         if self._derived:
             for name in names:
                 self._derived.pop(name, None)
-        ops.push_table(table, len(leaves), self.cursor, self.parallelism, self._push_through(keys))
+        through = self._push_through(keys)
+        if pending is not None:
+            done_field = next((i for i, (name, path, *_rest) in enumerate(leaves) if name == "done" and not path), -1)
+            if through is None and done_field >= 0 and data["done"] is pending.done_out:
+                pending.launch_with_push(table, len(leaves), done_field, self.cursor, self.parallelism)
+                self._advance()
+                return True
+            pending.launch()
+        ops.push_table(table, len(leaves), self.cursor, self.parallelism, through)
         self._advance()
         return True
 

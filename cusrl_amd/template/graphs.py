@@ -41,8 +41,8 @@ import torch
 
 from cusrl_amd.utils.metrics import MetricTap
 
-__all__ = ["GraphedAct", "GraphedRegion", "GraphedRolloutStep", "GraphedTrainStep", "capture_signature", "collective_phases",
-           "eager_phases"]
+__all__ = ["GraphedAct", "GraphedEpochs", "GraphedRegion", "GraphedRolloutStep", "GraphedTrainStep", "capture_signature",
+           "collective_phases", "eager_phases"]
 
 
 def _freeze(value):
@@ -180,7 +180,9 @@ class _Capture:
                 if tap.values:
                     if len(tap.values) > self.MAX_TAPS:
                         raise RuntimeError(f"more than {self.MAX_TAPS} metrics recorded inside one captured phase")
-                    self.accumulator[: len(tap.values)].add_(torch.stack(tap.values))
+                    from cusrl_amd import ops
+
+                    ops.accumulate_scalars_(self.accumulator, tap.values)  # one launch (torch: stack + add_)
         finally:
             if gc_was_enabled:
                 gc.enable()
@@ -232,6 +234,9 @@ class GraphedTrainStep:
         # running block sums of the fused objective (ops.DeferredLoss): the captured step runs the loss kernel without its
         # finalize launch; created by the eager warm-up, read and reset by flush_metrics
         self.deferred_loss = None
+        # replays of this step's body from a whole-epoch graph (GraphedEpochs): counted here so that the running loss sums
+        # are divided by the right number of evaluations
+        self.extra_replays = 0
 
     def eligible(self) -> bool:
         """False when an objective-phase hook synchronises across ranks (e.g. minibatch-wise advantage normalisation
@@ -338,7 +343,8 @@ class GraphedTrainStep:
         """Fold what the replays accumulated on the device into the agent's metrics.  ``deferred`` (a list the caller
         resolves with :meth:`resolve_deferred`): the loss sums are only ENQUEUED here, so that all steps of an update
         share one host read."""
-        replays = self.forward_backward.replays
+        replays = self.forward_backward.replays + self.extra_replays
+        self.extra_replays = 0
         self.forward_backward.flush_metrics()
         self.optimize.flush_metrics()
         if self.deferred_loss is None or replays <= 0 or (sums := self.deferred_loss.sums()) is None:
@@ -357,6 +363,87 @@ class GraphedTrainStep:
         if deferred:
             for (step, _, replays), sums in zip(deferred, torch.stack([entry[1] for entry in deferred]).tolist()):
                 step._record_deferred(sums, replays)
+
+
+class GraphedEpochs:
+    """The minibatch steps of ONE epoch back to back as one hipGraph (round 4) — built on top of the per-step graphs once
+    every step of an update replays from its own graph, like the whole-rollout graph on top of the per-step env graphs.
+
+    What it removes per minibatch step is what sits BETWEEN two step graphs: the copy of the index slice into the step's
+    static buffer (the slices are read in place from the sampler's persistent ``[E, S]`` permutation buffer,
+    ``MiniBatchSampler.draw_epochs``) and a replay boundary.  An epoch's graph may start as soon as its permutation's
+    event has fired; the later epochs' permutations keep being drawn on the side stream meanwhile.  One graph per epoch
+    (not one per update): a captured graph cannot wait for an event recorded outside of it.
+
+    Only with ONE graph per step (single process or the C-ABI collectives) and steps that are all captured under the
+    current signature; anything else keeps stepping graph by graph."""
+
+    def __init__(self, agent):
+        self.agent = agent
+        self.stream: torch.cuda.Stream = agent._graph_stream
+        self.epochs: dict[tuple, dict] = {}
+        self.signature: tuple | None = None
+        self.enabled = os.environ.get("CUSRL_EPOCH_GRAPHS", "1") != "0"
+        self.replays = 0
+
+    def _steps_of(self, plan_row, permutations, epoch):
+        """The (warm, captured) GraphedTrainStep of every minibatch of this epoch, or None if one is missing."""
+        agent, found = self.agent, []
+        for metadata, lo, hi in plan_row:
+            step = agent._graphed_steps.get(agent._step_key(metadata, hi - lo, 0))
+            if step is None or step.state != 2 or not step.single_graph or step.signature != self.signature:
+                return None
+            found.append((step, metadata, permutations[epoch, lo:hi]))
+        return found
+
+    def run(self, drawn) -> bool:
+        """One update from per-epoch graphs; False = conditions not met (the caller steps graph by graph — and must do so
+        WITHOUT consuming the generator again: it iterates the same ``drawn`` permutations)."""
+        agent = self.agent
+        if not self.enabled or agent.index_slices_in_place:
+            return False
+        permutations, events, plan = drawn
+        signature = (capture_signature(agent), agent.buffer.layout_version)
+        if signature != self.signature:
+            self.flush_metrics()
+            self.epochs.clear()
+            self.signature = signature
+        rows = [self._steps_of(plan[epoch], permutations, epoch) for epoch in range(len(plan))]
+        if any(row is None for row in rows):
+            return False
+        hot = set().union(*(step.hot_fields for row in rows for step, _, _ in row))
+        agent.buffer.prepare_sampling(hot)
+        if agent.flat_optimizer is not None:
+            agent.flat_optimizer.refresh()  # learning-rate changes reach the captured steps through device memory
+        main = torch.cuda.current_stream()
+        for epoch, row in enumerate(rows):
+            key = (epoch, permutations.data_ptr(), tuple(id(step) for step, _, _ in row))
+            entry = self.epochs.get(key)
+            main.wait_event(events[epoch])  # this epoch's permutation has been drawn
+            if entry is None:
+                entry = self.epochs[key] = {"capture": _Capture(agent)}
+                entry["capture"].capture(lambda row=row: self._body(row), self.stream, pool=agent._graph_pool)
+            entry["capture"].replay()
+            for step, _, _ in row:
+                step.extra_replays += 1
+        self.replays += 1
+        return True
+
+    def _body(self, row):
+        agent = self.agent
+        for step, metadata, indices in row:
+            saved = step.static_indices, step.metadata
+            step.static_indices = indices  # read in place
+            step.metadata = TrackedMetadata(metadata, agent._metadata_reads)
+            try:
+                step._whole_step()
+            finally:
+                step.static_indices, step.metadata = saved
+            step.carry = {}
+
+    def flush_metrics(self):
+        for entry in self.epochs.values():
+            entry["capture"].flush_metrics()
 
 
 class GraphedRegion:
@@ -515,6 +602,7 @@ class GraphedRolloutStep:
         self.rollouts: dict[tuple, dict] = {}
         self.rollout_replays = 0
         self.whole_rollouts = os.environ.get("CUSRL_WHOLE_ROLLOUT_GRAPH", "1") != "0"
+        self.fuse_epilogue_push = os.environ.get("CUSRL_FUSE_EPILOGUE_PUSH", "1") != "0"  # A/B switch
 
     # ------------------------------------------------------------------ eligibility
     def supported(self, observation, state) -> bool:
@@ -547,8 +635,16 @@ class GraphedRolloutStep:
         act._body()  # reads act.static_observation / static_state
         transition = agent.transition
         next_observation, next_state, reward, terminated, truncated, info = env.step(transition["action"])
-        stats.track_fused(reward, terminated, truncated, self.done, self.indices, self.count)
+        if self.fuse_epilogue_push and not agent.inference_mode and all(h.post_step_device_free for h in agent.hook if h._active):
+            # no hook touches the transition on the device between the epilogue and the append: ONE launch for both,
+            # issued by buffer.push (which falls back to two launches whenever it cannot take the steady-state path)
+            agent.buffer.pending_epilogue = stats.defer_fused(reward, terminated, truncated, self.done, self.indices, self.count)
+        else:
+            stats.track_fused(reward, terminated, truncated, self.done, self.indices, self.count)
         self.ready = agent.step(next_observation, reward, terminated, truncated, next_state, **{**info, "done": self.done})
+        if agent.buffer.pending_epilogue is not None:  # nobody appended (a hook suppressed the push): issue it now
+            pending, agent.buffer.pending_epilogue = agent.buffer.pending_epilogue, None
+            pending.launch()
         init_observation, init_state, _ = env.reset_static(self.indices, self.count)
         # the next act input = the env's next observation with the reset rows spliced in, one launch (the host-driven
         # loop does the same in two: the in-place row scatter of Trainer._splice_static, then GraphedAct's copy)

@@ -61,6 +61,14 @@ class Hook(Generic[AgentT]):
     # GraphedRolloutStep).  Stock hooks qualify; a user-defined hook that overrides either method sets this to opt in.
     rollout_capture_safe: bool = False
 
+    @property
+    def post_step_device_free(self) -> bool:
+        """Extension: this hook's ``post_step`` neither reads nor writes device memory of the transition (nothing it does
+        sits between the step epilogue and the buffer append on the device) — true for every hook that does not override
+        ``post_step``; a hook whose override is host-only says so by overriding this property.  When every active hook is
+        device-free the epilogue and the append of a captured env step are ONE launch (``cusrl_step_epilogue_push``)."""
+        return type(self).post_step is Hook.post_step
+
     def __init__(self, training_only: bool = False):
         self._modules: dict[str, nn.Module | None] = {}
         self._statefuls: dict[str, Any] = {}

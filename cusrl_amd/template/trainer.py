@@ -60,6 +60,16 @@ class EnvironmentStats:
                           self.len_buffer, self._episodes_dev, self._reward_sum, indices_out, count_out, self._parity)
         self.count_step()
 
+    def defer_fused(self, reward, terminated, truncated, done_out, indices_out, count_out):
+        """:meth:`track_fused` whose launch is handed to the buffer append of the same env step (one launch for both,
+        ``cusrl_step_epilogue_push``): returns the pending epilogue for ``Buffer.pending_epilogue``; counters as usual."""
+        from cusrl_amd import ops
+
+        pending = ops.PendingStepEpilogue(reward, terminated, truncated, done_out, self.episode_rew, self.episode_len, self.rew_buffer,
+                                          self.len_buffer, self._episodes_dev, self._reward_sum, indices_out, count_out, self._parity)
+        self.count_step()
+        return pending
+
     def count_step(self):
         """Host counters of one fused step (all a hipGraph replay of :meth:`track_fused` leaves to do)."""
         self.total_steps += self.num_envs

@@ -313,6 +313,15 @@ int cusrl_step_epilogue(const float *reward, const uint8_t *terminated, const ui
                         double *step_reward_sum, int64_t *indices_out, int32_t *count_out, int64_t N, int64_t D, int64_t R,
                         int parity, void *stream);
 int64_t cusrl_step_epilogue_max_envs(void);
+/* cusrl_step_epilogue AND cusrl_buffer_push of the same env step as ONE launch (actor_critic.py:273-282 + trainer.py:296-321):
+ * the epilogue blocks store `done` both to done_out and straight into the buffer's slab of fields[done_field] (whose src
+ * is ignored); every other field is appended as by cusrl_buffer_push.  For steps whose post_step hooks do no device
+ * work between the two (nothing may read the flag or edit the reward in between). */
+int cusrl_step_epilogue_push(const float *reward, const uint8_t *terminated, const uint8_t *truncated, uint8_t *done_out,
+                             float *episode_rew, float *episode_len, float *ring_rew, float *ring_len, uint64_t *num_episodes,
+                             double *step_reward_sum, int64_t *indices_out, int32_t *count_out, int64_t N, int64_t D, int64_t R,
+                             int parity, const cusrl_field_t *fields, int n_fields, int done_field, int64_t cursor,
+                             void *stream);
 
 /* ---- post-update policy statistics — cusrl/hook/on_policy/stats.py:28-40 for Normal policies ----
  * out[0] = mean_b KL(N(old_mean, old_std) || N(new_mean, new_std)) summed over the A action dims (kl_divergence),
@@ -503,6 +512,11 @@ int cusrl_amp_prepare(const float *state, const float *next_state, int64_t state
                       double max_count, float clamp, float *agent_out, float *expert_out, double *workspace, void *stream);
 int64_t cusrl_amp_prepare_max_elements(void);
 int64_t cusrl_amp_prepare_workspace(int64_t N, int64_t C);
+
+/* accumulator[i] += *values[i] for i < n <= 32 (values: HOST array of device pointers to fp32 scalars): the per-step
+ * running sums of the metrics a captured minibatch / env step records (cusrl/utils/metrics.py:17-28 keeps running means
+ * with four torch launches per metric and step).  One launch. */
+int cusrl_accumulate_scalars(const float *const *values, int n, float *accumulator, void *stream);
 
 /* ---- RewardShaping.post_step — cusrl/hook/mdp/reward.py:43-47 ----
  * reward = clamp(reward * scale + shift, lower, upper) in place (the product and the sum rounded separately like the two
