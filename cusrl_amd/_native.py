@@ -117,6 +117,7 @@ _SIGNATURES = {
                                   c_float, _P, _P, _P, _P]),
     "cusrl_amp_prepare_max_elements": (c_int64, []),
     "cusrl_amp_prepare_workspace": (c_int64, [c_int64, c_int64]),
+    "cusrl_synthetic_env_step": (c_int, [ctypes.c_uint64, _P, c_int64, c_int64, c_int64, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "cusrl_accumulate_scalars": (c_int, [POINTER(c_void_p), c_int, _P, _P]),
     "cusrl_reward_shaping": (c_int, [_P, c_float, c_float, c_float, c_float, c_int, c_int, c_int64, _P]),
     "cusrl_mse_loss_fwd_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P]),

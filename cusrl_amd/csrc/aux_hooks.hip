@@ -278,6 +278,78 @@ __global__ __launch_bounds__(kPrepThreads) void bce_pair_fwd_bwd_kernel(const fl
     }
 }
 
+// --------------------------------------------------------------------------------------------- synthetic benchmark env
+// One step of the i.i.d. benchmark task of BASELINE.json config 2 (cusrl_amd/testing/environment.py): next observation
+// ~ N(0, 1) [N, obs], reward ~ N(0, 1) [N, R], terminated ~ Bernoulli(p_term), truncated ~ Bernoulli(p_trunc), and one fresh
+// N(0, 1) row per env for the resets — ONE launch instead of five generator launches (rand, compare, 3 x randn).
+// Counter-based Philox4x32-10 keyed on (seed, step counter, stream, element): the step counter lives in device memory and is
+// advanced by the kernel itself, so a hipGraph replay draws fresh numbers like an eager call does.
+struct Philox {
+    uint32_t c[4];
+};
+__device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = uint64_t(0xD2511F53u) * c0, p1 = uint64_t(0xCD9E8D57u) * c2;
+        const uint32_t n0 = uint32_t(p1 >> 32) ^ c1 ^ k0, n1 = uint32_t(p1), n2 = uint32_t(p0 >> 32) ^ c3 ^ k1, n3 = uint32_t(p0);
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    return Philox{{c0, c1, c2, c3}};
+}
+__device__ __forceinline__ float philox_uniform(uint32_t x) { return float(x >> 8) * 5.9604645e-8f + 2.9802322e-8f; }  // (0, 1)
+__device__ __forceinline__ float4 philox_normal4(const Philox &r) {  // two Box-Muller pairs
+    const float r0 = sqrtf(-2.0f * logf(philox_uniform(r.c[0]))), r1 = sqrtf(-2.0f * logf(philox_uniform(r.c[2])));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * philox_uniform(r.c[1]), &s0, &c0);
+    sincosf(6.283185307179586f * philox_uniform(r.c[3]), &s1, &c1);
+    return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+}
+
+__global__ __launch_bounds__(kBlock) void synthetic_env_step_kernel(uint64_t seed, unsigned long long *__restrict__ counter,
+                                                                    int64_t N, int obs, int R, float p_term, float p_trunc,
+                                                                    float *__restrict__ next_obs, float *__restrict__ reward,
+                                                                    uint8_t *__restrict__ terminated,
+                                                                    uint8_t *__restrict__ truncated,
+                                                                    float *__restrict__ reset_rows, int64_t obs_quads,
+                                                                    int64_t reward_quads) {
+    // counter[0] = step number, counter[1] = arrival ticket.  Every block reads the step number first; the LAST block to
+    // arrive at the ticket (all others have read by then) advances it — so a hipGraph replay draws fresh numbers like an
+    // eager call, with no second launch and no host-side parity.  (Control flow only: no value depends on arrival order.)
+    const unsigned long long step = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
+    const uint32_t s0 = uint32_t(step), s1 = uint32_t(step >> 32);
+    const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t obs_total = N * obs, reward_total = N * R;
+    auto store4 = [](float *dst, int64_t base, int64_t total, const float4 &v) {
+        if (base + 3 < total && (reinterpret_cast<uintptr_t>(dst + base) & 15) == 0) {
+            *reinterpret_cast<float4 *>(dst + base) = v;
+        } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < 4 && base + j < total; ++j) dst[base + j] = e[j];
+        }
+    };
+    if (i < obs_quads) {  // stream 0: next observation, stream 1: reset rows
+        store4(next_obs, i * 4, obs_total, philox_normal4(philox4x32_10(uint32_t(i), uint32_t(i >> 32) | 0x00000000u, s0, s1, k0, k1)));
+        store4(reset_rows, i * 4, obs_total, philox_normal4(philox4x32_10(uint32_t(i), uint32_t(i >> 32) | 0x40000000u, s0, s1, k0, k1)));
+    }
+    if (i < reward_quads)  // stream 2
+        store4(reward, i * 4, reward_total, philox_normal4(philox4x32_10(uint32_t(i), uint32_t(i >> 32) | 0x80000000u, s0, s1, k0, k1)));
+    if (i < N) {  // stream 3: the two flags of env i
+        const Philox r = philox4x32_10(uint32_t(i), uint32_t(i >> 32) | 0xC0000000u, s0, s1, k0, k1);
+        terminated[i] = philox_uniform(r.c[0]) < p_term ? 1 : 0;
+        truncated[i] = philox_uniform(r.c[1]) < p_trunc ? 1 : 0;
+    }
+    __syncthreads();  // the whole block has read `step`
+    if (threadIdx.x == 0) {
+        const unsigned long long arrived = atomicAdd(counter + 1, 1ull);
+        if (arrived == gridDim.x - 1) {
+            __hip_atomic_store(counter + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(counter, step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------------- metric taps of a captured step
 // accumulator[i] += *value[i] for up to 32 scalars whose addresses travel by value in the kernarg segment: what a captured
 // step does with the 0-d metrics its hooks record (torch: stack + add_, two launches per step).
@@ -399,5 +471,21 @@ extern "C" int cusrl_bce_pair_fwd_bwd(const float *logit, int64_t rows, float we
     if (rows > (int64_t(1) << 19)) return CUSRL_E_UNSUPPORTED;  // one workgroup
     hipLaunchKernelGGL(bce_pair_fwd_bwd_kernel, dim3(1), dim3(kPrepThreads), 0, as_stream(stream), logit, rows, weight,
                        loss_out, d_logit);
+    return launch_status();
+}
+
+extern "C" int cusrl_synthetic_env_step(uint64_t seed, uint64_t *counter, int64_t N, int64_t obs_dim, int64_t reward_dim,
+                                        float p_terminate, float p_truncate, float *next_observation, float *reward,
+                                        uint8_t *terminated, uint8_t *truncated, float *reset_rows, void *stream) {
+    if (N <= 0 || obs_dim <= 0 || reward_dim <= 0) return CUSRL_E_INVALID;
+    if (!counter || !next_observation || !reward || !terminated || !truncated || !reset_rows) return CUSRL_E_INVALID;
+    if (obs_dim > INT32_MAX || reward_dim > INT32_MAX || N * obs_dim > (int64_t(1) << 40)) return CUSRL_E_UNSUPPORTED;
+    const int64_t obs_quads = ceil_div(N * obs_dim, 4), reward_quads = ceil_div(N * reward_dim, 4);
+    int64_t threads = obs_quads > reward_quads ? obs_quads : reward_quads;
+    if (N > threads) threads = N;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(synthetic_env_step_kernel, dim3(uint32_t(ceil_div(threads, kBlock))), dim3(kBlock), 0, s, seed,
+                       reinterpret_cast<unsigned long long *>(counter), N, int(obs_dim), int(reward_dim), p_terminate,
+                       p_truncate, next_observation, reward, terminated, truncated, reset_rows, obs_quads, reward_quads);
     return launch_status();
 }

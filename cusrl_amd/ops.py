@@ -1696,3 +1696,22 @@ def accumulate_scalars_(accumulator: torch.Tensor, values: Sequence[torch.Tensor
         table = (ctypes.c_void_p * len(chunk))(*[require_device(v, "value").data_ptr() for v in chunk])
         check(_native.lib().cusrl_accumulate_scalars(table, len(chunk), accumulator.data_ptr() + 4 * start, _stream()),
               "cusrl_accumulate_scalars")
+
+
+def synthetic_env_step(seed: int, counter: torch.Tensor, num_envs: int, obs_dim: int, reward_dim: int, p_terminate: float,
+                       p_truncate: float):
+    """One step of the i.i.d. benchmark env as ONE launch (``cusrl_synthetic_env_step``): returns
+    ``(next_observation [N, obs], reward [N, R], terminated [N, 1] bool, truncated [N, 1] bool, reset_rows [N, obs])``.
+    ``counter``: int64[2] device tensor (zeros at construction) that the launch itself advances."""
+    require_device(counter, "counter")
+    dev = counter.device
+    next_observation = torch.empty((num_envs, obs_dim), dtype=torch.float32, device=dev)
+    reset_rows = torch.empty((num_envs, obs_dim), dtype=torch.float32, device=dev)
+    reward = torch.empty((num_envs, reward_dim), dtype=torch.float32, device=dev)
+    terminated = torch.empty((num_envs, 1), dtype=torch.bool, device=dev)
+    truncated = torch.empty((num_envs, 1), dtype=torch.bool, device=dev)
+    check(_native.lib().cusrl_synthetic_env_step(seed & 0xFFFFFFFFFFFFFFFF, counter.data_ptr(), num_envs, obs_dim, reward_dim,
+                                                 float(p_terminate), float(p_truncate), next_observation.data_ptr(), reward.data_ptr(),
+                                                 terminated.data_ptr(), truncated.data_ptr(), reset_rows.data_ptr(), _stream()),
+          "cusrl_synthetic_env_step")
+    return next_observation, reward, terminated, truncated, reset_rows

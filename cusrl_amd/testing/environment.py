@@ -8,6 +8,8 @@ reset returning fresh N(0, 1) rows — everything generated on the env's device 
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from cusrl_amd.template.environment import Environment
@@ -20,7 +22,7 @@ class SyntheticEnvironment(Environment):
     def __init__(self, num_instances: int = 4096, observation_dim: int = 48, action_dim: int = 12, *,
                  state_dim: int | None = None, reward_dim: int = 1, terminate_prob: float = 0.01,
                  truncate_prob: float = 0.005, device=None, autoreset: bool = False, capturable: bool = True,
-                 **properties):
+                 fused: bool | None = None, seed: int | None = None, **properties):
         device = resolve_device(device)
         super().__init__(observation_dim, action_dim, num_instances=num_instances, state_dim=state_dim,
                          reward_dim=reward_dim, device=device, autoreset=autoreset, **properties)
@@ -30,6 +32,19 @@ class SyntheticEnvironment(Environment):
         # host synchronisation and replay whole env steps from hipGraphs (template/environment.py `capturable`)
         self.capturable = bool(capturable) and self.device.type == "cuda"
         self._flag_probs = torch.tensor([terminate_prob, truncate_prob], dtype=torch.float32, device=self.device).view(2, 1, 1)
+        # fused (default on a GPU, CUSRL_FUSED_ENV=0 / fused=False for the torch-generator form): a whole step — observation,
+        # reward, both flags and the rows for the resets — from ONE HIP launch (`cusrl_synthetic_env_step`: Philox keyed on a
+        # seed drawn from torch's generator here and a device-resident step counter) instead of five generator launches; the
+        # same distributions, another random stream.  No privileged state in this form.
+        if fused is None:
+            fused = os.environ.get("CUSRL_FUSED_ENV", "1") != "0"
+        self.fused = bool(fused) and self.device.type == "cuda" and state_dim is None
+        if self.fused:
+            # follows set_global_seed (seed + rank) without consuming any generator; `seed=` gives an instance its own stream
+            base = torch.initial_seed() if seed is None else int(seed)
+            self._seed = (base * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+            self._counter = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self._reset_rows: torch.Tensor | None = None
 
     def _randn(self, rows: int, cols: int | None):
         return None if cols is None else torch.randn(rows, cols, device=self.device)
@@ -39,12 +54,20 @@ class SyntheticEnvironment(Environment):
         return self._randn(rows, self.observation_dim), self._randn(rows, self.state_dim), {}
 
     def reset_static(self, indices, count):
+        if self.fused and self._reset_rows is not None and indices.numel() == self.num_instances:
+            return self._reset_rows, None, {}  # drawn by the step's own launch: one fresh row per index slot
         rows = indices.numel()  # one fresh row per index slot; the trainer's splice only takes the first `count`
         return self._randn(rows, self.observation_dim), self._randn(rows, self.state_dim), {}
 
     def step(self, action):
         assert isinstance(action, torch.Tensor) and action.shape == (self.num_instances, self.action_dim)
         n = self.num_instances
+        if self.fused:
+            from cusrl_amd import ops
+
+            next_observation, reward, terminated, truncated, self._reset_rows = ops.synthetic_env_step(
+                self._seed, self._counter, n, self.observation_dim, self.spec.reward_dim, self.terminate_prob, self.truncate_prob)
+            return next_observation, None, reward, terminated, truncated, {}
         # both flag vectors from one draw and ONE comparison against the [2, 1, 1] probabilities (the same float32
         # thresholds a Python scalar would be rounded to): [0] = terminated, [1] = truncated, each a contiguous [n, 1]
         flags = torch.rand(2, n, 1, device=self.device) < self._flag_probs

@@ -513,6 +513,16 @@ int cusrl_amp_prepare(const float *state, const float *next_state, int64_t state
 int64_t cusrl_amp_prepare_max_elements(void);
 int64_t cusrl_amp_prepare_workspace(int64_t N, int64_t C);
 
+/* ---- the synthetic benchmark env of BASELINE.json config 2 (cusrl_amd/testing/environment.py; the reference ships
+ * no such env — its step is this package's definition of the workload): next_observation ~ N(0, 1) [N, obs_dim],
+ * reward ~ N(0, 1) [N, reward_dim], terminated / truncated ~ Bernoulli(p) [N] bytes, reset_rows ~ N(0, 1) [N, obs_dim] (one
+ * fresh row per env for the resets), from Philox4x32-10 keyed on (seed, step number, stream, element) in ONE launch.
+ * counter: uint64[2] device words {step number, arrival ticket}, zero-initialised by the caller; the launch advances the
+ * step number itself (its last block), so a hipGraph replay draws fresh numbers. */
+int cusrl_synthetic_env_step(uint64_t seed, uint64_t *counter, int64_t N, int64_t obs_dim, int64_t reward_dim,
+                             float p_terminate, float p_truncate, float *next_observation, float *reward,
+                             uint8_t *terminated, uint8_t *truncated, float *reset_rows, void *stream);
+
 /* accumulator[i] += *values[i] for i < n <= 32 (values: HOST array of device pointers to fp32 scalars): the per-step
  * running sums of the metrics a captured minibatch / env step records (cusrl/utils/metrics.py:17-28 keeps running means
  * with four torch launches per metric and step).  One launch. */

@@ -206,3 +206,47 @@ def test_a_changed_hook_attribute_recaptures_the_step_graphs(cusrl):
     observation, state, _ = env.reset()
     trainer._rollout_and_update(observation, state)
     assert graphed.captured == 4 and all(torch.isfinite(p).all() for p in trainer.agent.parameters())
+
+
+def test_fused_synthetic_env_step_draws_the_documented_distributions(cusrl):
+    """cusrl_synthetic_env_step (ONE launch per env step): N(0, 1) observations / rewards / reset rows, Bernoulli flags at the
+    configured rates, fresh numbers every step — also when the step is replayed from a hipGraph (the launch advances its own
+    device-side step counter) — and the same stream for the same seed."""
+    from cusrl_amd import _native
+
+    def build():
+        cusrl.set_global_seed(11)
+        return cusrl.testing.SyntheticEnvironment(65536, 48, 12, device=DEV, terminate_prob=0.02, truncate_prob=0.01)
+
+    env = build()
+    assert env.fused
+    action = torch.zeros(65536, 12, device=DEV)
+    before = _native.launch_counts.get("cusrl_synthetic_env_step", 0)
+    steps = [env.step(action) for _ in range(3)]
+    assert _native.launch_counts["cusrl_synthetic_env_step"] - before == 3
+    for next_obs, state, reward, terminated, truncated, info in steps:
+        assert state is None and next_obs.shape == (65536, 48) and reward.shape == (65536, 1)
+        assert terminated.dtype == torch.bool and terminated.shape == (65536, 1) == truncated.shape
+        assert abs(next_obs.mean().item()) < 0.005 and abs(next_obs.var().item() - 1.0) < 0.01
+        assert abs(reward.mean().item()) < 0.02 and abs(reward.var().item() - 1.0) < 0.03
+        assert abs(terminated.float().mean().item() - 0.02) < 0.003 and abs(truncated.float().mean().item() - 0.01) < 0.002
+        # neighbouring elements / channels are uncorrelated
+        assert abs((next_obs[:, 0] * next_obs[:, 1]).mean().item()) < 0.02 and abs((next_obs[1:, 0] * next_obs[:-1, 0]).mean().item()) < 0.02
+    assert not torch.equal(steps[0][0], steps[1][0]) and not torch.equal(steps[1][0], steps[2][0])
+    rows, _, _ = env.reset_static(torch.zeros(65536, dtype=torch.int64, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV))
+    assert rows.shape == (65536, 48) and abs(rows.var().item() - 1.0) < 0.01 and not torch.equal(rows, steps[2][0])
+    again = build()
+    assert torch.equal(again.step(action)[0], steps[0][0])  # same seed, same stream
+    # replayed from a graph: every replay is a new step
+    stream, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        env.step(action)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=stream):
+        captured = env.step(action)[0]
+    graph.replay()
+    torch.cuda.synchronize()
+    first = captured.clone()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(first, captured) and abs(captured.var().item() - 1.0) < 0.01
