@@ -4,12 +4,14 @@
 // Reads  advantage 4 + old_logp 4 + action/mean/std 3*4A + return 4D + curr_value 4D (+ old_value 4D) bytes,
 // writes d_mean/d_std 2*4A + d_value 4D bytes per sample (264 B at A=12, D=1) — HBM-bound, ~60 flops/sample.
 //
-// Layout strategy (A % 4 == 0): the [B, A] matrices are streamed as a flat array of 16-byte chunks so that
-// every global access is a fully coalesced dwordx4 (lane i <-> chunk i), independent of the row length.  A
-// block owns 256 rows = 256*LPR chunks (LPR = A/4 chunks per row); per-chunk partial log-prob / entropy sums
-// are exchanged through LDS so that one lane per row finishes the scalar part (ratio, clipping, value loss),
-// publishes d(loss)/d(logp) through LDS, and the chunk owners (who still hold action/mean/std in registers)
-// emit the gradients.  Scalar statistics use wave64 shuffle reductions, fp64 partials per block, fixed order.
+// Layout (A % 4 == 0, A <= 32 — ppo_loss_rowgroup_kernel, round 3): ROW GROUPS.  The LPR = A/4 16-byte chunks of a row sit
+// in LPR adjacent lanes of one wave (63 of 64 lanes busy at A = 12), so a wave's load covers ~1 KB of contiguous bytes;
+// the row sums of log-prob / entropy are LPR neighbour shuffles and EVERY lane of the row evaluates the scalar part (ratio,
+// clipping, d loss / d logp) itself — no LDS tile, ONE barrier per block (for the block's fp64 partial sums).  A std handed
+// over as its [A] vector keeps d_std in four registers per lane, reduced over the wave's rows by a stride-LPR shuffle tree.
+// Per element one v_rcp_f32 of sigma and multiplications instead of five IEEE divisions (the textbook form was bound by its
+// own VALU instructions).  Any other width: ppo_loss_rowwise_kernel (one lane per row).  Scalar statistics: fp32 lane sums,
+// fp64 wave / block / grid sums in fixed order.
 #include <float.h>
 
 #include "common.hpp"

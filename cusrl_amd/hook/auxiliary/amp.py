@@ -14,7 +14,7 @@ from torch import Tensor, nn
 
 from cusrl_amd.nn.rms import RunningMeanStd
 from cusrl_amd.template.hook import Hook
-from cusrl_amd.utils.misc import get_first
+from cusrl_amd.utils.misc import get_first, host_form
 
 __all__ = ["AdversarialMotionPrior", "GradientPenaltyLoss"]
 
@@ -263,7 +263,8 @@ class AdversarialMotionPrior(Hook):
             else:
                 style_reward = ops.amp_style_reward_(torch.zeros_like(logit, dtype=torch.float32), logit.float(), self.reward_scale)
                 reward.add_(style_reward.to(reward.dtype))
-        else:  # CPU agents (host-logic tests, no GPU in the process): the reference's torch ops
+        else:  # test processes without a GPU only: the reference's torch ops
+            host_form("AdversarialMotionPrior.post_step")
             style_reward = self.reward_scale * -torch.log(torch.clamp(1 - 1 / (1 + torch.exp(-logit)), min=1e-4))
             reward.add_(style_reward)
         self.agent.record(amp_reward=style_reward)

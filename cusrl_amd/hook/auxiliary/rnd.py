@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from cusrl_amd.template.hook import Hook
-from cusrl_amd.utils.misc import get_first
+from cusrl_amd.utils.misc import get_first, host_form
 
 __all__ = ["RandomNetworkDistillation"]
 
@@ -76,7 +76,8 @@ class RandomNetworkDistillation(Hook):
                 staged = reward.new_zeros(reward.shape[:-1] + (1,)).contiguous()
                 bonus = ops.rnd_reward_(staged, target, prediction, self.reward_scale)
                 reward.add_(bonus)
-        else:  # CPU agents (host-logic tests, no GPU in the process): the reference's torch ops
+        else:  # test processes without a GPU only: the reference's torch ops
+            host_form("RandomNetworkDistillation.pre_update")
             bonus = self.reward_scale * (target - prediction).square().mean(dim=-1, keepdim=True).view(*reward.shape[:-1], 1)
             reward.add_(bonus)
         self.agent.record(rnd_reward=bonus)

@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 
 from cusrl_amd.template.hook import Hook
+from cusrl_amd.utils.misc import host_form
 
 __all__ = ["RewardShaping"]
 
@@ -30,7 +31,7 @@ class RewardShaping(Hook):
                 ops.reward_shaping_(staged, self.scale, self.shift, self.lower_bound, self.upper_bound)
                 reward.copy_(staged)
             return
-        # CPU agents (host-logic tests: no GPU in the process)
+        host_form("RewardShaping.post_step")  # test processes without a GPU only
         reward.mul_(self.scale).add_(self.shift)
         if bounded:
             reward.clamp_(min=self.lower_bound, max=self.upper_bound)

@@ -32,6 +32,9 @@ def mean_var_count(input: Tensor, mask: Tensor | None = None) -> tuple[Tensor, T
         from cusrl_amd import ops
 
         return ops.masked_col_stats(input.float(), None if mask is None else mask.reshape(-1))
+    from cusrl_amd.utils.misc import host_form
+
+    host_form("RunningMeanStd (mean_var_count)")  # test processes without a GPU only
     if mask is not None:
         input = input[mask.reshape(-1).bool()]
     count = torch.tensor([float(input.size(0))], dtype=torch.float64)

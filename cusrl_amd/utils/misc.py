@@ -13,7 +13,7 @@ import torch
 
 from cusrl_amd.utils.config import CONFIG
 
-__all__ = ["MISSING", "camel_to_snake", "get_first", "set_global_seed"]
+__all__ = ["MISSING", "camel_to_snake", "get_first", "host_form", "set_global_seed"]
 
 MISSING = object()
 
@@ -33,6 +33,17 @@ def set_global_seed(seed: int | None, deterministic: bool = False) -> int:
         torch.use_deterministic_algorithms(True)
     CONFIG.seed = seed
     return seed
+
+
+def host_form(what: str) -> None:
+    """Gate in front of the torch-op (host) form of a hook's device work.  The product has NO CPU path for the hot path: on
+    an MI355X every hook takes its HIP entry point, and a CPU tensor reaching one of these places raises — unless the
+    process opted in with ``CUSRL_HOST_FORMS=1``, which only the repository's own test infrastructure does (the host-logic
+    tests and the gloo workers run in processes without a GPU and exercise the hooks' bookkeeping there)."""
+    if os.environ.get("CUSRL_HOST_FORMS") != "1":
+        raise RuntimeError(
+            f"cusrl_amd: {what} received CPU tensors; the rollout + PPO-update hot path only runs as HIP kernels on an MI355X "
+            "(no CPU fallback by design).  Test infrastructure without a GPU sets CUSRL_HOST_FORMS=1.")
 
 
 def get_first(data: Mapping[str, Any], *keys: str) -> Any:

@@ -1,5 +1,10 @@
+import os
 import sys
 from pathlib import Path
+
+# the host-logic tests and the gloo workers exercise hook bookkeeping in processes without a GPU: opt in to the hooks' torch-op
+# (host) forms, which the product refuses otherwise (cusrl_amd/utils/misc.py host_form)
+os.environ.setdefault("CUSRL_HOST_FORMS", "1")
 
 import pytest
 
