@@ -70,7 +70,7 @@ def pmc_traffic(envs_per_gpu):
     cusrl_amd/csrc/buffer.hip recorded next to the numbers); otherwise null."""
     import hashlib
 
-    path = ROOT / "profiles" / "r03" / "pmc_summary.json"
+    path = ROOT / "profiles" / "r04" / "pmc_gather_summary.json"
     if envs_per_gpu != NUM_ENVS or not path.exists():
         return None, None
     summary = json.loads(path.read_text())
@@ -79,7 +79,7 @@ def pmc_traffic(envs_per_gpu):
     if not entry or summary.get("buffer_hip_sha256_16") != source:
         return None, None
     return entry["hbm_traffic_bytes"], (f"quoted: rocprofv3 PMC passes of this kernel source ({summary.get('commit', '?')}), "
-                                        "profiles/r03/pmc_summary.json; the 25 MB of sampled leaves are L2 / Infinity-Cache "
+                                        "profiles/r04/pmc_gather_summary.json; the 25 MB of sampled leaves are L2 / Infinity-Cache "
                                         "resident, the memory-side counters include the cache's hits")
 
 
@@ -394,9 +394,16 @@ def launch_ranks(args) -> int:
     env.setdefault("OMP_NUM_THREADS", "8")
     if args.share_gpu:
         env["CUSRL_SHARE_GPU"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
-    return subprocess.run(cmd, env=env).returncode
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+        done = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(done.stderr)
+        # the port was free when it was picked; somebody (an outgoing connection's source port) may have taken it since:
+        # that, and only that, is retried — before any rank has done work
+        if done.returncode == 0 or "EADDRINUSE" not in done.stderr:
+            return done.returncode
+    return done.returncode
 
 
 def main():

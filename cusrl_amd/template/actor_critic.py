@@ -290,7 +290,10 @@ class ActorCritic(Agent):
                 # once every step replays from its own graph, a whole epoch's steps replay from ONE graph that reads its
                 # index slices in place (template/graphs.py GraphedEpochs); until then — and whenever a condition does
                 # not hold — the steps run graph by graph over the very same permutations
-                drawn = self.sampler.draw_epochs(self.buffer) if hasattr(self.sampler, "draw_epochs") else None
+                from cusrl_amd.template.graphs import epoch_graphs_enabled
+
+                drawn = (self.sampler.draw_epochs(self.buffer)
+                         if epoch_graphs_enabled() and hasattr(self.sampler, "draw_epochs") else None)
                 if drawn is not None and self._graphed_epochs is None:
                     from cusrl_amd.template.graphs import GraphedEpochs
 

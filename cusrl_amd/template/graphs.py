@@ -365,6 +365,13 @@ class GraphedTrainStep:
                 step._record_deferred(sums, replays)
 
 
+def epoch_graphs_enabled() -> bool:
+    """Opt-in (``CUSRL_EPOCH_GRAPHS=1``): measured neutral on config 2 (update 5.82 vs 5.84 ms over 14 interleaved runs on two
+    boxes, profiles/r04/bench_epoch_graphs_ab.txt) — the copy and the replay boundary it removes per step are hidden behind
+    the device-bound GEMM chain — so the default stays one graph per minibatch step."""
+    return os.environ.get("CUSRL_EPOCH_GRAPHS", "0") == "1"
+
+
 class GraphedEpochs:
     """The minibatch steps of ONE epoch back to back as one hipGraph (round 4) — built on top of the per-step graphs once
     every step of an update replays from its own graph, like the whole-rollout graph on top of the per-step env graphs.
@@ -383,7 +390,7 @@ class GraphedEpochs:
         self.stream: torch.cuda.Stream = agent._graph_stream
         self.epochs: dict[tuple, dict] = {}
         self.signature: tuple | None = None
-        self.enabled = os.environ.get("CUSRL_EPOCH_GRAPHS", "1") != "0"
+        self.enabled = epoch_graphs_enabled()
         self.replays = 0
 
     def _steps_of(self, plan_row, permutations, epoch):

@@ -21,16 +21,19 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def _run(tmp_path, world: int, compile_: str, native: str, share_gpu: bool = False, extra_env=None, want_output=False):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "_dist_gpu_worker.py"), str(tmp_path), compile_, native]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if share_gpu:
         env["CUSRL_SHARE_GPU"] = "1"
     env.update(extra_env or {})
-    done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    for _ in range(3):  # a rendezvous port picked free may be taken by the time the store binds it: retry that, only that
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "_dist_gpu_worker.py"), str(tmp_path), compile_, native]
+        done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+        if done.returncode == 0 or "EADDRINUSE" not in done.stderr:
+            break
     assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
     results = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(world)]
     return (results, done.stdout + done.stderr) if want_output else results
