@@ -430,6 +430,14 @@ def main():
             result["cpu_baseline"] = run_cpu_baseline(args)
             result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 2)
         print(json.dumps(result), flush=True)
+    if world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+        # orderly shutdown of a multi-rank job: the line is out; leaving the process group's teardown to interpreter exit
+        # races RCCL's watchdog / proxy threads (a sporadic abort at exit would fail the whole torchrun job)
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        sys.stdout.flush(), sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -53,6 +53,14 @@ def main(out_dir: str, compile_: str, native: str):
         "allgather_calls": _native.launch_counts.get("cusrl_allgather", 0),
     }))
     distributed.barrier()
+    # orderly shutdown: leaving the process group's teardown to interpreter exit races RCCL's watchdog / proxy threads
+    # (sporadic SIGABRT at exit under load, after all results were written)
+    torch.cuda.synchronize()
+    torch.distributed.destroy_process_group()
+    sys.stdout.flush(), sys.stderr.flush()
+    import os
+
+    os._exit(0)
 
 
 if __name__ == "__main__":
