@@ -517,6 +517,57 @@ def test_gae_bit_exact_vs_oracle(ops, T, N, D, lamda_value):
     assert np.array_equal(host(adv), oracle.normalize(oadv, omean, ovar))
 
 
+@pytest.mark.parametrize("policy,block", [("0", "256"), ("5", "256"), ("7", "128"), ("5", "128"), ("7", "256")])
+@pytest.mark.parametrize("lamda_value", [None, 0.9])
+def test_gae_every_cache_policy_and_block_size_is_bit_exact(ops, monkeypatch, policy, block, lamda_value):
+    """The at-scale launch shapes of round 4 (cusrl_gae: cache policy per stream x block size, profiles/r04/gae_policy.md)
+    forced one by one on a rollout large enough to take the 4-columns-per-lane path: a cache policy must not change a bit."""
+    T, N = 6, 262144 + 4 * 37  # >= 4 * 256 * 256 columns, not a multiple of a block
+    rng = np.random.default_rng(int(policy) * 7 + int(block))
+    reward, value, nv = (rng.standard_normal((T, N, 1)).astype(np.float32) for _ in range(3))
+    done = rng.random((T, N, 1)) < 0.05
+    monkeypatch.setenv("CUSRL_GAE_POLICY", policy)
+    monkeypatch.setenv("CUSRL_GAE_BLOCK", block)
+    adv, ret, partials = ops.gae(dev(reward), dev(value), dev(nv), dev(done), 0.99, 0.95, lamda_value)
+    oadv, oret = oracle.gae(reward, done, value, nv, 0.99, 0.95, lamda_value)
+    assert np.array_equal(host(adv), oadv) and np.array_equal(host(ret), oret)
+    var, mean = ops.adv_stats_finalize(partials, T * N)
+    ovar, omean = oracle.var_mean(oadv)
+    np.testing.assert_allclose(host(mean), omean, rtol=1e-5, atol=1e-6)  # 1e-5 rel fp32
+    np.testing.assert_allclose(host(var), ovar, rtol=1e-5)
+
+
+def test_gae_beyond_the_infinity_cache_takes_the_streaming_policy_and_stays_bit_exact(ops):
+    """No override: 16.8 M slots x 21 B = 352 MB > 256 MB, so the launch itself picks non-temporal inputs / `return`."""
+    T, N = 8, 1 << 21
+    rng = np.random.default_rng(5)
+    reward, value, nv = (rng.standard_normal((T, N, 1)).astype(np.float32) for _ in range(3))
+    done = rng.random((T, N, 1)) < 0.02
+    adv, ret, _ = ops.gae(dev(reward), dev(value), dev(nv), dev(done), 0.99, 0.95, None)
+    oadv, oret = oracle.gae(reward, done, value, nv, 0.99, 0.95, None)
+    assert np.array_equal(host(adv), oadv) and np.array_equal(host(ret), oret)
+
+
+@pytest.mark.parametrize("policy", ["0", "3"])
+def test_push_streaming_policy_moves_the_same_bytes(ops, monkeypatch, policy):
+    """cusrl_buffer_push with the non-temporal form forced (it is chosen by footprint beyond the Infinity Cache) against the
+    oracle's slab assignment: every leaf, mixed widths, an unaligned one."""
+    monkeypatch.setenv("CUSRL_PUSH_POLICY", policy)
+    rng = np.random.default_rng(int(policy))
+    N, T = 5000, 3
+    steps = {"observation": rng.standard_normal((N, 48)).astype(np.float32), "action": rng.standard_normal((N, 12)).astype(np.float32),
+             "logp": rng.standard_normal((N, 1)).astype(np.float32), "done": rng.random((N, 1)) < 0.1,
+             "odd": rng.integers(0, 255, (N, 3)).astype(np.uint8)}
+    storage = {k: torch.zeros((T,) + v.shape, dtype=torch.from_numpy(v).dtype, device=DEV) for k, v in steps.items()}
+    expect = {k: np.zeros((T,) + v.shape, v.dtype) for k, v in steps.items()}
+    for cursor in (1, 2):
+        ops.buffer_push([(dev(v), storage[k]) for k, v in steps.items()], cursor, N)
+        for k, v in steps.items():
+            oracle.buffer_push(v, expect[k], cursor)
+    for k in steps:
+        assert np.array_equal(host(storage[k]), expect[k]), k
+
+
 def test_gae_propagates_nonfinite_like_reference(ops):
     # 0 * inf = nan in the reference's `not_done * c * A[t+1]`; the kernel multiplies too instead of selecting
     reward = np.zeros((3, 4, 1), np.float32)
