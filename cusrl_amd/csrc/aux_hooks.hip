@@ -434,6 +434,7 @@ extern "C" int cusrl_amp_style_reward_mean(const float *logit, float *reward, fl
 
 extern "C" int64_t cusrl_mse_loss_num_partials(int64_t n) {
     if (n <= 0) return 0;
+    if (n <= int64_t(kBlock) * 64) return 1;  // small batches (a discriminator batch: 6 K elements): one block finalises itself
     const int64_t want = ceil_div(n, int64_t(kBlock) * 8);
     return want > kMseMaxBlocks ? kMseMaxBlocks : want;
 }

@@ -166,7 +166,10 @@ class ActorCritic(Agent):
             self._graph_pool = torch.cuda.graph_pool_handle()
             # second branch of the captured minibatch step (critic forward / backward, hook/on_policy/value.py)
             self._branch_stream = torch.cuda.Stream(device=self.device)
-            self.concurrent_critic = os.environ.get("CUSRL_CONCURRENT_CRITIC", "1") != "0"
+            # True / False force it; None (default, CUSRL_CONCURRENT_CRITIC unset) = where it measured faster: the stock
+            # composition at minibatches of >= 4096 rows (GraphedTrainStep._critic_branch)
+            forced = os.environ.get("CUSRL_CONCURRENT_CRITIC")
+            self.concurrent_critic = None if forced is None else forced != "0"
             # captured minibatch steps run the fused objective without its one-block finalize launch (ops.DeferredLoss)
             self.defer_loss_finalize = os.environ.get("CUSRL_DEFER_LOSS_FINALIZE", "1") != "0"
             # opt-in: measured 0.1 ms per iteration SLOWER than the 4 us copy into a static index buffer (config 2, A/B on one

@@ -244,6 +244,25 @@ class GraphedTrainStep:
         or a stale host decision into a graph."""
         return "objective" not in eager_phases(self.agent)
 
+    def _critic_branch(self) -> bool:
+        """The critic as a second stream-branch of the captured step: forced by ``agent.concurrent_critic`` (True / False), else
+        only where it measured faster (profiles/r04/configs/config5_concurrent_critic_ab.txt) — the stock objective
+        composition at a minibatch of >= 4096 rows: config 2 update 7.63 -> 6.99 ms and config 3 12.14 -> 11.71 ms per
+        iteration WITH the branch; config 5 (RND + AMP chains in the same step) 16.8-17.4 -> 15.9-16.0 ms and config 1 (32-row
+        minibatches, launch-bound) 4.39 -> 4.08 ms WITHOUT it."""
+        agent = self.agent
+        if agent.concurrent_critic is not None:
+            return bool(agent.concurrent_critic)
+        from cusrl_amd.hook.auxiliary import AdversarialMotionPrior, RandomNetworkDistillation
+        from cusrl_amd.hook.on_policy.fused import FusedPpoObjective
+
+        if FusedPpoObjective.mode(agent.hook) != "fused":
+            return False
+        if any(hook._active and isinstance(hook, (AdversarialMotionPrior, RandomNetworkDistillation)) for hook in agent.hook):
+            return False
+        rows = 0 if self.static_indices is None else self.static_indices.numel() * (agent.buffer.capacity if self.temporal else 1)
+        return rows >= 4096
+
     def _whole_step(self):
         self._phase_a()
         if self.graph_collectives:
@@ -259,7 +278,7 @@ class GraphedTrainStep:
         agent.actor.clear_intermediate_repr()
         agent.critic.clear_intermediate_repr()
         agent.hook.pre_objective(self.metadata, batch)
-        agent._critic_stream = agent._branch_stream if agent.concurrent_critic else None
+        agent._critic_stream = agent._branch_stream if self._critic_branch() else None
         agent._deferred_loss_owner = self if agent.defer_loss_finalize else None
         try:
             with agent.autocast():
