@@ -5,11 +5,22 @@
 // products are plain FMAs on data already in registers, so ONE pass does all three: a lane owns one 16 B chunk of
 // the K axis, keeps its O x 4 slice of W and of the dW accumulator in VGPRs, streams X rows (coalesced float4,
 // 4 rows in flight), writes dX and accumulates dW / db.  HBM traffic = X read + dX write (+ dY), the floor.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace cusrl {
 
-constexpr int kHeadRowsPerBlock = 96;  // 24576-row minibatch = 256 blocks = one per CU (64: +1.5 us, 128: +2 us measured)
+// rows of the minibatch one block reduces: 96 -> a 24576-row minibatch is 256 blocks, one per CU (CUSRL_HEAD_ROWS overrides
+// it for sweeps: profiles/r04/narrow_head_rows.txt)
+static int head_rows_per_block() {
+    static const int rows = [] {
+        const char *e = getenv("CUSRL_HEAD_ROWS");
+        const int v = e ? atoi(e) : 0;
+        return v >= 8 && v <= 4096 ? v : 96;
+    }();
+    return rows;
+}
 constexpr int head_batch(int O) { return O > 8 ? 2 : 4; }  // X rows in flight per lane (VGPR budget: O x 12 + ...)
 constexpr int kHeadBiasPad = 16;  // db rides behind dW in the same partial row, padded to keep float4 alignment
 
@@ -21,19 +32,21 @@ __global__ __launch_bounds__(kBlock) void narrow_linear_bwd_kernel(const float *
                                                                    const float *__restrict__ input,
                                                                    const float *__restrict__ weight,
                                                                    float *__restrict__ grad_input,
-                                                                   float *__restrict__ partials, int64_t rows, int K) {
-    extern __shared__ float4 red[];  // [(groups - 1)][O + 1][lpr] dW (+ masked-dX column sum) slices, then [16][16] db
+                                                                   float *__restrict__ partials, int64_t rows, int K,
+                                                                   int rows_per_block) {
+    extern __shared__ float4 red[];  // [groups][O + 1][lpr] dW (+ masked-dX column sum) slices, then [groups][16] db
     constexpr int SL = O + 1;        // accumulator slices per lane: O rows of dW and the column sums of the masked dX
     const int lpr = K / 4;
     const int groups = kBlock / lpr;
     const int col = threadIdx.x % lpr, sub = threadIdx.x / lpr;
-    const int64_t row0 = int64_t(blockIdx.x) * kHeadRowsPerBlock;
-    const int64_t row_end = min(row0 + kHeadRowsPerBlock, rows);
+    const int64_t row0 = int64_t(blockIdx.x) * rows_per_block;
+    const int64_t row_end = min(row0 + rows_per_block, rows);
 
     constexpr int kHeadBatch = head_batch(O);
     float4 w[O], dw[SL];
+    float db[O];  // every lane of a row group reads the same dY row: each keeps the group's db sums (O adds per row)
 #pragma unroll
-    for (int o = 0; o < O; ++o) w[o] = reinterpret_cast<const float4 *>(weight)[o * lpr + col];
+    for (int o = 0; o < O; ++o) w[o] = reinterpret_cast<const float4 *>(weight)[o * lpr + col], db[o] = 0.f;
 #pragma unroll
     for (int o = 0; o < SL; ++o) dw[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t base = row0 + sub; base < row_end; base += int64_t(kHeadBatch) * groups) {
@@ -64,6 +77,7 @@ __global__ __launch_bounds__(kBlock) void narrow_linear_bwd_kernel(const float *
 #pragma unroll
             for (int o = 0; o < O; ++o) {
                 const float go = live[k] ? g[k][o] : 0.f;
+                db[o] += go;
                 dx.x = fmaf(go, w[o].x, dx.x), dx.y = fmaf(go, w[o].y, dx.y);
                 dx.z = fmaf(go, w[o].z, dx.z), dx.w = fmaf(go, w[o].w, dx.w);
                 dw[o].x = fmaf(go, x[k].x, dw[o].x), dw[o].y = fmaf(go, x[k].y, dw[o].y);
@@ -78,36 +92,34 @@ __global__ __launch_bounds__(kBlock) void narrow_linear_bwd_kernel(const float *
         }
     }
 
-    // combine the row groups of the block in fixed order: groups 1.. park their slices in LDS, group 0 adds them up
-    float *red_bias = reinterpret_cast<float *>(red + (groups - 1) * SL * lpr);  // [16 row parts][16 outputs]
-    if (sub > 0) {
+    // combine the row groups of the block in fixed order (group 0 first): every group parks its slices in LDS, then the
+    // SL x lpr float4 outputs are spread over ALL lanes of the block (2 outputs x `groups` LDS reads per lane at K = 128,
+    // O = 12 — round 3 had the 32 lanes of group 0 walk 13 x 7 reads each while the other three waves had retired)
+    float *red_bias = reinterpret_cast<float *>(red + groups * SL * lpr);  // [groups][16 outputs]
 #pragma unroll
-        for (int o = 0; o < SL; ++o) red[((sub - 1) * SL + o) * lpr + col] = dw[o];
-    }
-    {   // db: the block's dY rows were just read (L1/L2 hits); lane (part, o) sums rows part, part + 16, ...
-        const int o = threadIdx.x & 15, part = threadIdx.x >> 4;
-        float total = 0.f;
-        if (o < O)
-            for (int64_t row = row0 + part; row < row_end; row += 16) total += grad_out[row * O + o];
-        red_bias[part * 16 + o] = total;
+    for (int o = 0; o < SL; ++o) red[(sub * SL + o) * lpr + col] = dw[o];
+    if (col == 0) {
+#pragma unroll
+        for (int o = 0; o < kHeadBiasPad; ++o) red_bias[sub * kHeadBiasPad + o] = 0.f;
+#pragma unroll
+        for (int o = 0; o < O; ++o) red_bias[sub * kHeadBiasPad + o] = db[o];
     }
     __syncthreads();
     float *out = partials + int64_t(blockIdx.x) * (SL * K + kHeadBiasPad);
-    if (sub == 0) {
-#pragma unroll
-        for (int o = 0; o < SL; ++o) {
-            float4 total = dw[o];
-            for (int s = 1; s < groups; ++s) {
-                const float4 v = red[((s - 1) * SL + o) * lpr + col];
-                total.x += v.x, total.y += v.y, total.z += v.z, total.w += v.w;
-            }
-            reinterpret_cast<float4 *>(out)[o * lpr + col] = total;
+    const int slab = SL * lpr;  // float4 outputs of the block (dW rows, then the masked-dX column sums)
+    for (int i = threadIdx.x; i < slab; i += kBlock) {
+        float4 total = red[i];
+#pragma unroll 8
+        for (int s = 1; s < groups; ++s) {
+            const float4 v = red[s * slab + i];
+            total.x += v.x, total.y += v.y, total.z += v.z, total.w += v.w;
         }
+        reinterpret_cast<float4 *>(out)[i] = total;
     }
     if (threadIdx.x >= kBlock - kHeadBiasPad) {  // the last 16 threads finish db (columns >= O are zero padding)
         const int o = threadIdx.x - (kBlock - kHeadBiasPad);
         float total = 0.f;
-        for (int part = 0; part < 16; ++part) total += red_bias[part * 16 + o];
+        for (int s = 0; s < groups; ++s) total += red_bias[s * kHeadBiasPad + o];
         out[SL * K + o] = total;
     }
 }
@@ -157,14 +169,14 @@ template <int O, bool kReluInput>
 static int launch_narrow_bwd_as(const float *grad_out, const float *input, const float *weight, float *grad_input,
                                 float *partials, int64_t rows, int K, int64_t blocks, hipStream_t s) {
     const int lpr = K / 4, groups = kBlock / lpr;
-    const size_t lds = size_t(groups - 1) * (O + 1) * lpr * sizeof(float4) + 256 * sizeof(float);
+    const size_t lds = size_t(groups) * (O + 1) * lpr * sizeof(float4) + size_t(groups) * kHeadBiasPad * sizeof(float);
     if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in (the CU has 160 KB)
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&narrow_linear_bwd_kernel<O, kReluInput>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (err != hipSuccess) return int(err);
     }
     hipLaunchKernelGGL((narrow_linear_bwd_kernel<O, kReluInput>), dim3(uint32_t(blocks)), dim3(kBlock), lds, s, grad_out,
-                       input, weight, grad_input, partials, rows, K);
+                       input, weight, grad_input, partials, rows, K, head_rows_per_block());
     return launch_status();
 }
 
@@ -182,7 +194,7 @@ extern "C" int cusrl_narrow_linear_supported(int64_t in_features, int64_t out_fe
 }
 
 extern "C" int64_t cusrl_narrow_linear_num_partials(int64_t rows) {
-    return rows <= 0 ? 0 : cusrl::ceil_div(rows, cusrl::kHeadRowsPerBlock);
+    return rows <= 0 ? 0 : cusrl::ceil_div(rows, int64_t(cusrl::head_rows_per_block()));
 }
 
 extern "C" int cusrl_narrow_linear_bwd(const float *grad_out, const float *input, const float *weight,
@@ -197,7 +209,7 @@ extern "C" int cusrl_narrow_linear_bwd(const float *grad_out, const float *input
         return CUSRL_E_UNSUPPORTED;
     hipStream_t s = as_stream(stream);
     const int K = int(in_features);
-    const int64_t blocks = ceil_div(rows, kHeadRowsPerBlock);
+    const int64_t blocks = ceil_div(rows, int64_t(head_rows_per_block()));
     const bool relu = relu_input != 0;
     int rc = 0;
     switch (out_features) {

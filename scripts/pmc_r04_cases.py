@@ -10,6 +10,8 @@ name + ordinal in dispatch order, which this script records in ``<out>/cases.jso
   next_value_1m, normalize_1m        the launches in front of and behind the scan
   push_1m                            one step of all 11 leaves of the ppo transition (1.14 GB)
   gae_config2                        the config-2 launch (4096 envs: latency-bound, cache-resident)
+  narrow_head_bwd_12_config2         cusrl::narrow_linear_bwd_kernel<12> at B = 24 576 (0.20 of the roofline: counters first)
+  relu_bwd_colsum_256_config2        cusrl::colsum_chunked_kernel<true> at [24 576, 256] (the largest cusrl:: kernel of config 2)
 
 hot  = launches back to back.  cold = 1 GiB of fresh writes in front of every launch (the cache state a kernel meets in
 an update: full of somebody else's dirty lines).
@@ -100,6 +102,12 @@ def main(out_dir):
     done = torch.rand(T, N, 1, device=DEV) < 0.015
     adv, ret = torch.empty_like(reward), torch.empty_like(reward)
     run("gae_config2", "gae_kernel", lambda: ops.gae(reward, value, nv, done, 0.99, 0.95, None, adv, ret), 21 * S)
+    # ---- the two largest non-GEMM kernels of a config-2 minibatch step (callers of the path: MLP backward epilogues)
+    B = 24576
+    g12, h128, w12 = f(B, 12), torch.relu(f(B, 128)), f(12, 128)
+    run("narrow_head_bwd_12_config2", "narrow_linear_bwd_kernel", lambda: ops.narrow_linear_backward(g12, h128, w12), B * 4 * (12 + 256))
+    g256, y256 = f(B, 256), torch.relu(f(B, 256))
+    run("relu_bwd_colsum_256_config2", "colsum_chunked_kernel", lambda: ops.relu_backward_bias(g256, y256), B * 256 * 12)
     Path(out_dir).mkdir(parents=True, exist_ok=True)
     Path(out_dir, "cases.json").write_text(json.dumps(cases, indent=1))
 

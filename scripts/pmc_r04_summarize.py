@@ -57,6 +57,13 @@ def main(directory, out_path):
             d["wait_share"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
             d["issue_share"] = round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
             d["issue_stall_share"] = round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
+        if c.get("SQ_WAVE_CYCLES") and c.get("SQ_ACTIVE_INST_VALU") is not None:
+            d["valu_share"] = round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 3)
+            d["lds_share"] = round(c.get("SQ_ACTIVE_INST_LDS", 0.0) / c["SQ_WAVE_CYCLES"], 3)
+            d["vmem_share"] = round(c.get("SQ_ACTIVE_INST_VMEM", 0.0) / c["SQ_WAVE_CYCLES"], 3)
+            d["lds_issue_stall_share"] = round(c.get("SQ_WAIT_INST_LDS", 0.0) / c["SQ_WAVE_CYCLES"], 3)
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            d["lds_bank_conflict_share"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 3)
         if c.get("TCP_TCC_READ_REQ_sum"):
             d["read_latency_cycles"] = round(c.get("TCP_TCC_READ_REQ_LATENCY_sum", 0.0) / c["TCP_TCC_READ_REQ_sum"], 1)
         if c.get("TCP_TCC_WRITE_REQ_sum"):
