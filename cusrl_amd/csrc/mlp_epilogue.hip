@@ -1,11 +1,21 @@
 // Backward epilogues of the actor-critic MLP for gfx950: ReLU mask + bias gradient (column sums) in one pass.
 // autograd runs threshold_backward (read g, y; write g') and then sum(0) (read g') as two kernels — 23.8 + 11.7 us
 // for a [24576, 256] layer; here g and y are read once, g' written once, and the column sums ride along.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace cusrl {
 
-constexpr int kColRowsPerBlock = 64;  // rows of the matrix one block reduces (24576 rows -> 384 blocks)
+// rows of the matrix one block reduces (64: 24576 rows -> 384 blocks); CUSRL_COLSUM_ROWS overrides it for sweeps
+static int col_rows_per_block() {
+    static const int rows = [] {
+        const char *e = getenv("CUSRL_COLSUM_ROWS");
+        const int v = e ? atoi(e) : 0;
+        return v >= 4 && v <= 4096 ? v : 64;
+    }();
+    return rows;
+}
 constexpr int kColBatch = 4;          // row passes whose loads are issued together
 
 __device__ __forceinline__ void pin4(float4 (&r)[kColBatch]) {
@@ -21,12 +31,13 @@ template <bool kMask>
 __global__ __launch_bounds__(kBlock) void colsum_chunked_kernel(const float *__restrict__ grad,
                                                                 const float *__restrict__ output,
                                                                 float *__restrict__ grad_in,
-                                                                float *__restrict__ partials, int64_t rows, int H) {
+                                                                float *__restrict__ partials, int64_t rows, int H,
+                                                                int rows_per_block) {
     const int lpr = H / 4;                   // 16 B chunks per row
     const int rows_per_pass = kBlock / lpr;  // rows covered by the block per pass
     const int col = threadIdx.x % lpr, sub = threadIdx.x / lpr;
-    const int64_t row0 = int64_t(blockIdx.x) * kColRowsPerBlock;
-    const int64_t row_end = min(row0 + kColRowsPerBlock, rows);
+    const int64_t row0 = int64_t(blockIdx.x) * rows_per_block;
+    const int64_t row_end = min(row0 + rows_per_block, rows);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t base = row0 + sub; base < row_end; base += int64_t(kColBatch) * rows_per_pass) {
         float4 g[kColBatch], y[kColBatch];
@@ -153,7 +164,7 @@ using namespace cusrl;
 
 extern "C" int64_t cusrl_colsum_num_partials(int64_t rows, int64_t H) {
     if (rows <= 0 || H <= 0) return 0;
-    return colsum_chunked(H) ? ceil_div(rows, kColRowsPerBlock) : ceil_div(rows, int64_t(kBlock) * 4);
+    return colsum_chunked(H) ? ceil_div(rows, int64_t(cusrl::col_rows_per_block())) : ceil_div(rows, int64_t(kBlock) * 4);
 }
 
 extern "C" int cusrl_relu_bwd_colsum(const float *grad, const float *output, float *grad_in, float *partials,
@@ -169,10 +180,10 @@ extern "C" int cusrl_relu_bwd_colsum(const float *grad, const float *output, flo
     if (chunked) {
         if (output)
             hipLaunchKernelGGL(colsum_chunked_kernel<true>, dim3(uint32_t(P)), dim3(kBlock), 0, s, grad, output, grad_in,
-                               partials, rows, int(H));
+                               partials, rows, int(H), col_rows_per_block());
         else
             hipLaunchKernelGGL(colsum_chunked_kernel<false>, dim3(uint32_t(P)), dim3(kBlock), 0, s, grad, output, grad_in,
-                               partials, rows, int(H));
+                               partials, rows, int(H), col_rows_per_block());
     } else {
         if (!colsum) return CUSRL_E_UNSUPPORTED;  // partials-only mode exists for the chunked layout
         // the partial count was sized for the layout chosen by H alone; recompute for the row-wise launch shape
