@@ -246,10 +246,16 @@ class GraphedTrainStep:
 
     def _critic_branch(self) -> bool:
         """The critic as a second stream-branch of the captured step: forced by ``agent.concurrent_critic`` (True / False), else
-        only where it measured faster (profiles/r04/configs/config5_concurrent_critic_ab.txt) — the stock objective
-        composition at a minibatch of >= 4096 rows: config 2 update 7.63 -> 6.99 ms and config 3 12.14 -> 11.71 ms per
-        iteration WITH the branch; config 5 (RND + AMP chains in the same step) 16.8-17.4 -> 15.9-16.0 ms and config 1 (32-row
-        minibatches, launch-bound) 4.39 -> 4.08 ms WITHOUT it."""
+        on — the form every composition has been validated in since round 2 — except for the stock objective composition at
+        a minibatch below 4096 rows (launch-bound: config 1, 32-row minibatches, 4.39 -> 4.08 ms without the branch; config 2
+        update 7.63 -> 6.99 ms and config 3 12.14 -> 11.71 ms WITH it).
+
+        Compositions with an RND / AMP objective keep the branch although config 5 measured 16.8-17.4 -> 15.9-16.0 ms
+        without it (profiles/r04/configs/config5_concurrent_critic_ab.txt): the single-stream form of the AMP step is NOT
+        bit-reproducible run to run — tests/test_captured_rollout.py caught it; scripts/debug_amp_identity.py shows two
+        critic bias-gradient slots picking up the bytes of other small tensors of the same captured step (a 4-byte and a
+        512-byte overlap, the signature of a block reused while still referenced by a captured kernel).  Until that is
+        root-caused the single-stream form stays behind CUSRL_CONCURRENT_CRITIC=0 for those compositions."""
         agent = self.agent
         if agent.concurrent_critic is not None:
             return bool(agent.concurrent_critic)
@@ -259,7 +265,7 @@ class GraphedTrainStep:
         if FusedPpoObjective.mode(agent.hook) != "fused":
             return False
         if any(hook._active and isinstance(hook, (AdversarialMotionPrior, RandomNetworkDistillation)) for hook in agent.hook):
-            return False
+            return True
         rows = 0 if self.static_indices is None else self.static_indices.numel() * (agent.buffer.capacity if self.temporal else 1)
         return rows >= 4096
 

@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Debug: where do the host-driven and the captured amp runs of tests/test_captured_rollout.py diverge?"""
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+import cusrl_amd as cusrl  # noqa: E402
+
+DEV = "cuda:0"
+if os.environ.get("DEBUG_DETERMINISTIC") == "1":
+    torch.use_deterministic_algorithms(True, warn_only=True)
+cusrl.config.set_device(DEV)
+
+
+def factory(T):
+    if os.environ.get("DEBUG_KIND") == "continuous":
+        return cusrl.preset.PpoAgentFactory(num_steps_per_update=T, sampler_epochs=2, sampler_mini_batches=2,
+                                            compile=os.environ.get("DEBUG_COMPILE", "1") != "0",
+                                            optimizer_kwargs={"capturable": True, "fused": True})
+    k = 6
+    dataset = torch.randn(4096, 2 * k, device=DEV)
+    return cusrl.preset.AmpAgentFactory(amp_dataset_source=dataset, amp_state_indices=slice(k), extrinsic_reward_scale=0.5,
+                                        amp_reward_scale=2.0, num_steps_per_update=T, sampler_epochs=2, sampler_mini_batches=2,
+                                        compile=os.environ.get("DEBUG_COMPILE", "1") != "0", optimizer_kwargs={"capturable": True, "fused": True})
+
+
+def run(capture, iterations, T=8, N=256):
+    cusrl.set_global_seed(21)
+    env = cusrl.testing.DummyTorchEnvironment(num_instances=N, observation_dim=12, action_dim=4, device=DEV)
+    trainer = cusrl.Trainer(env, factory(T), num_iterations=iterations, verbose=False)
+    trainer.capture_rollout = capture
+    trainer.run_training_loop()
+    torch.cuda.synchronize()
+    return trainer
+
+
+def state(trainer):
+    agent = trainer.agent
+    out = {f"param/{n}": p.detach().clone() for n, p in agent.named_parameters()}
+    out.update({f"buffer/{k}": v.clone() for k, v in agent.buffer.storage.items()})
+    for hook in agent.hook:
+        for name, module in getattr(hook, "named_modules", lambda: [])():
+            pass
+        for attr in ("state_rms", "_state_rms", "rms", "transition_rms"):
+            m = getattr(hook, attr, None)
+            if m is not None and hasattr(m, "mean"):
+                out[f"{type(hook).__name__}.{attr}.mean"] = m.mean.clone()
+                out[f"{type(hook).__name__}.{attr}.var"] = m.var.clone()
+                out[f"{type(hook).__name__}.{attr}.count"] = m._count.clone()
+    for i, group in enumerate(agent.optimizer.state.values()):
+        for k, v in group.items():
+            if torch.is_tensor(v):
+                out[f"optim/{i}/{k}"] = v.clone()
+    out["cuda_rng"] = torch.cuda.get_rng_state(0)[-16:].clone()
+    return out
+
+
+def poison():
+    """Fill the caching allocator's free blocks with NaN so that a read of uninitialised memory shows."""
+    blocks = [torch.full((1 << 26,), float("nan"), device=DEV) for _ in range(8)]
+    small = [torch.full((n,), float("nan"), device=DEV) for n in (16, 64, 256, 1024, 4096, 16384, 65536, 1 << 18, 1 << 20) for _ in range(64)]
+    del blocks, small
+    torch.cuda.synchronize()
+
+
+def summarize(tag, a, b):
+    bad = [k for k in a if k in b and a[k].shape == b[k].shape and not torch.equal(a[k], b[k])]
+    nan = [k for k in b if b[k].is_floating_point() and torch.isnan(b[k]).any()]
+    groups = {}
+    for k in bad:
+        groups[k.split("/")[0]] = groups.get(k.split("/")[0], 0) + 1
+    print(f"{tag}: differ {groups} buffers {[k for k in bad if k.startswith('buffer/')]} other {[k for k in bad if not k.startswith(('buffer/', 'param/', 'optim/'))]}; NaN {nan[:6]}", flush=True)
+
+
+class Snap(cusrl.Trainer.Hook):
+    def __init__(self):
+        self.snaps = []
+
+    def post_update(self):
+        torch.cuda.synchronize()
+        self.snaps.append(state(self.trainer))
+
+
+def run_snap(capture, iterations, T=8, N=256):
+    cusrl.set_global_seed(21)
+    env = cusrl.testing.DummyTorchEnvironment(num_instances=N, observation_dim=12, action_dim=4, device=DEV)
+    hook = Snap()
+    trainer = cusrl.Trainer(env, factory(T), num_iterations=iterations, verbose=False, hooks=[hook])
+    trainer.capture_rollout = capture
+    trainer.run_training_loop()
+    return hook.snaps
+
+
+from cusrl_amd.template import graphs as _graphs  # noqa: E402
+
+RECORD = []
+_orig_run = _graphs.GraphedTrainStep.run
+
+
+def _wrapped(self, metadata, indices, *a, **k):
+    out = _orig_run(self, metadata, indices, *a, **k)
+    torch.cuda.synchronize()
+    agent = self.agent
+    carry = getattr(self, "carry", None) or {}
+    RECORD.append({"state": self.state, "grad": agent.flat_gradients.buffer.clone(), "indices": indices.clone(),
+                   "params": torch.cat([p.detach().reshape(-1) for p in agent.flat_gradients.params])})
+    return out
+
+
+_graphs.GraphedTrainStep.run = _wrapped
+
+
+def run_rec(n):
+    RECORD.clear()
+    cusrl.set_global_seed(21)
+    env = cusrl.testing.DummyTorchEnvironment(num_instances=256, observation_dim=12, action_dim=4, device=DEV)
+    trainer = cusrl.Trainer(env, factory(8), num_iterations=n, verbose=False)
+    trainer.capture_rollout = False
+    trainer.run_training_loop()
+    flat = trainer.agent.flat_gradients
+    names = {id(p): n for n, p in trainer.agent.named_parameters()}
+    segments = []
+    offset = 0
+    for p in flat.params:
+        segments.append((names.get(id(p), "?"), offset, offset + p.numel()))
+        offset += p.numel()
+    return list(RECORD), segments
+
+
+n_it = int(os.environ.get('DEBUG_ITERATIONS', '4'))
+a, seg = run_rec(n_it)
+b, _ = run_rec(n_it)
+print(f"{len(a)} steps recorded; DEBUG_DETERMINISTIC={os.environ.get('DEBUG_DETERMINISTIC')}")
+for i, (x, y) in enumerate(zip(a, b)):
+    same_idx = torch.equal(x["indices"], y["indices"])
+    same_grad = torch.equal(x["grad"], y["grad"])
+    same_par = torch.equal(x["params"], y["params"])
+    if not (same_idx and same_grad and same_par):
+        print(f"step {i}: graph state after {x['state']}/{y['state']} indices equal {same_idx} grads equal {same_grad} params equal {same_par}")
+    if not same_grad:
+        for name, s0, e0 in seg:
+            d = (x["grad"][s0:e0].double() - y["grad"][s0:e0].double()).abs()
+            if d.max() > 0:
+                xs, ys = x["grad"][s0:e0], y["grad"][s0:e0]
+                print(f"     {name}: max abs diff {d.max().item():.3e} ({int((d > 0).sum())}/{d.numel()}); run1 norm {xs.norm().item():.4e} run2 norm {ys.norm().item():.4e}")
+                for j in range(max(0, i - 3), i):
+                    print(f"         vs step {j}: run1==run1[{j}] {torch.equal(xs, a[j]['grad'][s0:e0])}, run2==run2[{j}] {torch.equal(ys, b[j]['grad'][s0:e0])}, "
+                          f"run1==run2[{j}] {torch.equal(xs, b[j]['grad'][s0:e0])}; norms at {j}: {a[j]['grad'][s0:e0].norm().item():.4e}")
+                print(f"         run1 head {xs[:6].tolist()}")
+                print(f"         run2 head {ys[:6].tolist()}")
+        break
+else:
+    print("all recorded steps bit-identical between the two runs")
