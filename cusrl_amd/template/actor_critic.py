@@ -166,8 +166,8 @@ class ActorCritic(Agent):
             self._graph_pool = torch.cuda.graph_pool_handle()
             # second branch of the captured minibatch step (critic forward / backward, hook/on_policy/value.py)
             self._branch_stream = torch.cuda.Stream(device=self.device)
-            # True / False force it; None (default, CUSRL_CONCURRENT_CRITIC unset) = where it measured faster: the stock
-            # composition at minibatches of >= 4096 rows (GraphedTrainStep._critic_branch)
+            # True / False force it; None (default, CUSRL_CONCURRENT_CRITIC unset) = the branch whenever the objective is the
+            # fused one (GraphedTrainStep._critic_branch: the single-stream form is not bit-reproducible yet)
             forced = os.environ.get("CUSRL_CONCURRENT_CRITIC")
             self.concurrent_critic = None if forced is None else forced != "0"
             # captured minibatch steps run the fused objective without its one-block finalize launch (ops.DeferredLoss)

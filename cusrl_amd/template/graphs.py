@@ -246,28 +246,21 @@ class GraphedTrainStep:
 
     def _critic_branch(self) -> bool:
         """The critic as a second stream-branch of the captured step: forced by ``agent.concurrent_critic`` (True / False), else
-        on — the form every composition has been validated in since round 2 — except for the stock objective composition at
-        a minibatch below 4096 rows (launch-bound: config 1, 32-row minibatches, 4.39 -> 4.08 ms without the branch; config 2
-        update 7.63 -> 6.99 ms and config 3 12.14 -> 11.71 ms WITH it).
+        on whenever the objective is the fused one — the form every composition has been validated in since round 2.
 
-        Compositions with an RND / AMP objective keep the branch although config 5 measured 16.8-17.4 -> 15.9-16.0 ms
-        without it (profiles/r04/configs/config5_concurrent_critic_ab.txt): the single-stream form of the AMP step is NOT
-        bit-reproducible run to run — tests/test_captured_rollout.py caught it; scripts/debug_amp_identity.py shows two
-        critic bias-gradient slots picking up the bytes of other small tensors of the same captured step (a 4-byte and a
-        512-byte overlap, the signature of a block reused while still referenced by a captured kernel).  Until that is
-        root-caused the single-stream form stays behind CUSRL_CONCURRENT_CRITIC=0 for those compositions."""
+        The single-stream form measured faster for launch-bound steps (config 1, 32-row minibatches: 4.39 -> 4.08 ms; config 5,
+        RND + AMP chains in the same step: 16.8-17.4 -> 15.6-16.0 ms; profiles/r04/configs/config5_concurrent_critic_ab.txt)
+        and slower for config 2 / 3 (6.99 vs 7.63, 11.71 vs 12.14 ms), but it is NOT bit-reproducible run to run:
+        tests/test_captured_rollout.py caught it for the AMP composition, scripts/debug_amp_identity.py shows the stock
+        composition has it too — single words of critic bias-gradient slots come back as never-initialised bytes plus 16,
+        a second slot as stale data (open defect).  Until that is root-caused the single-stream form
+        stays behind CUSRL_CONCURRENT_CRITIC=0."""
         agent = self.agent
         if agent.concurrent_critic is not None:
             return bool(agent.concurrent_critic)
-        from cusrl_amd.hook.auxiliary import AdversarialMotionPrior, RandomNetworkDistillation
         from cusrl_amd.hook.on_policy.fused import FusedPpoObjective
 
-        if FusedPpoObjective.mode(agent.hook) != "fused":
-            return False
-        if any(hook._active and isinstance(hook, (AdversarialMotionPrior, RandomNetworkDistillation)) for hook in agent.hook):
-            return True
-        rows = 0 if self.static_indices is None else self.static_indices.numel() * (agent.buffer.capacity if self.temporal else 1)
-        return rows >= 4096
+        return FusedPpoObjective.mode(agent.hook) == "fused"
 
     def _whole_step(self):
         self._phase_a()
