@@ -749,3 +749,39 @@ def test_recurrent_step_gemm_rows_are_bucketed_to_256_and_capped_by_the_batch():
 
     assert [_gemm_rows(n, 5536) for n in (1, 255, 256, 257, 4100, 5376, 5377, 5536)] == [256, 256, 256, 512, 4352, 5376, 5536, 5536]
     assert _gemm_rows(7, 7) == 7 and _gemm_rows(100, 100) == 100
+
+
+def test_critic_stream_branch_is_the_default_of_every_fused_composition(monkeypatch):
+    """GraphedTrainStep._critic_branch: forced by ``agent.concurrent_critic``; unset, the branch whenever the objective is
+    the fused one — the single-stream form of the captured step is not bit-reproducible yet, whatever
+    the minibatch size and whichever auxiliary objectives share the step."""
+    from types import SimpleNamespace
+
+    from cusrl_amd.hook.on_policy.fused import FusedPpoObjective
+    from cusrl_amd.template.graphs import GraphedTrainStep
+
+    mode = {"value": "fused"}
+    monkeypatch.setattr(FusedPpoObjective, "mode", staticmethod(lambda composite: mode["value"]))
+    step = GraphedTrainStep.__new__(GraphedTrainStep)
+    step.agent = SimpleNamespace(concurrent_critic=None, hook=[], buffer=SimpleNamespace(capacity=8))
+    step.static_indices, step.temporal = torch.zeros(32, dtype=torch.int64), False  # a launch-bound 32-row minibatch
+    assert step._critic_branch()
+    mode["value"] = "split"  # further objective hooks read curr_value on the main stream: one stream by construction
+    assert not step._critic_branch()
+    mode["value"] = None
+    assert not step._critic_branch()
+    mode["value"] = "fused"
+    step.agent.concurrent_critic = False
+    assert not step._critic_branch()
+    step.agent.concurrent_critic, mode["value"] = True, None
+    assert step._critic_branch()
+
+
+def test_every_script_and_package_module_compiles():
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    files = sorted(root.glob("scripts/*.py")) + sorted(root.glob("cusrl_amd/**/*.py")) + [root / "bench.py", root / "__graft_entry__.py"]
+    assert len(files) > 40
+    for file in files:
+        compile(file.read_text(), str(file), "exec")  # SyntaxError names the file
