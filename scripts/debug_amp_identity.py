@@ -1,5 +1,16 @@
 #!/usr/bin/env python3
-"""Debug: where do the host-driven and the captured amp runs of tests/test_captured_rollout.py diverge?"""
+"""Where do two runs of the same seeded training diverge?  (The single-stream form of the captured minibatch step is not
+bit-reproducible: DESIGN.md section 5, open defect; logs in profiles/r04/amp_identity/.)
+
+Two host-driven runs of the tests/test_captured_rollout.py workload (N = 256, T = 8, 2 epochs x 2 minibatches) in one process;
+the flat gradient buffer, the parameters and the index slice are recorded behind every minibatch step and compared.
+
+    CUSRL_CONCURRENT_CRITIC=0 python scripts/debug_amp_identity.py          # AMP composition, single-stream steps
+    CUSRL_CONCURRENT_CRITIC=0 DEBUG_KIND=continuous DEBUG_ITERATIONS=8 ...   # the stock composition needs a few more iterations
+    DEBUG_INGRAPH=1 ...            # + snapshots inside the captured step: behind the assembly, and of its deferred sources
+    DEBUG_DETERMINISTIC=1 ...      # torch.use_deterministic_algorithms(True, warn_only=True): empty tensors are NaN-filled
+    DEBUG_COMPILE=0 ...            # no hipGraphs at all
+"""
 import os
 import sys
 from pathlib import Path
@@ -112,6 +123,51 @@ def _wrapped(self, metadata, indices, *a, **k):
 
 _graphs.GraphedTrainStep.run = _wrapped
 
+# DEBUG_INGRAPH=1: persistent snapshots taken INSIDE the step (captured with it): the flat buffer right behind the assembly
+# launch, and every deferred partial buffer the assembly is about to reduce — tells whether the foreign words are already in
+# the assembly's sources, appear in its output, or are written behind it (Adam, taps).  Also prints, once per captured step,
+# the address range of every deferred partial buffer.
+if os.environ.get("DEBUG_INGRAPH") == "1":
+    from cusrl_amd import ops as _ops
+    from cusrl_amd.utils import distributed as _dist
+
+    _orig_assemble = _dist.FlatGradients.assemble
+
+    def _assemble(self, grads, split_slabs=None):
+        snaps = self.__dict__.setdefault("_debug_sources", {})
+        capturing = torch.cuda.is_current_stream_capturing()
+        for key, slabs in (split_slabs or {}).items():
+            if isinstance(slabs, _ops.DeferredColumns):
+                tag = (key, slabs.column)
+                if tag not in snaps:
+                    if capturing:
+                        continue  # (created by the eager warm-up; a shape first seen while capturing is skipped)
+                    snaps[tag] = torch.empty_like(slabs.partials)
+                if snaps[tag].shape == slabs.partials.shape:
+                    snaps[tag].copy_(slabs.partials)
+                if capturing:
+                    lo = slabs.partials.data_ptr()
+                    print(f"      capture: partials of param@{key:#x} column {slabs.column}: [{lo:#x}, {lo + slabs.partials.numel() * 4:#x}) "
+                          f"{tuple(slabs.partials.shape)} splits {slabs.splits}", flush=True)
+        _orig_assemble(self, grads, split_slabs)
+        if "_debug_after_assemble" not in self.__dict__:
+            if capturing:
+                return
+            self._debug_after_assemble = torch.empty_like(self.buffer)
+        self._debug_after_assemble.copy_(self.buffer)
+
+    _dist.FlatGradients.assemble = _assemble
+    _prev_wrapped = _graphs.GraphedTrainStep.run
+
+    def _wrapped_ingraph(self, metadata, indices, *a, **k):
+        out = _prev_wrapped(self, metadata, indices, *a, **k)
+        flat = self.agent.flat_gradients
+        RECORD[-1]["after_assemble"] = flat.__dict__.get("_debug_after_assemble", flat.buffer).clone()
+        RECORD[-1]["sources"] = {tag: t.clone() for tag, t in flat.__dict__.get("_debug_sources", {}).items()}
+        return out
+
+    _graphs.GraphedTrainStep.run = _wrapped_ingraph
+
 
 def run_rec(n):
     RECORD.clear()
@@ -151,6 +207,16 @@ for i, (x, y) in enumerate(zip(a, b)):
                           f"run1==run2[{j}] {torch.equal(xs, b[j]['grad'][s0:e0])}; norms at {j}: {a[j]['grad'][s0:e0].norm().item():.4e}")
                 print(f"         run1 head {xs[:6].tolist()}")
                 print(f"         run2 head {ys[:6].tolist()}")
+                if "after_assemble" in x:
+                    xa, ya = x["after_assemble"][s0:e0], y["after_assemble"][s0:e0]
+                    print(f"         right behind the assembly: run1 equals its end-of-step value {torch.equal(xa, xs)}, run2 {torch.equal(ya, ys)}, "
+                          f"run1 == run2 {torch.equal(xa, ya)}; heads {xa[:3].tolist()} / {ya[:3].tolist()}")
+        for tag in x.get("sources", {}):
+            xs_, ys_ = x["sources"][tag], y["sources"].get(tag)
+            if ys_ is not None and xs_.shape == ys_.shape and not torch.equal(xs_, ys_):
+                where = (xs_ != ys_).nonzero()
+                print(f"     deferred partials of param@{tag[0]:#x} column {tag[1]} differ in {where.shape[0]} words, first at {where[0].tolist()}: "
+                      f"{xs_[tuple(where[0])].item()!r} / {ys_[tuple(where[0])].item()!r}")
         break
 else:
     print("all recorded steps bit-identical between the two runs")
