@@ -8,7 +8,8 @@ the flat gradient buffer, the parameters and the index slice are recorded behind
     CUSRL_CONCURRENT_CRITIC=0 python scripts/debug_amp_identity.py          # AMP composition, single-stream steps
     CUSRL_CONCURRENT_CRITIC=0 DEBUG_KIND=continuous DEBUG_ITERATIONS=8 ...   # the stock composition needs a few more iterations
     DEBUG_INGRAPH=1 ...            # + snapshots inside the captured step: behind the assembly, and of its deferred sources
-    DEBUG_DETERMINISTIC=1 ...      # torch.use_deterministic_algorithms(True, warn_only=True): empty tensors are NaN-filled
+    DEBUG_DETERMINISTIC=1 ...      # torch.use_deterministic_algorithms(True, warn_only=True): empty tensors are NaN-filled,
+                                   # rocBLAS atomics off; =2: the same without the NaN fill
     DEBUG_COMPILE=0 ...            # no hipGraphs at all
 """
 import os
@@ -21,8 +22,10 @@ import torch  # noqa: E402
 import cusrl_amd as cusrl  # noqa: E402
 
 DEV = "cuda:0"
-if os.environ.get("DEBUG_DETERMINISTIC") == "1":
-    torch.use_deterministic_algorithms(True, warn_only=True)
+if os.environ.get("DEBUG_DETERMINISTIC") in ("1", "2"):
+    torch.use_deterministic_algorithms(True, warn_only=True)  # (also: rocBLAS atomics mode "not allowed")
+    if os.environ["DEBUG_DETERMINISTIC"] == "2":  # ... without NaN-filling every torch.empty (isolates the atomics mode)
+        torch.utils.deterministic.fill_uninitialized_memory = False
 cusrl.config.set_device(DEV)
 
 
