@@ -1,5 +1,5 @@
 #!/bin/bash
-# First GPU call of the next session (≈ 1 min): the probes DESIGN.md section 7 item 4 lists for the single-stream defect.
+# First GPU call of the next session (≈ 1 min): the probes DESIGN.md section 7 ("What comes next", item 4) lists for the single-stream defect.
 #   gpurun --timeout 300 -- 'bash scripts/gpu_r05_defect.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r05_defect
