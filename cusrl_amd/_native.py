@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "libcusrl_hip.so"
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_FIELDS = 24
 MAX_PACKED = 16
 
@@ -124,6 +124,8 @@ _SIGNATURES = {
     "cusrl_mse_loss_num_partials": (c_int64, [c_int64]),
     "cusrl_sumsq_fwd_bwd": (c_int, [_P, c_int64, c_double, c_double, _P, _P, _P, _P]),
     "cusrl_bce_pair_fwd_bwd": (c_int, [_P, c_int64, c_float, _P, _P, _P]),
+    "cusrl_graph_census": (c_int, [_P, POINTER(c_int64), c_int, ctypes.c_char_p, c_int64, POINTER(c_int64)]),
+    "cusrl_graph_replace_memsets": (c_int, [_P, POINTER(c_int64)]),
     "cusrl_comm_available": (c_int, []),
     "cusrl_comm_last_error": (c_char_p, []),
     "cusrl_comm_unique_id": (c_int, [_P]),

@@ -531,6 +531,17 @@ static void launch_gae_scaled(int policy, int blk, bool two, uint32_t blocks, hi
 #undef CUSRL_GAE_ARGS
 }
 
+// Partial rows no block of the chosen launch shape writes.  A KERNEL, not hipMemsetAsync: a memset becomes a memset NODE when
+// the caller is being captured into a hipGraph, and this repo keeps captured regions free of those.
+__global__ __launch_bounds__(cusrl::kBlock) void zero_f64_kernel(double *__restrict__ p, int64_t n) {
+    for (int64_t i = int64_t(blockIdx.x) * cusrl::kBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * cusrl::kBlock) p[i] = 0.0;
+}
+
+static void zero_partial_rows(double *p, int64_t n, hipStream_t s) {
+    const int64_t blocks = cusrl::ceil_div(n, cusrl::kBlock);
+    hipLaunchKernelGGL(zero_f64_kernel, dim3(uint32_t(blocks > 1024 ? 1024 : blocks)), dim3(cusrl::kBlock), 0, s, p, n);
+}
+
 extern "C" int64_t cusrl_gae_num_partials(int64_t T, int64_t N, int64_t D) {
     (void)T;
     if (N <= 0 || D <= 0) return 0;
@@ -560,10 +571,7 @@ extern "C" int cusrl_gae(const float *reward, const float *value, const float *n
         // the host sizes `stat_partials` with cusrl_gae_num_partials (>= blocks); unused rows are zeroed
         if (stat_partials) {
             const int64_t rows = cusrl_gae_num_partials(T, N, D);
-            if (rows > blocks)
-                if (hipError_t e = hipMemsetAsync(stat_partials + blocks * D * 2, 0,
-                                                  sizeof(double) * size_t((rows - blocks) * D * 2), s))
-                    return int(e);
+            if (rows > blocks) zero_partial_rows(stat_partials + blocks * D * 2, (rows - blocks) * D * 2, s);
         }
         launch_gae_scaled(policy, blk, two, uint32_t(blocks), s, reward, value, next_value, done, advantage, ret,
                           stat_partials, int(T), N, int(D), g, c_adv, c_val);
@@ -573,10 +581,7 @@ extern "C" int cusrl_gae(const float *reward, const float *value, const float *n
         const int64_t blocks = ceil_div(C, kWave);
         if (stat_partials) {
             const int64_t rows = cusrl_gae_num_partials(T, N, D);
-            if (rows > blocks)
-                if (hipError_t e = hipMemsetAsync(stat_partials + blocks * D * 2, 0,
-                                                  sizeof(double) * size_t((rows - blocks) * D * 2), s))
-                    return int(e);
+            if (rows > blocks) zero_partial_rows(stat_partials + blocks * D * 2, (rows - blocks) * D * 2, s);
         }
         if (two)
             hipLaunchKernelGGL((gae_kernel<1, 32, true, kWave>), dim3(uint32_t(blocks)), dim3(kWave), 0, s, reward, value,
@@ -589,10 +594,7 @@ extern "C" int cusrl_gae(const float *reward, const float *value, const float *n
         if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
         if (stat_partials) {
             const int64_t rows = cusrl_gae_num_partials(T, N, D);
-            if (rows > blocks)
-                if (hipError_t e = hipMemsetAsync(stat_partials + blocks * D * 2, 0,
-                                                  sizeof(double) * size_t((rows - blocks) * D * 2), s))
-                    return int(e);
+            if (rows > blocks) zero_partial_rows(stat_partials + blocks * D * 2, (rows - blocks) * D * 2, s);
         }
         if (two)
             hipLaunchKernelGGL((gae_kernel<1, 8, true>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, reward, value,

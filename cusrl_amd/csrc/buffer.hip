@@ -827,12 +827,17 @@ extern "C" int cusrl_window_indices(const int64_t *start, const int64_t *env, in
     return launch_status();
 }
 
+__global__ void zero_count_kernel(int32_t *count) { __hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 extern "C" int64_t cusrl_flag_blocks(int64_t n) { return n <= 0 ? 0 : ceil_div(n, kFlagChunk); }
 
 extern "C" int cusrl_compact_flags(const uint8_t *flags, int64_t n, int32_t *block_counts, int recount,
                                    int64_t *indices_out, int32_t *count_out, void *stream) {
     if (n < 0 || !count_out) return CUSRL_E_INVALID;
-    if (n == 0) return static_cast<int>(hipMemsetAsync(count_out, 0, sizeof(int32_t), as_stream(stream)));
+    if (n == 0) {  // (a kernel, not hipMemsetAsync: no memset nodes in captured regions)
+        hipLaunchKernelGGL(zero_count_kernel, dim3(1), dim3(1), 0, as_stream(stream), count_out);
+        return launch_status();
+    }
     if (!flags || !block_counts || !indices_out) return CUSRL_E_INVALID;
     const int64_t blocks = cusrl_flag_blocks(n);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;

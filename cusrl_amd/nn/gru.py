@@ -155,7 +155,7 @@ def _sum_slabs(weight: Tensor, slabs: Tensor) -> Tensor | None:
     if sink is not None and weight.is_leaf and key not in sink:
         sink[key] = slabs.view(slabs.shape[0], -1)
         return None
-    return slabs.sum(0)
+    return ops.sum_slabs(slabs) if slabs.is_cuda and slabs.dtype == torch.float32 else slabs.sum(0)
 
 
 def _new_output(x: Tensor, L: int, B: int, H: int, sizes: list[int] | None) -> Tensor:
@@ -227,10 +227,10 @@ class _LstmLayer(torch.autograd.Function):
         if need[0]:
             d_x = torch.mm(pre.view(L * B, 4 * H), w_ih).view(x.shape)
         if need[3]:
-            d_w_ih = torch.bmm(pre.transpose(1, 2), x).sum(0) if L > 1 else torch.mm(pre[0].t(), x[0])
+            d_w_ih = ops.sum_slabs(torch.bmm(pre.transpose(1, 2), x)) if L > 1 else torch.mm(pre[0].t(), x[0])
         if need[4]:
             h_prev = torch.cat([h0.unsqueeze(0), out[:-1]]) if L > 1 else h0.unsqueeze(0)
-            d_w_hh = torch.bmm(pre.transpose(1, 2), h_prev).sum(0) if L > 1 else torch.mm(pre[0].t(), h_prev[0])
+            d_w_hh = ops.sum_slabs(torch.bmm(pre.transpose(1, 2), h_prev)) if L > 1 else torch.mm(pre[0].t(), h_prev[0])
         if (ctx.has_b_ih and need[5]) or (ctx.has_b_hh and need[6]):
             d_b = _column_sums(pre.view(L * B, 4 * H))
         return (d_x, dh if need[1] else None, dc if need[2] else None, d_w_ih, d_w_hh,
@@ -287,10 +287,10 @@ class _RnnLayer(torch.autograd.Function):
         if need[0]:
             d_x = torch.mm(d_pre.view(L * B, H), w_ih).view(x.shape)
         if need[2]:
-            d_w_ih = torch.bmm(d_pre.transpose(1, 2), x).sum(0) if L > 1 else torch.mm(d_pre[0].t(), x[0])
+            d_w_ih = ops.sum_slabs(torch.bmm(d_pre.transpose(1, 2), x)) if L > 1 else torch.mm(d_pre[0].t(), x[0])
         if need[3]:
             h_prev = torch.cat([h0.unsqueeze(0), out[:-1]]) if L > 1 else h0.unsqueeze(0)
-            d_w_hh = torch.bmm(d_pre.transpose(1, 2), h_prev).sum(0) if L > 1 else torch.mm(d_pre[0].t(), h_prev[0])
+            d_w_hh = ops.sum_slabs(torch.bmm(d_pre.transpose(1, 2), h_prev)) if L > 1 else torch.mm(d_pre[0].t(), h_prev[0])
         if (ctx.has_b_ih and need[4]) or (ctx.has_b_hh and need[5]):
             d_b = _column_sums(d_pre.view(L * B, H))
         return (d_x, dh if need[1] else None, d_w_ih, d_w_hh, d_b if ctx.has_b_ih and need[4] else None,
@@ -298,9 +298,8 @@ class _RnnLayer(torch.autograd.Function):
 
 
 def _column_sums(matrix: Tensor) -> Tensor:
-    rows = matrix.shape[0]
-    if rows >= 4096 and matrix.shape[1] % 4 == 0:
-        return ops.relu_backward_bias(matrix, None)[1]  # the one-pass column-sum kernel of the MLP's bias gradients
+    if matrix.is_cuda and matrix.dtype == torch.float32:
+        return ops.relu_backward_bias(matrix.contiguous(), None)[1]  # the one-pass column-sum kernel of the MLP's bias gradients
     return matrix.sum(0)
 
 

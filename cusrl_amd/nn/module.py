@@ -4,6 +4,7 @@ hipBLASLt MFMA kernels (BASELINE.json north_star); none of the judged HIP kernel
 
 from __future__ import annotations
 
+import os
 from collections.abc import Iterable, Sequence
 from contextlib import contextmanager
 from dataclasses import dataclass
@@ -36,6 +37,12 @@ _split_grad_sink: dict[int, torch.Tensor] | None = None
 # layers take torch's own differentiable ops whatever the batch size; outside the context a second differentiation
 # of the custom backward raises (``once_differentiable``) instead of silently treating it as a constant.
 _plain_linear_depth = 0
+# Rows from which a differentiated fp32 linear layer on the GPU takes ``_WideBatchLinear``: EVERY batch size since round 5.  Up
+# to round 4 batches below 4096 rows went through torch's ``addmm`` backward, whose bias gradient is an ATen ``sum`` — a
+# global reduce_kernel with a semaphore zeroed by a memset node once the batch has >= ~1024 rows, and a captured step
+# containing those is not replayed reliably by this stack.  ``CUSRL_WIDE_LINEAR_MIN_ROWS`` restores
+# a threshold for A/B runs and for the defect's reproduction (scripts/debug_amp_identity.py).
+_WIDE_MIN_ROWS = int(os.environ.get("CUSRL_WIDE_LINEAR_MIN_ROWS", "1"))
 
 
 @contextmanager
@@ -152,7 +159,7 @@ class _WideBatchLinear(torch.autograd.Function):
                 if sink is not None and weight.data_ptr() not in sink:
                     sink[weight.data_ptr()] = slabs  # summed by the flat-gradient assembly
                 else:
-                    grad_weight = slabs.sum(0)
+                    grad_weight = ops.sum_slabs(slabs)
             else:
                 grad_weight = grad_output.t() @ input
         return grad_input, grad_weight, grad_bias, None, None
@@ -185,7 +192,7 @@ def linear_act(input: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | N
     if _device_fp32(input, weight) and (bias is not None or not relu):
         # the custom backward is once-differentiable: only take it where it pays (wide minibatches); small batches keep
         # torch's own double-differentiable ops (the AMP gradient penalty differentiates through the discriminator twice)
-        if (torch.is_grad_enabled() and (weight.requires_grad or input.requires_grad) and input.shape[0] >= 4096
+        if (torch.is_grad_enabled() and (weight.requires_grad or input.requires_grad) and input.shape[0] >= _WIDE_MIN_ROWS
                 and not _plain_linear_depth):
             return _WideBatchLinear.apply(input, weight, bias, _batch_splits(input.shape[0]), relu)
         if torch.is_grad_enabled() and (weight.requires_grad or input.requires_grad):

@@ -1309,6 +1309,38 @@ def categorical_policy_stats(old_logits: torch.Tensor, new_logits: torch.Tensor,
     return out
 
 
+# ------------------------------------------------------------------------------------------------ captured-graph census
+def graph_census(graph: "torch.cuda.CUDAGraph") -> dict:
+    """What a captured hipGraph is made of (``cusrl_graph_census``): ``{"kernel": n, "memcpy": n, "memset": n, "other": n,
+    "names": [mangled kernel names in node order]}``.  ``graph`` must have been created with ``keep_graph=True``."""
+    import ctypes
+
+    lib = _native.lib()
+    raw = ctypes.c_void_p(int(graph.raw_cuda_graph()))
+    counts = (ctypes.c_int64 * 16)()
+    need = ctypes.c_int64(0)
+    capacity = 1 << 16
+    while True:
+        names = ctypes.create_string_buffer(capacity)
+        check(lib.cusrl_graph_census(raw, counts, 16, names, capacity, ctypes.byref(need)), "cusrl_graph_census")
+        if need.value <= capacity:
+            break
+        capacity = need.value
+    listed = names.raw[: need.value].decode(errors="replace").split("\n")[:-1]
+    return {"kernel": counts[0], "memcpy": counts[1], "memset": counts[2], "other": sum(counts[3:]), "names": listed}
+
+
+def graph_replace_memsets(graph: "torch.cuda.CUDAGraph") -> int:
+    """Turn every memset node of a kept, not yet instantiated hipGraph into a fill-kernel node (``cusrl_graph_replace_memsets``);
+    returns how many were replaced."""
+    import ctypes
+
+    replaced = ctypes.c_int64(0)
+    check(_native.lib().cusrl_graph_replace_memsets(ctypes.c_void_p(int(graph.raw_cuda_graph())), ctypes.byref(replaced)),
+          "cusrl_graph_replace_memsets")
+    return int(replaced.value)
+
+
 # ------------------------------------------------------------------------------------------------ MLP backward epilogue
 def relu_backward_bias(grad_output: torch.Tensor, output: torch.Tensor | None, defer: bool = False):
     """``(grad_output * (output > 0), masked.sum(0))`` in one pass; with ``output=None`` just the column sums
@@ -1323,8 +1355,6 @@ def relu_backward_bias(grad_output: torch.Tensor, output: torch.Tensor | None, d
     chunkable = H % 4 == 0 and H // 4 <= 256 and 256 % (H // 4) == 0
     defer = defer and chunkable and grad_output.data_ptr() % 16 == 0 and (output is None or output.data_ptr() % 16 == 0)
     colsum = None if defer else torch.empty(H, dtype=torch.float32, device=grad_output.device)
-    if output is None and not chunkable and H > 1:
-        return grad_output, grad_output.sum(0)  # narrow odd widths (e.g. a 12-wide policy head): torch's reduce is fine
     if output is None:
         grad_in, out_ptr, in_ptr = grad_output, None, None
     else:
@@ -1408,8 +1438,18 @@ class DeferredColumns:
         self.partials, self.splits, self.row_stride, self.column, self.numel = partials, splits, row_stride, column, numel
 
     def materialize(self) -> torch.Tensor:
-        rows = self.partials.reshape(-1)[: self.splits * self.row_stride].view(self.splits, self.row_stride)
-        return rows[:, self.column : self.column + self.numel].sum(0)
+        out = torch.empty(self.numel, dtype=torch.float32, device=self.partials.device)
+        assemble_gradients([(self, 0, self.numel, self.splits)], out)
+        return out
+
+
+def sum_slabs(slabs: torch.Tensor) -> torch.Tensor:
+    """``slabs.sum(0)`` of a contiguous ``[S, ...]`` fp32 stack in fixed order through ``cusrl_assemble_gradients`` (one piece):
+    no ATen reduction — a global ``reduce_kernel`` brings a semaphore memset node into a captured step."""
+    out = torch.empty(slabs.shape[1:], dtype=torch.float32, device=slabs.device)
+    if out.numel():
+        assemble_gradients([(slabs, 0, out.numel(), slabs.shape[0])], out.view(-1))  # (validates device / dtype / layout)
+    return out
 
 
 def assemble_gradients(pieces: Sequence[tuple], flat: torch.Tensor, want_sumsq: bool = False):

@@ -153,15 +153,17 @@ class _Capture:
         self.tap_counts: list[int] = []
         self.accumulator: torch.Tensor | None = None
         self.replays = 0
+        self.census: dict | None = None
 
     MAX_TAPS = 256  # (a whole-rollout graph taps every env step's metrics)
+    censuses: list[dict] = []  # node census of the most recent captures of the process (tests, scripts/graph_census.py)
 
     def capture(self, fn, stream: torch.cuda.Stream, pool=None):
         tap = MetricTap()
         self.agent.metrics.tap(tap)
         # persistent (allocated outside the capture, so replays do not re-zero it); taps accumulate into it in-graph
         self.accumulator = torch.zeros(self.MAX_TAPS, dtype=torch.float32, device=self.agent.device)
-        graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph(keep_graph=True)  # kept for the node census below; instantiated right behind it
         # Python's cyclic collector must not run inside the capture: finalisers of unrelated garbage (an old agent's
         # pinned host buffers, events, graphs) issue stream operations that are illegal while capturing and abort
         # the process.  Collect now, keep the collector off for the duration of the capture.
@@ -188,6 +190,22 @@ class _Capture:
                 gc.enable()
             self.agent.metrics.tap(None)
         self.tap_names, self.tap_counts = tap.names, tap.counts
+        from cusrl_amd import ops
+
+        self.census = ops.graph_census(graph)
+        if self.census["memset"] and os.environ.get("CUSRL_GRAPH_MEMSETS", "replace") != "keep":
+            # This stack does not replay memset nodes reliably (scripts/probe_aten_reduce_capture.py) and
+            # ATen's split reductions — any `.sum()` / `.mean()` over >= ~1024 rows a hook issues — zero their semaphores
+            # with one: every memset node becomes a fill-kernel node with the same edges before the graph is instantiated.
+            replaced = ops.graph_replace_memsets(graph)
+            self.census = ops.graph_census(graph)
+            self.census["memset_replaced"] = replaced
+            if self.census["memset"]:
+                raise RuntimeError(f"{self.census['memset']} memset nodes left in a captured region after the replacement")
+        self.census["region"] = getattr(fn, "__qualname__", "region")
+        _Capture.censuses.append(self.census)
+        del _Capture.censuses[:-512]
+        graph.instantiate()
         self.graph = graph
         return result
 

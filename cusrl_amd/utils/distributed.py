@@ -504,7 +504,7 @@ class FlatGradients:
             slabs = split_slabs.pop(p.data_ptr(), None) if split_slabs else None
             pending = isinstance(slabs, ops.DeferredColumns)  # partial rows of a column-sum kernel
             if slabs is not None and grad is not None:  # the parameter was used more than once in the graph
-                grad, slabs = grad + (slabs.materialize() if pending else slabs.sum(0)).view_as(grad), None
+                grad, slabs = grad + (slabs.materialize() if pending else ops.sum_slabs(slabs)).view_as(grad), None
             if slabs is not None:
                 pieces.append((slabs, offset, n, slabs.splits if pending else slabs.shape[0]))
             elif grad is not None:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CUSRL_ABI_VERSION 4
+#define CUSRL_ABI_VERSION 5
 #define CUSRL_MAX_FIELDS 24 /* leaves per push / gather launch; larger tables are split by the host */
 #define CUSRL_MAX_PACKED 16 /* 1-8 byte entries of the per-slot record (cusrl_pack_rows); wide fields count as leaves */
 #define CUSRL_MAX_RECORD_BYTES 1024
@@ -45,6 +45,23 @@ typedef struct {
 int cusrl_abi_version(void);
 /* Human-readable text for a return code (host string, static storage). */
 const char *cusrl_error_string(int code);
+
+/* Node census of a captured hipGraph (`graph` = hipGraph_t): a host-side walk, no launch, no stream.  The reference's
+ * `compile=True` (cusrl/template/actor_critic.py:217-220) hands its loops to torch.compile; here they are hipGraphs, and
+ * what a captured step is made of is checkable: type_counts[k] (HOST, n_types entries) = number of nodes of
+ * hipGraphNodeType k (0 kernel, 1 memcpy, 2 memset, ...); `names` (HOST, `capacity` bytes, may be NULL with capacity 0)
+ * receives the mangled names of the kernel nodes in node order, '\n'-terminated, truncated at capacity;
+ * *names_len = bytes the full list needs.  The host refuses to replay a captured minibatch step that contains memset
+ * nodes or ATen global-reduce kernels (template/graphs.py: they do not replay reliably on this stack). */
+int cusrl_graph_census(void *graph, int64_t *type_counts, int n_types, char *names, int64_t capacity, int64_t *names_len);
+
+/* Replace every memset node of a captured, not yet instantiated hipGraph by a kernel node (a plain fill kernel) with the
+ * same destination, value, extent and edges; *replaced_out (HOST, may be NULL) = how many.  Host-side graph surgery, no
+ * launch.  What torch.compile does for the reference's `compile=True` (cusrl/template/hook.py:396-399) is a hipGraph here,
+ * and the ROCm 7.0 runtime of PyTorch 2.10 does not replay memset nodes reliably (scripts/probe_aten_reduce_capture.py:
+ * ATen's split reductions zero their semaphores with hipMemsetAsync, Reduce.cuh:1294-1301) — a captured region is only
+ * instantiated once it has none.  CUSRL_E_UNSUPPORTED: a memset node with an element size other than 1 / 2 / 4. */
+int cusrl_graph_replace_memsets(void *graph, int64_t *replaced_out);
 
 /* ---- a1  Buffer.push — cusrl/template/buffer.py:124-151 (`storage[cursor] = value` per leaf) ----
  * fields[i].src = step leaf [N, row_bytes];  fields[i].dst = storage leaf base [T, N, row_bytes].

@@ -223,3 +223,8 @@ for i, (x, y) in enumerate(zip(a, b)):
         break
 else:
     print("all recorded steps bit-identical between the two runs")
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from graph_census import summarize  # noqa: E402
+
+summarize(_graphs._Capture.censuses)
