@@ -198,7 +198,7 @@ def _agree(problem: str, device) -> bool:
     return verdict.item() == 0
 
 
-def establish_native_comm(factory, device, rank: int, world: int):
+def establish_native_comm(factory, device, rank: int, world: int, capture_probe=None):
     """Create the C-ABI communicator and prove it, in stages every rank walks through TOGETHER — each stage ends in a
     verdict all-reduce over the process group, and a rank that failed locally still issues every process-group collective of
     the stage it is in, so that no two ranks are ever inside different collectives (the failure mode of an earlier version:
@@ -208,7 +208,9 @@ def establish_native_comm(factory, device, rank: int, world: int):
       2. eager probe a 64-float ``allreduce_mean_`` ENQUEUED ON A SIDE STREAM (a half-issued collective must not block the
                      stream the process-group collectives synchronise with); verdict "every rank enqueued"; only then the
                      side stream is joined and the result compared with the closed form; verdict "every rank agrees"
-      3. captured    the same all-reduce captured into a hipGraph and replayed once; verdict
+      3. captured    the same all-reduce captured into a hipGraph (local; verdict "every rank captured"), replayed on a
+                     side stream without a device-wide synchronisation (verdict "every rank enqueued its replay"), then
+                     joined and compared (verdict)
 
     Returns ``(comm, "")`` or ``(None, reason)`` — the same outcome on every rank.  A communicator that may have a
     half-issued collective in flight is aborted (``cusrl_comm_abort``), never destroyed (destroy waits for its kernels).
@@ -256,12 +258,46 @@ def establish_native_comm(factory, device, rank: int, world: int):
     if not _agree(problem, device):
         comm.close()
         return None, problem or "another rank saw a wrong all-reduce result"
-    # ---- stage 3: what the route exists for — the all-reduce INSIDE a hipGraph
-    if device.type == "cuda":
-        problem = "injected fault (CUSRL_COMM_FAULT)" if faulty("capture") else _probe_captured_allreduce(comm)
+    # ---- stage 3: what the route exists for — the all-reduce INSIDE a hipGraph.  Same discipline as stage 2: a rank whose
+    # capture failed must not leave its peers inside a replay that waits for its half, so (a) capture — local, nothing is
+    # enqueued — and agree, (b) replay on a side stream WITHOUT a device-wide synchronisation and agree that every rank
+    # enqueued, (c) only then join the side stream and compare.
+    if capture_probe is None and device.type == "cuda":
+        capture_probe = _capture_allreduce_probe  # (the CPU tests of this protocol hand in a host-side stand-in)
+    if capture_probe is not None:
+        captured = None
+        try:
+            if faulty("capture"):
+                raise RuntimeError("injected fault (CUSRL_COMM_FAULT)")
+            captured = capture_probe(comm, rank, world)
+        except Exception as error:
+            problem = f"cusrl_allreduce_mean inside a hipGraph: {type(error).__name__}: {error}"
         if not _agree(problem, device):
-            comm.abort()  # a capture that went wrong on some rank leaves the others' replay waiting
+            comm.abort()  # (nothing was replayed anywhere, but a capture that broke half-way leaves the handle in no state to trust)
             return None, problem or "another rank could not capture the all-reduce"
+        graph, probe, expect, side = captured
+        try:
+            if faulty("replay"):
+                raise RuntimeError("injected fault (CUSRL_COMM_FAULT)")
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):
+                    graph.replay()
+            else:
+                graph.replay()
+        except Exception as error:
+            problem = f"replay of a captured cusrl_allreduce_mean: {type(error).__name__}: {error}"
+        if not _agree(problem, device):  # some rank never replayed its half: the others' kernels would wait forever
+            comm.abort()
+            return None, problem or "another rank could not replay the captured all-reduce"
+        if side is not None:
+            torch.cuda.current_stream(device).wait_stream(side)
+        getattr(comm, "complete", lambda: None)()
+        if not torch.allclose(probe, expect, rtol=1e-6, atol=0):
+            problem = "a captured cusrl_allreduce_mean replayed a wrong result"
+        if not _agree(problem, device):
+            comm.close()
+            return None, problem or "another rank saw a wrong result from the captured all-reduce"
     return comm, ""
 
 
@@ -288,27 +324,20 @@ def native_comm() -> RcclComm | None:
     return _native_comm
 
 
-def _probe_captured_allreduce(comm: RcclComm) -> str:
-    """Capture a 64-float ``cusrl_allreduce_mean`` into a hipGraph on a side stream, replay it once and compare with the
-    closed-form mean over the ranks; returns '' or what went wrong.  Collective: every rank runs it at the same point."""
-    try:
-        device, world = comm.device, comm.world_size
-        base = torch.arange(64, dtype=torch.float32, device=device)
-        probe = base * (CONFIG.rank + 1)
-        expect = base * ((world + 1) / 2)  # mean over ranks of (rank + 1)
-        stream = torch.cuda.Stream(device=device)
-        stream.wait_stream(torch.cuda.current_stream(device))
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
-            comm.allreduce_mean_(probe)
-        torch.cuda.current_stream(device).wait_stream(stream)
-        graph.replay()
-        torch.cuda.synchronize(device)
-        if not torch.allclose(probe, expect, rtol=1e-6, atol=0):
-            return "a captured cusrl_allreduce_mean replayed a wrong result"
-    except Exception as error:
-        return f"cusrl_allreduce_mean inside a hipGraph: {type(error).__name__}: {error}"
-    return ""
+def _capture_allreduce_probe(comm: RcclComm, rank: int, world: int):
+    """Capture a 64-float ``cusrl_allreduce_mean`` into a hipGraph on a side stream (local work: nothing is enqueued on the
+    communicator until somebody replays the graph).  Returns ``(graph, probe, expected mean, side stream)``."""
+    device = comm.device
+    base = torch.arange(64, dtype=torch.float32, device=device)
+    probe = base * (rank + 1)
+    expect = base * ((world + 1) / 2)  # mean over ranks of (rank + 1)
+    stream = torch.cuda.Stream(device=device)
+    stream.wait_stream(torch.cuda.current_stream(device))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+        comm.allreduce_mean_(probe)
+    torch.cuda.current_stream(device).wait_stream(stream)
+    return graph, probe, expect, stream
 
 
 def collective_route() -> str:

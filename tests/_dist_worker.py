@@ -101,8 +101,22 @@ def main(out_dir: str):
         def abort(self):
             self.aborted = True
 
+    class HostGraph:
+        """Stand-in for the captured all-reduce: capturing enqueues nothing, a replay enqueues the collective."""
+
+        def __init__(self, comm, probe):
+            self.comm, self.probe = comm, probe
+
+        def replay(self):
+            self.comm.allreduce_mean_(self.probe)
+
+    def host_capture(comm, rank_, world):
+        base = torch.arange(64, dtype=torch.float32)
+        probe = base * (rank_ + 1)
+        return HostGraph(comm, probe), probe, base * ((world + 1) / 2), None
+
     outcomes = {}
-    for scenario in ("", "create:0", "create:1", "probe:0", "probe:1"):
+    for scenario in ("", "create:0", "create:1", "probe:0", "probe:1", "capture:0", "capture:1", "replay:0", "replay:1"):
         os.environ["CUSRL_COMM_FAULT"] = scenario
         created = []
 
@@ -110,7 +124,7 @@ def main(out_dir: str):
             created.append(HostComm())
             return created[-1]
 
-        comm, reason = distributed.establish_native_comm(factory, torch.device("cpu"), rank, 2)
+        comm, reason = distributed.establish_native_comm(factory, torch.device("cpu"), rank, 2, capture_probe=host_capture)
         check = torch.tensor([float(rank + 1)])
         torch.distributed.all_reduce(check)  # the process group is still in step: 1 + 2
         outcomes[scenario or "none"] = {"ok": comm is not None, "reason": reason, "in_step": check.item() == 3.0,

@@ -1,0 +1,183 @@
+"""Correctness soak of the CAPTURED minibatch step (GPU): every replay's flat gradient against an independent evaluation.
+
+What must hold is the reference's ``_train_step`` (cusrl/template/actor_critic.py:302-320): the gradient the optimizer sees
+is d(value_loss + surrogate_loss + entropy_loss [+ further objectives]) / d(parameters) on THIS minibatch at THESE parameters.
+Round 4's suite compared captured steps only with other forms of this repository or at 8 envs x 16 steps; a defect that put
+foreign words into two bias-gradient slots of replayed steps at 1024-row minibatches went through it (DESIGN.md section 5:
+memset nodes of replayed hipGraphs).  Here, for {stock, AMP, split} compositions x {1024, 4096, 24 576}-row minibatches, the
+step is captured and then replayed >= 64 times on fresh index slices, and after EVERY replay
+
+* the actor's and the critic's gradients are recomputed with plain torch autograd in float64 from the parameters the step
+  started from and the rows its index slice names (plain indexing of the buffer leaves; formulas as in
+  cusrl/hook/on_policy/ppo.py:10-18, value.py:121-137, nn/module/distribution.py:207-213) and every parameter's window of
+  the flat buffer is held to 1e-5 of that tensor's largest reference entry;
+* no bias-gradient window may come back bit-identical to the previous replay's (a stale slot), every word is finite;
+* the captured graph itself is checked: no memset node, no ATen ``reduce_kernel`` (cusrl_graph_census).
+
+(The check style follows the reference's cusrl_test/_helpers.py:76-94: run the real loop, inspect what it produced.)
+"""
+
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SIZES = {  # minibatch rows -> (envs, horizon, minibatches, epochs, obs, act, iterations after the capture)
+    1024: (256, 8, 2, 2, 12, 4, 16),
+    4096: (1024, 8, 2, 2, 12, 4, 16),
+    24576: (4096, 24, 4, 2, 48, 12, 8),
+}
+
+
+@pytest.fixture(scope="module")
+def cusrl():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    import cusrl_amd
+
+    cusrl_amd.config.set_device(DEV)
+    return cusrl_amd
+
+
+def _probe_hook(cusrl, weight):
+    class PolicyTermsProbe(cusrl.Hook):
+        """A user-written objective with plain torch reductions (what brings ATen's split reduce_kernel into a captured step)."""
+
+        def objective(self, metadata, batch):
+            ratio, entropy = batch["action_prob_ratio"], batch["curr_entropy"]
+            penalty = (ratio - 1.2).square().mean() + 0.1 * (batch["action_logp_ratio"] + 0.3).square().mean() - 0.05 * entropy.mean()
+            return {"probe_loss": weight * (penalty + 0.01 * batch["curr_action_logp"].mean())}
+
+    return PolicyTermsProbe()
+
+
+PROBE_WEIGHT = 0.5
+
+
+def _factory(cusrl, kind, T, minibatches, epochs):
+    common = dict(num_steps_per_update=T, sampler_epochs=epochs, sampler_mini_batches=minibatches, compile=True,
+                  optimizer_kwargs={"capturable": True, "fused": True})
+    if kind == "amp":
+        k = 6
+        dataset = torch.randn(4096, 2 * k, device=DEV)
+        return cusrl.preset.AmpAgentFactory(amp_dataset_source=dataset, amp_state_indices=slice(k), extrinsic_reward_scale=0.5,
+                                            amp_reward_scale=2.0, **common)
+    factory = cusrl.preset.PpoAgentFactory(**common)
+    if kind == "split":
+        factory = factory.to_underlying()
+        factory.register_hook(_probe_hook(cusrl, PROBE_WEIGHT), after="entropy_loss")
+    return factory
+
+
+def _reference_gradients(agent, names, params_before, indices, kind):
+    """float64 autograd of the step's objective on the rows ``indices`` names, at ``params_before`` (dict name -> fp32 tensor)."""
+    p = {name: value.double().requires_grad_(True) for name, value in params_before.items()
+         if name.startswith(("actor.", "critic."))}
+    rows = lambda key: agent.buffer.storage[key].flatten(0, 1)[indices].double()  # noqa: E731
+    obs, action, old_logp = rows("observation"), rows("action"), rows("action_logp")
+    advantage, ret = rows("advantage"), rows("return")
+
+    def mlp(prefix, x):
+        for i in (0, 2):
+            x = torch.relu(x @ p[f"{prefix}.backbone.layers.{i}.weight"].t() + p[f"{prefix}.backbone.layers.{i}.bias"])
+        return x
+
+    mean = mlp("actor", obs) @ p["actor.distribution.mean_head.weight"].t() + p["actor.distribution.mean_head.bias"]
+    std = p["actor.distribution.std.param"].expand_as(mean)  # identity bijector (the preset's default)
+    logp = (-((action - mean) ** 2) / (2 * std**2) - std.log() - math.log(math.sqrt(2 * math.pi))).sum(-1, keepdim=True)
+    entropy = (0.5 + 0.5 * math.log(2 * math.pi) + std.log()).sum(-1, keepdim=True)
+    logp_ratio = logp - old_logp
+    ratio = logp_ratio.exp()
+    hooks = agent.hook
+    surrogate, value_hook, entropy_hook = hooks["ppo_surrogate_loss"], hooks["value_loss"], hooks["entropy_loss"]
+    lo, hi = float(torch.tensor(1.0 - surrogate.clip_ratio, dtype=torch.float32)), float(torch.tensor(1.0 + surrogate.clip_ratio, dtype=torch.float32))
+    loss = -torch.min(advantage * ratio, advantage * ratio.clamp(lo, hi)).mean() * surrogate.weight
+    value = mlp("critic", obs) @ p["critic.value_head.weight"].t() + p["critic.value_head.bias"]
+    if value_hook.loss_clip is None:
+        loss = loss + (value - ret).square().mean() * value_hook.weight
+    else:
+        old = rows("value")
+        clipped = old + (value - old).clamp(-value_hook.loss_clip, value_hook.loss_clip)
+        loss = loss + torch.max((value - ret).square(), (clipped - ret).square()).mean() * value_hook.weight
+    loss = loss - entropy.mean() * entropy_hook.weight
+    if kind == "split":
+        penalty = (ratio - 1.2).square().mean() + 0.1 * (logp_ratio + 0.3).square().mean() - 0.05 * entropy.mean()
+        loss = loss + PROBE_WEIGHT * (penalty + 0.01 * logp.mean())
+    grads = torch.autograd.grad(loss, list(p.values()))
+    # rows whose ratio sits within fp32 noise of a clip bound may legitimately fall on either side (oracle.ppo_loss_f64)
+    margin = torch.minimum((ratio - lo).abs(), (ratio - hi).abs()).min()
+    return dict(zip(p, grads)), float(margin)
+
+
+@pytest.mark.parametrize("rows", [1024, 4096, 24576])
+@pytest.mark.parametrize("kind", ["stock", "amp", "split"])
+def test_every_replay_of_a_captured_step_matches_float64_autograd(cusrl, kind, rows, gradient_parity):
+    from cusrl_amd.hook.on_policy.fused import FusedPpoObjective
+    from cusrl_amd.template import graphs
+
+    N, T, minibatches, epochs, obs_dim, act_dim, soak_iterations = SIZES[rows]
+    assert N * T // minibatches == rows
+    cusrl.set_global_seed(33)
+    env = cusrl.testing.DummyTorchEnvironment(num_instances=N, observation_dim=obs_dim, action_dim=act_dim, device=DEV)
+    warm = 3  # iteration 0: eager warm-up of every step, 1: capture, 2: first pure replays
+    trainer = cusrl.Trainer(env, _factory(cusrl, kind, T, minibatches, epochs), num_iterations=warm + soak_iterations, verbose=False)
+    agent = trainer.agent
+    assert FusedPpoObjective.mode(agent.hook) == ("split" if kind == "split" else "fused")
+    flat = agent.flat_gradients
+    names = {id(p): name for name, p in agent.named_parameters()}
+    windows = [(names[id(p)], offset, p.numel(), tuple(p.shape)) for p, offset in zip(flat.params, flat.offsets)]
+    assert any(name.startswith("critic.") for name, *_ in windows) and any(name.startswith("actor.") for name, *_ in windows)
+    record = {"replays": 0, "worst": {}, "previous": None, "near_clip": 0}
+    original = graphs.GraphedTrainStep.run
+
+    def run(self, metadata, indices, *args, **kwargs):
+        before = {name: p.detach().clone() for name, p in agent.named_parameters()}
+        was_captured = self.state == 2
+        original(self, metadata, indices, *args, **kwargs)
+        if not (was_captured and self.state == 2):
+            return
+        torch.cuda.synchronize()
+        grads = flat.buffer.clone()
+        assert torch.isfinite(grads).all(), f"replay {record['replays']}: non-finite words in the flat gradient buffer"
+        reference, margin = _reference_gradients(agent, names, before, indices, kind)
+        record["near_clip"] += margin < 1e-6
+        for name, offset, numel, shape in windows:
+            mine = grads[offset : offset + numel]
+            if name in reference:
+                want = reference[name].reshape(-1)
+                scale = want.abs().max().clamp_min(1e-30)
+                error = float((mine.double() - want).abs().max() / scale)
+                record["worst"][name] = max(record["worst"].get(name, 0.0), error)
+                # a row within 1e-6 of a clip bound may fall on the other side in fp32: its share of the gradient is <= 1 / rows
+                bound = 1e-5 if margin >= 1e-6 else 1e-5 + 4.0 / rows
+                assert error <= bound, (f"replay {record['replays']} ({kind}, {rows} rows): {name} off by {error:.3e} of its largest entry; "
+                                        f"first words {mine[:4].tolist()} vs {want[:4].tolist()}")
+            if name.endswith(".bias") and record["previous"] is not None:
+                assert not torch.equal(mine, record["previous"][offset : offset + numel]), \
+                    f"replay {record['replays']}: {name} came back bit-identical to the previous replay (stale slot)"
+        record["previous"] = grads
+        record["replays"] += 1
+
+    graphs.GraphedTrainStep.run = run
+    try:
+        trainer.run_training_loop()
+    finally:
+        graphs.GraphedTrainStep.run = original
+    torch.cuda.synchronize()
+    assert record["replays"] >= 64, record["replays"]
+    steps = list(agent._graphed_steps.values())
+    assert steps and all(step.state == 2 for step in steps)
+    for step in steps:  # the structural rule behind the fix
+        census = step.forward_backward.census
+        assert census["memset"] == 0, census
+        reduces = [n for n in census["names"] if "reduce_kernel" in n]
+        if kind == "split":  # the probe hook's own .mean() calls are ATen reductions: allowed, their memset nodes replaced
+            assert census.get("memset_replaced", 0) > 0 or rows < 1024 or not reduces
+        else:
+            assert not reduces, reduces[:3]
+    for name, error in record["worst"].items():
+        gradient_parity(f"captured_step_soak[{kind},{rows},{name}]", [1.0 + error], [1.0], 1e-5 + 4.0 / rows)  # (recorded)
+    print(f"captured-step soak {kind} {rows} rows: {record['replays']} replays, worst error "
+          f"{max(record['worst'].values()):.2e} of a tensor's largest entry ({record['near_clip']} replays with a ratio within 1e-6 of a clip bound)")

@@ -91,7 +91,7 @@ def test_native_communicator_start_up_is_collective_safe_at_every_stage(ranks):
     """establish_native_comm with a fault injected on one rank at one stage (CUSRL_COMM_FAULT): both ranks finish (no rank
     is left inside a collective its peer never enters), report the same outcome, the faulty rank names the fault, a
     communicator with a possibly half-issued collective is aborted (not destroyed), and the process group stays in step."""
-    for scenario in ("none", "create:0", "create:1", "probe:0", "probe:1"):
+    for scenario in ("none", "create:0", "create:1", "probe:0", "probe:1", "capture:0", "capture:1", "replay:0", "replay:1"):
         a, b = (r["comm_protocol"][scenario] for r in ranks)
         assert a["ok"] == b["ok"] == (scenario == "none"), scenario
         assert a["in_step"] and b["in_step"], scenario
@@ -104,5 +104,5 @@ def test_native_communicator_start_up_is_collective_safe_at_every_stage(ranks):
         for rank, outcome in enumerate((a, b)):
             if stage == "create":  # the healthy rank created a communicator nothing was enqueued on: plain destroy
                 assert outcome["closed"] == (rank != int(faulty)) and not outcome["aborted"], scenario
-            else:  # the healthy rank's probe is enqueued and will never complete: abort, on every rank
+            else:  # the healthy rank's probe / replay is enqueued and will never complete (or its capture broke): abort, on every rank
                 assert outcome["aborted"] and not outcome["closed"], scenario

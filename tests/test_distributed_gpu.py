@@ -59,6 +59,7 @@ def test_ppo_preset_over_rccl_single_rank(tmp_path, compile_, native):
     ({"CUSRL_RCCL_LIBRARY": "/nonexistent/librccl.so"}, "RCCL is not available"),  # the library the user named cannot be loaded
     ({"CUSRL_COMM_FAULT": "probe:0"}, "injected fault"),    # the eager probe fails: communicator aborted, not destroyed
     ({"CUSRL_COMM_FAULT": "capture:0"}, "injected fault"),  # RCCL "cannot be captured" on this stack
+    ({"CUSRL_COMM_FAULT": "replay:0"}, "injected fault"),   # the captured all-reduce cannot be replayed
 ])
 def test_c_abi_route_falls_back_to_torch_distributed_and_says_so(tmp_path, fault, needle):
     """The default route of an RCCL job verifies itself at start-up (establish_native_comm); when a stage fails the job logs
@@ -73,7 +74,7 @@ def test_c_abi_route_falls_back_to_torch_distributed_and_says_so(tmp_path, fault
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
-@pytest.mark.parametrize("fault", ["create:1", "probe:1", "capture:0"])
+@pytest.mark.parametrize("fault", ["create:1", "probe:1", "capture:0", "capture:1", "replay:1"])
 def test_two_rccl_ranks_agree_on_the_fallback_when_one_rank_fails(tmp_path, fault):
     ranks = _run(tmp_path, 2, "1", "1", extra_env={"CUSRL_COMM_FAULT": fault})
     _assert_lockstep(ranks)
