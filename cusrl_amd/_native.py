@@ -79,6 +79,7 @@ _SIGNATURES = {
     "cusrl_gru_gates_bwd": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P]),
     "cusrl_gru_gates_bwd_bias": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P, _P]),
     "cusrl_gru_bias_partial_rows": (c_int64, [c_int64]),
+    "cusrl_gru_bias_supported": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "cusrl_lstm_gates_fwd": (c_int, [_P] * 8 + [c_int64, c_int64, c_int64, _P]),
     "cusrl_lstm_gates_bwd": (c_int, [_P] * 7 + [c_int64, c_int64, c_int64, _P]),
     "cusrl_rnn_cell_fwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, c_int, _P]),

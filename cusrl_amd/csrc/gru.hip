@@ -507,6 +507,17 @@ extern "C" int cusrl_gru_gates_bwd(float *gi, float *gh, const float *b_hh, cons
 
 extern "C" int64_t cusrl_gru_bias_partial_rows(int64_t B) { return B <= 0 ? 0 : cusrl::ceil_div(B, cusrl::bias_rows()); }
 
+// 1: cusrl_gru_gates_bwd_bias takes a launch with these pointers (every other argument valid); 0: CUSRL_E_UNSUPPORTED.
+// The ONE statement of that eligibility rule: the host asks here instead of restating it.
+extern "C" int cusrl_gru_bias_supported(int64_t H, const float *gi, const float *gh, const float *b_hh, const float *h_prev,
+                                        const float *d_out, const float *dh, const float *bias_partials) {
+    using namespace cusrl;
+    if (H <= 0 || H > INT32_MAX / 3) return 0;
+    const bool vec4 = gru_vec4(H, gi, gh, b_hh, h_prev, d_out, dh) && aligned(bias_partials, 16);
+    const int64_t cols = vec4 ? H / 4 : H;
+    return cols <= kBlock && kBlock % cols == 0 && kBlock / cols <= bias_rows();
+}
+
 extern "C" int cusrl_gru_gates_bwd_bias(float *gi, float *gh, const float *b_hh, const float *h_prev, const float *d_out,
                                         float *dh, const int64_t *lengths, int64_t t, int64_t B, int64_t H,
                                         float *bias_partials, void *stream) {
@@ -514,12 +525,10 @@ extern "C" int cusrl_gru_gates_bwd_bias(float *gi, float *gh, const float *b_hh,
     if (B < 0 || H <= 0 || t < 0) return CUSRL_E_INVALID;
     if (B == 0) return 0;
     if (!gi || !gh || !h_prev || !dh || !bias_partials) return CUSRL_E_INVALID;
-    if (H > INT32_MAX / 3) return CUSRL_E_UNSUPPORTED;
+    // (wide or narrow layers whose column chunks do not tile a block: the caller keeps the plain pass + column sums)
+    if (!cusrl_gru_bias_supported(H, gi, gh, b_hh, h_prev, d_out, dh, bias_partials)) return CUSRL_E_UNSUPPORTED;
     const bool vec4 = gru_vec4(H, gi, gh, b_hh, h_prev, d_out, dh) && aligned(bias_partials, 16);
-    const int64_t cols = vec4 ? H / 4 : H;
-    if (cols > kBlock || kBlock % cols != 0) return CUSRL_E_UNSUPPORTED;  // the caller keeps the plain pass + column sums
     const int rows_per_block = bias_rows();
-    if (kBlock / cols > rows_per_block) return CUSRL_E_UNSUPPORTED;  // narrow layers: more row groups than rows per block
     const int64_t blocks = ceil_div(B, rows_per_block);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     if (vec4)

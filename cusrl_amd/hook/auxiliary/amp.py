@@ -55,10 +55,6 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
     pass, expert pass, penalty) whose weight gradients it then adds up.  Here the two passes share one ``[2N, .]`` batch
     and every weight gradient is produced once: ~40 launches instead of ~80 per minibatch step, the same arithmetic."""
 
-    # set by the hook around ``apply``: the two outputs are differentiated with unit gradients (no GradScaler, the flat
-    # gradient path), so the backward uses the forward kernels' gradients as they are instead of rescaling them
-    unit_grad_hint = False
-
     @staticmethod
     def forward(ctx, agent, expert, target, ones, loss_weight, penalty_weight, *parameters):
         """``expert is None``: ``agent`` already is the joint ``[2N, C]`` batch (agent rows first), e.g. filled by ONE row
@@ -93,7 +89,7 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
             flat = input_gradient.reshape(-1)
             penalty = torch.dot(flat, flat) / rows * (penalty_weight * loss_weight)
             ctx.save_for_backward(logit, target, ones, input_gradient, *hidden, *units, *weights)
-        ctx.on_device, ctx.unit_grad = on_device, _ReluDiscriminatorObjective.unit_grad_hint
+        ctx.on_device = on_device
         ctx.layers, ctx.rows = len(weights), rows
         ctx.loss_weight, ctx.penalty_weight = loss_weight, penalty_weight
         return discrimination, penalty
@@ -105,8 +101,11 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
         logit, target, ones, input_gradient, *saved = ctx.saved_tensors  # ones: [1, 2N], column sums as GEMMs
         hidden, units, weights = saved[:layers], saved[layers:2 * layers - 1], saved[2 * layers - 1:]
         # --- penalty: d/dW_k of mean || u_1 W_1 ||^2, the masks being constants
-        if ctx.on_device:  # `input_gradient` already is 2 g pw lw / rows, `logit` already d loss / d logit (forward kernels)
-            d_input = input_gradient if ctx.unit_grad else input_gradient * grad_penalty
+        from cusrl_amd.nn.module import is_unit_gradient
+
+        if ctx.on_device:  # `input_gradient` already is 2 g pw lw / rows, `logit` already d loss / d logit (forward kernels):
+            # used as they are when the incoming gradient IS the agent's unit scalar (the summands as separate roots), else scaled
+            d_input = input_gradient if is_unit_gradient(grad_penalty) else input_gradient * grad_penalty
         else:
             d_input = input_gradient * (grad_penalty * (2.0 * ctx.penalty_weight * ctx.loss_weight / rows))
         penalty_grads = [units[0].t() @ d_input]
@@ -118,7 +117,7 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
         penalty_grads.append(ones[:, :rows] @ _masked(d_units, hidden[layers - 1][rows:], 0))
         # --- discrimination: an ordinary MLP backward over the joint batch, the penalty's share added by the GEMM
         if ctx.on_device:
-            d_out = logit if ctx.unit_grad else logit * grad_discrimination
+            d_out = logit if is_unit_gradient(grad_discrimination) else logit * grad_discrimination
         else:
             d_out = (torch.sigmoid(logit) - target) * (grad_discrimination * (ctx.loss_weight / logit.shape[0]))
         gradients: list[Tensor] = []
@@ -296,14 +295,9 @@ class AdversarialMotionPrior(Hook):
                     or self._targets.dtype != agent_transition.dtype):
                 self._targets = torch.cat((agent_transition.new_zeros(rows, 1), agent_transition.new_ones(rows, 1)))
                 self._ones = agent_transition.new_ones(1, 2 * rows)
-            _ReluDiscriminatorObjective.unit_grad_hint = (not getattr(self.agent, "grad_scaler_enabled", False)
-                                                          and getattr(self.agent, "flat_gradients", None) is not None)
-            try:
-                discrimination, penalty = _ReluDiscriminatorObjective.apply(
-                    agent_transition if joint is None else joint, expert_transition if joint is None else None, self._targets,
-                    self._ones, self.loss_weight, self.grad_penalty_weight, *parameters)
-            finally:
-                _ReluDiscriminatorObjective.unit_grad_hint = False
+            discrimination, penalty = _ReluDiscriminatorObjective.apply(
+                agent_transition if joint is None else joint, expert_transition if joint is None else None, self._targets,
+                self._ones, self.loss_weight, self.grad_penalty_weight, *parameters)
             return {"amp_discrimination_loss": discrimination, "amp_grad_penalty_loss": penalty}
         expert_transition.requires_grad_(True)
         from cusrl_amd.nn.module import double_differentiable

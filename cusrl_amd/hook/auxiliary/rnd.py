@@ -21,21 +21,23 @@ class _MseLossFunction(torch.autograd.Function):
     (``cusrl_mse_loss_fwd_bwd``) instead of sub / square / mean forward and fill / mse_backward behind it."""
 
     @staticmethod
-    def forward(ctx, prediction, target, unit_grad):
+    def forward(ctx, prediction, target):
         from cusrl_amd import ops
 
         loss, grad = ops.mse_loss_fwd_bwd(prediction, target)
         ctx.save_for_backward(grad)
-        ctx.unit_grad, ctx.shape = unit_grad, prediction.shape
+        ctx.shape = prediction.shape
         return loss
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_loss):
+        from cusrl_amd.nn.module import is_unit_gradient
+
         (grad,) = ctx.saved_tensors
-        if not ctx.unit_grad:  # GradScaler, or a caller that rescales the loss
+        if not is_unit_gradient(grad_loss):  # GradScaler, or a caller that rescales the loss: anything but the agent's unit scalar
             grad = grad * grad_loss
-        return grad.view(ctx.shape), None, None
+        return grad.view(ctx.shape), None
 
 
 class RandomNetworkDistillation(Hook):
@@ -89,6 +91,5 @@ class RandomNetworkDistillation(Hook):
         if (prediction.is_cuda and type(criterion) is nn.MSELoss and criterion.reduction == "mean"
                 and prediction.dtype == torch.float32 and target.dtype == torch.float32 and not target.requires_grad):
             # forward + backward of the squared error in one HIP pass; a user-supplied criterion keeps torch's ops
-            unit = not getattr(self.agent, "grad_scaler_enabled", False) and getattr(self.agent, "flat_gradients", None) is not None
-            return {"rnd_loss": _MseLossFunction.apply(prediction, target, unit)}
+            return {"rnd_loss": _MseLossFunction.apply(prediction, target)}
         return {"rnd_loss": criterion(prediction, target)}

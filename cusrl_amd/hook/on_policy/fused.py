@@ -75,15 +75,18 @@ class _FusedPpoFunction(torch.autograd.Function):
         if grad_total is None:
             return (None,) * 15
         shapes = ctx.shapes
-        if ctx.deferred_std is not None:
-            from cusrl_amd.nn import module as nn_module
+        from cusrl_amd.nn import module as nn_module
 
+        if ctx.deferred_std is not None:
+            if not nn_module.is_unit_gradient(grad_total):
+                raise RuntimeError("the deferred-finalize form of the fused PPO objective is differentiated with the agent's unit "
+                                   "gradient only (captured steps); something rescaled its loss")
             d_mean, d_value = ctx.saved_tensors
             d_std = nn_module._hand_over(nn_module._split_grad_sink, ctx.std_key, ctx.deferred_std)
             return (d_mean.view(shapes[0]), None if d_std is None else d_std.view(shapes[1]), d_value.view(shapes[2]),
                     *([None] * 12))
         d_mean, d_std, d_value = ctx.saved_tensors
-        if not ctx.unit_grad:  # GradScaler (fp16 autocast) or a caller that rescales the loss
+        if not (ctx.unit_grad and nn_module.is_unit_gradient(grad_total)):  # GradScaler, or a caller that rescales the loss
             d_mean, d_std, d_value = d_mean * grad_total, d_std * grad_total, d_value * grad_total
         return (d_mean.view(shapes[0]), d_std.view(shapes[1]), d_value.view(shapes[2]), *([None] * 12))
 
@@ -111,8 +114,10 @@ class _FusedCategoricalPpoFunction(torch.autograd.Function):
     def backward(ctx, grad_total, *_unused):
         if grad_total is None:
             return (None,) * 14
+        from cusrl_amd.nn.module import is_unit_gradient
+
         d_logits, d_value = ctx.saved_tensors
-        if not ctx.unit_grad:
+        if not (ctx.unit_grad and is_unit_gradient(grad_total)):
             d_logits, d_value = d_logits * grad_total, d_value * grad_total
         return (d_logits.view(ctx.shapes[0]), d_value.view(ctx.shapes[1]), *([None] * 12))
 

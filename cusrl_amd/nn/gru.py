@@ -97,7 +97,7 @@ class _GruLayer(torch.autograd.Function):
         want_bias = (ctx.has_b_ih and need[4]) or (b_hh is not None and need[5])
         bias_rows = ops.gru_bias_partial_rows(B)
         bias_partials = None
-        if want_bias and ops.gru_bias_partials_supported(H, gi, gh, b_hh, h0, out, d_out, dh):
+        if want_bias and ops.gru_bias_partials_supported(H, gi, gh, b_hh, h0, d_out, dh) and out.data_ptr() % 16 == 0:
             # partial rows no launch writes (row subsets of a length-sorted batch without device-side lengths, skipped
             # steps) must read as zero
             full = sizes is None or in_kernel_tails and sizes[-1] > 0
@@ -127,6 +127,9 @@ class _GruLayer(torch.autograd.Function):
             d_w_ih = _sum_slabs(w_ih, torch.bmm(gi.transpose(1, 2), x)) if L > 1 else torch.mm(gi[0].t(), x[0])
         if need[3]:
             # slab t pairs d_gh[t] with the state that entered step t: h0 for t = 0, out[t - 1] after that = states[:-1]
+            if ctx.states is None:
+                raise RuntimeError("the fused GRU layer keeps its states for ONE backward pass (they are released with it): "
+                                   "a second backward through the same graph needs a fresh forward")
             h_prev = ctx.states[:-1]
             ctx.states = None
             d_w_hh = _sum_slabs(w_hh, torch.bmm(gh.transpose(1, 2), h_prev)) if L > 1 else torch.mm(gh[0].t(), h_prev[0])

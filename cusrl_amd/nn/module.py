@@ -17,7 +17,7 @@ from torch.nn.functional import linear
 from cusrl_amd.utils.nest import iterate_nested
 
 __all__ = ["Linear", "LinearFp32", "linear_act", "Mlp", "Module", "ModuleFactory", "disable_autocast", "double_differentiable",
-           "resolve_activation_fn"]
+           "is_unit_gradient", "register_unit_gradient", "resolve_activation_fn"]
 
 
 def disable_autocast(device_type: str):
@@ -43,6 +43,24 @@ _plain_linear_depth = 0
 # containing those is not replayed reliably by this stack.  ``CUSRL_WIDE_LINEAR_MIN_ROWS`` restores
 # a threshold for A/B runs and for the defect's reproduction (scripts/debug_amp_identity.py).
 _WIDE_MIN_ROWS = int(os.environ.get("CUSRL_WIDE_LINEAR_MIN_ROWS", "1"))
+
+
+# Backward shortcuts for a UNIT incoming gradient.  The loss summands of a step are differentiated as separate roots with a
+# persistent ones-scalar as their grad_output (ActorCritic._backward); a custom Function whose forward kernel already
+# produced d loss / d input may hand that out unscaled — but only if the gradient that actually ARRIVES is that very
+# scalar.  The engine passes a root's grad_output through untouched, so its address identifies it; anything a caller did
+# to the loss (a hook re-weighting the objectives, GradScaler, accumulation) arrives as a different tensor and is
+# multiplied in.  (Up to round 4 the shortcut was taken on a hint computed at forward time.)
+_unit_gradients: set[int] = set()
+
+
+def register_unit_gradient(ones: torch.Tensor) -> torch.Tensor:
+    _unit_gradients.add(ones.data_ptr())
+    return ones
+
+
+def is_unit_gradient(grad: torch.Tensor | None) -> bool:
+    return grad is not None and grad.dim() == 0 and grad.data_ptr() in _unit_gradients
 
 
 @contextmanager

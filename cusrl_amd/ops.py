@@ -1052,12 +1052,12 @@ def gru_gates_backward(gi: torch.Tensor, gh: torch.Tensor, b_hh: torch.Tensor | 
           "cusrl_gru_gates_bwd")
 
 
-def gru_bias_partials_supported(H: int, *tensors: torch.Tensor) -> bool:
-    """Can :func:`gru_gates_backward` fold the bias gradients in (column chunks must tile a 256-thread block)?"""
-    vec4 = H % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in tensors)
-    cols = H // 4 if vec4 else H
-    rows_per_block = -(-4096 // max(gru_bias_partial_rows(4096), 1))
-    return 0 < cols <= 256 and 256 % cols == 0 and 256 // cols <= rows_per_block
+def gru_bias_partials_supported(H: int, gi, gh, b_hh, h_prev, d_out, dh, bias_partials=None) -> bool:
+    """Can :func:`gru_gates_backward` fold the bias gradients in?  Asked of the library (``cusrl_gru_bias_supported``: pointer
+    alignment + column chunks that tile a 256-thread block); ``bias_partials=None``: a fresh allocation (256-byte aligned)."""
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    return bool(_native.lib().cusrl_gru_bias_supported(H, ptr(gi), ptr(gh), ptr(b_hh), ptr(h_prev), ptr(d_out), ptr(dh),
+                                                       256 if bias_partials is None else bias_partials.data_ptr()))
 
 
 def gru_bias_partial_rows(B: int) -> int:

@@ -20,7 +20,7 @@ from typing import Any
 import torch
 
 from cusrl_amd.nn.actor import Actor, Value
-from cusrl_amd.nn.module import collect_split_weight_grads
+from cusrl_amd.nn.module import collect_split_weight_grads, register_unit_gradient
 from cusrl_amd.template.agent import Agent, AgentFactory, preserve_io_format
 from cusrl_amd.template.buffer import Buffer, Sampler
 from cusrl_amd.template.environment import EnvironmentSpec
@@ -166,8 +166,8 @@ class ActorCritic(Agent):
             self._graph_pool = torch.cuda.graph_pool_handle()
             # second branch of the captured minibatch step (critic forward / backward, hook/on_policy/value.py)
             self._branch_stream = torch.cuda.Stream(device=self.device)
-            # True / False force it; None (default, CUSRL_CONCURRENT_CRITIC unset) = the branch whenever the objective is the
-            # fused one (GraphedTrainStep._critic_branch: the single-stream form is not bit-reproducible yet)
+            # True / False force it; None (default, CUSRL_CONCURRENT_CRITIC unset) = per composition, where it measured faster
+            # (GraphedTrainStep._critic_branch)
             forced = os.environ.get("CUSRL_CONCURRENT_CRITIC")
             self.concurrent_critic = None if forced is None else forced != "0"
             # captured minibatch steps run the fused objective without its one-block finalize launch (ops.DeferredLoss)
@@ -382,7 +382,8 @@ class ActorCritic(Agent):
             return
         first = roots[0]
         if self._unit_grad is None or self._unit_grad.dtype != first.dtype:
-            self._unit_grad = torch.ones((), dtype=first.dtype, device=first.device)  # persistent: no ones_like per step
+            # persistent (no ones_like per step) and registered: custom backwards recognise it by address (nn/module.py)
+            self._unit_grad = register_unit_gradient(torch.ones((), dtype=first.dtype, device=first.device))
         units = [self._unit_grad if term.dtype == first.dtype else torch.ones((), dtype=term.dtype, device=term.device)
                  for term in roots]
         with collect_split_weight_grads() as split_slabs:

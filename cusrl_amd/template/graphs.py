@@ -263,22 +263,30 @@ class GraphedTrainStep:
         return "objective" not in eager_phases(self.agent)
 
     def _critic_branch(self) -> bool:
-        """The critic as a second stream-branch of the captured step: forced by ``agent.concurrent_critic`` (True / False), else
-        on whenever the objective is the fused one — the form every composition has been validated in since round 2.
+        """The critic as a second stream-branch of the captured step: forced by ``agent.concurrent_critic`` (True / False,
+        ``CUSRL_CONCURRENT_CRITIC``), else only where it measured faster (profiles/r05/stream_ab.txt, profiles/r04/configs/
+        config5_concurrent_critic_ab.txt) — the stock fused composition at a minibatch of >= 4096 rows: config 2 7.57 -> 6.96 ms
+        and config 3 12.14 -> 11.71 ms per iteration WITH the branch; config 5 (RND + AMP chains in the same step)
+        16.9 -> 15.7 ms and config 1 (32-row minibatches, launch-bound) 4.25 -> 3.87 ms WITHOUT it.
 
-        The single-stream form measured faster for launch-bound steps (config 1, 32-row minibatches: 4.39 -> 4.08 ms; config 5,
-        RND + AMP chains in the same step: 16.8-17.4 -> 15.6-16.0 ms; profiles/r04/configs/config5_concurrent_critic_ab.txt)
-        and slower for config 2 / 3 (6.99 vs 7.63, 11.71 vs 12.14 ms), but it is NOT bit-reproducible run to run:
-        tests/test_captured_rollout.py caught it for the AMP composition, scripts/debug_amp_identity.py shows the stock
-        composition has it too — single words of critic bias-gradient slots come back as never-initialised bytes plus 16,
-        a second slot as stale data (open defect).  Until that is root-caused the single-stream form
-        stays behind CUSRL_CONCURRENT_CRITIC=0."""
+        History: round 4 withdrew this per-composition choice because the single-stream form was not bit-reproducible.  That
+        was not a property of the stream layout: replayed hipGraphs do not execute their MEMSET nodes reliably on this stack,
+        and below 4096 rows the bias gradients came from ATen's split ``sum`` whose semaphore is zeroed by one
+        (scripts/probe_aten_reduce_capture.py).  No captured region contains a memset node any more
+        (``_Capture.capture``), and both layouts are held to a float64 evaluation of every replay
+        (tests/test_captured_step_soak.py)."""
         agent = self.agent
         if agent.concurrent_critic is not None:
             return bool(agent.concurrent_critic)
+        from cusrl_amd.hook.auxiliary import AdversarialMotionPrior, RandomNetworkDistillation
         from cusrl_amd.hook.on_policy.fused import FusedPpoObjective
 
-        return FusedPpoObjective.mode(agent.hook) == "fused"
+        if FusedPpoObjective.mode(agent.hook) != "fused":
+            return False
+        if any(hook._active and isinstance(hook, (AdversarialMotionPrior, RandomNetworkDistillation)) for hook in agent.hook):
+            return False
+        rows = 0 if self.static_indices is None else self.static_indices.numel() * (agent.buffer.capacity if self.temporal else 1)
+        return rows >= 4096
 
     def _whole_step(self):
         self._phase_a()

@@ -264,6 +264,10 @@ int cusrl_gru_gates_bwd(float *gi, float *gh, const float *b_hh, const float *h_
 int cusrl_gru_gates_bwd_bias(float *gi, float *gh, const float *b_hh, const float *h_prev, const float *d_out, float *dh,
                              const int64_t *lengths, int64_t t, int64_t B, int64_t H, float *bias_partials, void *stream);
 int64_t cusrl_gru_bias_partial_rows(int64_t B);
+/* 1 when cusrl_gru_gates_bwd_bias accepts a launch with this hidden size and these (device) pointers — alignment and the
+ * column-chunk tiling decide — 0 when it would return CUSRL_E_UNSUPPORTED: the host asks instead of restating the rule. */
+int cusrl_gru_bias_supported(int64_t H, const float *gi, const float *gh, const float *b_hh, const float *h_prev,
+                             const float *d_out, const float *dh, const float *bias_partials);
 
 /* The same for torch.nn.LSTM (gate order i, f, g, o), the default core of RecurrentPpoAgentFactory (cusrl/preset/ppo.py:189):
  *   pre = gi + gh + b_hh; c <- sigmoid(pre_f) * c + sigmoid(pre_i) * tanh(pre_g); h <- sigmoid(pre_o) * tanh(c); out = h.

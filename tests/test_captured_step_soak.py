@@ -181,3 +181,28 @@ def test_every_replay_of_a_captured_step_matches_float64_autograd(cusrl, kind, r
         gradient_parity(f"captured_step_soak[{kind},{rows},{name}]", [1.0 + error], [1.0], 1e-5 + 4.0 / rows)  # (recorded)
     print(f"captured-step soak {kind} {rows} rows: {record['replays']} replays, worst error "
           f"{max(record['worst'].values()):.2e} of a tensor's largest entry ({record['near_clip']} replays with a ratio within 1e-6 of a clip bound)")
+
+
+@pytest.mark.parametrize("concurrent", [False, True])
+@pytest.mark.parametrize("kind", ["stock", "amp", "split"])
+def test_two_seeded_runs_of_the_captured_loop_are_bit_identical(cusrl, kind, concurrent):
+    """Same seed, same process, 8 iterations at 1024-row minibatches, single-stream and with the critic on its branch stream
+    (split compositions are single-stream by construction): every parameter and every buffer leaf bit-identical.  This is
+    the symptom the round-4 defect was found by (scripts/debug_amp_identity.py) — in BOTH stream layouts now."""
+    N, T, minibatches, epochs = 256, 8, 2, 2
+    finals = []
+    for _ in range(2):
+        cusrl.set_global_seed(21)
+        env = cusrl.testing.DummyTorchEnvironment(num_instances=N, observation_dim=12, action_dim=4, device=DEV)
+        trainer = cusrl.Trainer(env, _factory(cusrl, kind, T, minibatches, epochs), num_iterations=8, verbose=False)
+        trainer.agent.concurrent_critic = concurrent
+        trainer.run_training_loop()
+        torch.cuda.synchronize()
+        agent = trainer.agent
+        assert all(step.state == 2 for step in agent._graphed_steps.values())
+        state = {f"param/{name}": p.detach().clone() for name, p in agent.named_parameters()}
+        state.update({f"buffer/{key}": leaf.clone() for key, leaf in agent.buffer.storage.items()})
+        state["grad"] = agent.flat_gradients.buffer.clone()
+        finals.append(state)
+    differing = [key for key in finals[0] if not torch.equal(finals[0][key], finals[1][key])]
+    assert not differing, differing[:8]

@@ -752,12 +752,13 @@ def test_recurrent_step_gemm_rows_are_bucketed_to_256_and_capped_by_the_batch():
     assert _gemm_rows(7, 7) == 7 and _gemm_rows(100, 100) == 100
 
 
-def test_critic_stream_branch_is_the_default_of_every_fused_composition(monkeypatch):
-    """GraphedTrainStep._critic_branch: forced by ``agent.concurrent_critic``; unset, the branch whenever the objective is
-    the fused one — the single-stream form of the captured step is not bit-reproducible yet, whatever
-    the minibatch size and whichever auxiliary objectives share the step."""
+def test_critic_stream_branch_default_is_chosen_per_composition(monkeypatch):
+    """GraphedTrainStep._critic_branch: forced by ``agent.concurrent_critic``; unset, the branch only where it measured
+    faster — the stock fused composition at >= 4096-row minibatches (profiles/r05/stream_ab.txt); launch-bound small
+    minibatches, RND / AMP chains in the same step and split compositions take one stream."""
     from types import SimpleNamespace
 
+    from cusrl_amd.hook.auxiliary import RandomNetworkDistillation
     from cusrl_amd.hook.on_policy.fused import FusedPpoObjective
     from cusrl_amd.template.graphs import GraphedTrainStep
 
@@ -766,6 +767,16 @@ def test_critic_stream_branch_is_the_default_of_every_fused_composition(monkeypa
     step = GraphedTrainStep.__new__(GraphedTrainStep)
     step.agent = SimpleNamespace(concurrent_critic=None, hook=[], buffer=SimpleNamespace(capacity=8))
     step.static_indices, step.temporal = torch.zeros(32, dtype=torch.int64), False  # a launch-bound 32-row minibatch
+    assert not step._critic_branch()
+    step.static_indices = torch.zeros(4096, dtype=torch.int64)
+    assert step._critic_branch()
+    step.static_indices, step.temporal = torch.zeros(512, dtype=torch.int64), True  # 512 env columns x 8 steps
+    assert step._critic_branch()
+    rnd = RandomNetworkDistillation.__new__(RandomNetworkDistillation)
+    rnd._active = True
+    step.agent.hook = [rnd]  # an auxiliary objective chain in the same step: one stream
+    assert not step._critic_branch()
+    rnd._active = False
     assert step._critic_branch()
     mode["value"] = "split"  # further objective hooks read curr_value on the main stream: one stream by construction
     assert not step._critic_branch()
