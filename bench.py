@@ -46,6 +46,7 @@ def parse_args():
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-kernel-pass", action="store_true")
     parser.add_argument("--no-scale-pass", action="store_true", help="skip the 1 048 576-env roofline-scale kernel pass")
+    parser.add_argument("--no-env-ab", action="store_true", help="skip the torch-generator-env timing beside the fused env")
     parser.add_argument("--native-collectives", action="store_true",
                         help="(default since round 3, kept for old command lines) collectives through the C ABI")
     parser.add_argument("--torch-collectives", action="store_true",
@@ -81,6 +82,39 @@ def pmc_traffic(envs_per_gpu):
     return entry["hbm_traffic_bytes"], (f"quoted: rocprofv3 PMC passes of this kernel source ({summary.get('commit', '?')}), "
                                         "profiles/r04/pmc_gather_summary.json; the 25 MB of sampled leaves are L2 / Infinity-Cache "
                                         "resident, the memory-side counters include the cache's hits")
+
+
+def rocprof_gather(bytes_per_launch):
+    """The dominant kernel's average duration in the committed rocprofv3 kernel trace of this very command (per-grid split of
+    ``rocprofv3 --kernel-trace --stats -- python bench.py``, scripts/collect_r05.sh): the profile-side figure next to the
+    graph-timed one.  The tool adds ~1.5 us to sub-10 us dispatches, so this fraction is the lower of the two.  Quoted like
+    the PMC traffic: only while the kernel source is the one the profile was taken from."""
+    import csv
+    import hashlib
+
+    for round_dir in ("r05", "r04"):
+        path = ROOT / "profiles" / round_dir / "rocprofv3_cusrl_kernels_by_grid.csv"
+        if not path.exists():
+            continue
+        stamp = ROOT / "profiles" / round_dir / "rocprofv3_bench_line.json"
+        rows = [r for r in csv.DictReader(open(path)) if r["kernel"] == "cusrl::gather_kernel"]
+        if not rows:
+            continue
+        row = max(rows, key=lambda r: int(r["calls"]) * int(r["grid_size_threads"]))  # the in-step minibatch gather
+        us = int(row["avg_ns"]) / 1e3
+        source = hashlib.sha256((ROOT / "cusrl_amd" / "csrc" / "buffer.hip").read_bytes()).hexdigest()[:16]
+        recorded = None
+        if stamp.exists():
+            try:
+                recorded = json.loads(stamp.read_text()).get("buffer_hip_sha256_16")
+            except (ValueError, OSError):
+                recorded = None
+        if recorded is not None and recorded != source:
+            continue
+        return {"avg_us": round(us, 3), "calls": int(row["calls"]), "grid_size_threads": int(row["grid_size_threads"]),
+                "frac": round(bytes_per_launch / us / 1e3 / HBM_PEAK_GBS, 4) if us > 0 else None,
+                "source": f"profiles/{round_dir}/rocprofv3_cusrl_kernels_by_grid.csv"}
+    return None
 
 
 def graph_time(fn, launches=10, replays=20):
@@ -130,6 +164,33 @@ def cusrl_iterate(schema):
     from cusrl_amd.utils.nest import iterate_nested
 
     return iterate_nested(schema)
+
+
+def torch_generator_env_ms(args, device):
+    """ms per iteration of the same workload with the synthetic env in its torch-generator form (``fused=False``): the A/B that
+    separates what the benchmark's env fixture contributes to the headline from what the path does."""
+    import cusrl_amd as cusrl
+
+    cusrl.set_global_seed(42)
+    env = cusrl.testing.SyntheticEnvironment(args.envs_per_gpu, OBS_DIM, ACT_DIM, device=device, autoreset=args.autoreset, fused=False)
+    factory = cusrl.preset.PpoAgentFactory(compile=not args.eager, optimizer_kwargs={"fused": True, "capturable": True})
+    trainer = cusrl.Trainer(env, factory, num_iterations=10**9, verbose=False)
+    observation, state, _ = env.reset(randomize_episode_progress=True)
+    for _ in range(max(args.warmup, 6)):  # (every graph of the loop is captured by iteration 4)
+        observation, state = trainer._rollout_and_update(observation, state)
+        trainer.iteration += 1
+    steps = min(args.steps, 20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        observation, state = trainer._rollout_and_update(observation, state)
+        trainer.iteration += 1
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    env.close()
+    del trainer
+    torch.cuda.empty_cache()
+    return round(ms, 3)
 
 
 def run_gpu(args, rank, world):
@@ -219,6 +280,10 @@ def run_gpu(args, rank, world):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    env_ab_ms = None
+    if getattr(env, "fused", False) and world == 1 and not args.no_env_ab:
+        env_ab_ms = torch_generator_env_ms(args, device)
+
     kernels = {}
     if not args.no_kernel_pass and rank == 0:
         # every HIP kernel of the path stand-alone at this workload's sizes, replayed from a hipGraph between one
@@ -252,6 +317,7 @@ def run_gpu(args, rank, world):
 
     steps_per_iteration = args.envs_per_gpu * HORIZON * world
     traffic, traffic_source = pmc_traffic(args.envs_per_gpu)
+    profile = rocprof_gather(dominant["bytes_per_launch"]) if dominant and args.envs_per_gpu == NUM_ENVS else None
     dominant = dominant or {"achieved_GBps": 0.0, "bytes_per_launch": 0, "avg_us": 0.0, "rows": 0, "fields": [], "leaves": 0,
                             "packed_leaves": 0, "row_bytes": 0}
     # a one-rank torchrun job still runs every collective (process group of one): report it as what it is
@@ -286,6 +352,10 @@ def run_gpu(args, rank, world):
             **({"share_gpu": True, "test_only": "all ranks drive cuda:0 over gloo: exercises the multi-rank path on one GPU, "
                                                 "NOT a scaling measurement"} if args.share_gpu else {}),
             "hipgraph": not args.eager,
+            # the benchmark's synthetic env steps as ONE launch (cusrl_synthetic_env_step); the torch-generator form of the same
+            # env (5 generator launches per step) is timed beside it below: the difference is the benchmark fixture, not the path
+            "fused_env": bool(getattr(env, "fused", False)),
+            "torch_generator_env_ms_per_step": env_ab_ms,
             "captured_env_steps": (trainer._graphed_rollout.captured if trainer._graphed_rollout is not None else 0),
             "epoch_graph_updates": (agent._graphed_epochs.replays if getattr(agent, "_graphed_epochs", None) is not None else 0),
             "autoreset": args.autoreset,
@@ -305,6 +375,9 @@ def run_gpu(args, rank, world):
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(dominant["achieved_GBps"] / HBM_PEAK_GBS, 4),
+            # the same launch in the committed rocprofv3 kernel trace of this command (the tool inflates sub-10 us dispatches)
+            "frac_rocprof": (profile or {}).get("frac"),
+            "rocprof": profile,
             "traffic": traffic,
             "traffic_source": traffic_source,
             "bytes_per_launch": dominant["bytes_per_launch"],
@@ -315,7 +388,9 @@ def run_gpu(args, rank, world):
             # the north-star criterion (GAE + loss >= 40 % of the HBM roofline) where a roofline can physically be shown:
             # the same C-ABI launches at 1 048 576 envs x 24 steps, algorithmic bytes / graph-timed duration / 8 TB/s
             "at_scale": {"envs": 1 << 20, "timing": "hipGraph of 10 launches between one HIP-event pair (scripts/kernel_bench.py)",
-                         "counters": "profiles/r04/pmc/pmc_summary.json", **scale},
+                         "counters": "profiles/r04/pmc/pmc_summary.json, profiles/r05/pmc/pmc_summary.json", **scale},
+            # ... and flat, for consumers that keep scalars only
+            **{f"at_scale_{key}_frac": entry["frac"] for key, entry in scale.items()},
         },
         "kernels": kernels,
     }

@@ -13,6 +13,7 @@
 // own VALU instructions).  Any other width: ppo_loss_rowwise_kernel (one lane per row).  Scalar statistics: fp32 lane sums,
 // fp64 wave / block / grid sums in fixed order.
 #include <float.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -219,7 +220,13 @@ __device__ __forceinline__ void value_scalars(float cv, float R, float v, const 
 }
 
 // kFull: every optional output is wanted (the training step) — no per-store pointer tests.
-template <int LPR, bool kStdVec, bool kFull>
+// kWaveRows (round 5): a wave's rows of ALL its rounds are one contiguous run (R * kRowsPerWave <= 64 rows), so the nine
+// per-row scalar streams (advantage, old log-prob, return, value[, old value] in; log-prob, entropy, log-ratio, ratio,
+// d_value out) move as ONE dword access per stream and wave — lane L holds row L of the run, values travel between the
+// row-major lanes and the row groups by wave shuffles — instead of one access per stream and ROUND with a third of the
+// lanes active: 53 -> 20 vector-memory instructions per wave at A = 12 (the kernel moved 1.02x its algorithmic bytes
+// and still sat at 0.61-0.67 of the HBM roofline: it was bound by memory INSTRUCTIONS, not bytes).
+template <int LPR, bool kStdVec, bool kFull, bool kWaveRows>
 __global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
     const float *__restrict__ advantage, const float *__restrict__ old_logp, const float *__restrict__ action,
     const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ ret,
@@ -257,22 +264,52 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
     float4 x[R], mu[R], sg[kStdVec ? 1 : R];
     float adv[R], olp[R], pre_ret[R], pre_cv[R], pre_ov[R];
     if (kStdVec) sg[0] = sb[sub];
+    constexpr unsigned kRunRows = unsigned(R * G::kRowsPerWave);  // rows of one wave over all its rounds (kWaveRows)
+    const unsigned run_row0 = wave * kRunRows;
+    // kWaveRows: lane L requests the scalars of row L of the wave's run (clamped like every other load)
+    float s_adv = 0.f, s_olp = 0.f, s_ret = 0.f, s_cv = 0.f, s_ov = 0.f;
+    if (kWaveRows) {
+        const unsigned srow = min(run_row0 + lane, rows_here - 1u);
+        s_adv = advb[srow];
+        s_olp = olpb[srow];
+        if (D == 1) {  // uniform
+            s_ret = retb[srow];
+            s_cv = cvb[srow];
+            if (p.value_clip >= 0.0f) s_ov = ovb[srow];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        lrow[k] = (unsigned(k) * kWavesPerBlock + wave) * G::kRowsPerWave + rloc;
+        lrow[k] = kWaveRows ? run_row0 + unsigned(k) * G::kRowsPerWave + rloc
+                            : (unsigned(k) * kWavesPerBlock + wave) * G::kRowsPerWave + rloc;
         valid[k] = holder && lrow[k] < rows_here;
         const unsigned crow = min(lrow[k], rows_here - 1u);
         q[k] = crow * LPR + sub;
         x[k] = xb[q[k]];
         mu[k] = mb[q[k]];
         if (!kStdVec) sg[k] = sb[q[k]];
-        adv[k] = advb[crow];
-        olp[k] = olpb[crow];
         pre_ret[k] = pre_cv[k] = pre_ov[k] = 0.f;
-        if (D == 1) {  // uniform
-            pre_ret[k] = retb[crow];
-            pre_cv[k] = cvb[crow];
-            if (p.value_clip >= 0.0f) pre_ov[k] = ovb[crow];
+        if (!kWaveRows) {
+            adv[k] = advb[crow];
+            olp[k] = olpb[crow];
+            if (D == 1) {  // uniform
+                pre_ret[k] = retb[crow];
+                pre_cv[k] = cvb[crow];
+                if (p.value_clip >= 0.0f) pre_ov[k] = ovb[crow];
+            }
+        }
+    }
+    if (kWaveRows) {  // row-major lanes -> row groups (a clamped row's lane holds the clamped row's values: same semantics)
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int src = int(unsigned(k) * G::kRowsPerWave + rloc) & (kWave - 1);
+            adv[k] = __shfl(s_adv, src, kWave);
+            olp[k] = __shfl(s_olp, src, kWave);
+            if (D == 1) {
+                pre_ret[k] = __shfl(s_ret, src, kWave);
+                pre_cv[k] = __shfl(s_cv, src, kWave);
+                if (p.value_clip >= 0.0f) pre_ov[k] = __shfl(s_ov, src, kWave);
+            }
         }
     }
 
@@ -302,6 +339,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
         for (int j = 0; j < LPR; ++j) entropy += __shfl(en, int(row_lane0) + j, kWave);
     };
     if (kStdVec) prepare_std(sg[0]);
+    float o_logp = 0.f, o_entropy = 0.f, o_lr = 0.f, o_ratio = 0.f, o_vgrad = 0.f;  // kWaveRows: row (run_row0 + lane)'s outputs
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if (!kStdVec) prepare_std(sg[k]);
@@ -334,13 +372,37 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
         if (valid[k]) {
             if (kFull || dmb) dmb[lrow[k] * LPR + sub] = make_float4(gm[0], gm[1], gm[2], gm[3]);
             if (!kStdVec && (kFull || dsb)) dsb[lrow[k] * LPR + sub] = make_float4(gs[0], gs[1], gs[2], gs[3]);
-            if (sub == 0) {
+            if (!kWaveRows && sub == 0) {
                 if (kFull || lpo) lpo[lrow[k]] = logp;
                 if (kFull || eno) eno[lrow[k]] = entropy;
                 if (kFull || lro) lro[lrow[k]] = r.lr;
                 if (kFull || rao) rao[lrow[k]] = r.ratio;
                 if (D == 1 && (kFull || dvb)) dvb[lrow[k]] = v_grad;
             }
+        }
+        if (kWaveRows) {  // row groups -> row-major lanes: lane L collects row L of the run from the group that holds it
+            const int src = int((lane % G::kRowsPerWave) * LPR) & (kWave - 1);
+            const bool mine = lane / G::kRowsPerWave == unsigned(k);
+            const float c_logp = __shfl(logp, src, kWave), c_lr = __shfl(r.lr, src, kWave), c_ratio = __shfl(r.ratio, src, kWave);
+            if (mine) o_logp = c_logp, o_lr = c_lr, o_ratio = c_ratio;
+            if (!kStdVec) {
+                const float c_en = __shfl(entropy, src, kWave);
+                if (mine) o_entropy = c_en;
+            }
+            if (D == 1) {
+                const float c_vg = __shfl(v_grad, src, kWave);
+                if (mine) o_vgrad = c_vg;
+            }
+        }
+    }
+    if (kWaveRows) {
+        const unsigned orow = run_row0 + lane;
+        if (lane < kRunRows && orow < rows_here) {
+            if (kFull || lpo) lpo[orow] = o_logp;
+            if (kFull || eno) eno[orow] = kStdVec ? entropy : o_entropy;  // a std vector: the same entropy for every row
+            if (kFull || lro) lro[orow] = o_lr;
+            if (kFull || rao) rao[orow] = o_ratio;
+            if (D == 1 && (kFull || dvb)) dvb[orow] = o_vgrad;
         }
     }
     double acc[kLossSums];
@@ -626,15 +688,26 @@ extern "C" int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const 
     return launch_finalize(partials, blocks, B, A, D, p, losses_out, nullptr, nullptr, s);
 }
 
-#define CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, FULL)                                                                        \
-    hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, VEC, FULL>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, advantage, \
-                       old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out, entropy_out,      \
-                       logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials, int(defer))
+#define CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, FULL, WAVE_ROWS)                                                             \
+    hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, VEC, FULL, WAVE_ROWS>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, \
+                       advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out,        \
+                       entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,          \
+                       int(defer))
+#define CUSRL_LAUNCH_ROWGROUP_FULL(LPR, VEC, WAVE_ROWS)                                                                \
+    if (full) CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, true, WAVE_ROWS);                                                     \
+    else CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, false, WAVE_ROWS)
 #define CUSRL_LAUNCH_ROWGROUP(LPR)                                                                                     \
-    if (std_vector && full) CUSRL_LAUNCH_ROWGROUP_AS(LPR, true, true);                                                 \
-    else if (std_vector) CUSRL_LAUNCH_ROWGROUP_AS(LPR, true, false);                                                   \
-    else if (full) CUSRL_LAUNCH_ROWGROUP_AS(LPR, false, true);                                                         \
-    else CUSRL_LAUNCH_ROWGROUP_AS(LPR, false, false)
+    if (std_vector && wave_rows) { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, true, true); }                                      \
+    else if (std_vector) { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, true, false); }                                             \
+    else if (wave_rows) { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, false, true); }                                              \
+    else { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, false, false); }
+
+// the scalar streams of a wave's rows as one access per stream (kWaveRows); CUSRL_LOSS_WAVE_ROWS=0 keeps round 3's
+// one-access-per-round form for A/B runs
+static bool loss_wave_rows() {
+    const char *e = getenv("CUSRL_LOSS_WAVE_ROWS");  // (read per call: the A/B scripts flip it inside one process)
+    return !(e && e[0] == '0');
+}
 
 extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action,
                                       const float *mean, const float *std, const float *ret, const float *curr_value,
@@ -662,6 +735,7 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     // the training step wants every output: that variant carries no per-store pointer tests
     const bool full = logp_out && entropy_out && logp_ratio_out && ratio_out && d_mean && d_value && (std_vector || d_std);
+    const bool wave_rows = loss_wave_rows();
     if (chunked) {
         switch (A / 4) {
             case 1: CUSRL_LAUNCH_ROWGROUP(1); break;
