@@ -314,7 +314,14 @@ class GraphedTrainStep:
         if objectives is not None:
             loss = objectives.terms() if agent.flat_gradients is not None else objectives.loss()
             agent._zero_grad()
-            agent._backward(loss)
+            from cusrl_amd.nn import module as nn_module
+
+            if self._critic_branch() and os.environ.get("CUSRL_STAGGER_CRITIC", "0") == "1":
+                nn_module._branch_stagger = {"main": torch.cuda.current_stream(), "branch": agent._branch_stream, "event": None}
+            try:
+                agent._backward(loss)
+            finally:
+                nn_module._branch_stagger = None
             agent.grad_scaler.unscale_(agent.optimizer)
         self.carry = {"batch": batch, "objectives": objectives}
 

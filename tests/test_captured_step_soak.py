@@ -79,9 +79,19 @@ def _reference_gradients(agent, names, params_before, indices, kind):
     obs, action, old_logp = rows("observation"), rows("action"), rows("action_logp")
     advantage, ret = rows("advantage"), rows("return")
 
+    obs32 = agent.buffer.storage["observation"].flatten(0, 1)[indices]
+
     def mlp(prefix, x):
+        """float64 values and float64 autograd, but each ReLU's on / off decision is the fp32 one: a pre-activation within fp32
+        rounding of zero (~0.4 of the 10^6 units of a replay) would otherwise flip between the two precisions and move a
+        weight-gradient row by ~1 / rows of its largest entry — a property of the kink, not of the step.  The fp32 decisions
+        come from an eager re-execution of the very library call the step's forward makes (same shapes, same arguments:
+        the libraries are bit-reproducible call to call, scripts/gemm_determinism.py)."""
+        x32 = obs32
         for i in (0, 2):
-            x = torch.relu(x @ p[f"{prefix}.backbone.layers.{i}.weight"].t() + p[f"{prefix}.backbone.layers.{i}.bias"])
+            weight, bias = f"{prefix}.backbone.layers.{i}.weight", f"{prefix}.backbone.layers.{i}.bias"
+            x32 = torch._addmm_activation(params_before[bias], x32, params_before[weight].t())  # + ReLU in the GEMM epilogue
+            x = torch.where(x32 > 0, x @ p[weight].t() + p[bias], torch.zeros((), dtype=torch.float64, device=x.device))
         return x
 
     mean = mlp("actor", obs) @ p["actor.distribution.mean_head.weight"].t() + p["actor.distribution.mean_head.bias"]
