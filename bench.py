@@ -71,17 +71,21 @@ def pmc_traffic(envs_per_gpu):
     cusrl_amd/csrc/buffer.hip recorded next to the numbers); otherwise null."""
     import hashlib
 
-    path = ROOT / "profiles" / "r04" / "pmc_gather_summary.json"
-    if envs_per_gpu != NUM_ENVS or not path.exists():
+    if envs_per_gpu != NUM_ENVS:
         return None, None
-    summary = json.loads(path.read_text())
     source = hashlib.sha256((ROOT / "cusrl_amd" / "csrc" / "buffer.hip").read_bytes()).hexdigest()[:16]
-    entry = summary.get("gather_minibatch_hot_plain")  # the six leaves a PPO step reads, gathered plainly (round 3)
-    if not entry or summary.get("buffer_hip_sha256_16") != source:
-        return None, None
-    return entry["hbm_traffic_bytes"], (f"quoted: rocprofv3 PMC passes of this kernel source ({summary.get('commit', '?')}), "
-                                        "profiles/r04/pmc_gather_summary.json; the 25 MB of sampled leaves are L2 / Infinity-Cache "
-                                        "resident, the memory-side counters include the cache's hits")
+    for round_dir in ("r05", "r04"):
+        path = ROOT / "profiles" / round_dir / "pmc_gather_summary.json"
+        if not path.exists():
+            continue
+        summary = json.loads(path.read_text())
+        entry = summary.get("gather_minibatch_hot_plain")  # the six leaves a PPO step reads, gathered plainly (round 3)
+        if not entry or summary.get("buffer_hip_sha256_16") != source:
+            continue
+        return entry["hbm_traffic_bytes"], (f"quoted: rocprofv3 PMC passes of this kernel source ({summary.get('commit', '?')}), "
+                                            f"profiles/{round_dir}/pmc_gather_summary.json; the 25 MB of sampled leaves are L2 / "
+                                            "Infinity-Cache resident, the memory-side counters include the cache's hits")
+    return None, None
 
 
 def rocprof_gather(bytes_per_launch):
@@ -260,13 +264,40 @@ def run_gpu(args, rank, world):
     dominant = dominant_kernel(agent) if rank == 0 else None
     # the gradient all-reduce of one optimizer step at this run's world size (a collective: EVERY rank times it), as the
     # step issues it: the C-ABI call captured in a hipGraph, or torch.distributed's eager call between two graphs
-    allreduce_us = None
+    allreduce_us = split_allreduce_us = None
     if torch.distributed.is_available() and torch.distributed.is_initialized() and agent.flat_gradients is not None:
         flat = agent.flat_gradients.buffer
         scratch = torch.zeros_like(flat)
         comm = cusrl.utils.distributed.native_comm()
         if comm is not None:
             allreduce_us = graph_time(lambda: comm.allreduce_mean_(scratch))
+            # ... and the per-network split route (CONFIG.split_gradient_allreduce): the critic's window on a side stream through
+            # a second communicator next to the rest on the main stream — both routes' durations in every multi-rank line, so
+            # that the first 8-GPU session is one A/B (the split route's point is the overlap with the actor's backward, which
+            # this stand-alone figure does not contain: it says what the two half-size collectives cost side by side)
+            second = cusrl.utils.distributed.branch_comm()
+            if second is None:
+                second, _ = cusrl.utils.distributed.establish_native_comm(cusrl.utils.distributed.RcclComm.from_process_group, device,
+                                                                         rank, world)
+            if second is not None:
+                critic = {id(p) for p in agent.critic.parameters()}
+                ids = [i for i, p in enumerate(agent.flat_gradients.params) if id(p) in critic]
+                lo = agent.flat_gradients.offsets[ids[0]]
+                hi = agent.flat_gradients.offsets[ids[-1] + 1] if ids[-1] + 1 < len(agent.flat_gradients.offsets) else flat.numel()
+                side = torch.cuda.Stream(device=device)
+
+                def split_route():
+                    main = torch.cuda.current_stream()
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        second.allreduce_mean_(scratch[lo:hi])
+                    if lo > 0:
+                        comm.allreduce_mean_(scratch[:lo])
+                    if hi < scratch.numel():
+                        comm.allreduce_mean_(scratch[hi:])
+                    main.wait_stream(side)
+
+                split_allreduce_us = graph_time(split_route)
         else:
             torch.cuda.synchronize()
             t_ar = time.perf_counter()
@@ -347,6 +378,8 @@ def run_gpu(args, rank, world):
             "collectives": cusrl.utils.distributed.collective_route(),
             "gradient_allreduce": None if allreduce_us is None else {
                 "floats": int(agent.flat_gradients.buffer.numel()), "avg_us": round(allreduce_us, 2), "per_iteration": 20,
+                "split_route_avg_us": None if split_allreduce_us is None else round(split_allreduce_us, 2),
+                "split_route_active": bool(getattr(agent, "_split_plan", None)),
                 "timing": "hipGraph of 10 calls x 20 replays" if cusrl.utils.distributed.native_comm() is not None
                           else "50 eager calls, host clock"},
             **({"share_gpu": True, "test_only": "all ranks drive cuda:0 over gloo: exercises the multi-rank path on one GPU, "

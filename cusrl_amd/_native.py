@@ -7,10 +7,12 @@ The library is the product: there is no CPU or eager fallback.  If it has not be
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libcusrl_hip.so"
+# (CUSRL_HIP_LIBRARY: another build of the same library, e.g. one of scripts/build_loss_variants.sh's A/B variants)
+LIB_PATH = Path(os.environ.get("CUSRL_HIP_LIBRARY") or Path(__file__).resolve().parent / "libcusrl_hip.so")
 ABI_VERSION = 5
 MAX_FIELDS = 24
 MAX_PACKED = 16

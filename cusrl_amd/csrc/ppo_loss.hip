@@ -112,11 +112,31 @@ __device__ __forceinline__ double wave_sum_to_last_lane(double v) {
     return v;
 }
 
+template <int kCtrl>
+__device__ __forceinline__ float dpp_move_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), kCtrl, 0xf, 0xf, false));
+}
+
+// the same tree in fp32 (one v_add_f32 with a DPP operand per step): CUSRL_LOSS_F32_WAVE_SUMS, a sweep knob
+__device__ __forceinline__ float wave_sum_to_last_lane_f32(float v) {
+    v += dpp_move_f32<0xb1>(v);
+    v += dpp_move_f32<0x4e>(v);
+    v += dpp_move_f32<0x124>(v);
+    v += dpp_move_f32<0x128>(v);
+    v += dpp_move_f32<0x142>(v);
+    v += dpp_move_f32<0x143>(v);
+    return v;
+}
+
 __device__ __forceinline__ void park_wave_sums(const double (&acc)[kLossSums], double (*scratch)[kLossSums]) {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
     for (int k = 0; k < kLossSums; ++k) {
+#ifdef CUSRL_LOSS_F32_WAVE_SUMS
+        const double total = double(wave_sum_to_last_lane_f32(float(acc[k])));
+#else
         const double total = wave_sum_to_last_lane(acc[k]);
+#endif
         if (lane == kWave - 1) scratch[wave][k] = total;
     }
 }
@@ -160,7 +180,10 @@ template <int LPR>
 struct RowGroup {
     static constexpr int kRowsPerWave = kWave / LPR;
     static constexpr int kActive = kRowsPerWave * LPR;
-    static constexpr int kRounds = LPR >= 4 ? 4 : LPR;
+#ifndef CUSRL_LOSS_ROUNDS_CAP
+#define CUSRL_LOSS_ROUNDS_CAP 4  // (a sweep knob: scripts/build_loss_variants.sh)
+#endif
+    static constexpr int kRounds = (LPR >= 4 ? 4 : LPR) < CUSRL_LOSS_ROUNDS_CAP ? (LPR >= 4 ? 4 : LPR) : CUSRL_LOSS_ROUNDS_CAP;
     static constexpr int kRowsPerBlock = kWavesPerBlock * kRowsPerWave * kRounds;
     static constexpr int kTreeStart = kRowsPerWave > 32 ? 32 : kRowsPerWave > 16 ? 16 : kRowsPerWave > 8 ? 8 : 4;
 };
@@ -226,15 +249,19 @@ __device__ __forceinline__ void value_scalars(float cv, float R, float v, const 
 // row-major lanes and the row groups by wave shuffles — instead of one access per stream and ROUND with a third of the
 // lanes active: 53 -> 20 vector-memory instructions per wave at A = 12 (the kernel moved 1.02x its algorithmic bytes
 // and still sat at 0.61-0.67 of the HBM roofline: it was bound by memory INSTRUCTIONS, not bytes).
+#ifdef CUSRL_LOSS_WAVES_PER_EU
+#define CUSRL_LOSS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(CUSRL_LOSS_WAVES_PER_EU)))
+#else
+#define CUSRL_LOSS_OCCUPANCY
+#endif
 template <int LPR, bool kStdVec, bool kFull, bool kWaveRows>
-__global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
+__global__ __launch_bounds__(kBlock) CUSRL_LOSS_OCCUPANCY void ppo_loss_rowgroup_kernel(
     const float *__restrict__ advantage, const float *__restrict__ old_logp, const float *__restrict__ action,
     const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ ret,
     const float *__restrict__ curr_value, const float *__restrict__ old_value, int64_t B, int D, LossParams p,
     float *__restrict__ logp_out, float *__restrict__ entropy_out, float *__restrict__ lr_out,
     float *__restrict__ ratio_out, float *__restrict__ d_mean, float *__restrict__ d_std,
-    float *__restrict__ d_value, double *__restrict__ partials, float *__restrict__ d_std_partials, int accumulate,
-    int tiles) {
+    float *__restrict__ d_value, double *__restrict__ partials, float *__restrict__ d_std_partials, int accumulate) {
     using G = RowGroup<LPR>;
     constexpr int R = G::kRounds;
     __shared__ double acc_wave[kWavesPerBlock][kLossSums];
@@ -242,81 +269,31 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
     const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const unsigned sub = lane % LPR, rloc = lane / LPR;  // chunk within the row, row within the wave's round
     const bool holder = lane < unsigned(G::kActive);
-    constexpr unsigned kRunRows = unsigned(R * G::kRowsPerWave);  // rows of one wave over all its rounds (kWaveRows)
-    const unsigned run_row0 = wave * kRunRows;
-    const unsigned row_lane0 = lane - sub;
+    // block-relative addressing: the block's base pointers are uniform (scalar registers) and everything a lane adds to
+    // them is an unsigned 32-bit offset — no 64-bit vector address arithmetic in the rounds
+    const int64_t block_row0 = int64_t(blockIdx.x) * G::kRowsPerBlock;
+    const unsigned rows_here = unsigned(min(int64_t(G::kRowsPerBlock), B - block_row0));
+    const float4 *__restrict__ xb = reinterpret_cast<const float4 *>(action) + block_row0 * LPR;
+    const float4 *__restrict__ mb = reinterpret_cast<const float4 *>(mean) + block_row0 * LPR;
+    const float4 *__restrict__ sb = reinterpret_cast<const float4 *>(std) + (kStdVec ? 0 : block_row0 * LPR);
+    const float *__restrict__ advb = advantage + block_row0, *__restrict__ olpb = old_logp + block_row0;
+    const float *__restrict__ retb = ret + block_row0 * D, *__restrict__ cvb = curr_value + block_row0 * D;
+    const float *__restrict__ ovb = old_value ? old_value + block_row0 * D : nullptr;
+    float4 *__restrict__ dmb = d_mean ? reinterpret_cast<float4 *>(d_mean) + block_row0 * LPR : nullptr;
+    float4 *__restrict__ dsb = (!kStdVec && d_std) ? reinterpret_cast<float4 *>(d_std) + block_row0 * LPR : nullptr;
+    float *__restrict__ dvb = d_value ? d_value + block_row0 * D : nullptr;
+    float *__restrict__ lpo = logp_out ? logp_out + block_row0 : nullptr, *__restrict__ eno = entropy_out ? entropy_out + block_row0 : nullptr;
+    float *__restrict__ lro = lr_out ? lr_out + block_row0 : nullptr, *__restrict__ rao = ratio_out ? ratio_out + block_row0 : nullptr;
 
-    // Arithmetic: per element ONE hardware reciprocal of sigma (v_rcp_f32, <= 1 ulp) and multiplications instead of the five
-    // IEEE divisions of the textbook form — with those the kernel is bound by its VALU instructions, not by HBM (round 2:
-    // matrix and vector form both took 340 us at 1 M envs for 1.74 and 1.13 GB).  z = (x - mu) / sigma:
-    //   log-prob term  -z^2 / 2 - log sigma - log sqrt(2 pi)                 distribution.py:207-209
-    //   d logp/d mu = z / sigma,  d logp/d sigma = (z^2 - 1) / sigma,  d entropy/d sigma = 1 / sigma
-    // A few ulp from the reference's op order, far inside the 1e-5 the losses and gradients are held to.  With a std vector
-    // reciprocal, logarithm and the row's entropy do not depend on the row at all: once per lane.
-    // A lane sums its rows' scalars in fp32 (kRounds rows per tile); waves and blocks are reduced in fp64.
-    float lane_sum[kLossSums] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    double acc[kLossSums] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    float4 ds_acc = make_float4(0.f, 0.f, 0.f, 0.f);  // std-vector mode: this lane's column group, summed over its rows
-    float inv[4], ls[4], entropy = 0.0f;
-    auto prepare_std = [&](const float4 &s) {
-        const float ss[4] = {s.x, s.y, s.z, s.w};
-        float en = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            inv[j] = __builtin_amdgcn_rcpf(ss[j]);
-            ls[j] = logf(ss[j]);
-            en += entropy_const() + ls[j];  // distribution.py:211-213
-        }
-        entropy = 0.0f;  // the row's sum, chunk 0 first (the order of a sequential sum over the row)
-#pragma unroll
-        for (int j = 0; j < LPR; ++j) entropy += __shfl(en, int(row_lane0) + j, kWave);
-    };
-    if (kStdVec) prepare_std(reinterpret_cast<const float4 *>(std)[sub]);
-
-    // A block walks `tiles` consecutive tiles of kRowsPerBlock rows (round 5).  What a wave pays ONCE — the std vector's
-    // reciprocals / logarithms / entropy, the d_std shuffle tree, five fp64 wave sums, the block exchange — is 42 % of the
-    // kernel's vector instructions at one tile per block; the kernel moved 1.02x its bytes with the SIMDs ~50 % busy and
-    // HBM at 0.66 (profiles/r05/pmc): neither saturated, both phases too short to hide each other.  Small minibatches
-    // (config 2: 98 blocks) keep one tile per block — they want every CU.
-    // The tile's base pointers are the (uniform) kernel arguments themselves, bumped from tile to tile — one live set of
-    // scalar registers (a fresh set of thirteen 64-bit bases per tile next to the arguments overflowed the SGPR file
-    // and spilled into vector registers) — and everything a lane adds to them is an unsigned 32-bit offset.
-    int64_t rows_left = B - int64_t(blockIdx.x) * tiles * G::kRowsPerBlock;
-    {
-        const int64_t first = int64_t(blockIdx.x) * tiles * G::kRowsPerBlock;
-        action += first * (4 * LPR), mean += first * (4 * LPR);
-        if (!kStdVec) std += first * (4 * LPR);
-        advantage += first, old_logp += first, ret += first * D, curr_value += first * D;
-        if (old_value) old_value += first * D;
-        if (d_mean) d_mean += first * (4 * LPR);
-        if (!kStdVec && d_std) d_std += first * (4 * LPR);
-        if (d_value) d_value += first * D;
-        if (logp_out) logp_out += first;
-        if (entropy_out) entropy_out += first;
-        if (lr_out) lr_out += first;
-        if (ratio_out) ratio_out += first;
-    }
-#pragma unroll 1
-    for (int tile = 0; tile < tiles && rows_left > 0; ++tile, rows_left -= G::kRowsPerBlock) {
-    const unsigned rows_here = unsigned(min(int64_t(G::kRowsPerBlock), rows_left));
-    const float4 *__restrict__ xb = reinterpret_cast<const float4 *>(action);
-    const float4 *__restrict__ mb = reinterpret_cast<const float4 *>(mean);
-    const float4 *__restrict__ sb = reinterpret_cast<const float4 *>(std);
-    const float *__restrict__ advb = advantage, *__restrict__ olpb = old_logp;
-    const float *__restrict__ retb = ret, *__restrict__ cvb = curr_value;
-    const float *__restrict__ ovb = old_value;
-    float4 *__restrict__ dmb = reinterpret_cast<float4 *>(d_mean);
-    float4 *__restrict__ dsb = kStdVec ? nullptr : reinterpret_cast<float4 *>(d_std);
-    float *__restrict__ dvb = d_value;
-    float *__restrict__ lpo = logp_out, *__restrict__ eno = entropy_out;
-    float *__restrict__ lro = lr_out, *__restrict__ rao = ratio_out;
-
-    // ---- every load of the tile's rows is requested up front, unpredicated (rows past the end re-read the tile's last
+    // ---- every load of the block's rows is requested up front, unpredicated (rows past the end re-read the block's last
     // row; their results are never stored): the matrix chunks and the per-row scalars of the scalar part
     unsigned lrow[R], q[R];
     bool valid[R];
     float4 x[R], mu[R], sg[kStdVec ? 1 : R];
     float adv[R], olp[R], pre_ret[R], pre_cv[R], pre_ov[R];
+    if (kStdVec) sg[0] = sb[sub];
+    constexpr unsigned kRunRows = unsigned(R * G::kRowsPerWave);  // rows of one wave over all its rounds (kWaveRows)
+    const unsigned run_row0 = wave * kRunRows;
     // kWaveRows: lane L requests the scalars of row L of the wave's run (clamped like every other load)
     float s_adv = 0.f, s_olp = 0.f, s_ret = 0.f, s_cv = 0.f, s_ov = 0.f;
     if (kWaveRows) {
@@ -364,6 +341,32 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
         }
     }
 
+    // Arithmetic: per element ONE hardware reciprocal of sigma (v_rcp_f32, <= 1 ulp) and multiplications instead of the five
+    // IEEE divisions of the textbook form — with those the kernel is bound by its VALU instructions, not by HBM (round 2:
+    // matrix and vector form both took 340 us at 1 M envs for 1.74 and 1.13 GB).  z = (x - mu) / sigma:
+    //   log-prob term  -z^2 / 2 - log sigma - log sqrt(2 pi)                 distribution.py:207-209
+    //   d logp/d mu = z / sigma,  d logp/d sigma = (z^2 - 1) / sigma,  d entropy/d sigma = 1 / sigma
+    // A few ulp from the reference's op order, far inside the 1e-5 the losses and gradients are held to.  With a std vector
+    // reciprocal, logarithm and the row's entropy do not depend on the row at all: once per lane.
+    // A lane sums its (at most kRounds) rows' scalars in fp32; waves and blocks are reduced in fp64.
+    float lane_sum[kLossSums] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 ds_acc = make_float4(0.f, 0.f, 0.f, 0.f);  // std-vector mode: this lane's column group, summed over its rows
+    const unsigned row_lane0 = lane - sub;
+    float inv[4], ls[4], entropy = 0.0f;
+    auto prepare_std = [&](const float4 &s) {
+        const float ss[4] = {s.x, s.y, s.z, s.w};
+        float en = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            inv[j] = __builtin_amdgcn_rcpf(ss[j]);
+            ls[j] = logf(ss[j]);
+            en += entropy_const() + ls[j];  // distribution.py:211-213
+        }
+        entropy = 0.0f;  // the row's sum, chunk 0 first (the order of a sequential sum over the row)
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) entropy += __shfl(en, int(row_lane0) + j, kWave);
+    };
+    if (kStdVec) prepare_std(sg[0]);
     float o_logp = 0.f, o_entropy = 0.f, o_lr = 0.f, o_ratio = 0.f, o_vgrad = 0.f;  // kWaveRows: row (run_row0 + lane)'s outputs
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -430,30 +433,15 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
             if (D == 1 && (kFull || dvb)) dvb[orow] = o_vgrad;
         }
     }
+    double acc[kLossSums];
+#pragma unroll
+    for (int k = 0; k < kLossSums; ++k) acc[k] = double(lane_sum[k]);
     if (D != 1) {  // several value channels (uniform, rare): the generic per-row walk, fp64 sums
 #pragma unroll
         for (int k = 0; k < R; ++k)
             if (valid[k] && sub == 0)
-                value_terms(ret, curr_value, old_value, d_value, lrow[k], D, p, acc[0], acc[4]);
+                value_terms(ret, curr_value, old_value, d_value, block_row0 + lrow[k], D, p, acc[0], acc[4]);
     }
-    {   // on to the next tile
-        constexpr int64_t step = G::kRowsPerBlock;
-        action += step * (4 * LPR), mean += step * (4 * LPR);
-        if (!kStdVec) std += step * (4 * LPR);
-        advantage += step, old_logp += step, ret += step * D, curr_value += step * D;
-        if (old_value) old_value += step * D;
-        if (d_mean) d_mean += step * (4 * LPR);
-        if (!kStdVec && d_std) d_std += step * (4 * LPR);
-        if (d_value) d_value += step * D;
-        if (logp_out) logp_out += step;
-        if (entropy_out) entropy_out += step;
-        if (lr_out) lr_out += step;
-        if (ratio_out) ratio_out += step;
-    }
-    }  // tiles
-
-#pragma unroll
-    for (int k = 0; k < kLossSums; ++k) acc[k] += double(lane_sum[k]);
 
     if (kStdVec) {
         // column sums over the wave's rows: lanes of equal `sub` sit LPR apart -> a shuffle tree with stride LPR; the
@@ -653,23 +641,9 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double 
 
 using namespace cusrl;
 
-// Tiles a block of the row-group kernel walks: 1 while that still leaves fewer than 16 blocks per CU (latency-bound
-// minibatches want every CU), 2 / 4 beyond (what a wave pays once is amortised, see the kernel).  CUSRL_LOSS_TILES forces it.
-static int loss_tiles(int64_t B, int64_t A) {
-    if (A <= 0 || A % 4 != 0 || A / 4 > 8 || B <= 0) return 1;
-    if (const char *e = getenv("CUSRL_LOSS_TILES")) {
-        const int forced = atoi(e);
-        if (forced >= 1 && forced <= 16) return forced;
-    }
-    const int64_t blocks = ceil_div(B, loss_rows_per_block(A));
-    return blocks >= int64_t(256) * 64 ? 4 : (blocks >= int64_t(256) * 32 ? 2 : 1);
-}
-
 // partial rows (= blocks) the main kernel of a [B, A] minibatch writes; A = 0: the categorical / row-wise form
 extern "C" int64_t cusrl_ppo_loss_blocks(int64_t B, int64_t A) {
-    if (B <= 0) return 0;
-    const int64_t blocks = ceil_div(B, A > 0 ? loss_rows_per_block(A) : kBlock);
-    return A > 0 ? ceil_div(blocks, int64_t(loss_tiles(B, A))) : blocks;
+    return B <= 0 ? 0 : ceil_div(B, A > 0 ? loss_rows_per_block(A) : kBlock);
 }
 
 // rows of the fp64 workspace, enough for any action width: one per block, plus one per 256-block slice when the
@@ -746,7 +720,7 @@ extern "C" int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const 
     hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, VEC, FULL, WAVE_ROWS>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, \
                        advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out,        \
                        entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,          \
-                       int(defer), tiles)
+                       int(defer))
 #define CUSRL_LAUNCH_ROWGROUP_FULL(LPR, VEC, WAVE_ROWS)                                                                \
     if (full) CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, true, WAVE_ROWS);                                                     \
     else CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, false, WAVE_ROWS)
@@ -785,8 +759,7 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
                          (!d_mean || aligned(d_mean, 16)) && (!d_std || std_vector || aligned(d_std, 16)) &&
                          (!d_std_partials || aligned(d_std_partials, 16));
     if (std_vector && !chunked) return CUSRL_E_UNSUPPORTED;  // the row-vector form exists for the 16-byte-chunk layout
-    const int tiles = chunked ? loss_tiles(B, A) : 1;
-    const int64_t blocks = ceil_div(ceil_div(B, chunked ? loss_rows_per_block(A) : kBlock), int64_t(tiles));
+    const int64_t blocks = ceil_div(B, chunked ? loss_rows_per_block(A) : kBlock);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     // the training step wants every output: that variant carries no per-store pointer tests
     const bool full = logp_out && entropy_out && logp_ratio_out && ratio_out && d_mean && d_value && (std_vector || d_std);

@@ -177,6 +177,7 @@ class ActorCritic(Agent):
             self.index_slices_in_place = os.environ.get("CUSRL_INPLACE_INDICES", "0") != "0"
             self._graphed_act = GraphedAct(self)
         self.flat_gradients: FlatGradients | None = None
+        self._split_plan = False  # per-network split of the backward: not looked at yet (None = does not apply)
         self._unit_grad: torch.Tensor | None = None
         if isinstance(self.optimizer, torch.optim.Optimizer) and not self.grad_scaler_enabled:
             self.flat_gradients = FlatGradients(self.optimizer)
@@ -386,9 +387,74 @@ class ActorCritic(Agent):
             self._unit_grad = register_unit_gradient(torch.ones((), dtype=first.dtype, device=first.device))
         units = [self._unit_grad if term.dtype == first.dtype else torch.ones((), dtype=term.dtype, device=term.device)
                  for term in roots]
-        with collect_split_weight_grads() as split_slabs:
-            grads = torch.autograd.grad(roots, flat.params, grad_outputs=units, allow_unused=True)
-        flat.assemble(grads, split_slabs)
+        plan = self._split_backward_plan()
+        if plan is None:
+            with collect_split_weight_grads() as split_slabs:
+                grads = torch.autograd.grad(roots, flat.params, grad_outputs=units, allow_unused=True)
+            flat.assemble(grads, split_slabs)
+            return
+        # Per-network split (CONFIG.split_gradient_allreduce; cusrl/utils/distributed.py:145-172 reduces once, behind the
+        # whole backward): the critic first — its window is assembled and averaged on the branch stream through the second
+        # communicator while the actor's backward, issued right behind, runs on the main stream.  Same autograd nodes, same
+        # kernels, same operands as the one-pass backward; the loss node they share is evaluated by both passes.
+        from cusrl_amd.utils import distributed
+
+        critic_ids, other_ids, windows = plan
+        main, branch = torch.cuda.current_stream(), self._branch_stream
+        # collectives inside the backward need a route that may be enqueued here: eager, or capturable (the C ABI)
+        inline = not torch.cuda.is_current_stream_capturing() or distributed.native_comm() is not None
+        flat.absent, flat.split_windows = [], windows
+        branch.wait_stream(main)
+        with torch.cuda.stream(branch):
+            with collect_split_weight_grads() as slabs:
+                grads = torch.autograd.grad(roots, [flat.params[i] for i in critic_ids], grad_outputs=units, allow_unused=True,
+                                            retain_graph=True)
+            flat.assemble(grads, slabs, subset=critic_ids)
+            if inline:
+                comm = distributed.branch_comm()
+                if comm is not None:
+                    comm.allreduce_mean_(windows[0])
+                else:
+                    distributed.reduce_mean_(windows[0])
+        with collect_split_weight_grads() as slabs:
+            grads = torch.autograd.grad(roots, [flat.params[i] for i in other_ids], grad_outputs=units, allow_unused=True)
+        flat.assemble(grads, slabs, subset=other_ids)
+        if inline:
+            for window in windows[1:]:
+                distributed.reduce_mean_(window)
+        main.wait_stream(branch)
+        flat.reduced = inline
+
+    def _split_backward_plan(self):
+        """``(critic parameter indices, the others' indices, [critic window, other windows ...])`` of the flat gradient buffer
+        when the per-network split of the backward applies — a multi-rank job with ``CONFIG.split_gradient_allreduce``, a
+        GPU agent with a branch stream, critic parameters forming one run of the buffer — else None.  Computed once."""
+        if self._split_plan is not False:
+            return self._split_plan
+        self._split_plan = None
+        from cusrl_amd.utils.config import CONFIG, configure_distributed
+
+        flat = self.flat_gradients
+        if (flat is None or not CONFIG.split_gradient_allreduce or not configure_distributed() or self.device.type != "cuda"
+                or getattr(self, "_branch_stream", None) is None):
+            return None
+        critic = {id(p) for p in self.critic.parameters()}
+        if critic & {id(p) for p in self.actor.parameters()}:
+            return None  # shared parameters: one pass
+        critic_ids = [i for i, p in enumerate(flat.params) if id(p) in critic]
+        other_ids = [i for i, p in enumerate(flat.params) if id(p) not in critic]
+        if not critic_ids or not other_ids or critic_ids != list(range(critic_ids[0], critic_ids[-1] + 1)):
+            return None
+        runs, run = [], [other_ids[0]]
+        for i in other_ids[1:]:
+            if i == run[-1] + 1:
+                run.append(i)
+            else:
+                runs.append(run)
+                run = [i]
+        runs.append(run)
+        self._split_plan = (critic_ids, other_ids, [flat.window(critic_ids)] + [flat.window(r) for r in runs])
+        return self._split_plan
 
     def _train_step(self, metadata: dict[str, Any], batch: dict[str, Any]):
         self.actor.clear_intermediate_repr()

@@ -38,6 +38,14 @@ class _Config:
         # collectives).  CUSRL_NATIVE_COLLECTIVES=0 (or CONFIG.native_collectives = False before the agent is built)
         # forces the torch.distributed route: eager all-reduce between two graphs per minibatch step.
         self.native_collectives = env.get("CUSRL_NATIVE_COLLECTIVES", "1") != "0"
+        # Per-network split of the gradient all-reduce (cusrl/utils/distributed.py:145-172 is ONE all-reduce behind the whole
+        # backward): the critic's parameters are differentiated first, their window of the flat buffer is assembled and
+        # averaged on the branch stream through a second communicator WHILE the actor's backward runs; the actor's window
+        # follows on the main stream.  Same kernels, same operands: bit-identical parameters (tests/test_distributed_*).
+        # Off by default — whether two half-size collectives overlapped with backward beat one full-size collective behind
+        # it on 8 xGMI-connected ranks has never been measured (no multi-GPU box in any round); bench.py prints both routes'
+        # durations so that the first such session is one A/B.  CUSRL_SPLIT_ALLREDUCE=1 or CONFIG.split_gradient_allreduce.
+        self.split_gradient_allreduce = env.get("CUSRL_SPLIT_ALLREDUCE", "0") == "1"
         # Building an agent on a GPU loads the measured rocBLAS / hipBLASLt kernel selection through PyTorch TunableOp
         # (utils/tuning.py) — a PROCESS-WIDE setting: other torch code in the process gets the same kernel choice for
         # the GEMM shapes listed in the file.  CONFIG.tuned_gemms = False before the first agent is built (or

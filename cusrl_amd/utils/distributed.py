@@ -14,7 +14,7 @@ SURVEY.md §5), so the design goal is the fewest, copy-free collectives:
 from __future__ import annotations
 
 import os
-from collections.abc import Iterable
+from collections.abc import Iterable, Sequence
 from typing import Any, TypeVar
 
 import numpy as np
@@ -188,6 +188,7 @@ class RcclComm:
 
 _native_comm: RcclComm | None = None
 _native_comm_failed: str | None = None
+_branch_comm: RcclComm | None = None  # second communicator: the critic window's all-reduce on the branch stream (split route)
 
 
 def _agree(problem: str, device) -> bool:
@@ -321,7 +322,23 @@ def native_comm() -> RcclComm | None:
                   flush=True)
         else:
             _native_comm = comm
+            if CONFIG.split_gradient_allreduce:
+                # two collectives in flight on two streams need two communicators (RCCL serialises the operations of one);
+                # created right here, i.e. at the same point on every rank; without it the split route reduces both
+                # windows through the one communicator, one after the other
+                global _branch_comm
+                second, problem = establish_native_comm(RcclComm.from_process_group, CONFIG.device, CONFIG.rank, CONFIG.world_size)
+                if second is None:
+                    print(f"\033[1;33mcusrl_amd: second C-ABI communicator unavailable on rank {CONFIG.rank} ({problem}); the split "
+                          "gradient all-reduce uses one communicator for both windows\033[0m", flush=True)
+                _branch_comm = second
     return _native_comm
+
+
+def branch_comm() -> RcclComm | None:
+    """The communicator of the critic window's all-reduce (``CONFIG.split_gradient_allreduce``), else None."""
+    native_comm()
+    return _branch_comm
 
 
 def _capture_allreduce_probe(comm: RcclComm, rank: int, world: int):
@@ -517,18 +534,30 @@ class FlatGradients:
             self.attach()
         self.buffer.zero_()
 
-    def assemble(self, grads, split_slabs: dict[int, torch.Tensor] | None = None):
+    def assemble(self, grads, split_slabs: dict[int, torch.Tensor] | None = None, subset: Sequence[int] | None = None):
         """Write every parameter's gradient into its slot with ONE launch (``cusrl_assemble_gradients``).
         ``grads[i]`` is parameter i's gradient or None; ``split_slabs`` maps a parameter's storage address to the
-        unsummed ``[S, ...]`` partial gradients its split-batch GEMM left behind (cusrl_amd/nn/module.py)."""
+        unsummed ``[S, ...]`` partial gradients its split-batch GEMM left behind (cusrl_amd/nn/module.py).
+        ``subset`` (indices into ``params``, ``grads`` aligned with it): only those parameters' windows are written — the
+        per-network split of the backward (``ActorCritic._backward``) assembles critic and actor windows separately; slabs
+        of parameters outside the subset (the shared loss node hands the std vector's over in both passes) are dropped."""
         from cusrl_amd import ops
 
         pieces = []
+        if subset is None:
+            params, offsets = self.params, self.offsets
+        else:
+            params, offsets = [self.params[i] for i in subset], [self.offsets[i] for i in subset]
+            mine = {p.data_ptr() for p in params}
+            for key in [key for key in (split_slabs or {}) if key not in mine]:
+                del split_slabs[key]
         # parameters autograd returned no gradient for (unused this step): torch's optimizers skip them; the flat Adam
         # step reads this list and leaves their windows untouched (utils/flat_optimizer.py)
-        self.absent = [i for i, (p, grad) in enumerate(zip(self.params, grads))
-                       if grad is None and not (split_slabs and p.data_ptr() in split_slabs)]
-        for p, grad, offset in zip(self.params, grads, self.offsets):
+        absent = [(i if subset is None else subset[i]) for i, (p, grad) in enumerate(zip(params, grads))
+                  if grad is None and not (split_slabs and p.data_ptr() in split_slabs)]
+        # (a split backward assembles window by window: the caller empties `absent` first, every window adds its own)
+        self.absent = absent if subset is None else sorted(set(self.absent) | set(absent))
+        for p, grad, offset in zip(params, grads, offsets):
             n = p.numel()
             slabs = split_slabs.pop(p.data_ptr(), None) if split_slabs else None
             pending = isinstance(slabs, ops.DeferredColumns)  # partial rows of a column-sum kernel
@@ -544,8 +573,16 @@ class FlatGradients:
             raise RuntimeError("split weight gradients were produced for tensors that are not optimizer parameters")
         # single process: nothing changes the gradients between here and the clipping, so the assembly also leaves the
         # partial sums of squares the clipping coefficient needs (with several ranks the all-reduce comes in between)
-        self._sumsq = ops.assemble_gradients(pieces, self.buffer, want_sumsq=not configure_distributed())
+        self._sumsq = ops.assemble_gradients(pieces, self.buffer, want_sumsq=not configure_distributed() and subset is None)
         self._sumsq_version = self.buffer._version
+
+    def window(self, indices: Sequence[int]) -> torch.Tensor:
+        """The contiguous stretch of the buffer that holds the (consecutive) parameters ``indices``, padding included."""
+        first, last = indices[0], indices[-1]
+        if list(indices) != list(range(first, last + 1)):
+            raise ValueError("a gradient window is a run of consecutive parameters")
+        end = self.offsets[last + 1] if last + 1 < len(self.offsets) else self.buffer.numel()
+        return self.buffer[self.offsets[first] : end]
 
     def take_sumsq(self) -> torch.Tensor | None:
         """The squared-norm partials the last :meth:`assemble` produced, if the gradients are still what it wrote (any
@@ -560,6 +597,16 @@ def reduce_gradients(optimizer: torch.optim.Optimizer, flat: FlatGradients | Non
         return
     if flat is not None and flat.intact():
         flat._sumsq = None  # the averaged gradients have another norm
+        if getattr(flat, "reduced", False):  # the split route already averaged both windows inside the backward
+            flat.reduced = False
+            return
+        windows = getattr(flat, "split_windows", None)
+        if CONFIG.split_gradient_allreduce and windows:
+            # the split route where the collectives cannot be issued inside the backward (a captured phase on a route that
+            # cannot be captured: torch.distributed's collectives): the same windows, one after the other, here
+            for window in windows:
+                reduce_mean_(window)
+            return
         reduce_mean_(flat.buffer)
         return
     params = [p for group in optimizer.param_groups for p in group["params"] if p.grad is not None]

@@ -49,6 +49,7 @@ def main(out_dir: str, compile_: str, native: str):
         "native": distributed.native_comm() is not None, "single_graph": graphs, "route": distributed.collective_route(),
         "captured_env_steps": trainer._graphed_rollout.captured if trainer._graphed_rollout is not None else 0,
         "advantage_head": trainer.agent.buffer["advantage"].flatten()[:8].tolist(),
+        "split_backward": bool(trainer.agent._split_plan),
         "allreduce_calls": _native.launch_counts.get("cusrl_allreduce_mean", 0),
         "allgather_calls": _native.launch_counts.get("cusrl_allgather", 0),
     }))

@@ -124,6 +124,34 @@ def test_two_ranks_sharing_one_gpu_over_gloo_stay_in_lockstep(tmp_path, compile_
             assert r["captured_env_steps"] == 8
 
 
+@pytest.mark.parametrize("compile_", ["0", "1"])
+def test_split_gradient_allreduce_changes_no_bit_two_ranks_over_gloo(tmp_path, compile_):
+    """CONFIG.split_gradient_allreduce (critic differentiated first, its window averaged on the branch stream while the actor's
+    backward runs; cusrl/utils/distributed.py:145-172 is one all-reduce behind the whole backward): two ranks on the one GPU
+    over gloo end with the very parameters the single collective gives, rank for rank."""
+    (tmp_path / "one").mkdir(), (tmp_path / "split").mkdir()
+    single = _run(tmp_path / "one", 2, compile_, "1", share_gpu=True)
+    split = _run(tmp_path / "split", 2, compile_, "1", share_gpu=True, extra_env={"CUSRL_SPLIT_ALLREDUCE": "1"})
+    _assert_lockstep(split)
+    for a, b in zip(single, split):
+        assert not a["split_backward"] and b["split_backward"] == (compile_ == "1")  # (the branch stream exists under compile=True)
+        assert a["param_bytes"] == b["param_bytes"] and a["param_sum"] == b["param_sum"]
+
+
+@pytest.mark.parametrize("native", ["0", "1"])
+def test_split_gradient_allreduce_changes_no_bit_one_rccl_rank(tmp_path, native):
+    """The same on one RCCL rank, both collective routes: with the C ABI the two windows' all-reduces are nodes of the step's
+    hipGraph (two communicators, two streams), with torch.distributed they run eagerly between the step's two graphs."""
+    (tmp_path / "one").mkdir(), (tmp_path / "split").mkdir()
+    (single,) = _run(tmp_path / "one", 1, "1", native)
+    (split,) = _run(tmp_path / "split", 1, "1", native, extra_env={"CUSRL_SPLIT_ALLREDUCE": "1"})
+    assert split["split_backward"] and not single["split_backward"]
+    assert split["native"] == (native == "1") and single["param_bytes"] == split["param_bytes"]
+    if native == "1":
+        assert split["single_graph"] and all(split["single_graph"])  # both windows' collectives captured inside the step
+        assert split["allreduce_calls"] > single["allreduce_calls"]
+
+
 def test_bench_launches_its_own_ranks_and_prints_one_line(tmp_path):
     """``python bench.py --gpus 2 --share-gpu`` (test-only flag): bench.py starts its own two ranks under
     torch.distributed.run, both drive cuda:0 over gloo, rank 0 prints ONE JSON line that says what it is."""
