@@ -73,14 +73,6 @@ def double_differentiable():
         _plain_linear_depth -= 1
 
 
-# Stagger of the critic's stream-branch inside a captured minibatch step (template/graphs.py sets it around the backward):
-# both branches open their backward with a bandwidth-bound narrow-head pass and the two then run through the memory system
-# side by side (narrow_linear_bwd<1>: 8.7 us alone, 16.6 us next to the actor's; profiles/r04/rocprofv3_cusrl_kernels_by_grid
-# .csv).  With the stagger the critic's head pass waits for the actor's: from there on one branch's streaming epilogue runs
-# under the other's GEMM.  {"main": stream, "branch": stream, "event": event recorded behind the actor's head pass}
-_branch_stagger: dict | None = None
-
-
 @contextmanager
 def collect_split_weight_grads():
     global _split_grad_sink
@@ -158,17 +150,9 @@ class _WideBatchLinear(torch.autograd.Function):
             if ctx.narrow and ctx.needs_input_grad[1]:  # policy-mean / value head: dX, dW and db from one pass
                 fuse_relu = ctx.input_is_relu_output and ctx.needs_input_grad[0]
                 sink = _split_grad_sink
-                stagger = _branch_stagger
-                if stagger is not None:
-                    current = torch.cuda.current_stream()
-                    if current == stagger["branch"] and stagger["event"] is not None:
-                        current.wait_event(stagger["event"])  # the critic's head pass starts behind the actor's
                 grad_input, grad_weight, grad_bias, masked_colsum = ops.narrow_linear_backward(
                     grad_output.contiguous(), input, weight, need_input_grad=ctx.needs_input_grad[0], relu_input=fuse_relu,
                     defer=sink is not None)
-                if stagger is not None and stagger["event"] is None and current == stagger["main"]:
-                    stagger["event"] = torch.cuda.Event()
-                    stagger["event"].record(current)
                 grad_weight = _hand_over(sink, weight.data_ptr(), grad_weight)
                 grad_bias = _hand_over(sink, ctx.bias_key, grad_bias) if ctx.has_bias else None
                 if fuse_relu:

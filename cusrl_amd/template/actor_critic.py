@@ -404,18 +404,36 @@ class ActorCritic(Agent):
         # collectives inside the backward need a route that may be enqueued here: eager, or capturable (the C ABI)
         inline = not torch.cuda.is_current_stream_capturing() or distributed.native_comm() is not None
         flat.absent, flat.split_windows = [], windows
-        branch.wait_stream(main)
-        with torch.cuda.stream(branch):
+        # The critic's pass and its window's assembly run where the critic's autograd nodes run: on the branch stream when the
+        # step evaluated the critic there (GraphedTrainStep._critic_branch), else on the main stream — gradients are consumed on
+        # the stream whose allocator pool they came from.  Only the all-reduce, which touches nothing but the persistent flat
+        # buffer, always goes to the branch stream.
+        on_branch = getattr(self, "_critic_backward_stream", None) is branch
+
+        def critic_pass():
             with collect_split_weight_grads() as slabs:
                 grads = torch.autograd.grad(roots, [flat.params[i] for i in critic_ids], grad_outputs=units, allow_unused=True,
                                             retain_graph=True)
             flat.assemble(grads, slabs, subset=critic_ids)
+
+        def critic_reduce():
             if inline:
                 comm = distributed.branch_comm()
                 if comm is not None:
                     comm.allreduce_mean_(windows[0])
                 else:
                     distributed.reduce_mean_(windows[0])
+
+        if on_branch:
+            branch.wait_stream(main)
+            with torch.cuda.stream(branch):
+                critic_pass()
+                critic_reduce()
+        else:
+            critic_pass()
+            branch.wait_stream(main)
+            with torch.cuda.stream(branch):
+                critic_reduce()
         with collect_split_weight_grads() as slabs:
             grads = torch.autograd.grad(roots, [flat.params[i] for i in other_ids], grad_outputs=units, allow_unused=True)
         flat.assemble(grads, slabs, subset=other_ids)

@@ -304,6 +304,7 @@ class GraphedTrainStep:
         agent.critic.clear_intermediate_repr()
         agent.hook.pre_objective(self.metadata, batch)
         agent._critic_stream = agent._branch_stream if self._critic_branch() else None
+        agent._critic_backward_stream = agent._critic_stream  # (where the critic's autograd nodes will run: _backward's split route)
         agent._deferred_loss_owner = self if agent.defer_loss_finalize else None
         try:
             with agent.autocast():
@@ -314,14 +315,7 @@ class GraphedTrainStep:
         if objectives is not None:
             loss = objectives.terms() if agent.flat_gradients is not None else objectives.loss()
             agent._zero_grad()
-            from cusrl_amd.nn import module as nn_module
-
-            if self._critic_branch() and os.environ.get("CUSRL_STAGGER_CRITIC", "0") == "1":
-                nn_module._branch_stagger = {"main": torch.cuda.current_stream(), "branch": agent._branch_stream, "event": None}
-            try:
-                agent._backward(loss)
-            finally:
-                nn_module._branch_stagger = None
+            agent._backward(loss)
             agent.grad_scaler.unscale_(agent.optimizer)
         self.carry = {"batch": batch, "objectives": objectives}
 

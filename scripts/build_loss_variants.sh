@@ -11,14 +11,11 @@ build() { tag=$1; shift
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $OUT/ppo_loss_$tag.o -ldl -o $OUT/libcusrl_hip_$tag.so
   rm -f $OUT/ppo_loss_$tag.o; echo built $tag; }
 build base &
-build wpe8 -DCUSRL_LOSS_WAVES_PER_EU=8 &
 build r2 -DCUSRL_LOSS_ROUNDS_CAP=2 &
-wait
-build r2wpe8 -DCUSRL_LOSS_ROUNDS_CAP=2 -DCUSRL_LOSS_WAVES_PER_EU=8 &
 build f32 -DCUSRL_LOSS_F32_WAVE_SUMS &
-build f32wpe8 -DCUSRL_LOSS_F32_WAVE_SUMS -DCUSRL_LOSS_WAVES_PER_EU=8 &
 wait
-build r1 -DCUSRL_LOSS_ROUNDS_CAP=1 &
-build r1wpe8 -DCUSRL_LOSS_ROUNDS_CAP=1 -DCUSRL_LOSS_WAVES_PER_EU=8 -DCUSRL_LOSS_F32_WAVE_SUMS &
+build r2f32 -DCUSRL_LOSS_ROUNDS_CAP=2 -DCUSRL_LOSS_F32_WAVE_SUMS &
+build r2f32wpe7 -DCUSRL_LOSS_ROUNDS_CAP=2 -DCUSRL_LOSS_F32_WAVE_SUMS -DCUSRL_LOSS_WAVES_PER_EU=7 &
+build r2f32wpe6 -DCUSRL_LOSS_ROUNDS_CAP=2 -DCUSRL_LOSS_F32_WAVE_SUMS -DCUSRL_LOSS_WAVES_PER_EU=6 &
 wait
 ls -la $OUT

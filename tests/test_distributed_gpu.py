@@ -67,7 +67,8 @@ def test_c_abi_route_falls_back_to_torch_distributed_and_says_so(tmp_path, fault
     (result,), output = _run(tmp_path, 1, "1", "1", extra_env=fault, want_output=True)
     assert not result["native"] and "torch.distributed rccl" in result["route"] and needle in result["route"]
     assert output.count("C-ABI RCCL communicator unavailable") == 1 and needle in output
-    assert result["allreduce_calls"] <= 1  # at most the start-up probe went through the abandoned communicator
+    # at most the start-up probe (and, for a replay fault, the capture of the second probe) went through the abandoned communicator
+    assert result["allreduce_calls"] <= (2 if "replay" in str(fault) else 1)
     assert result["single_graph"] and not any(result["single_graph"])
     for key in ("Agent/value_loss", "Agent/surrogate_loss", "Agent/entropy_loss", "Agent/kl_divergence"):
         assert math.isfinite(result["info"][key]), key
