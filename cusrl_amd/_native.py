@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 from pathlib import Path
 
-# (CUSRL_HIP_LIBRARY: another build of the same library, e.g. one of scripts/build_loss_variants.sh's A/B variants)
+# (CUSRL_HIP_LIBRARY: another build of the same library — A/B runs of compile-time variants, profiles/r05/loss_variants_ab.txt)
 LIB_PATH = Path(os.environ.get("CUSRL_HIP_LIBRARY") or Path(__file__).resolve().parent / "libcusrl_hip.so")
 ABI_VERSION = 5
 MAX_FIELDS = 24

@@ -19,6 +19,18 @@
 
 namespace cusrl {
 
+// the [B, A] streams with the non-temporal hint (kStream); clang's builtins take native vectors
+typedef float loss_native_float4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 loss_nt_load(const float4 *p) {
+    const loss_native_float4 v = __builtin_nontemporal_load(reinterpret_cast<const loss_native_float4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void loss_nt_store(float4 *p, const float4 &v) {
+    loss_native_float4 n;
+    n.x = v.x, n.y = v.y, n.z = v.z, n.w = v.w;
+    __builtin_nontemporal_store(n, reinterpret_cast<loss_native_float4 *>(p));
+}
+
 struct LossParams {
     float lo, hi;            // fp32(1 - clip), fp32(1 + clip)                         ppo.py:16
     float value_clip;        // < 0: plain MSE                                          value.py:131-135
@@ -112,31 +124,11 @@ __device__ __forceinline__ double wave_sum_to_last_lane(double v) {
     return v;
 }
 
-template <int kCtrl>
-__device__ __forceinline__ float dpp_move_f32(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), kCtrl, 0xf, 0xf, false));
-}
-
-// the same tree in fp32 (one v_add_f32 with a DPP operand per step): CUSRL_LOSS_F32_WAVE_SUMS, a sweep knob
-__device__ __forceinline__ float wave_sum_to_last_lane_f32(float v) {
-    v += dpp_move_f32<0xb1>(v);
-    v += dpp_move_f32<0x4e>(v);
-    v += dpp_move_f32<0x124>(v);
-    v += dpp_move_f32<0x128>(v);
-    v += dpp_move_f32<0x142>(v);
-    v += dpp_move_f32<0x143>(v);
-    return v;
-}
-
 __device__ __forceinline__ void park_wave_sums(const double (&acc)[kLossSums], double (*scratch)[kLossSums]) {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
     for (int k = 0; k < kLossSums; ++k) {
-#ifdef CUSRL_LOSS_F32_WAVE_SUMS
-        const double total = double(wave_sum_to_last_lane_f32(float(acc[k])));
-#else
         const double total = wave_sum_to_last_lane(acc[k]);
-#endif
         if (lane == kWave - 1) scratch[wave][k] = total;
     }
 }
@@ -180,10 +172,7 @@ template <int LPR>
 struct RowGroup {
     static constexpr int kRowsPerWave = kWave / LPR;
     static constexpr int kActive = kRowsPerWave * LPR;
-#ifndef CUSRL_LOSS_ROUNDS_CAP
-#define CUSRL_LOSS_ROUNDS_CAP 4  // (a sweep knob: scripts/build_loss_variants.sh)
-#endif
-    static constexpr int kRounds = (LPR >= 4 ? 4 : LPR) < CUSRL_LOSS_ROUNDS_CAP ? (LPR >= 4 ? 4 : LPR) : CUSRL_LOSS_ROUNDS_CAP;
+    static constexpr int kRounds = LPR >= 4 ? 4 : LPR;
     static constexpr int kRowsPerBlock = kWavesPerBlock * kRowsPerWave * kRounds;
     static constexpr int kTreeStart = kRowsPerWave > 32 ? 32 : kRowsPerWave > 16 ? 16 : kRowsPerWave > 8 ? 8 : 4;
 };
@@ -249,13 +238,14 @@ __device__ __forceinline__ void value_scalars(float cv, float R, float v, const 
 // row-major lanes and the row groups by wave shuffles — instead of one access per stream and ROUND with a third of the
 // lanes active: 53 -> 20 vector-memory instructions per wave at A = 12 (the kernel moved 1.02x its algorithmic bytes
 // and still sat at 0.61-0.67 of the HBM roofline: it was bound by memory INSTRUCTIONS, not bytes).
-#ifdef CUSRL_LOSS_WAVES_PER_EU
-#define CUSRL_LOSS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(CUSRL_LOSS_WAVES_PER_EU)))
-#else
-#define CUSRL_LOSS_OCCUPANCY
-#endif
-template <int LPR, bool kStdVec, bool kFull, bool kWaveRows>
-__global__ __launch_bounds__(kBlock) CUSRL_LOSS_OCCUPANCY void ppo_loss_rowgroup_kernel(
+// kStream (round 5): the [B, A] streams — action, mean, (std,) d_mean, (d_std) — with the non-temporal hint, loads AND stores,
+// chosen by footprint (loss_streaming below).  Beyond the 256 MB Infinity Cache every line these streams leave in the caches
+// is dead weight that evicts somebody's dirty line: 0.60 -> 0.70 of the HBM roofline in the std-vector form, 0.62-0.68 ->
+// 0.71 in the matrix form on one box (profiles/r05/loss_variants_ab.txt).  Both halves are needed: non-temporal loads alone
+// are SLOWER than the default policy (0.59) and non-temporal stores alone neutral — which is what round 4's policy sweep
+// ran into.  The per-row scalar streams (4 B per row each) keep the default policy.
+template <int LPR, bool kStdVec, bool kFull, bool kWaveRows, bool kStream>
+__global__ __launch_bounds__(kBlock) void ppo_loss_rowgroup_kernel(
     const float *__restrict__ advantage, const float *__restrict__ old_logp, const float *__restrict__ action,
     const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ ret,
     const float *__restrict__ curr_value, const float *__restrict__ old_value, int64_t B, int D, LossParams p,
@@ -313,9 +303,15 @@ __global__ __launch_bounds__(kBlock) CUSRL_LOSS_OCCUPANCY void ppo_loss_rowgroup
         valid[k] = holder && lrow[k] < rows_here;
         const unsigned crow = min(lrow[k], rows_here - 1u);
         q[k] = crow * LPR + sub;
-        x[k] = xb[q[k]];
-        mu[k] = mb[q[k]];
-        if (!kStdVec) sg[k] = sb[q[k]];
+        if (kStream) {
+            x[k] = loss_nt_load(xb + q[k]);
+            mu[k] = loss_nt_load(mb + q[k]);
+            if (!kStdVec) sg[k] = loss_nt_load(sb + q[k]);
+        } else {
+            x[k] = xb[q[k]];
+            mu[k] = mb[q[k]];
+            if (!kStdVec) sg[k] = sb[q[k]];
+        }
         pre_ret[k] = pre_cv[k] = pre_ov[k] = 0.f;
         if (!kWaveRows) {
             adv[k] = advb[crow];
@@ -398,8 +394,13 @@ __global__ __launch_bounds__(kBlock) CUSRL_LOSS_OCCUPANCY void ppo_loss_rowgroup
         if (D == 1) lane_sum[0] += own * v_loss, lane_sum[4] += own * pre_cv[k];  // metric `value` = curr_value.sum(-1)
         if (kStdVec) ds_acc.x += live * gs[0], ds_acc.y += live * gs[1], ds_acc.z += live * gs[2], ds_acc.w += live * gs[3];
         if (valid[k]) {
-            if (kFull || dmb) dmb[lrow[k] * LPR + sub] = make_float4(gm[0], gm[1], gm[2], gm[3]);
-            if (!kStdVec && (kFull || dsb)) dsb[lrow[k] * LPR + sub] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+            if (kStream) {
+                if (kFull || dmb) loss_nt_store(dmb + (lrow[k] * LPR + sub), make_float4(gm[0], gm[1], gm[2], gm[3]));
+                if (!kStdVec && (kFull || dsb)) loss_nt_store(dsb + (lrow[k] * LPR + sub), make_float4(gs[0], gs[1], gs[2], gs[3]));
+            } else {
+                if (kFull || dmb) dmb[lrow[k] * LPR + sub] = make_float4(gm[0], gm[1], gm[2], gm[3]);
+                if (!kStdVec && (kFull || dsb)) dsb[lrow[k] * LPR + sub] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+            }
             if (!kWaveRows && sub == 0) {
                 if (kFull || lpo) lpo[lrow[k]] = logp;
                 if (kFull || eno) eno[lrow[k]] = entropy;
@@ -716,19 +717,33 @@ extern "C" int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const 
     return launch_finalize(partials, blocks, B, A, D, p, losses_out, nullptr, nullptr, s);
 }
 
-#define CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, FULL, WAVE_ROWS)                                                             \
-    hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, VEC, FULL, WAVE_ROWS>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, \
-                       advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out,        \
-                       entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,          \
+#define CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, FULL, WAVE_ROWS, STREAM)                                                     \
+    hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, VEC, FULL, WAVE_ROWS, STREAM>), dim3(uint32_t(blocks)), dim3(kBlock), \
+                       0, s, advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out,     \
+                       entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,            \
                        int(defer))
+// (the streaming policy exists for the training step's launch, kFull)
 #define CUSRL_LAUNCH_ROWGROUP_FULL(LPR, VEC, WAVE_ROWS)                                                                \
-    if (full) CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, true, WAVE_ROWS);                                                     \
-    else CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, false, WAVE_ROWS)
+    if (full && streaming) CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, true, WAVE_ROWS, true);                                  \
+    else if (full) CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, true, WAVE_ROWS, false);                                         \
+    else CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, false, WAVE_ROWS, false)
 #define CUSRL_LAUNCH_ROWGROUP(LPR)                                                                                     \
     if (std_vector && wave_rows) { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, true, true); }                                      \
     else if (std_vector) { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, true, false); }                                             \
     else if (wave_rows) { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, false, true); }                                              \
     else { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, false, false); }
+
+// Cache policy by footprint, like the GAE scan's (advantage.hip): while the launch's bytes fit the 256 MB Infinity Cache the
+// default policy is the fastest (config 2's in-step launch moves 4.4 MB out of L2); beyond it the [B, A] streams go past the
+// caches.  CUSRL_LOSS_POLICY = 0 | 1 forces one (A/B measurements).
+static bool loss_streaming(int64_t B, int64_t A, int64_t D, bool std_vector) {
+    if (const char *e = getenv("CUSRL_LOSS_POLICY")) {
+        if (e[0] == '0') return false;
+        if (e[0] == '1') return true;
+    }
+    const int64_t per_row = 8 + (std_vector ? 8 : 12) * A + 8 * D + (std_vector ? 4 : 8) * A + 4 * D + 16;
+    return B * per_row > (int64_t(256) << 20);
+}
 
 // the scalar streams of a wave's rows as one access per stream (kWaveRows); CUSRL_LOSS_WAVE_ROWS=0 keeps round 3's
 // one-access-per-round form for A/B runs
@@ -764,6 +779,7 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
     // the training step wants every output: that variant carries no per-store pointer tests
     const bool full = logp_out && entropy_out && logp_ratio_out && ratio_out && d_mean && d_value && (std_vector || d_std);
     const bool wave_rows = loss_wave_rows();
+    const bool streaming = loss_streaming(B, A, D, std_vector);
     if (chunked) {
         switch (A / 4) {
             case 1: CUSRL_LAUNCH_ROWGROUP(1); break;

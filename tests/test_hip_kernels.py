@@ -1227,6 +1227,44 @@ def test_ppo_loss_std_vector_equals_repeated_matrix(ops, B, A, D, vclip):
     assert not ops.ppo_loss_accepts_std_vector(7)
 
 
+@pytest.mark.parametrize("A", [4, 12, 16, 32])
+@pytest.mark.parametrize("form", ["std_vector", "std_matrix"])
+def test_ppo_loss_layouts_and_cache_policies_change_no_bit(ops, form, A, monkeypatch):
+    """The objective's launch variants of round 5 — per-row scalar streams moved once per wave or once per round
+    (CUSRL_LOSS_WAVE_ROWS), the [B, A] streams with the non-temporal hint (the footprint policy's choice beyond the Infinity
+    Cache, forced here with CUSRL_LOSS_POLICY=1) — move the same bytes through the same arithmetic: every per-sample output and
+    gradient bit-identical across the four combinations at a ragged batch size (a partial last block, a partial last wave);
+    the two scalar-stream layouts sum the loss terms in different lane orders, so the seven loss scalars agree to fp32
+    rounding.  (The default combination is what the golden / oracle tests above hold to the reference.)"""
+    rng = np.random.default_rng(31 + A)
+    B, D = 24576 + 37, 1
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    adv, ret = f(B, 1), f(B, D)
+    curr_value, old_value = ret + 0.3 * f(B, D), ret + 0.3 * f(B, D)
+    mean = f(B, A)
+    vector = (rng.random(A) + 0.5).astype(np.float32)
+    std = vector if form == "std_vector" else np.repeat(vector[None], B, 0)
+    action = (mean + vector * f(B, A)).astype(np.float32)
+    old_logp, _ = oracle.normal_logp_entropy(action, mean + 0.02 * f(B, A), np.repeat(vector[None], B, 0))
+    args = tuple(dev(x) for x in (adv, old_logp, action, mean, std, ret, curr_value, old_value))
+    kw = dict(clip=0.2, value_clip=0.2, w_sur=1.0, w_val=0.5, w_ent=0.01)
+    results = {}
+    for wave_rows in ("1", "0"):
+        for policy in ("0", "1"):
+            monkeypatch.setenv("CUSRL_LOSS_WAVE_ROWS", wave_rows)
+            monkeypatch.setenv("CUSRL_LOSS_POLICY", policy)
+            results[wave_rows, policy] = ops.ppo_loss_fwd_bwd(*args, **kw)
+    base = results["1", "0"]
+    for key, other in results.items():
+        for name in ("logp", "entropy", "ratio", "logp_ratio", "d_mean", "d_value") + (("d_std",) if form == "std_matrix" else ()):
+            assert torch.equal(other[name], base[name]), (key, name)
+        if key[0] == "1":  # same lane order of the sums: bit-identical scalars and std-vector gradient
+            assert torch.equal(other["losses"], base["losses"]) and torch.equal(other["d_std"], base["d_std"]), key
+        else:
+            torch.testing.assert_close(other["losses"], base["losses"], rtol=2e-6, atol=1e-7)
+            torch.testing.assert_close(other["d_std"], base["d_std"], rtol=1e-5, atol=1e-5 * float(base["d_std"].abs().max()))
+
+
 @pytest.mark.parametrize("form", ["std_vector", "std_matrix", "categorical"])
 def test_ppo_loss_deferred_finalize_accumulates_block_rows(ops, form):
     """CUSRL_LOSS_DEFER (what a captured minibatch step runs): one launch, no finalize.  Two launches add their block sums
