@@ -41,7 +41,39 @@ def _hidden(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
     return torch.relu(torch.addmm(bias, x, weight.t()))
 
 
-_masked = torch.ops.aten.threshold_backward  # (gradient, activation, 0): the gradient where the ReLU let the value through
+_threshold = torch.ops.aten.threshold_backward  # (gradient, activation, 0): the gradient where the ReLU let the value through
+
+
+def _device_rows(gradient: Tensor, activation: Tensor) -> bool:
+    return (gradient.is_cuda and gradient.dtype == torch.float32 and activation.dtype == torch.float32 and gradient.dim() == 2
+            and gradient.is_contiguous() and activation.is_contiguous() and gradient.shape == activation.shape
+            and gradient.data_ptr() % 16 == 0 and activation.data_ptr() % 16 == 0)
+
+
+def _masked(gradient: Tensor, activation: Tensor, _threshold_value: int = 0) -> Tensor:
+    """``gradient`` where ``activation > 0`` else 0 — on the device through the MLP backward's one-pass mask kernel
+    (``cusrl_relu_bwd_colsum``; its column sums ride along unused), else torch's ``threshold_backward``."""
+    if _device_rows(gradient, activation):
+        from cusrl_amd import ops
+
+        return ops.relu_backward_bias(gradient, activation, defer=True)[0]
+    return _threshold(gradient, activation, 0)
+
+
+def _masked_with_bias(gradient: Tensor, activation: Tensor, bias_key: int, ones: Tensor):
+    """``(masked gradient, its column sums = the gradient of the bias in front of that ReLU)``.  On the device both come from
+    ONE launch, and with the agent's flat gradient buffer open (``nn/module.py::_split_grad_sink``) the column sums stay the
+    kernel's partial rows, handed to the gradient assembly under the bias parameter's address (then ``None`` is returned for
+    them) — instead of a mask launch plus a ``ones @ d_out`` GEMM."""
+    if _device_rows(gradient, activation):
+        from cusrl_amd import ops
+        from cusrl_amd.nn import module as nn_module
+
+        sink = nn_module._split_grad_sink
+        masked, colsum = ops.relu_backward_bias(gradient, activation, defer=sink is not None)
+        return masked, nn_module._hand_over(sink, bias_key, colsum)
+    masked = _threshold(gradient, activation, 0)
+    return masked, (ones @ masked).reshape(-1)
 
 
 class _ReluDiscriminatorObjective(torch.autograd.Function):
@@ -75,7 +107,7 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
         else:
             discrimination, d_logit = nn.functional.binary_cross_entropy_with_logits(logit, target) * loss_weight, None
         # d logit / d expert, layer by layer from the output: u_k = m_k * (u_{k+1} W_{k+1})
-        units = [_masked(weights[-1].expand(rows, -1), hidden[-1][rows:], 0)]
+        units = [_threshold(weights[-1].expand(rows, -1), hidden[-1][rows:], 0)]  # (a broadcast operand: torch's kernel)
         for weight, activation in zip(reversed(weights[1:-1]), reversed(hidden[1:-1])):
             units.append(_masked(units[-1] @ weight, activation[rows:], 0))
         units.reverse()  # units[k - 1] = u_k
@@ -91,6 +123,7 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
             ctx.save_for_backward(logit, target, ones, input_gradient, *hidden, *units, *weights)
         ctx.on_device = on_device
         ctx.layers, ctx.rows = len(weights), rows
+        ctx.bias_keys = tuple(bias.data_ptr() for bias in biases)  # the backward hands deferred bias column sums over under them
         ctx.loss_weight, ctx.penalty_weight = loss_weight, penalty_weight
         return discrimination, penalty
 
@@ -120,12 +153,13 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
             d_out = logit if is_unit_gradient(grad_discrimination) else logit * grad_discrimination
         else:
             d_out = (torch.sigmoid(logit) - target) * (grad_discrimination * (ctx.loss_weight / logit.shape[0]))
-        gradients: list[Tensor] = []
+        gradients: list[Tensor | None] = []
+        bias_gradient: Tensor | None = (ones @ d_out).reshape(-1)  # the logit's bias: the column sum of a [2N, 1] matrix
         for k in range(layers - 1, -1, -1):
-            gradients.append((ones @ d_out).reshape(-1))
+            gradients.append(bias_gradient)
             gradients.append(torch.addmm(penalty_grads[k], d_out.t(), hidden[k]))
-            if k:
-                d_out = _masked(d_out @ weights[k], hidden[k], 0)
+            if k:  # through the ReLU in front of layer k: mask AND the bias gradient of layer k - 1 from one launch
+                d_out, bias_gradient = _masked_with_bias(d_out @ weights[k], hidden[k], ctx.bias_keys[k - 1], ones)
         gradients.reverse()  # weight_1, bias_1, weight_2, ...
         return (None, None, None, None, None, None, *gradients)
 
