@@ -510,6 +510,9 @@ class FlatGradients:
         self.buffer = torch.zeros(total, dtype=torch.float32, device=device)
         self.views = []
         self.absent: list[int] = []
+        # the per-network split of the backward (ActorCritic._backward): the windows it reduces, and whether it already did
+        self.split_windows: list[torch.Tensor] | None = None
+        self.reduced = False
         self._sumsq: torch.Tensor | None = None
         self._sumsq_version = -1
         for p, offset in zip(self.params, self.offsets):
@@ -597,10 +600,10 @@ def reduce_gradients(optimizer: torch.optim.Optimizer, flat: FlatGradients | Non
         return
     if flat is not None and flat.intact():
         flat._sumsq = None  # the averaged gradients have another norm
-        if getattr(flat, "reduced", False):  # the split route already averaged both windows inside the backward
+        if flat.reduced:  # the split route already averaged both windows inside the backward
             flat.reduced = False
             return
-        windows = getattr(flat, "split_windows", None)
+        windows = flat.split_windows
         if CONFIG.split_gradient_allreduce and windows:
             # the split route where the collectives cannot be issued inside the backward (a captured phase on a route that
             # cannot be captured: torch.distributed's collectives): the same windows, one after the other, here
