@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Where do two runs of the same seeded training diverge?  (The single-stream form of the captured minibatch step is not
-bit-reproducible: DESIGN.md section 5, open defect; logs in profiles/r04/amp_identity/.)
+"""Where do two runs of the same seeded training diverge?  (Round 4's open defect — single words of bias-gradient slots of
+replayed steps — root-caused in round 5: memset nodes of replayed hipGraphs; logs in
+profiles/r04/amp_identity/ and profiles/r05/defect/.  The shipped tree no longer shows it; to REPRODUCE it put the memset nodes
+back: ``CUSRL_WIDE_LINEAR_MIN_ROWS=4096 CUSRL_GRAPH_MEMSETS=keep CUSRL_CONCURRENT_CRITIC=0 python scripts/debug_amp_identity.py``.)
 
 Two host-driven runs of the tests/test_captured_rollout.py workload (N = 256, T = 8, 2 epochs x 2 minibatches) in one process;
 the flat gradient buffer, the parameters and the index slice are recorded behind every minibatch step and compared.

@@ -12,8 +12,10 @@ SETS[write]="WRITE_SIZE"
 SETS[sq]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VMEM GRBM_GUI_ACTIVE"
 SETS[sq2]="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU"
 SETS[latency]="TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum"
-SETS[ta]="TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TA_BUFFER_WAVEFRONTS_sum TA_FLAT_WAVEFRONTS_sum"
-for NAME in fetch write sq sq2 latency ta; do
+SETS[l2]="TCC_HIT_sum TCC_MISS_sum"
+SETS[ea_read]="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum"
+SETS[ea_write]="TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum"
+for NAME in fetch write sq sq2 latency l2 ea_read ea_write; do
   OUT=/tmp/pmc_r05_$NAME; rm -rf "$OUT"
   timeout 300 rocprofv3 --pmc ${SETS[$NAME]} --kernel-trace --output-format csv -d "$OUT" -o pmc -- \
       python "$R/scripts/pmc_r05_cases.py" "$R/gpurun_out/$TAG" > /tmp/pmc_r05_$NAME.log 2>&1 < /dev/null

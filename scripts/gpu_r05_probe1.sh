@@ -12,7 +12,8 @@ for kind in amp continuous; do
   for rows in 4096 1; do
     echo "== $kind single stream, CUSRL_WIDE_LINEAR_MIN_ROWS=$rows"
     if [ $kind = continuous ]; then export DEBUG_KIND=continuous DEBUG_ITERATIONS=8; else unset DEBUG_KIND; export DEBUG_ITERATIONS=4; fi
-    CUSRL_WIDE_LINEAR_MIN_ROWS=$rows timeout 300 python scripts/debug_amp_identity.py 2>&1 | tail -40
+    # (rows=4096 is round 4's configuration: it only reproduces the defect with the memset nodes left in place)
+    CUSRL_GRAPH_MEMSETS=keep CUSRL_WIDE_LINEAR_MIN_ROWS=$rows timeout 300 python scripts/debug_amp_identity.py 2>&1 | tail -40
   done
 done 2>&1 | grep -v amdgpu.ids | cut -c1-400 > "$OUT/identity.txt"
 unset CUSRL_CONCURRENT_CRITIC DEBUG_KIND DEBUG_ITERATIONS

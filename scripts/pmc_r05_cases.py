@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Round-5 PMC cases: the fused PPO objective at roofline scale (1 048 576 envs x 24 steps / 4 minibatches = 6 291 456 rows,
-A = 12), in round 3's scalar-stream form (one dword access per stream and ROUND, CUSRL_LOSS_WAVE_ROWS=0) and in round 5's
-(one access per stream and WAVE), each launched a few times under ``rocprofv3 --pmc <one counter set> --kernel-trace``
-(scripts/gpu_pmc_r05.sh runs one pass per set; scripts/pmc_r04_summarize.py averages the launches of each case).
+A = 12), each launched a few times under ``rocprofv3 --pmc <one counter set> --kernel-trace`` (scripts/gpu_pmc_r05.sh runs one
+pass per set; scripts/pmc_r04_summarize.py averages the launches of each case):
 
-  loss_std_vector_1m_{per_round,per_wave}   cusrl::ppo_loss_rowgroup_kernel<3, true, true, *>  (the preset's form, 180 B / row)
-  loss_std_matrix_1m_{per_round,per_wave}   cusrl::ppo_loss_rowgroup_kernel<3, false, true, *> (276 B / row)
-  loss_config2_{per_round,per_wave}         the in-step launch of config 2 (24 576 rows: latency-bound, cache-resident)
+  *_per_round   round 4's kernel: the per-row scalar streams moved once per ROUND (CUSRL_LOSS_WAVE_ROWS=0), default cache policy
+  *_per_wave    round 5's scalar-stream layout (once per WAVE), default cache policy (CUSRL_LOSS_POLICY=0)
+  *_streaming   what ships at this size: the [B, A] streams non-temporal, loads and stores (CUSRL_LOSS_POLICY=1)
+
+  loss_std_vector_1m_*   cusrl::ppo_loss_rowgroup_kernel<3, true, true, ...>  (the preset's form, 180 B / row)
+  loss_std_matrix_1m_*   cusrl::ppo_loss_rowgroup_kernel<3, false, true, ...> (276 B / row)
+  loss_config2_*         the in-step launch of config 2 (24 576 rows: latency-bound, cache-resident; default policy by footprint)
 """
 import json
 import os
@@ -53,8 +56,9 @@ def main(out_dir):
                  ret=f(B, 1), curr_value=f(B, 1), old_value=f(B, 1))
         v = dict(a, std=torch.rand(act, device=DEV) + 0.5)
         matrix_bytes = B * (8 + 3 * 4 * act + 8 + 2 * 4 * act + 4 + 16)
-        for layout, flag in (("per_round", "0"), ("per_wave", "1")):
-            env = {"CUSRL_LOSS_WAVE_ROWS": flag}
+        variants = (("per_round", "0", "0"), ("per_wave", "1", "0")) + ((("streaming", "1", "1"),) if tag == "1m" else ())
+        for layout, flag, policy in variants:
+            env = {"CUSRL_LOSS_WAVE_ROWS": flag, "CUSRL_LOSS_POLICY": policy}
             if tag == "1m":
                 run(f"loss_std_matrix_{tag}_{layout}", "ppo_loss_rowgroup_kernel", lambda: ops.ppo_loss_fwd_bwd(*a.values(), **kw), matrix_bytes, env)
             run(f"loss_std_vector_{tag}_{layout}" if tag == "1m" else f"loss_{tag}_{layout}", "ppo_loss_rowgroup_kernel",
