@@ -47,6 +47,9 @@ def parse_args():
     parser.add_argument("--no-kernel-pass", action="store_true")
     parser.add_argument("--no-scale-pass", action="store_true", help="skip the 1 048 576-env roofline-scale kernel pass")
     parser.add_argument("--no-env-ab", action="store_true", help="skip the torch-generator-env timing beside the fused env")
+    parser.add_argument("--time-split-route", action="store_true",
+                        help="multi-rank runs: also time the per-network split of the gradient all-reduce (a second communicator is "
+                             "created for it); implied by CUSRL_SPLIT_ALLREDUCE=1")
     parser.add_argument("--native-collectives", action="store_true",
                         help="(default since round 3, kept for old command lines) collectives through the C ABI")
     parser.add_argument("--torch-collectives", action="store_true",
@@ -275,8 +278,10 @@ def run_gpu(args, rank, world):
             # a second communicator next to the rest on the main stream — both routes' durations in every multi-rank line, so
             # that the first 8-GPU session is one A/B (the split route's point is the overlap with the actor's backward, which
             # this stand-alone figure does not contain: it says what the two half-size collectives cost side by side)
+            # (only when asked — `--time-split-route`, or the route is switched on: two communicators with collectives in flight
+            # on two streams is exactly the hazard the route carries, and the default scaling run must not depend on it)
             second = cusrl.utils.distributed.branch_comm()
-            if second is None:
+            if second is None and args.time_split_route:
                 second, _ = cusrl.utils.distributed.establish_native_comm(cusrl.utils.distributed.RcclComm.from_process_group, device,
                                                                          rank, world)
             if second is not None:
@@ -297,7 +302,10 @@ def run_gpu(args, rank, world):
                         comm.allreduce_mean_(scratch[hi:])
                     main.wait_stream(side)
 
-                split_allreduce_us = graph_time(split_route)
+                try:  # (every rank runs the same code on the same stack: a failure here is a failure on all of them)
+                    split_allreduce_us = graph_time(split_route)
+                except Exception as error:
+                    print(f"bench: split-route all-reduce timing skipped ({type(error).__name__}: {error})", file=sys.stderr)
         else:
             torch.cuda.synchronize()
             t_ar = time.perf_counter()
@@ -313,7 +321,10 @@ def run_gpu(args, rank, world):
 
     env_ab_ms = None
     if getattr(env, "fused", False) and world == 1 and not args.no_env_ab:
-        env_ab_ms = torch_generator_env_ms(args, device)
+        try:
+            env_ab_ms = torch_generator_env_ms(args, device)
+        except Exception as error:  # an A/B beside the headline must never cost the line itself
+            print(f"bench: torch-generator env A/B skipped ({type(error).__name__}: {error})", file=sys.stderr)
 
     kernels = {}
     if not args.no_kernel_pass and rank == 0:

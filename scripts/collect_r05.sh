@@ -30,7 +30,7 @@ for c in config1 config5; do for i in 1 2; do for v in 0 1; do
 done; done; done | tee -a "$O/stream_ab.txt"
 # one RCCL rank (torchrun): C-ABI collectives captured inside the step graph (default), the per-network split route, torch.distributed
 for flag in "" "--torch-collectives"; do for split in 0 1; do
-  CUSRL_SPLIT_ALLREDUCE=$split python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 $B $flag 2>/dev/null | tail -1 | brief "rccl_one_rank$flag split=$split"
+  CUSRL_SPLIT_ALLREDUCE=$split python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 $B --time-split-route $flag 2>/dev/null | tail -1 | brief "rccl_one_rank$flag split=$split"
 done; done | tee "$O/bench_rccl_one_rank.txt"
 python scripts/kernel_bench.py --envs 4096 1048576 --json "$O/kernel_bench_graph_timed.json" 2>/dev/null | grep -v amdgpu > "$O/kernel_bench_graph_timed.txt"
 for c in "config1 --compile" "config2 --compile" "config3 --compile" "config4" "config5 --compile"; do

@@ -158,6 +158,8 @@ def test_every_replay_of_a_captured_step_matches_float64_autograd(cusrl, kind, r
             if name in reference:
                 want = reference[name].reshape(-1)
                 scale = want.abs().max().clamp_min(1e-30)
+                if name.endswith(".std.param"):  # the std vector's gradient: A sums over the rows, like a bias of the policy head
+                    scale = torch.maximum(scale, reference[name[: -len("std.param")] + "mean_head.weight"].abs().max())
                 if name.endswith(".bias") and (weight := name[: -len("bias")] + "weight") in reference:
                     # a bias gradient is a plain sum of `rows` signed terms that cancels to ~1e-3 of their absolute sum (a
                     # 1-element value-head bias has no other entry to be measured against): its yardstick is its layer's
@@ -191,7 +193,8 @@ def test_every_replay_of_a_captured_step_matches_float64_autograd(cusrl, kind, r
         if kind != "split":  # (the probe hook's own .mean() calls are ATen reductions: allowed — any memset node they bring is replaced)
             assert not reduces, reduces[:3]
     for name, error in record["worst"].items():
-        gradient_parity(f"captured_step_soak[{kind},{rows},{name}]", [1.0 + error], [1.0], 1e-5 + 4.0 / rows)  # (recorded)
+        # (recorded; the bound in force was 1e-5 unless a replay had a ratio within 1e-6 of a clip bound)
+        gradient_parity(f"captured_step_soak[{kind},{rows},{name}]", [1.0 + error], [1.0], 1e-5 if not record["near_clip"] else 1e-5 + 4.0 / rows)
     print(f"captured-step soak {kind} {rows} rows: {record['replays']} replays, worst error "
           f"{max(record['worst'].values()):.2e} of a tensor's largest entry ({record['near_clip']} replays with a ratio within 1e-6 of a clip bound)")
 
