@@ -550,11 +550,13 @@ def main():
             result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 2)
         print(json.dumps(result), flush=True)
     if world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
-        # orderly shutdown of a multi-rank job: the line is out; leaving the process group's teardown to interpreter exit
-        # races RCCL's watchdog / proxy threads (a sporadic abort at exit would fail the whole torchrun job)
+        # shutdown of a multi-rank job: the line is out and every rank is past the last collective.  Neither interpreter exit
+        # nor destroy_process_group() is a safe way out — both race ProcessGroupNCCL's watchdog thread, which polls its works'
+        # events while communicator and events are being destroyed (a sporadic abort at exit would fail the whole torchrun
+        # job after the measurement) — so the process ends its threads with itself
         torch.cuda.synchronize()
         torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        torch.cuda.synchronize()
         sys.stdout.flush(), sys.stderr.flush()
         os._exit(0)
 

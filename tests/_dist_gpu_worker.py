@@ -54,10 +54,12 @@ def main(out_dir: str, compile_: str, native: str):
         "allgather_calls": _native.launch_counts.get("cusrl_allgather", 0),
     }))
     distributed.barrier()
-    # orderly shutdown: leaving the process group's teardown to interpreter exit races RCCL's watchdog / proxy threads
-    # (sporadic SIGABRT at exit under load, after all results were written)
     torch.cuda.synchronize()
-    torch.distributed.destroy_process_group()
+    # The results are on disk and every rank is past the last collective: say so, then leave WITHOUT tearing the process group
+    # down.  torch.distributed.destroy_process_group() (and, worse, interpreter exit) races ProcessGroupNCCL's watchdog thread —
+    # it polls its works' events while the communicator and the events are being destroyed; once in a few dozen runs a HIP
+    # call of its loop fails and the process aborts after all the work is done.  os._exit ends the threads with the process.
+    print(f"WORKER_RESULTS_WRITTEN rank {rank}", flush=True)
     sys.stdout.flush(), sys.stderr.flush()
     import os
 
