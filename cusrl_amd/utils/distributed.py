@@ -14,6 +14,7 @@ SURVEY.md §5), so the design goal is the fewest, copy-free collectives:
 from __future__ import annotations
 
 import os
+from contextlib import contextmanager
 from collections.abc import Iterable, Sequence
 from typing import Any, TypeVar
 
@@ -71,9 +72,40 @@ def print_rank0(*args, **kwargs):
         print(*args, **kwargs)
 
 
+_pg_stream: "torch.cuda.Stream | None" = None
+
+
+@contextmanager
+def _process_group_stream(device=None):
+    """Issue a ``torch.distributed`` collective of an RCCL job on a dedicated stream that NEVER captures.
+
+    ProcessGroupNCCL records a collective's completion event on the stream the call is issued on, and its watchdog thread
+    keeps polling that event until its next wake-up after the event has fired (up to ~100 ms).  If the stream begins a
+    hipGraph capture in that window — the agent's graph stream does, a few milliseconds after the eager warm-up of a step
+    issued its gradient all-reduce there — the poll fails with "operation not permitted on an event last recorded in a
+    capturing stream" and the watchdog aborts the process (seen as a sporadic SIGABRT of one-rank RCCL test jobs on the
+    torch.distributed route, round 5).  So the process-group collectives of this package hop to their own stream: the
+    caller's stream is joined before and after, i.e. the collective stays ordered exactly where it was issued.  Operands
+    must be allocated by the caller (outside this context); what is allocated inside is consumed inside."""
+    device = torch.device(CONFIG.device if device is None else device)
+    if (device.type != "cuda" or torch.distributed.get_backend() != torch.distributed.Backend.NCCL
+            or torch.cuda.is_current_stream_capturing()):
+        yield
+        return
+    global _pg_stream
+    if _pg_stream is None or _pg_stream.device != device:
+        _pg_stream = torch.cuda.Stream(device=device)
+    current = torch.cuda.current_stream(device)
+    _pg_stream.wait_stream(current)
+    with torch.cuda.stream(_pg_stream):
+        yield
+    current.wait_stream(_pg_stream)
+
+
 def barrier():
     if configure_distributed():
-        torch.distributed.barrier()
+        with _process_group_stream():
+            torch.distributed.barrier()
 
 
 class RcclComm:
@@ -131,11 +163,13 @@ class RcclComm:
                 payload[0] = cls.unique_id()
             except Exception as error:
                 problem = f"{type(error).__name__}: {error}"
-        torch.distributed.broadcast_object_list(payload, src=0)  # None when rank 0 could not draw an id
+        with _process_group_stream():
+            torch.distributed.broadcast_object_list(payload, src=0)  # None when rank 0 could not draw an id
         if payload[0] is None and not problem:
             problem = "rank 0 could not draw a communicator id"
         ready = torch.tensor([1.0 if problem else 0.0], device=CONFIG.device)
-        torch.distributed.all_reduce(ready, op=torch.distributed.ReduceOp.MAX)
+        with _process_group_stream():
+            torch.distributed.all_reduce(ready, op=torch.distributed.ReduceOp.MAX)
         if ready.item() > 0:
             raise _native.NativeError(problem or "another rank cannot create its communicator")
         return cls(CONFIG.world_size, CONFIG.rank, payload[0])
@@ -195,7 +229,8 @@ def _agree(problem: str, device) -> bool:
     """Collective over the PROCESS GROUP (never over the communicator under test): True when no rank reported a problem.
     Every rank calls this the same number of times in the same order, whatever happened to it locally."""
     verdict = torch.tensor([1.0 if problem else 0.0], device=device)
-    torch.distributed.all_reduce(verdict, op=torch.distributed.ReduceOp.MAX)
+    with _process_group_stream(device):
+        torch.distributed.all_reduce(verdict, op=torch.distributed.ReduceOp.MAX)
     return verdict.item() == 0
 
 
@@ -374,7 +409,8 @@ def gather_obj(obj: _T) -> list[_T]:
     if not configure_distributed():
         return [obj]
     out: list[Any] = [None] * CONFIG.world_size
-    torch.distributed.all_gather_object(out, obj)
+    with _process_group_stream():
+        torch.distributed.all_gather_object(out, obj)
     return out
 
 
@@ -399,7 +435,8 @@ def _average_same_keys(info: dict[str, float]) -> dict[str, float] | None:
     body = [float(v) for v in values] if plain else []
     device = "cpu" if torch.distributed.get_backend() == torch.distributed.Backend.GLOO else CONFIG.device
     packed = torch.tensor(head + body + [0.0] * (_LOG_SLOTS - len(body)), dtype=torch.float64, device=device)
-    torch.distributed.all_reduce(packed, op=torch.distributed.ReduceOp.SUM)
+    with _process_group_stream(packed.device):
+        torch.distributed.all_reduce(packed, op=torch.distributed.ReduceOp.SUM)
     world = CONFIG.world_size
     summed = packed.tolist()
     s_low, s_high, q_low, q_high, count, all_plain = summed[:6]
@@ -437,7 +474,8 @@ def broadcast_parameters(parameters: Iterable[torch.nn.Parameter]):
     if (comm := native_comm()) is not None and flat.is_cuda:
         comm.broadcast_(flat, 0)
     else:
-        torch.distributed.broadcast(flat, src=0)
+        with _process_group_stream(flat.device):
+            torch.distributed.broadcast(flat, src=0)
     offset = 0
     for p in params:
         n = p.numel()
@@ -456,7 +494,8 @@ def gather_stack(tensor: torch.Tensor) -> torch.Tensor:
         torch.distributed.all_gather(parts, tensor)
         return torch.stack(parts, dim=0)
     out = tensor.new_empty(CONFIG.world_size, *tensor.shape)
-    torch.distributed.all_gather_into_tensor(out, tensor)
+    with _process_group_stream(tensor.device):
+        torch.distributed.all_gather_into_tensor(out, tensor)
     return out
 
 
@@ -469,7 +508,8 @@ def reduce_mean_(tensor: torch.Tensor) -> torch.Tensor:
     if torch.distributed.get_backend() == torch.distributed.Backend.GLOO:
         torch.distributed.all_reduce(tensor, op=torch.distributed.ReduceOp.SUM)
         return tensor.div_(CONFIG.world_size)
-    torch.distributed.all_reduce(tensor, op=torch.distributed.ReduceOp.AVG)
+    with _process_group_stream(tensor.device):
+        torch.distributed.all_reduce(tensor, op=torch.distributed.ReduceOp.AVG)
     return tensor
 
 
