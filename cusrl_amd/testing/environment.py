@@ -54,8 +54,11 @@ class SyntheticEnvironment(Environment):
         return self._randn(rows, self.observation_dim), self._randn(rows, self.state_dim), {}
 
     def reset_static(self, indices, count):
+        # the trainer always asks for one row per env slot (`indices` has `num_instances` entries, `count` of them meaningful): those
+        # rows come out of the step's own launch.  Any other request (a caller resetting a subset by hand) is served from torch's
+        # generator — the same N(0, 1) rows, another stream; the fused stream stays what the step counter says it is.
         if self.fused and self._reset_rows is not None and indices.numel() == self.num_instances:
-            return self._reset_rows, None, {}  # drawn by the step's own launch: one fresh row per index slot
+            return self._reset_rows, None, {}
         rows = indices.numel()  # one fresh row per index slot; the trainer's splice only takes the first `count`
         return self._randn(rows, self.observation_dim), self._randn(rows, self.state_dim), {}
 
