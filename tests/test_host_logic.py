@@ -494,6 +494,66 @@ def test_flat_gradient_assembly_builds_one_piece_per_parameter(monkeypatch):
         flat.assemble([plain, None, None, None, twice_grad], {12345: slabs})
 
 
+def test_flat_gradient_assembly_by_window_for_the_split_backward(monkeypatch):
+    """``FlatGradients.assemble(subset=...)`` (the per-network split of the backward, ActorCritic._backward): only the subset's
+    windows are written, slabs of parameters outside the subset (the shared loss node hands the std vector's over in both passes)
+    are dropped instead of rejected, ``absent`` accumulates over the windows, ``window()`` spans consecutive parameters with
+    their alignment padding."""
+    import torch
+
+    from cusrl_amd import ops
+    from cusrl_amd.utils.distributed import FlatGradients
+
+    torch.manual_seed(1)
+    params = [torch.nn.Parameter(torch.zeros(4, 3)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 2)),
+              torch.nn.Parameter(torch.zeros(6))]
+    flat = FlatGradients(torch.optim.SGD(params, lr=0.1))
+    assert flat.offsets == [0, 12, 20, 24] and flat.buffer.numel() == 32  # 16-byte windows: 12, 5 -> 8, 4, 6 -> 8
+
+    def fake_assemble(pieces, buffer, want_sumsq=False):
+        assert not want_sumsq  # a window's squared norm is not the buffer's
+        for src, offset, numel, splits in pieces:
+            buffer[offset : offset + numel] = 0 if src is None or splits == 0 else src.reshape(splits, numel).sum(0)
+
+    monkeypatch.setattr(ops, "assemble_gradients", fake_assemble)
+    flat.buffer.fill_(7.0)
+    flat.absent = []
+    critic = [2, 3]
+    g2 = torch.randn(2, 2)
+    foreign = {params[1].data_ptr(): torch.randn(3, 5)}  # a slab of a parameter outside the subset: dropped
+    flat.assemble([g2, None], foreign, subset=critic)
+    assert not foreign and flat.absent == [3]
+    assert torch.equal(flat.buffer[20:24], g2.reshape(-1)) and float(flat.buffer[24:30].abs().sum()) == 0.0
+    assert torch.equal(flat.buffer[:20], torch.full((20,), 7.0))  # the other windows untouched
+    g0, slabs1 = torch.randn(4, 3), torch.randn(3, 5)
+    flat.assemble([g0, None], {params[1].data_ptr(): slabs1}, subset=[0, 1])
+    assert flat.absent == [3]
+    torch.testing.assert_close(flat.buffer[:12], g0.reshape(-1))
+    torch.testing.assert_close(flat.buffer[12:17], slabs1.sum(0))
+    assert flat.window(critic).data_ptr() == flat.buffer[20:].data_ptr() and flat.window(critic).numel() == 12
+    assert flat.window([0, 1]).numel() == 20
+    with pytest.raises(ValueError, match="consecutive"):
+        flat.window([0, 2])
+
+
+def test_graph_census_families():
+    """scripts/graph_census.py sorts mangled kernel names into the families the captured-step rule is stated in."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("graph_census", Path(__file__).resolve().parent.parent / "scripts" / "graph_census.py")
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    assert module.family("_ZN2at6native13reduce_kernelILi512ELi1ENS0_8ReduceOpIfNS0_7MeanOpsIffffEEjfLi4ELi4EEEEEvT1_") == "aten_reduce"
+    assert module.family("_ZN5cusrl13gather_kernelENS_10GatherArgsEPKcPKlllli") == "cusrl"
+    assert module.family("Cijk_Alik_Bljk_SB_MT64x64x32_MI16x16x4x1") == "gemm"
+    assert module.family("_ZN2at6native29vectorized_elementwise_kernelILi4EZZZNS0_16tanh_kernel_cudaE") == "aten_other"
+    census = [{"region": "step", "kernel": 3, "memcpy": 0, "memset": 1, "names": ["_ZN2at6native13reduce_kernelIx", "_ZN5cusrl1aE", "Cijk_x"]}]
+    import io
+
+    totals = module.summarize(census, out=io.StringIO())
+    assert totals == {"memset": 1, "aten_reduce": 1, "graphs": 1}
+
+
 def test_lazy_batch_is_a_dict_that_gathers_on_first_access():
     """LazyBatch (template/buffer.py) against a stand-in buffer: which fields are fetched when, dict protocol, expiry."""
     from cusrl_amd.template.buffer import LazyBatch
