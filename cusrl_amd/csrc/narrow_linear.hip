@@ -159,6 +159,47 @@ __global__ __launch_bounds__(kBlock) void narrow_linear_finalize_kernel(const fl
     }
 }
 
+
+// FORWARD of a one-output linear layer (the value head, a discriminator's logit): y[b] = x[b, :] . w + bias — a row dot
+// product, memory-bound (4K bytes read per 4 written).  torch's addmm has no bias epilogue for a one-column output: it
+// materialises the broadcast bias with a copy launch and then runs a skinny GEMM (4.8 + 4.5 us at [24576, 128]); here the
+// kLanes = min(64, K / 4) lanes of a row group each take 16-byte chunks of the row (one chunk for K <= 256), the group is
+// reduced by log2(kLanes) wave shuffles and its first lane adds the bias and stores.  Four row groups' loads in flight per lane.
+template <int kLanes>
+__global__ __launch_bounds__(kBlock) void narrow_dot_fwd_kernel(const float *__restrict__ input, const float *__restrict__ weight,
+                                                                const float *__restrict__ bias, float *__restrict__ output,
+                                                                int64_t rows, int K) {
+    constexpr int kRowsPerWave = kWave / kLanes, kInFlight = 4;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int sub = lane % kLanes, rloc = lane / kLanes;
+    const int chunks = K / 4;  // a multiple of kLanes
+    const int64_t wave = int64_t(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+    const int64_t row0 = wave * (kRowsPerWave * kInFlight);
+    if (row0 >= rows) return;  // uniform per wave
+    const float b = bias ? bias[0] : 0.f;
+    float acc[kInFlight] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = sub; c < chunks; c += kLanes) {
+        const float4 w = reinterpret_cast<const float4 *>(weight)[c];
+        float4 x[kInFlight];
+#pragma unroll
+        for (int k = 0; k < kInFlight; ++k) {  // rows past the end: clamped (their sums are never stored)
+            const int64_t row = min(row0 + int64_t(k) * kRowsPerWave + rloc, rows - 1);
+            x[k] = reinterpret_cast<const float4 *>(input)[row * chunks + c];
+        }
+#pragma unroll
+        for (int k = 0; k < kInFlight; ++k)
+            acc[k] += (x[k].x * w.x + x[k].y * w.y) + (x[k].z * w.z + x[k].w * w.w);
+    }
+#pragma unroll
+    for (int k = 0; k < kInFlight; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int off = kLanes / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+        const int64_t row = row0 + int64_t(k) * kRowsPerWave + rloc;
+        if (sub == 0 && row < rows) output[row] = v + b;
+    }
+}
+
 static bool narrow_shape_ok(int64_t K, int64_t O) {
     if (O < 1 || O > 16 || K < 32 || K > 1024 || K % 4) return false;
     const int64_t lpr = K / 4;
@@ -227,5 +268,28 @@ extern "C" int cusrl_narrow_linear_bwd(const float *grad_out, const float *input
     const int H = (int(out_features) + 1) * K + kHeadBiasPad;
     hipLaunchKernelGGL(narrow_linear_finalize_kernel, dim3(uint32_t(ceil_div(H, 64))), dim3(kBlock), 0, s, partials,
                        blocks, H, packed);
+    return launch_status();
+}
+
+extern "C" int cusrl_narrow_linear_fwd(const float *input, const float *weight, const float *bias, float *output,
+                                       int64_t rows, int64_t in_features, int64_t out_features, void *stream) {
+    using namespace cusrl;
+    if (!input || !weight || !output || rows <= 0) return CUSRL_E_INVALID;
+    if (out_features != 1 || !narrow_shape_ok(in_features, 1)) return CUSRL_E_UNSUPPORTED;  // wider heads: the library GEMM
+    if (!aligned(input, 16) || !aligned(weight, 16)) return CUSRL_E_UNSUPPORTED;
+    const int K = int(in_features), lanes = K / 4 >= kWave ? kWave : K / 4;
+    const int64_t waves = ceil_div(rows, int64_t(kWave / lanes) * 4), blocks = ceil_div(waves, int64_t(kWavesPerBlock));
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    hipStream_t s = as_stream(stream);
+    switch (lanes) {
+#define CUSRL_DOT_CASE(N)                                                                                              \
+    case N:                                                                                                            \
+        hipLaunchKernelGGL(narrow_dot_fwd_kernel<N>, dim3(uint32_t(blocks)), dim3(kBlock), 0, s, input, weight, bias,   \
+                           output, rows, K);                                                                           \
+        break;
+        CUSRL_DOT_CASE(8) CUSRL_DOT_CASE(16) CUSRL_DOT_CASE(32) CUSRL_DOT_CASE(64)
+#undef CUSRL_DOT_CASE
+        default: return CUSRL_E_UNSUPPORTED;
+    }
     return launch_status();
 }

@@ -96,7 +96,12 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
         hidden = [agent if expert is None else torch.cat((agent, expert))]
         for weight, bias in zip(weights[:-1], biases[:-1]):
             hidden.append(_hidden(hidden[-1], weight, bias))
-        logit = torch.addmm(biases[-1], hidden[-1], weights[-1].t())
+        if hidden[-1].is_cuda and weights[-1].shape[0] == 1:
+            from cusrl_amd.nn.module import _one_output_linear
+
+            logit = _one_output_linear(hidden[-1], weights[-1], biases[-1])  # one row-dot launch (no broadcast-bias copy + GEMM)
+        else:
+            logit = torch.addmm(biases[-1], hidden[-1], weights[-1].t())
         on_device = logit.is_cuda and logit.dtype == torch.float32
         if on_device:
             # loss AND d loss / d logit of the joint batch from ONE launch (log_sigmoid / mul / add / mean forward and

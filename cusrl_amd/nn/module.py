@@ -122,7 +122,7 @@ class _WideBatchLinear(torch.autograd.Function):
             ctx.save_for_backward(input, weight, output)
             output._cusrl_relu_output = True  # lets a narrow head behind it play this ReLU's backward (see backward)
         else:
-            output = linear(input, weight, bias)
+            output = _one_output_linear(input, weight, bias)
             ctx.save_for_backward(input, weight)
         ctx.splits, ctx.relu, ctx.has_bias = splits, relu, bias is not None
         ctx.bias_key = bias.data_ptr() if bias is not None else None
@@ -184,6 +184,16 @@ class _WideBatchLinear(torch.autograd.Function):
         return grad_input, grad_weight, grad_bias, None, None
 
 
+def _one_output_linear(input: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """``linear(input, weight, bias)``; a one-output head (the value head, a discriminator's logit) as ONE row-dot launch —
+    torch's addmm has no bias epilogue for a one-column output and issues a broadcast-bias copy in front of a skinny GEMM."""
+    from cusrl_amd import ops
+
+    if weight.shape[0] == 1 and ops.narrow_linear_forward_supported(input, weight):
+        return ops.narrow_linear_forward(input, weight, bias)
+    return linear(input, weight, bias)
+
+
 def _narrow_head(weight: torch.Tensor) -> bool:
     from cusrl_amd import ops
 
@@ -220,6 +230,8 @@ def linear_act(input: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | N
             return torch.relu(output) if relu else output
         if relu:
             return torch._addmm_activation(bias, input, weight.t())
+        if not torch.is_grad_enabled() or not (weight.requires_grad or input.requires_grad):
+            return _one_output_linear(input, weight, bias)
     output = linear(input, weight, bias)
     return torch.relu(output) if relu else output
 

@@ -1377,6 +1377,27 @@ def narrow_linear_supported(in_features: int, out_features: int) -> bool:
     return bool(_native.lib().cusrl_narrow_linear_supported(in_features, out_features))
 
 
+def narrow_linear_forward_supported(input: torch.Tensor, weight: torch.Tensor) -> bool:
+    """A one-output head over a contiguous, 16-byte aligned fp32 ``[B, K]`` device matrix with K a power of two in 32..1024."""
+    return (weight.dim() == 2 and weight.shape[0] == 1 and input.dim() == 2 and input.is_cuda and input.dtype == torch.float32
+            and weight.dtype == torch.float32 and input.is_contiguous() and weight.is_contiguous() and input.shape[0] > 0
+            and input.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and narrow_linear_supported(weight.shape[1], 1))
+
+
+def narrow_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """``input @ weight.T + bias`` for a ONE-output linear layer (value head, discriminator logit) in one launch
+    (``cusrl_narrow_linear_fwd``: a row dot product) instead of torch's broadcast-bias copy + skinny GEMM."""
+    input, weight = _f32(input, "input"), _f32(weight, "weight")
+    rows, K = input.shape
+    out = torch.empty((rows, 1), dtype=torch.float32, device=input.device)
+    check(
+        _native.lib().cusrl_narrow_linear_fwd(input.data_ptr(), weight.data_ptr(), None if bias is None else _f32(bias, "bias").data_ptr(),
+                                              out.data_ptr(), rows, K, 1, _stream()),
+        "cusrl_narrow_linear_fwd",
+    )
+    return out
+
+
 def narrow_linear_backward(grad_output: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
                            need_input_grad: bool = True, relu_input: bool = False, defer: bool = False):
     """``(grad_output @ weight, grad_output.T @ input, grad_output.sum(0))`` of a linear layer with at most 16

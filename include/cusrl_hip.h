@@ -408,6 +408,12 @@ int cusrl_narrow_linear_bwd(const float *grad_out, const float *input, const flo
                             int relu_input, void *stream);
 int64_t cusrl_narrow_linear_num_partials(int64_t rows);
 int cusrl_narrow_linear_supported(int64_t in_features, int64_t out_features);
+/* Forward of a ONE-output linear layer — the value head (cusrl/nn/module/critic.py:87-88), a discriminator's logit
+ * (cusrl/hook/auxiliary/amp.py:138-147): output[b] = input[b, :] . weight + bias[0] (bias may be NULL), one launch instead
+ * of torch's broadcast-bias copy + skinny GEMM.  out_features must be 1 (wider heads keep the library GEMM and its bias
+ * epilogue), in_features as for cusrl_narrow_linear_supported; input / weight 16-byte aligned. */
+int cusrl_narrow_linear_fwd(const float *input, const float *weight, const float *bias, float *output, int64_t rows,
+                            int64_t in_features, int64_t out_features, void *stream);
 
 /* ---- gradient-norm clipping (hook/on_policy/gradient_clipping.py:67-83 -> torch.nn.utils.clip_grad_norm_) ----
  * norm_out[0] = ||grad||_2 (pre-clip, the `grad_norm/default` metric); grad *= min(max_norm / (norm + 1e-6), 1).

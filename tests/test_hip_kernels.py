@@ -1132,6 +1132,53 @@ def test_head_behind_relu_backbone_matches_plain_autograd():
             torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-4 * float(b.abs().max()))
 
 
+@pytest.mark.parametrize("K", [32, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("rows", [1, 7, 24576, 98304 + 3])
+def test_one_output_linear_forward_vs_float64(ops, rows, K):
+    """cusrl_narrow_linear_fwd (value head / discriminator logit: cusrl/nn/module/critic.py:87-88, hook/auxiliary/amp.py:138-147):
+    ``x @ w.T + b`` of a one-output layer as a row dot product, against float64 — within fp32 rounding of the sum of |x| |w|."""
+    from cusrl_amd import _native
+
+    torch.manual_seed(rows + K)
+    x, w, b = torch.randn(rows, K, device=DEV), torch.randn(1, K, device=DEV), torch.randn(1, device=DEV)
+    assert ops.narrow_linear_forward_supported(x, w)
+    before = _native.launch_counts.get("cusrl_narrow_linear_fwd", 0)
+    for bias in (b, None):
+        got = ops.narrow_linear_forward(x, w, bias)
+        want = x.double() @ w.double().t() + (0.0 if bias is None else bias.double())
+        scale = (x.abs().double() @ w.abs().double().t())
+        assert got.shape == (rows, 1)
+        assert float(((got.double() - want).abs() / scale.clamp_min(1e-30)).max()) < 4e-7
+    assert _native.launch_counts["cusrl_narrow_linear_fwd"] == before + 2
+    assert not ops.narrow_linear_forward_supported(x, torch.randn(2, K, device=DEV))            # wider heads: the library GEMM
+    assert not ops.narrow_linear_forward_supported(torch.randn(rows, 48, device=DEV), torch.randn(1, 48, device=DEV))
+    assert not ops.narrow_linear_forward_supported(x.t().contiguous().t(), w) or rows == 1 or K == 1   # a strided view
+
+
+def test_one_output_head_takes_the_row_dot_launch_in_both_modes():
+    """``cusrl_amd.nn.Linear`` with one output: the forward is the row-dot launch with and without autograd, the backward the
+    narrow-head pass; values and gradients against torch's own linear."""
+    from cusrl_amd import _native
+    from cusrl_amd.nn.module import Linear
+
+    torch.manual_seed(9)
+    head = Linear(128, 1).to(DEV)
+    x = torch.randn(4096, 128, device=DEV, requires_grad=True)
+    before = _native.launch_counts.get("cusrl_narrow_linear_fwd", 0)
+    with torch.no_grad():
+        plain = head(x)
+    out = head(x)
+    assert _native.launch_counts["cusrl_narrow_linear_fwd"] == before + 2 and torch.equal(plain, out.detach())
+    out.square().sum().backward()
+    got = [head.weight.grad.clone(), head.bias.grad.clone(), x.grad.clone()]
+    head.weight.grad = head.bias.grad = x.grad = None
+    ref = torch.nn.functional.linear(x, head.weight, head.bias)
+    torch.testing.assert_close(out.detach(), ref.detach(), rtol=1e-5, atol=1e-5)
+    ref.square().sum().backward()
+    for a, b in zip(got, [head.weight.grad, head.bias.grad, x.grad]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+
+
 def test_narrow_head_autograd_matches_plain_linear():
     from cusrl_amd.nn.module import Linear
 
