@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
-"""Does a captured ATen global reduce (``x.sum(0)`` split over gridDim.y blocks: staging buffer + semaphore zeroed by a
-hipMemsetAsync MEMSET NODE, ATen/native/cuda/Reduce.cuh:1294-1301, 693-703) replay correctly on this stack?
+"""Do the MEMSET NODES of a replayed hipGraph execute on this stack?  (They do not, reliably: DESIGN.md section 5.)
 
-Plain torch, no cusrl_amd: a chain of column sums with small allocations between them (so that a freed semaphore block is
-handed to the next tensor inside one capture, as in a captured backward), replayed N times with changing inputs; every replay
-is compared on the device against a float64 sum.  Variants: one graph; two graphs sharing a pool, alternating; with eager
-kernels between replays; back-to-back replays without a host sync.
+Plain torch — `cusrl_amd` is never imported; only the "replaced" variants dlopen libcusrl_hip.so for its graph-surgery entry
+point.  Two kinds of cases, each replayed N times with every replay checked on the device:
 
-    python scripts/probe_aten_reduce_capture.py [replays]
+* a bare ``hipMemsetAsync`` node between two kernels (``buf += 5; memset(buf, 0); buf += 1; out = buf``): ``out`` must be 1;
+* a chain of column sums ``x.sum(0)`` with small allocations between them — ATen splits such a reduction over gridDim.y
+  blocks with a staging buffer and a semaphore zeroed by hipMemsetAsync (ATen/native/cuda/Reduce.cuh:1294-1301, 693-703), a
+  memset node once captured — with changing inputs, compared against a float64 sum.  Variants: one graph; two graphs sharing a
+  pool, alternating; eager kernels between replays; back-to-back replays without a host sync;
+
+each as captured and with every memset node replaced by a fill-kernel node (``cusrl_graph_replace_memsets``).
+
+    python scripts/probe_aten_reduce_capture.py [replays]      # PROBE_QUICK=1: two shapes, two modes
 """
 import os
 import sys
