@@ -13,7 +13,7 @@ from pathlib import Path
 
 # (CUSRL_HIP_LIBRARY: another build of the same library — A/B runs of compile-time variants, profiles/r05/loss_variants_ab.txt)
 LIB_PATH = Path(os.environ.get("CUSRL_HIP_LIBRARY") or Path(__file__).resolve().parent / "libcusrl_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_FIELDS = 24
 MAX_PACKED = 16
 
@@ -75,6 +75,8 @@ _SIGNATURES = {
     "cusrl_ppo_loss_num_partials": (c_int64, [c_int64]),
     "cusrl_ppo_loss_std_partial_rows": (c_int64, [c_int64]),
     "cusrl_ppo_loss_blocks": (c_int64, [c_int64, c_int64]),
+    "cusrl_value_loss_fwd_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_double, c_double, _P, _P, _P, c_int, _P]),
+    "cusrl_value_loss_blocks": (c_int64, [c_int64, c_int64]),
     "cusrl_normal_sample_logp": (c_int, [_P] * 5 + [c_int64, c_int64, c_int64, _P, _P, _P, _P]),
     "cusrl_categorical_sample_logp": (c_int, [_P] * 4 + [c_int64, c_int64, _P]),
     "cusrl_gru_gates_fwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, _P]),
@@ -100,6 +102,9 @@ _SIGNATURES = {
     "cusrl_categorical_terms_bwd": (c_int, [_P] * 7 + [c_int64, c_int64, _P, _P]),
     "cusrl_relu_bwd_colsum": (c_int, [_P] * 5 + [c_int64, c_int64, _P]),
     "cusrl_colsum_num_partials": (c_int64, [c_int64, c_int64]),
+    "cusrl_input_layer_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, _P, _P, _P]),
+    "cusrl_input_layer_supported": (c_int, [c_int64, c_int64]),
+    "cusrl_input_layer_row_blocks": (c_int64, [c_int64, c_int64]),
     "cusrl_narrow_linear_bwd": (c_int, [_P] * 6 + [c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_narrow_linear_num_partials": (c_int64, [c_int64]),
     "cusrl_narrow_linear_supported": (c_int, [c_int64, c_int64]),
@@ -109,7 +114,7 @@ _SIGNATURES = {
     "cusrl_assemble_gradients": (c_int, [POINTER(GradPiece), c_int64, _P, _P, _P]),
     "cusrl_assemble_gradients_blocks": (c_int64, [POINTER(GradPiece), c_int64]),
     "cusrl_grad_sumsq": (c_int, [_P, c_int64, _P, _P]),
-    "cusrl_adam_step": (c_int, [_P] * 6 + [c_int64, c_double, c_double, c_double, c_double, c_int, c_int, _P, c_int64, c_float, _P, _P, _P]),
+    "cusrl_adam_step": (c_int, [_P] * 6 + [c_int64, c_double, c_double, c_double, c_double, c_int, c_int, _P, c_int64, c_float, _P, _P, _P, _P]),
     "cusrl_masked_col_stats": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, _P]),
     "cusrl_masked_stats_num_partials": (c_int64, [c_int64, c_int64]),
     "cusrl_rms_merge": (c_int, [_P] * 7 + [c_float, c_double, c_int64, _P]),

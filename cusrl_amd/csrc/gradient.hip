@@ -99,9 +99,19 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float *__restrict__ p
                                                            float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
                                                            float *__restrict__ step, const float *__restrict__ lr,
                                                            const double *__restrict__ clip_partials,
-                                                           float *__restrict__ norm_out, unsigned int *__restrict__ ticket,
-                                                           int64_t n, AdamParams a) {
+                                                           float *__restrict__ norm_out, float *__restrict__ norm_accumulator,
+                                                           unsigned int *__restrict__ ticket, int64_t n, AdamParams a) {
     __shared__ float shared[4];  // clip coefficient, step size, sqrt(bias_correction2), new step count
+    // The four streams of this thread's FIRST float4 are requested before anything else: they do not depend on the clipping
+    // coefficient, and the chain partial rows -> norm -> coefficient below is a memory round trip of its own (round 6: the
+    // launch is latency, not bandwidth — 370 KB per buffer — and sits on the serial tail of every minibatch step).
+    const int64_t n4 = n / 4;
+    float4 *p4 = reinterpret_cast<float4 *>(param), *m4 = reinterpret_cast<float4 *>(exp_avg),
+           *v4 = reinterpret_cast<float4 *>(exp_avg_sq);
+    const float4 *g4 = reinterpret_cast<const float4 *>(grad);
+    const int64_t i0 = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), m0 = p0, v0 = p0, g0 = p0;
+    if (i0 < n4) p0 = p4[i0], m0 = m4[i0], v0 = v4[i0], g0 = g4[i0];
     if (threadIdx.x < kWave) {
         float coef = 1.0f;
         if (clip_partials) {  // uniform branch; the partials of cusrl_grad_sumsq (<= 64) or of the gradient assembly
@@ -113,7 +123,10 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float *__restrict__ p
                 const float c = a.max_norm / (norm + 1e-6f);  // clip_grad_norm_: max_norm / (total_norm + 1e-6)
                 coef = c < 1.0f ? c : (c != c ? c : 1.0f);
             }
-            if (threadIdx.x == 0 && blockIdx.x == 0 && norm_out) norm_out[0] = norm;
+            if (threadIdx.x == 0 && blockIdx.x == 0) {
+                if (norm_out) norm_out[0] = norm;
+                if (norm_accumulator) norm_accumulator[0] += norm;  // the running sum a captured step's metric tap keeps
+            }
         }
         if (threadIdx.x == 0) {
             // every block reads the counter here, before the LAST block to finish bumps it (see the ticket below)
@@ -140,13 +153,11 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float *__restrict__ p
         v = beta2 * v + omb2 * (g * g);               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
         p -= step_size * (m / (sqrtf(v) / bc2_sqrt + a.eps));
     };
-    const int64_t n4 = n / 4;
-    float4 *p4 = reinterpret_cast<float4 *>(param), *m4 = reinterpret_cast<float4 *>(exp_avg),
-           *v4 = reinterpret_cast<float4 *>(exp_avg_sq);
-    const float4 *g4 = reinterpret_cast<const float4 *>(grad);
-    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < n4; i += int64_t(gridDim.x) * kBlock) {
-        float4 p = p4[i], m = m4[i], v = v4[i];
-        const float4 g = g4[i];
+    for (int64_t i = i0; i < n4; i += int64_t(gridDim.x) * kBlock) {
+        float4 p = p0, m = m0, v = v0;
+        const float4 g = g0;
+        const int64_t next = i + int64_t(gridDim.x) * kBlock;
+        if (next < n4) p0 = p4[next], m0 = m4[next], v0 = v4[next], g0 = g4[next];
         update(p.x, g.x, m.x, v.x), update(p.y, g.y, m.y, v.y), update(p.z, g.z, m.z, v.z), update(p.w, g.w, m.w, v.w);
         p4[i] = p, m4[i] = m, v4[i] = v;
     }
@@ -154,10 +165,13 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float *__restrict__ p
         const int64_t i = n4 * 4 + threadIdx.x;
         update(param[i], grad[i], exp_avg[i], exp_avg_sq[i]);
     }
-    // the last block to finish publishes the new step count and re-arms the ticket (self-resetting, graph-safe)
+    // The last block to finish publishes the new step count and re-arms the ticket (self-resetting, graph-safe).  No fence
+    // around the ticket (round 6): what has to be ordered is every block's READ of step[0] — consumed by the stores above,
+    // hence complete before this barrier — in front of the last block's write, and the ticket's atomic provides exactly that;
+    // the written values are only read by LATER launches.  An agent-scope fence writes back and invalidates the XCD's whole L2
+    // on this part, once per block, on the serial tail of every minibatch step.
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
             step[0] = t;
             *ticket = 0u;
@@ -178,8 +192,8 @@ extern "C" int cusrl_grad_sumsq(const float *grad, int64_t n, double *partials, 
 extern "C" int cusrl_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step,
                                const float *lr, int64_t n, double beta1, double beta2, double eps, double weight_decay,
                                int decoupled_weight_decay, int maximize, const double *clip_partials,
-                               int64_t num_clip_partials, float max_norm, float *norm_out, uint32_t *ticket,
-                               void *stream) {
+                               int64_t num_clip_partials, float max_norm, float *norm_out, float *norm_accumulator,
+                               uint32_t *ticket, void *stream) {
     using namespace cusrl;
     if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !step || !lr || !ticket) return CUSRL_E_INVALID;
     if (clip_partials && (num_clip_partials < 1 || num_clip_partials > kMaxClipPartials)) return CUSRL_E_INVALID;
@@ -189,7 +203,7 @@ extern "C" int cusrl_adam_step(float *param, const float *grad, float *exp_avg, 
                  int(num_clip_partials)};
     const int64_t blocks = ceil_div(n / 4 > 0 ? n / 4 : 1, kBlock);
     adam_step_kernel<<<int(blocks > 1024 ? 1024 : blocks), kBlock, 0, as_stream(stream)>>>(
-        param, grad, exp_avg, exp_avg_sq, step, lr, clip_partials, norm_out, ticket, n, a);
+        param, grad, exp_avg, exp_avg_sq, step, lr, clip_partials, norm_out, norm_accumulator, ticket, n, a);
     return launch_status();
 }
 

@@ -619,7 +619,8 @@ __device__ __forceinline__ void finalize_losses(const double *partials, int64_t 
         sums[k] = block_sum(s, scratch);
     }
     if (threadIdx.x == 0) {
-        losses_out[0] = float(sums[0] / double(B * D)) * p.w_val;   // mean * weight              value.py:137
+        // (D == 0: the value term is evaluated by cusrl_value_loss_fwd_bwd on the critic's stream — it contributes nothing here)
+        losses_out[0] = D > 0 ? float(sums[0] / double(B * D)) * p.w_val : 0.0f;   // mean * weight   value.py:137
         losses_out[1] = -float(sums[1] / double(B)) * p.w_sur;      // -mean(min(...)) * weight   ppo.py:13-18,55
         losses_out[2] = -float(sums[2] / double(B)) * p.w_ent;      // -mean(entropy) * weight    ppo.py:83-84
         losses_out[3] = float(sums[3] / double(B));                 // mean |logp ratio|          common.py:47 metric
@@ -638,9 +639,96 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_finalize_kernel(const double 
     finalize_losses(partials, P, B, D, p, losses_out, d_std_partials, A, d_std_vector);
 }
 
+
+// ---- the value term on its own (round 6) -----------------------------------------------------------------------------
+// ValueLoss.objective, cusrl/hook/on_policy/value.py:85-89,121-137: mean((cv - R)^2) * w, or the clipped form.  The critic and
+// the actor share nothing until the losses are summed (actor_critic.py:309), and a sum differentiated with a unit gradient
+// splits into its summands: with the critic on its own stream of a captured minibatch step (template/graphs.py) the value term
+// is evaluated THERE, right behind the value head — critic forward -> this launch -> critic backward never meets the actor's
+// stream in the middle of the step (one fork and one join per step instead of two each).  Same per-element arithmetic as
+// value_scalars above: d_value is bit-identical to what the one-launch objective writes.
+constexpr int kValueSums = 2;             // sum of the (clipped) squared errors, sum of the values (metric `value`, value.py:141)
+constexpr int kValueElemsPerBlock = kBlock * 4;
+
+__global__ __launch_bounds__(kBlock) void value_loss_kernel(const float *__restrict__ ret, const float *__restrict__ curr_value,
+                                                            const float *__restrict__ old_value, int64_t n, LossParams p,
+                                                            float *__restrict__ d_value, double *__restrict__ partials,
+                                                            int accumulate) {
+    __shared__ double scratch[kWavesPerBlock][kValueSums];
+    const int64_t base = int64_t(blockIdx.x) * kValueElemsPerBlock + threadIdx.x;
+    float cv[4], R[4], ov[4];
+    bool live[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // every load requested before anything is computed
+        const int64_t i = base + int64_t(k) * kBlock;
+        live[k] = i < n;
+        const int64_t c = live[k] ? i : n - 1;
+        cv[k] = curr_value[c], R[k] = ret[c];
+        ov[k] = p.value_clip >= 0.0f ? old_value[c] : 0.0f;
+    }
+    float loss_sum = 0.f, value_sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float loss, grad;
+        value_scalars(cv[k], R[k], ov[k], p, loss, grad);
+        if (live[k]) {
+            loss_sum += loss, value_sum += cv[k];
+            if (d_value) d_value[base + int64_t(k) * kBlock] = grad;
+        }
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const double l = wave_sum_to_last_lane(double(loss_sum)), v = wave_sum_to_last_lane(double(value_sum));
+    if (lane == kWave - 1) scratch[wave][0] = l, scratch[wave][1] = v;
+    __syncthreads();
+    if (threadIdx.x < kValueSums) {
+        double total = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) total += scratch[w][threadIdx.x];
+        double *slot = partials + int64_t(blockIdx.x) * kValueSums + threadIdx.x;
+        *slot = accumulate ? *slot + total : total;
+    }
+}
+
+// losses_out[0] = weighted value loss, losses_out[1] = mean of curr_value.sum(-1)
+__global__ __launch_bounds__(kBlock) void value_loss_finalize_kernel(const double *__restrict__ partials, int64_t P, int64_t B,
+                                                                     int64_t D, float w_val, float *__restrict__ losses_out) {
+    __shared__ double scratch[kWavesPerBlock];
+    for (int k = 0; k < kValueSums; ++k) {
+        double s = 0.0;
+        for (int64_t i = threadIdx.x; i < P; i += kBlock) s += partials[i * kValueSums + k];
+        const double total = block_sum(s, scratch);
+        if (threadIdx.x == 0) losses_out[k] = k == 0 ? float(total / double(B * D)) * w_val : float(total / double(B));
+    }
+}
+
 }  // namespace cusrl
 
 using namespace cusrl;
+
+static LossParams loss_params(int64_t B, int64_t D, double clip, double value_clip, double w_sur, double w_val, double w_ent);
+
+extern "C" int64_t cusrl_value_loss_blocks(int64_t B, int64_t D) {
+    return B <= 0 || D <= 0 ? 0 : ceil_div(B * D, kValueElemsPerBlock);
+}
+
+extern "C" int cusrl_value_loss_fwd_bwd(const float *ret, const float *curr_value, const float *old_value, int64_t B, int64_t D,
+                                        double value_clip, double w_val, float *losses_out, float *d_value, double *partials,
+                                        int flags, void *stream) {
+    if (B <= 0 || D <= 0) return CUSRL_E_INVALID;
+    const bool defer = (flags & CUSRL_LOSS_DEFER) != 0;
+    if (!ret || !curr_value || !partials || (!losses_out && !defer)) return CUSRL_E_INVALID;
+    if (value_clip >= 0.0 && !old_value) return CUSRL_E_INVALID;
+    const int64_t blocks = cusrl_value_loss_blocks(B, D);
+    if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    const LossParams p = loss_params(B, D, 0.2, value_clip, 0.0, w_val, 0.0);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(value_loss_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, s, ret, curr_value, old_value, B * D, p, d_value,
+                       partials, int(defer));
+    if (int rc = launch_status()) return rc;
+    if (defer) return 0;
+    hipLaunchKernelGGL(value_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, partials, blocks, B, D, float(w_val), losses_out);
+    return launch_status();
+}
 
 // partial rows (= blocks) the main kernel of a [B, A] minibatch writes; A = 0: the categorical / row-wise form
 extern "C" int64_t cusrl_ppo_loss_blocks(int64_t B, int64_t A) {
@@ -666,7 +754,7 @@ static LossParams loss_params(int64_t B, int64_t D, double clip, double value_cl
     p.value_clip = value_clip < 0.0 ? -1.0f : float(value_clip);
     p.g_sur = float(-w_sur / double(B));
     p.g_ent = float(-w_ent / double(B));
-    p.g_val = float(w_val / double(B * D));
+    p.g_val = D > 0 ? float(w_val / double(B * D)) : 0.0f;
     p.w_sur = float(w_sur);
     p.w_val = float(w_val);
     p.w_ent = float(w_ent);
@@ -699,11 +787,12 @@ extern "C" int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const 
                                                   float *losses_out, float *logp_out, float *entropy_out,
                                                   float *logp_ratio_out, float *ratio_out, float *d_logits,
                                                   float *d_value, double *partials, int flags, void *stream) {
-    if (B <= 0 || A <= 0 || D <= 0) return CUSRL_E_INVALID;
+    if (B <= 0 || A <= 0 || D < 0) return CUSRL_E_INVALID;  // D == 0: no value term (see cusrl_value_loss_fwd_bwd)
     const bool defer = (flags & CUSRL_LOSS_DEFER) != 0;
-    if (!advantage || !old_logp || !action || !logits || !ret || !curr_value || (!losses_out && !defer) || !partials)
+    if (!advantage || !old_logp || !action || !logits || (D > 0 && (!ret || !curr_value)) || (!losses_out && !defer) || !partials)
         return CUSRL_E_INVALID;
-    if (value_clip >= 0.0 && !old_value) return CUSRL_E_INVALID;
+    if (D > 0 && value_clip >= 0.0 && !old_value) return CUSRL_E_INVALID;
+    if (D == 0) value_clip = -1.0, d_value = nullptr;
     if (A > INT32_MAX || D > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     const LossParams p = loss_params(B, D, clip, value_clip, w_sur, w_val, w_ent);
     hipStream_t s = as_stream(stream);
@@ -759,15 +848,16 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
                                       float *logp_out, float *entropy_out, float *logp_ratio_out, float *ratio_out,
                                       float *d_mean, float *d_std, float *d_value, double *partials,
                                       int64_t std_rows, float *d_std_partials, int flags, void *stream) {
-    if (B <= 0 || A <= 0 || D <= 0) return CUSRL_E_INVALID;
+    if (B <= 0 || A <= 0 || D < 0) return CUSRL_E_INVALID;  // D == 0: no value term (see cusrl_value_loss_fwd_bwd)
     if (std_rows != B && std_rows != 1) return CUSRL_E_INVALID;
     const bool defer = (flags & CUSRL_LOSS_DEFER) != 0;
     const bool std_vector = std_rows == 1 && B != 1;
     if (std_vector && (d_std || defer) && !d_std_partials) return CUSRL_E_INVALID;
-    if (!advantage || !old_logp || !action || !mean || !std || !ret || !curr_value || (!losses_out && !defer) || !partials)
+    if (!advantage || !old_logp || !action || !mean || !std || (D > 0 && (!ret || !curr_value)) || (!losses_out && !defer) || !partials)
         return CUSRL_E_INVALID;
-    if (value_clip >= 0.0 && !old_value) return CUSRL_E_INVALID;
+    if (D > 0 && value_clip >= 0.0 && !old_value) return CUSRL_E_INVALID;
     if (A > INT32_MAX || D > INT32_MAX) return CUSRL_E_UNSUPPORTED;
+    if (D == 0) value_clip = -1.0, d_value = nullptr;
     const LossParams p = loss_params(B, D, clip, value_clip, w_sur, w_val, w_ent);
     hipStream_t s = as_stream(stream);
     const bool chunked = A % 4 == 0 && A / 4 <= 8 && aligned(action, 16) && aligned(mean, 16) && aligned(std, 16) &&
@@ -777,7 +867,7 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
     const int64_t blocks = ceil_div(B, chunked ? loss_rows_per_block(A) : kBlock);
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     // the training step wants every output: that variant carries no per-store pointer tests
-    const bool full = logp_out && entropy_out && logp_ratio_out && ratio_out && d_mean && d_value && (std_vector || d_std);
+    const bool full = logp_out && entropy_out && logp_ratio_out && ratio_out && d_mean && (d_value || D == 0) && (std_vector || d_std);
     const bool wave_rows = loss_wave_rows();
     const bool streaming = loss_streaming(B, A, D, std_vector);
     if (chunked) {

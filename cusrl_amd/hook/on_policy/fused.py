@@ -42,7 +42,9 @@ def _side_outputs(out, deferred, like):
 
 
 class _FusedPpoFunction(torch.autograd.Function):
-    """total = value_loss + surrogate_loss + entropy_loss; gradients precomputed by the forward kernel."""
+    """total = value_loss + surrogate_loss + entropy_loss; gradients precomputed by the forward kernel.
+    ``curr_value = ret = None``: the launch carries no value term (:class:`_ValueTermFunction` evaluated it on the critic's
+    stream): total = surrogate_loss + entropy_loss."""
 
     @staticmethod
     def forward(ctx, mean, std, curr_value, advantage, old_logp, action, ret, old_value, clip, value_clip,
@@ -53,18 +55,22 @@ class _FusedPpoFunction(torch.autograd.Function):
         )
         d_std = out["d_std"]
         ctx.deferred_std = None
+        saved = [out["d_mean"]]
         if isinstance(d_std, ops.DeferredColumns):
             # the blocks' column sums of d_std: `std` is the parameter itself here, so they go straight to the flat
             # gradient assembly (backward) instead of through a reduction launch
             ctx.deferred_std, ctx.std_key = d_std, std.data_ptr()
-            ctx.save_for_backward(out["d_mean"], out["d_value"])
         else:
-            ctx.save_for_backward(out["d_mean"], d_std, out["d_value"])
+            saved.append(d_std)
+        ctx.has_value = curr_value is not None
+        if ctx.has_value:
+            saved.append(out["d_value"])
+        ctx.save_for_backward(*saved)
         # the five side outputs never receive a gradient; without this autograd would materialise a zero tensor for
         # each of them on every backward (5 fill launches per minibatch)
         ctx.set_materialize_grads(False)
         ctx.unit_grad = unit_grad
-        ctx.shapes = (mean.shape, std.shape, curr_value.shape)
+        ctx.shapes = (mean.shape, std.shape, curr_value.shape if ctx.has_value else None)
         total, losses = _side_outputs(out, deferred, mean)
         side = (losses, out["logp"], out["entropy"], out["logp_ratio"], out["ratio"])
         ctx.mark_non_differentiable(*side)
@@ -77,18 +83,54 @@ class _FusedPpoFunction(torch.autograd.Function):
         shapes = ctx.shapes
         from cusrl_amd.nn import module as nn_module
 
+        saved = list(ctx.saved_tensors)
+        d_mean = saved.pop(0)
+        d_value = saved.pop() if ctx.has_value else None
         if ctx.deferred_std is not None:
             if not nn_module.is_unit_gradient(grad_total):
                 raise RuntimeError("the deferred-finalize form of the fused PPO objective is differentiated with the agent's unit "
                                    "gradient only (captured steps); something rescaled its loss")
-            d_mean, d_value = ctx.saved_tensors
             d_std = nn_module._hand_over(nn_module._split_grad_sink, ctx.std_key, ctx.deferred_std)
-            return (d_mean.view(shapes[0]), None if d_std is None else d_std.view(shapes[1]), d_value.view(shapes[2]),
-                    *([None] * 12))
-        d_mean, d_std, d_value = ctx.saved_tensors
+            return (d_mean.view(shapes[0]), None if d_std is None else d_std.view(shapes[1]),
+                    None if d_value is None else d_value.view(shapes[2]), *([None] * 12))
+        d_std = saved.pop()
         if not (ctx.unit_grad and nn_module.is_unit_gradient(grad_total)):  # GradScaler, or a caller that rescales the loss
-            d_mean, d_std, d_value = d_mean * grad_total, d_std * grad_total, d_value * grad_total
-        return (d_mean.view(shapes[0]), d_std.view(shapes[1]), d_value.view(shapes[2]), *([None] * 12))
+            d_mean, d_std = d_mean * grad_total, d_std * grad_total
+            d_value = None if d_value is None else d_value * grad_total
+        return (d_mean.view(shapes[0]), d_std.view(shapes[1]), None if d_value is None else d_value.view(shapes[2]),
+                *([None] * 12))
+
+
+class _ValueTermFunction(torch.autograd.Function):
+    """value_loss alone (value.py:85-89,121-137), one launch on the CURRENT stream — the critic's branch of a captured minibatch
+    step: critic forward -> this -> critic backward never meets the actor's stream inside the step.  ``losses`` =
+    (weighted value loss, mean value) — absent (empty) in the deferred-finalize form, like the one-launch objective's."""
+
+    @staticmethod
+    def forward(ctx, curr_value, ret, old_value, weight, value_clip, unit_grad, deferred):
+        out = ops.value_loss_fwd_bwd(ret, curr_value, old_value, value_clip=value_clip, w_val=weight, deferred=deferred)
+        ctx.save_for_backward(out["d_value"])
+        ctx.set_materialize_grads(False)
+        ctx.unit_grad, ctx.shape = unit_grad, curr_value.shape
+        if deferred is None:
+            losses = out["losses"]
+            total = losses[0]
+        else:  # placeholders nobody reads: unit-gradient backward, values through ops.DeferredLoss
+            total = torch.empty((), dtype=torch.float32, device=curr_value.device)
+            losses = torch.empty(0, dtype=torch.float32, device=curr_value.device)
+        ctx.mark_non_differentiable(losses)
+        return total, losses
+
+    @staticmethod
+    def backward(ctx, grad_total, _unused=None):
+        if grad_total is None:
+            return (None,) * 7
+        from cusrl_amd.nn.module import is_unit_gradient
+
+        (d_value,) = ctx.saved_tensors
+        if not (ctx.unit_grad and is_unit_gradient(grad_total)):
+            d_value = d_value * grad_total
+        return (d_value.view(ctx.shape), *([None] * 6))
 
 
 class _FusedCategoricalPpoFunction(torch.autograd.Function):
@@ -101,10 +143,11 @@ class _FusedCategoricalPpoFunction(torch.autograd.Function):
             advantage, old_logp, action, logits, ret, curr_value, old_value,
             clip=clip, value_clip=value_clip, w_sur=w_sur, w_val=w_val, w_ent=w_ent, want_grads=True, deferred=deferred,
         )
-        ctx.save_for_backward(out["d_logits"], out["d_value"])
+        ctx.has_value = curr_value is not None
+        ctx.save_for_backward(out["d_logits"], *((out["d_value"],) if ctx.has_value else ()))
         ctx.set_materialize_grads(False)
         ctx.unit_grad = unit_grad
-        ctx.shapes = (logits.shape, curr_value.shape)
+        ctx.shapes = (logits.shape, curr_value.shape if ctx.has_value else None)
         total, losses = _side_outputs(out, deferred, logits)
         side = (losses, out["logp"], out["entropy"], out["logp_ratio"], out["ratio"])
         ctx.mark_non_differentiable(*side)
@@ -116,10 +159,12 @@ class _FusedCategoricalPpoFunction(torch.autograd.Function):
             return (None,) * 14
         from cusrl_amd.nn.module import is_unit_gradient
 
-        d_logits, d_value = ctx.saved_tensors
+        d_logits, *rest = ctx.saved_tensors
+        d_value = rest[0] if rest else None
         if not (ctx.unit_grad and is_unit_gradient(grad_total)):
-            d_logits, d_value = d_logits * grad_total, d_value * grad_total
-        return (d_logits.view(ctx.shapes[0]), d_value.view(ctx.shapes[1]), *([None] * 12))
+            d_logits = d_logits * grad_total
+            d_value = None if d_value is None else d_value * grad_total
+        return (d_logits.view(ctx.shapes[0]), None if d_value is None else d_value.view(ctx.shapes[1]), *([None] * 12))
 
 
 class _PolicyTermsFunction(torch.autograd.Function):
@@ -183,6 +228,9 @@ class FusedPpoObjective:
         self.surrogate: tuple | None = None
         self.entropy: float | None = None
         self.pending_streams: list = []
+        # (total, losses, stream) of the value term when it was evaluated by its own launch on the critic's stream
+        self.value_root: tuple | None = None
+        self.value_dim = 1
 
     # ------------------------------------------------------------------ arming
     @staticmethod
@@ -257,6 +305,29 @@ class FusedPpoObjective:
         self.value = (curr_value, old_value, ret, weight, loss_clip)
         return {"value_loss": None}
 
+    def evaluate_value(self, curr_value, old_value, ret, weight: float, loss_clip: float | None, stream):
+        """The value term NOW, on the current stream (``stream``: the critic's branch) instead of inside the one-launch
+        objective: its own root of the step's backward (``Objectives.terms().branch``), so the critic's forward, loss and
+        backward form ONE branch of the captured step.  Only in the plain fused mode with a unit-gradient backward."""
+        D, B = ret.shape[-1], ret.numel() // max(ret.shape[-1], 1)
+        self.value_dim = D
+        deferred = self._deferred_value(ret.device, B, D)
+        total, losses = _ValueTermFunction.apply(curr_value, ret, old_value, weight, loss_clip, self.unit_grad, deferred)
+        self.value = (None, None, None, weight, loss_clip)
+        self.value_root = (total, losses, stream, deferred is not None)
+        return {"value_loss": None}
+
+    def _deferred_value(self, device, B: int, D: int):
+        """The step's :class:`ops.DeferredLoss` for the value term's launch: same conditions as :meth:`_deferred`; the rows are
+        created (outside any capture) by whichever of the two launches of the eager warm-up comes first."""
+        owner = self.owner
+        if owner is None or not self.unit_grad:
+            return None
+        current = owner.deferred_loss
+        if current is None or (current.B, current.D) != (B, D) or not torch.cuda.is_current_stream_capturing():
+            return None
+        return None if current.blocks > ops.DeferredLoss.MAX_BLOCKS else current
+
     def join(self, stream):
         """A term was produced on another stream: the loss launch waits for it."""
         self.pending_streams.append(stream)
@@ -306,7 +377,7 @@ class FusedPpoObjective:
     def resolve(self, objectives, batch: dict[str, Any]):
         if any(term is None for term in (self.value, self.policy, self.surrogate, self.entropy)):
             raise RuntimeError("fused PPO objective armed but a term hook did not report; this is a bug")
-        curr_value, old_value, ret, w_val, value_clip = self.value
+        curr_value, old_value, ret, w_val, value_clip = self.value  # (all None but the weight: evaluate_value ran the term)
         action_dist, action, old_logp = self.policy
         advantage, clip, w_sur = self.surrogate
         if advantage is None:  # surrogate term dropped (split mode): zero weight, any [B, 1] tensor serves as operand
@@ -316,7 +387,7 @@ class FusedPpoObjective:
         self.pending_streams.clear()
         if "logits" in action_dist:  # one-hot categorical policy (discrete action space)
             logits = action_dist["logits"].float()
-            deferred = self._deferred(logits.device, logits.shape[-1], ret.shape[-1], logits.numel() // logits.shape[-1], True, None)
+            deferred = self._deferred(logits.device, logits.shape[-1], self._value_dim(ret), logits.numel() // logits.shape[-1], True, None)
             total, losses, logp, entropy, logp_ratio, ratio = _FusedCategoricalPpoFunction.apply(
                 logits, curr_value, advantage, old_logp, action, ret, old_value,
                 clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad, deferred,
@@ -328,12 +399,15 @@ class FusedPpoObjective:
         if row_vector is not None and std.dim() == 2 and std.stride(0) == 0 and ops.ppo_loss_accepts_std_vector(std.shape[-1]):
             std = row_vector  # the [A] vector the batch view repeats: broadcast inside the kernel, d_std comes back as [A]
         mean = action_dist["mean"]
-        deferred = self._deferred(mean.device, mean.shape[-1], ret.shape[-1], mean.numel() // mean.shape[-1], False, std)
+        deferred = self._deferred(mean.device, mean.shape[-1], self._value_dim(ret), mean.numel() // mean.shape[-1], False, std)
         total, losses, logp, entropy, logp_ratio, ratio = _FusedPpoFunction.apply(
             mean, std, curr_value, advantage, old_logp, action, ret, old_value,
             clip, value_clip, w_sur, w_val, self.entropy, self.unit_grad, deferred,
         )
         self._publish(objectives, batch, advantage, total, losses, logp, entropy, logp_ratio, ratio, deferred, self)
+
+    def _value_dim(self, ret) -> int:
+        return self.value_dim if ret is None else ret.shape[-1]
 
     def _deferred(self, device, A: int, D: int, B: int, categorical: bool, std):
         """The :class:`ops.DeferredLoss` of the captured minibatch step this objective belongs to, or None.  Taken only
@@ -371,6 +445,9 @@ class FusedPpoObjective:
         fused_keys = tuple(k for k in ("value_loss", "surrogate_loss", "entropy_loss") if k not in dropped)
         objectives.total = total
         objectives.fused_keys = fused_keys
+        value_root = context.value_root if context is not None else None
+        if value_root is not None:  # the value term is a root of its own, living on the critic's stream
+            objectives.branch_root = (value_root[0], value_root[2])
         if deferred is not None:
             # captured step without a finalize launch: the loss values exist as running block sums (ops.DeferredLoss),
             # read once per update by GraphedTrainStep.flush_metrics; agent.record skips the None entries
@@ -382,6 +459,13 @@ class FusedPpoObjective:
         # the means the hooks record after every minibatch, already reduced by the kernel (no extra launches)
         rows = advantage.numel()
         batch["_fused_metrics"] = {"ratio": (mean_abs_ratio, rows), "entropy": (mean_entropy, rows), "value": (mean_value, rows)}
+        if value_root is not None:
+            if value_root[3]:  # its launch deferred the finalize although this one could not: its sums reach the metrics alone
+                value_loss = None
+                del batch["_fused_metrics"]["value"]
+            else:  # (produced on the critic's stream; read by the metrics after the step's join)
+                value_loss, mean_value = value_root[1].unbind(0)
+                batch["_fused_metrics"]["value"] = (mean_value, rows)
         for key, value in (("value_loss", value_loss), ("surrogate_loss", surrogate_loss), ("entropy_loss", entropy_loss)):
             if key in fused_keys:
                 objectives[key] = value

@@ -218,14 +218,26 @@ class ValueLoss(Hook):
         if branch is not None:
             # inside a minibatch step that is (being) captured: the critic's forward — and, because autograd replays
             # every node on the stream its forward ran on, its backward — goes to a second stream.  The two networks
-            # share nothing until the loss kernel, so the captured graph gets two independent branches whose latency-
-            # bound small kernels fill the gaps of the other branch's GEMM tails.  Joined in FusedPpoObjective.resolve.
+            # share nothing until their losses are summed, so the captured graph gets two independent branches whose
+            # latency-bound small kernels fill the gaps of the other branch's GEMM tails.
             main = torch.cuda.current_stream()
+            separate = getattr(self.agent, "separate_value_root", False) and fused.unit_grad
+            if separate:  # (read on the main stream, in front of the fork: a lazy batch gathers a field where it is first touched)
+                ret, old_value = batch["return"], (batch["value"] if self.loss_clip is not None else None)
             branch.wait_stream(main)  # the gather of `state` was issued on `main`
             with torch.cuda.stream(branch):
                 curr_value = self.agent.critic.evaluate(state, memory=memory, done=done)
+                if separate:
+                    # round 6: the value term right here, on the critic's stream, as its own root of the backward — the
+                    # branch runs critic forward -> value term -> critic backward and meets the actor's stream ONCE, in
+                    # front of the gradient assembly (ActorCritic._backward), instead of joining for the one-launch
+                    # objective and forking again for the backward
+                    terms = fused.evaluate_value(curr_value, old_value, ret, self.weight, self.loss_clip, branch)
             curr_value.record_stream(main)
-            fused.join(branch)
+            if separate:
+                batch["curr_value"] = curr_value
+                return terms
+            fused.join(branch)  # the one-launch objective waits for the branch (FusedPpoObjective.resolve)
         else:
             curr_value = self.agent.critic.evaluate(state, memory=memory, done=done)
         batch["curr_value"] = curr_value
@@ -243,7 +255,7 @@ class ValueLoss(Hook):
     def post_objective(self, metadata, batch):
         curr_value: Tensor = batch["curr_value"]
         if (reduced := batch.get("_fused_metrics")) is not None:
-            if not reduced.get("deferred"):  # (captured step: read once per update from the kernel's running sums)
+            if not reduced.get("deferred") and "value" in reduced:  # (captured step: read once per update from the kernel's running sums)
                 self.agent.metrics.record_reduced("value", *reduced["value"])
         else:
             self.agent.record(value=curr_value.sum(dim=-1))

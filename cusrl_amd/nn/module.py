@@ -44,6 +44,9 @@ _plain_linear_depth = 0
 # containing those is not replayed reliably by this stack.  ``CUSRL_WIDE_LINEAR_MIN_ROWS`` restores
 # a threshold for A/B runs and for the defect's reproduction (scripts/debug_amp_identity.py).
 _WIDE_MIN_ROWS = int(os.environ.get("CUSRL_WIDE_LINEAR_MIN_ROWS", "1"))
+# The first layer's backward as one launch (round 6, ops.input_layer_backward); CUSRL_INPUT_LAYER_KERNEL=0: the mask + column-sum
+# pass followed by the split-batch weight-gradient GEMM of rounds 2-5 (A/B switch)
+_INPUT_LAYER_KERNEL = os.environ.get("CUSRL_INPUT_LAYER_KERNEL", "1") != "0"
 
 
 # Backward shortcuts for a UNIT incoming gradient.  The loss summands of a step are differentiated as separate roots with a
@@ -52,16 +55,32 @@ _WIDE_MIN_ROWS = int(os.environ.get("CUSRL_WIDE_LINEAR_MIN_ROWS", "1"))
 # scalar.  The engine passes a root's grad_output through untouched, so its address identifies it; anything a caller did
 # to the loss (a hook re-weighting the objectives, GradScaler, accumulation) arrives as a different tensor and is
 # multiplied in.  (Up to round 4 the shortcut was taken on a hint computed at forward time.)
-_unit_gradients: set[int] = set()
+# address -> weak reference of the registered scalar.  The entry lives exactly as long as the tensor does: while the tensor
+# is alive nothing else can own its storage, so an equal address IS that tensor; when it dies (an agent dropped, a sweep
+# building agent after agent) its address leaves the registry with it, and the allocator may hand the block to anything.
+_unit_gradients: dict[int, "weakref.ref[torch.Tensor]"] = {}
 
 
 def register_unit_gradient(ones: torch.Tensor) -> torch.Tensor:
-    _unit_gradients.add(ones.data_ptr())
+    import weakref
+
+    address = ones.data_ptr()
+    _unit_gradients[address] = weakref.ref(ones)
+    weakref.finalize(ones, _forget_unit_gradient, address)
     return ones
 
 
+def _forget_unit_gradient(address: int) -> None:
+    ref = _unit_gradients.get(address)
+    if ref is not None and ref() is None:  # (a newer registration of a recycled address stays)
+        del _unit_gradients[address]
+
+
 def is_unit_gradient(grad: torch.Tensor | None) -> bool:
-    return grad is not None and grad.dim() == 0 and grad.data_ptr() in _unit_gradients
+    if grad is None or grad.dim() != 0:
+        return False
+    ref = _unit_gradients.get(grad.data_ptr())
+    return ref is not None and ref() is not None
 
 
 @contextmanager
@@ -140,6 +159,14 @@ class _WideBatchLinear(torch.autograd.Function):
             input, weight, output = ctx.saved_tensors
             sink = _split_grad_sink
             premasked = getattr(grad_output, "_cusrl_premasked", None)
+            if (_INPUT_LAYER_KERNEL and premasked is None and not ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+                    and ctx.has_bias and ctx.needs_input_grad[2]):
+                grad_output = grad_output.contiguous()
+                if ops.input_layer_supported(grad_output, output, input, weight):
+                    # the bottom layer (its input — the observation — needs no gradient): ReLU mask, bias gradient and weight
+                    # gradient from ONE pass over dY, Y and X, nothing written back per row (cusrl_input_layer_bwd)
+                    d_weight, d_bias = ops.input_layer_backward(grad_output, output, input)
+                    return None, d_weight, d_bias, None, None
             if premasked is not None and premasked[1] == grad_output._version and ctx.has_bias:
                 grad_bias = premasked[0]  # the head behind this ReLU already masked its dX and summed its columns
             else:

@@ -41,6 +41,8 @@ __all__ = [
     "normal_sample_logp",
     "categorical_sample_logp",
     "gru_gates_forward",
+    "input_layer_backward",
+    "input_layer_supported",
     "gru_gates_backward",
     "lstm_gates_forward",
     "lstm_gates_backward",
@@ -54,6 +56,7 @@ __all__ = [
     "normalize_from_partials_",
     "ppo_loss_categorical_fwd_bwd",
     "ppo_loss_fwd_bwd",
+    "value_loss_fwd_bwd",
     "masked_col_stats",
     "relu_backward_bias",
     "require_device",
@@ -428,12 +431,15 @@ def gather_rows_packed(
     capacity: int,
     parallelism: int,
     temporal: bool = False,
+    out: Sequence[torch.Tensor] | None = None,
+    packed_out: Sequence[torch.Tensor] | None = None,
 ) -> tuple[list[torch.Tensor], list[torch.Tensor]]:
     """:func:`gather_rows` for ``storages`` plus, from the SAME launch, the leaves ``packed_names`` of ``pack`` read
     through its per-slot record (one sector per sampled slot for all of them).  Results are identical to gathering
-    the leaves themselves as long as the record is current (``pack.build()`` after the last write to a packed leaf)."""
+    the leaves themselves as long as the record is current (``pack.build()`` after the last write to a packed leaf).
+    ``out`` / ``packed_out``: destinations the caller owns, one per plain / packed leaf."""
     if not packed_names:
-        return gather_rows(storages, indices, capacity, parallelism, temporal), []
+        return gather_rows(storages, indices, capacity, parallelism, temporal, out=out), []
     if len(storages) > _native.MAX_FIELDS:
         raise ValueError("gather_rows_packed: too many plain leaves for one launch")
     require_device(indices, "indices")
@@ -443,9 +449,19 @@ def gather_rows_packed(
         indices = indices.contiguous()
     batch = indices.numel()
     lead = (capacity, batch) if temporal else (batch,)
-    outputs = [torch.empty(lead + tuple(s.shape[2:]), dtype=s.dtype, device=s.device) for s in storages]
     sources = [pack.leaves[name] for name in packed_names]
-    packed_outputs = [torch.empty(lead + tuple(s.shape[2:]), dtype=s.dtype, device=s.device) for s in sources]
+    rows_out = batch * (capacity if temporal else 1)
+
+    def destinations(given, leaves):
+        if given is None:
+            return [torch.empty(lead + tuple(s.shape[2:]), dtype=s.dtype, device=s.device) for s in leaves]
+        given = list(given)
+        for dst, src in zip(given, leaves):
+            if not dst.is_contiguous() or dst.dtype != src.dtype or dst.numel() != rows_out * _row_elems(src):
+                raise ValueError("gather_rows_packed: an 'out' tensor does not match its leaf (contiguous, same dtype, batch rows)")
+        return given
+
+    outputs, packed_outputs = destinations(out, storages), destinations(packed_out, sources)
     if batch == 0:
         return outputs, packed_outputs
     table = (Field * max(len(storages), 1))()
@@ -757,25 +773,36 @@ class DeferredLoss:
     (``CUSRL_LOSS_DEFER``): nothing inside an optimizer step reads the loss VALUES — the backward takes a unit gradient —
     so the captured step skips the one-block finalize launch; every block adds its sums to its own row of ``rows``
     (persistent, zero-filled here, outside the capture) and :meth:`drain` forms the per-replay means once per update on
-    the host.  ``weights`` = (w_val, w_sur, w_ent) the capture froze."""
+    the host.  ``weights`` = (w_val, w_sur, w_ent) the capture froze.  The value term evaluated by its own launch on the
+    critic's stream (:func:`value_loss_fwd_bwd`) keeps its two sums in ``value_rows``: two launches on two streams must not
+    read-modify-write the same words."""
 
-    __slots__ = ("rows", "B", "A", "D", "weights", "blocks", "armed")
+    __slots__ = ("rows", "value_rows", "value_armed", "value_weight", "policy_has_value", "B", "A", "D", "weights", "blocks", "armed")
 
     def __init__(self, B: int, A: int, D: int, device, categorical: bool):
         self.B, self.A, self.D = B, A, D
-        self.blocks = int(_native.lib().cusrl_ppo_loss_blocks(B, 0 if categorical else A))
-        self.rows = torch.zeros((max(int(_native.lib().cusrl_ppo_loss_num_partials(B)), 1), 5), dtype=torch.float64, device=device)
+        lib = _native.lib()
+        self.blocks = int(lib.cusrl_ppo_loss_blocks(B, 0 if categorical else A))
+        self.rows = torch.zeros((max(int(lib.cusrl_ppo_loss_num_partials(B)), 1), 5), dtype=torch.float64, device=device)
+        self.value_rows = torch.zeros((max(int(lib.cusrl_value_loss_blocks(B, D)), 1), 2), dtype=torch.float64, device=device)
         self.weights: tuple[float, float, float] | None = None
-        self.armed = False  # a launch has been recorded against these rows
+        self.value_weight: float | None = None
+        self.armed = False  # a launch of the (policy / whole) objective has been recorded against `rows`
+        self.value_armed = False  # ... of the separate value term against `value_rows`
+        self.policy_has_value = True
 
     MAX_BLOCKS = 256  # beyond this the per-row read-modify-write and the host-side sum stop being negligible
 
     def sums(self) -> torch.Tensor | None:
         """The five running sums as a device tensor (no host read) and a reset of the rows; None if nothing ran."""
-        if not self.armed or self.weights is None:
+        if not (self.armed or self.value_armed):
             return None
         total = self.rows[: self.blocks].sum(0)
         self.rows.zero_()
+        if self.value_armed:  # sums 0 (squared value error) and 4 (value) came from the separate launch
+            value = self.value_rows.sum(0)
+            self.value_rows.zero_()
+            total = torch.stack((value[0], total[1], total[2], total[3], value[1]))
         return total
 
     def drain(self, replays: int) -> dict[str, tuple[float, int]] | None:
@@ -785,16 +812,20 @@ class DeferredLoss:
         return self.metrics(total.tolist())
 
     def metrics(self, sums: Sequence[float]) -> dict[str, tuple[float, int]]:
-        w_val, w_sur, w_ent = self.weights
         B, D = self.B, self.D
-        return {
-            "value_loss": (sums[0] / (B * D) * w_val, 1),
-            "surrogate_loss": (-sums[1] / B * w_sur, 1),
-            "entropy_loss": (-sums[2] / B * w_ent, 1),
-            "ratio": (sums[3] / B, B),
-            "entropy": (sums[2] / B, B),
-            "value": (sums[4] / B, B),
-        }
+        out: dict[str, tuple[float, int]] = {}
+        if self.value_armed or (self.armed and self.policy_has_value):
+            w_val = self.value_weight if self.value_armed else self.weights[0]
+            out["value_loss"] = (sums[0] / (B * D) * w_val, 1)
+        if self.armed:
+            _, w_sur, w_ent = self.weights
+            out["surrogate_loss"] = (-sums[1] / B * w_sur, 1)
+            out["entropy_loss"] = (-sums[2] / B * w_ent, 1)
+            out["ratio"] = (sums[3] / B, B)
+            out["entropy"] = (sums[2] / B, B)
+        if "value_loss" in out:
+            out["value"] = (sums[4] / B, B)
+        return out
 
 
 def ppo_loss_fwd_bwd(
@@ -803,8 +834,8 @@ def ppo_loss_fwd_bwd(
     action: torch.Tensor,
     mean: torch.Tensor,
     std: torch.Tensor,
-    ret: torch.Tensor,
-    curr_value: torch.Tensor,
+    ret: torch.Tensor | None,
+    curr_value: torch.Tensor | None,
     old_value: torch.Tensor | None,
     *,
     clip: float,
@@ -820,29 +851,34 @@ def ppo_loss_fwd_bwd(
 
     ``std`` is either the ``[B, A]`` matrix or the ``[A]`` vector it repeats (a state-independent std,
     :func:`ppo_loss_accepts_std_vector`): then it is broadcast inside the kernel and ``d_std`` is the ``[A]`` gradient of
-    the vector.
+    the vector.  ``ret = curr_value = None``: the launch carries no value term (:func:`value_loss_fwd_bwd` evaluates it on
+    the critic's stream); ``losses[0]``, ``losses[5]`` are 0 and there is no ``d_value``.
 
     ``deferred`` (a :class:`DeferredLoss` of this shape): ONE launch, no finalize — ``losses`` is absent from the result,
     the block sums accumulate in ``deferred.rows``, and with a std vector ``d_std`` comes back as
     :class:`DeferredColumns` (the blocks' column sums, reduced by ``assemble_gradients``)."""
     advantage, old_logp = _f32(advantage, "advantage"), _f32(old_logp, "action_logp")
     action, mean, std = _f32(action, "action"), _f32(mean, "mean"), _f32(std, "std")
-    ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
+    no_value = ret is None and curr_value is None
+    if not no_value:
+        ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
     A = mean.shape[-1]
     B = mean.numel() // A
-    D = ret.shape[-1]
+    D = 0 if no_value else ret.shape[-1]
     std_vector = std.dim() == 1 and B != 1
     if std_vector and not (std.numel() == A and ppo_loss_accepts_std_vector(A)):
         raise ValueError("ppo_loss: a std vector must have one entry per action dim (and the action width a multiple of 4, <= 32)")
     if advantage.numel() != B or old_logp.numel() != B or action.shape != mean.shape or (not std_vector and std.numel() != B * A):
         raise ValueError("ppo_loss: inconsistent batch shapes")
-    if ret.numel() != B * D or curr_value.shape != ret.shape:
+    if no_value:
+        value_clip = old_value = None
+    elif ret.numel() != B * D or curr_value.shape != ret.shape:
         raise ValueError("ppo_loss: return / value shapes differ")
     if value_clip is not None:
         if old_value is None:
             raise ValueError("ppo_loss: the clipped value loss needs the old value")
         old_value = _f32(old_value, "value")
-    if deferred is not None and (deferred.B, deferred.A, deferred.D) != (B, A, D):
+    if deferred is not None and (deferred.B, deferred.A) != (B, A) or (deferred is not None and not no_value and deferred.D != D):
         raise ValueError("ppo_loss: the deferred-loss rows belong to another minibatch shape")
     dev = mean.device
     lib = _native.lib()
@@ -856,14 +892,16 @@ def ppo_loss_fwd_bwd(
         out["losses"] = torch.empty(7, dtype=torch.float32, device=dev)  # 3 weighted losses, 3 metric means, total
     defer_std = deferred is not None and std_vector and want_grads
     if want_grads:
-        out["d_mean"], out["d_value"] = torch.empty_like(mean), torch.empty_like(curr_value)
+        out["d_mean"] = torch.empty_like(mean)
+        if not no_value:
+            out["d_value"] = torch.empty_like(curr_value)
         if not defer_std:
             out["d_std"] = torch.empty_like(std)
     if deferred is None:
         partials = torch.empty((int(lib.cusrl_ppo_loss_num_partials(B)), 5), dtype=torch.float64, device=dev)
     else:
         partials = deferred.rows
-        deferred.weights, deferred.armed = (float(w_val), float(w_sur), float(w_ent)), True
+        deferred.weights, deferred.armed, deferred.policy_has_value = (float(w_val), float(w_sur), float(w_ent)), True, not no_value
     std_partials = (torch.empty((int(lib.cusrl_ppo_loss_std_partial_rows(B)), A), dtype=torch.float32, device=dev)
                     if std_vector and want_grads else None)
     if defer_std:
@@ -879,7 +917,8 @@ def ppo_loss_fwd_bwd(
                      + (4 * D if value_clip is not None else 0)),
         lambda: lib.cusrl_ppo_loss_fwd_bwd(
             advantage.data_ptr(), old_logp.data_ptr(), action.data_ptr(), mean.data_ptr(), std.data_ptr(),
-            ret.data_ptr(), curr_value.data_ptr(), None if old_value is None or value_clip is None else old_value.data_ptr(),
+            None if no_value else ret.data_ptr(), None if no_value else curr_value.data_ptr(),
+            None if old_value is None or value_clip is None else old_value.data_ptr(),
             B, A, D, float(clip), -1.0 if value_clip is None else float(value_clip), float(w_sur), float(w_val), float(w_ent),
             ptr("losses"), ptr("logp"), ptr("entropy"), ptr("logp_ratio"), ptr("ratio"), ptr("d_mean"), ptr("d_std"), ptr("d_value"),
             partials.data_ptr(), 1 if std_vector else B, None if std_partials is None else std_partials.data_ptr(),
@@ -910,19 +949,23 @@ def ppo_loss_categorical_fwd_bwd(
     same ``losses`` layout and per-sample outputs, gradients ``d_logits`` / ``d_value``; ``deferred`` as there."""
     advantage, old_logp = _f32(advantage, "advantage"), _f32(old_logp, "action_logp")
     action, logits = _f32(action, "action"), _f32(logits, "logits")
-    ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
+    no_value = ret is None and curr_value is None  # (the value term from value_loss_fwd_bwd, see ppo_loss_fwd_bwd)
+    if not no_value:
+        ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
     A = logits.shape[-1]
     B = logits.numel() // A
-    D = ret.shape[-1]
+    D = 0 if no_value else ret.shape[-1]
     if advantage.numel() != B or old_logp.numel() != B or action.shape != logits.shape:
         raise ValueError("ppo_loss_categorical: inconsistent batch shapes")
-    if ret.numel() != B * D or curr_value.shape != ret.shape:
+    if no_value:
+        value_clip = old_value = None
+    elif ret.numel() != B * D or curr_value.shape != ret.shape:
         raise ValueError("ppo_loss_categorical: return / value shapes differ")
     if value_clip is not None:
         if old_value is None:
             raise ValueError("ppo_loss_categorical: the clipped value loss needs the old value")
         old_value = _f32(old_value, "value")
-    if deferred is not None and (deferred.B, deferred.A, deferred.D) != (B, A, D):
+    if deferred is not None and ((deferred.B, deferred.A) != (B, A) or (not no_value and deferred.D != D)):
         raise ValueError("ppo_loss_categorical: the deferred-loss rows belong to another minibatch shape")
     dev = logits.device
     lib = _native.lib()
@@ -932,9 +975,11 @@ def ppo_loss_categorical_fwd_bwd(
         partials = torch.empty((int(lib.cusrl_ppo_loss_num_partials(B)), 5), dtype=torch.float64, device=dev)
     else:
         partials = deferred.rows
-        deferred.weights, deferred.armed = (float(w_val), float(w_sur), float(w_ent)), True
+        deferred.weights, deferred.armed, deferred.policy_has_value = (float(w_val), float(w_sur), float(w_ent)), True, not no_value
     if want_grads:
-        out["d_logits"], out["d_value"] = torch.empty_like(logits), torch.empty_like(curr_value)
+        out["d_logits"] = torch.empty_like(logits)
+        if not no_value:
+            out["d_value"] = torch.empty_like(curr_value)
 
     def ptr(name):
         return out[name].data_ptr() if name in out else None
@@ -943,12 +988,53 @@ def ppo_loss_categorical_fwd_bwd(
         "cusrl_ppo_loss_categorical_fwd_bwd",
         lambda: B * (8 + 8 * A + 8 * D + ((4 * A + 4 * D) if want_grads else 0) + 16 + (4 * D if value_clip is not None else 0)),
         lambda: lib.cusrl_ppo_loss_categorical_fwd_bwd(
-            advantage.data_ptr(), old_logp.data_ptr(), action.data_ptr(), logits.data_ptr(), ret.data_ptr(), curr_value.data_ptr(),
+            advantage.data_ptr(), old_logp.data_ptr(), action.data_ptr(), logits.data_ptr(),
+            None if no_value else ret.data_ptr(), None if no_value else curr_value.data_ptr(),
             None if old_value is None or value_clip is None else old_value.data_ptr(), B, A, D, float(clip),
             -1.0 if value_clip is None else float(value_clip), float(w_sur), float(w_val), float(w_ent), ptr("losses"), ptr("logp"),
             ptr("entropy"), ptr("logp_ratio"), ptr("ratio"), ptr("d_logits"), ptr("d_value"), partials.data_ptr(),
             LOSS_DEFER if deferred is not None else 0, _stream(),
         ),
+    )
+    return out
+
+
+def value_loss_fwd_bwd(ret: torch.Tensor, curr_value: torch.Tensor, old_value: torch.Tensor | None, *, value_clip: float | None,
+                       w_val: float, want_grad: bool = True, deferred: DeferredLoss | None = None) -> dict[str, torch.Tensor]:
+    """The value term alone (value.py:85-89,121-137), forward and backward in one launch on the CURRENT stream:
+    ``losses`` = (weighted value loss, mean of ``curr_value.sum(-1)``) and ``d_value``.  ``deferred``: no finalize launch,
+    the block sums accumulate in ``deferred.value_rows`` (and ``losses`` is absent)."""
+    ret, curr_value = _f32(ret, "return"), _f32(curr_value, "curr_value")
+    if curr_value.shape != ret.shape or ret.dim() < 1:
+        raise ValueError("value_loss: return / value shapes differ")
+    D = ret.shape[-1]
+    B = ret.numel() // max(D, 1)
+    if value_clip is not None:
+        if old_value is None:
+            raise ValueError("value_loss: the clipped value loss needs the old value")
+        old_value = _f32(old_value, "value")
+        if old_value.numel() != ret.numel():
+            raise ValueError("value_loss: return / old value shapes differ")
+    if deferred is not None and (deferred.B, deferred.D) != (B, D):
+        raise ValueError("value_loss: the deferred-loss rows belong to another minibatch shape")
+    dev, lib = ret.device, _native.lib()
+    out: dict[str, torch.Tensor] = {}
+    if want_grad:
+        out["d_value"] = torch.empty_like(curr_value)
+    if deferred is None:
+        out["losses"] = torch.empty(2, dtype=torch.float32, device=dev)
+        partials = torch.empty((max(int(lib.cusrl_value_loss_blocks(B, D)), 1), 2), dtype=torch.float64, device=dev)
+    else:
+        partials = deferred.value_rows
+        deferred.value_armed, deferred.value_weight = True, float(w_val)
+    _observed(
+        "cusrl_value_loss_fwd_bwd",
+        lambda: B * D * (8 + (4 if want_grad else 0) + (4 if value_clip is not None else 0)),
+        lambda: lib.cusrl_value_loss_fwd_bwd(
+            ret.data_ptr(), curr_value.data_ptr(), None if value_clip is None else old_value.data_ptr(), B, D,
+            -1.0 if value_clip is None else float(value_clip), float(w_val),
+            out["losses"].data_ptr() if deferred is None else None, out["d_value"].data_ptr() if want_grad else None,
+            partials.data_ptr(), LOSS_DEFER if deferred is not None else 0, _stream()),
     )
     return out
 
@@ -1369,6 +1455,37 @@ def relu_backward_bias(grad_output: torch.Tensor, output: torch.Tensor | None, d
     return grad_in, (DeferredColumns(partials, num_partials, H, 0, H) if colsum is None else colsum)
 
 
+# ------------------------------------------------------------------------------------------------ first layer of an MLP
+def input_layer_supported(grad_output: torch.Tensor, output: torch.Tensor | None, input: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Shapes and layouts ``cusrl_input_layer_bwd`` takes: fp32, contiguous, 16-byte aligned, K % 4 == 0 (<= 60), H % 64 == 0."""
+    H, K = weight.shape
+    tensors = [grad_output, input] + ([] if output is None else [output])
+    return (bool(_native.lib().cusrl_input_layer_supported(K, H)) and input.dim() == 2 and grad_output.shape == (input.shape[0], H)
+            and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in tensors)
+            and (output is None or output.shape == grad_output.shape) and input.shape[0] > 0)
+
+
+def input_layer_backward(grad_output: torch.Tensor, output: torch.Tensor | None, input: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """``(dW [H, K], db [H])`` of ``y = relu(x W^T + b)`` for an input that needs no gradient, from ONE pass over ``grad_output``,
+    ``output`` (the ReLU's output; None: no activation) and ``input`` (``cusrl_input_layer_bwd``); both are windows of one
+    ``[H * K + H]`` row."""
+    grad_output, input = _f32(grad_output, "grad_output"), _f32(input, "input")
+    rows, K = input.shape
+    H = grad_output.shape[-1]
+    lib = _native.lib()
+    dev = input.device
+    width = H * K + H
+    partials = torch.empty((int(lib.cusrl_input_layer_row_blocks(rows, H)), width), dtype=torch.float32, device=dev)
+    grads = torch.empty(width, dtype=torch.float32, device=dev)
+    _observed(
+        "cusrl_input_layer_bwd",
+        lambda: rows * 4 * ((2 if output is not None else 1) * H + K) + (partials.numel() * 2 + width) * 4,
+        lambda: lib.cusrl_input_layer_bwd(grad_output.data_ptr(), None if output is None else _f32(output, "output").data_ptr(),
+                                          input.data_ptr(), rows, K, H, partials.data_ptr(), grads.data_ptr(), _stream()),
+    )
+    return grads[: H * K].view(H, K), grads[H * K :]
+
+
 # ------------------------------------------------------------------------------------------------ narrow heads
 _HEAD_PAD = 16
 
@@ -1525,8 +1642,11 @@ def grad_sumsq(flat_grad: torch.Tensor) -> torch.Tensor:
 def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
               step: torch.Tensor, lr: torch.Tensor, ticket: torch.Tensor, *, betas: tuple[float, float], eps: float,
               weight_decay: float, decoupled: bool, maximize: bool = False, clip_partials: torch.Tensor | None = None,
-              max_norm: float | None = None, norm_out: torch.Tensor | None = None):
-    """One Adam / AdamW step over flat fp32 buffers, in place (``step`` and ``lr`` are 1-element device tensors)."""
+              max_norm: float | None = None, norm_out: torch.Tensor | None = None, norm_accumulator: torch.Tensor | None = None):
+    """One Adam / AdamW step over flat fp32 buffers, in place (``step`` and ``lr`` are 1-element device tensors).
+    ``norm_accumulator`` (a 1-element fp32 view): the pre-clip gradient norm is also added to it."""
+    if norm_accumulator is not None:
+        _f32(norm_accumulator, "norm_accumulator")
     for tensor, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (step, "step"), (lr, "lr")):
         _f32(tensor, name)
     require_device(ticket, "ticket")
@@ -1541,7 +1661,7 @@ def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, ex
             float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(decoupled), int(maximize),
             None if clip_partials is None else clip_partials.data_ptr(), 0 if clip_partials is None else clip_partials.numel(),
             -1.0 if max_norm is None else float(max_norm), None if norm_out is None else norm_out.data_ptr(),
-            ticket.data_ptr(), _stream()),
+            None if norm_accumulator is None else norm_accumulator.data_ptr(), ticket.data_ptr(), _stream()),
         "cusrl_adam_step",
     )
 

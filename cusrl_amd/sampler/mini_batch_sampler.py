@@ -147,13 +147,15 @@ class MiniBatchSampler(Sampler):
                 }
                 yield metadata, device_indices[j * size : (j + 1) * size]
 
-    def draw_epochs(self, buffer: Buffer):
+    def draw_epochs(self, buffer: Buffer, after: "torch.cuda.Event | None" = None):
         """Every epoch's permutation drawn NOW, in epoch order, on the draw-ahead stream into one persistent ``[E, S]`` index
         buffer: ``(permutations, [event per epoch], [(metadata, slice bounds)] per epoch)``, or None when a condition of
         :meth:`iter_indices`'s draw-ahead does not hold (no shuffle, CPU-generator permutations, ``prefetch`` off because a
         hook or a dropout layer draws random numbers inside the steps).  Same generator calls in the same order as the
         epoch-by-epoch iteration.  For consumers that replay a whole epoch's minibatch steps from one hipGraph
-        (template/graphs.py GraphedEpochs): each slice lives at a fixed address, an epoch may start once its event fired."""
+        (template/graphs.py GraphedEpochs): each slice lives at a fixed address, an epoch may start once its event fired.
+        ``after``: an event behind the last reader of the rows drawn by the previous call (the consumer's last replay); without
+        it the draw waits for everything the current stream has been given so far — ``pre_update``'s kernels included."""
         if not (buffer.full and buffer.cursor == 0):
             raise RuntimeError("MiniBatchSampler requires a full buffer with cursor reset to 0")
         perm_device = self.permutation_device or buffer.device
@@ -169,7 +171,10 @@ class MiniBatchSampler(Sampler):
             slab = self._index_buffers[key] = [torch.empty((self.num_epochs, num_samples), dtype=torch.int64, device=perm_device)]
         permutations = slab[0]
         main, side = torch.cuda.current_stream(perm_device), _prefetch_stream(perm_device)
-        side.wait_stream(main)  # the previous update's steps have read these rows
+        if after is not None:
+            side.wait_event(after)  # the previous update's steps have read these rows
+        else:
+            side.wait_stream(main)
         events, plan = [], []
         with torch.cuda.stream(side):
             for epoch in range(self.num_epochs):
@@ -233,8 +238,8 @@ class AutoMiniBatchSampler(Sampler):
     def persistent_indices(self) -> bool:
         return self._last is not None and self._last.persistent_indices
 
-    def draw_epochs(self, buffer: Buffer):
-        return self._dispatch(buffer).draw_epochs(buffer)
+    def draw_epochs(self, buffer: Buffer, after=None):
+        return self._dispatch(buffer).draw_epochs(buffer, after)
 
     def _dispatch(self, buffer: Buffer) -> MiniBatchSampler:
         temporal = any(key.split(".")[0].endswith("memory") for key in buffer)

@@ -151,6 +151,7 @@ class ActorCritic(Agent):
         self._graphed_act = None
         self._graphed_steps: dict[tuple, Any] = {}
         self._graphed_epochs = None
+        self._minibatches_done = None  # event behind the last minibatch step of the previous update (its index rows may be redrawn)
         self._graph_key_reads = 0
         self._graph_budget_warned = False
         self._metadata_reads: set[str] = set()  # metadata keys hooks read inside captured steps (graphs.TrackedMetadata)
@@ -172,13 +173,13 @@ class ActorCritic(Agent):
             self.concurrent_critic = None if forced is None else forced != "0"
             # captured minibatch steps run the fused objective without its one-block finalize launch (ops.DeferredLoss)
             self.defer_loss_finalize = os.environ.get("CUSRL_DEFER_LOSS_FINALIZE", "1") != "0"
-            # opt-in: measured 0.1 ms per iteration SLOWER than the 4 us copy into a static index buffer (config 2, A/B on one
-            # box) — two index-buffer addresses per slot double the number of step graphs and their activation pools
-            self.index_slices_in_place = os.environ.get("CUSRL_INPLACE_INDICES", "0") != "0"
             self._graphed_act = GraphedAct(self)
         self.flat_gradients: FlatGradients | None = None
         self._split_plan = False  # per-network split of the backward: not looked at yet (None = does not apply)
-        self._unit_grad: torch.Tensor | None = None
+        self._networks = False  # critic / other parameter windows: not looked at yet (None = they share parameters)
+        self._unit_grads: dict[tuple, torch.Tensor] = {}
+        # the value term of the stock composition as its own launch + root on the critic's branch of a captured step (A/B switch)
+        self._separate_value_term = os.environ.get("CUSRL_SEPARATE_VALUE_TERM", "1") != "0"
         if isinstance(self.optimizer, torch.optim.Optimizer) and not self.grad_scaler_enabled:
             self.flat_gradients = FlatGradients(self.optimizer)
         self.flat_optimizer = None
@@ -189,6 +190,7 @@ class ActorCritic(Agent):
 
             if FlatAdam.eligible(self.optimizer, self.flat_gradients):
                 self.flat_optimizer = FlatAdam(self.optimizer, self.flat_gradients)
+                self.flat_optimizer.metrics = self.metrics
         self._set_training_mode(False)
         self.hook.post_init()
         broadcast_parameters(self.parameters())
@@ -292,39 +294,43 @@ class ActorCritic(Agent):
             if graphed:
                 # every epoch's permutation drawn up front on the draw-ahead stream (same generator calls, same order):
                 # once every step replays from its own graph, a whole epoch's steps replay from ONE graph that reads its
-                # index slices in place (template/graphs.py GraphedEpochs); until then — and whenever a condition does
-                # not hold — the steps run graph by graph over the very same permutations
-                from cusrl_amd.template.graphs import epoch_graphs_enabled
+                # index slices in place and gathers each step's rows while the step before it runs (template/graphs.py
+                # GraphedEpochs); until then — and whenever a condition does not hold — the steps run graph by graph over
+                # the very same permutations
+                from cusrl_amd.template.graphs import GraphedEpochs, epoch_graphs_enabled
 
-                drawn = (self.sampler.draw_epochs(self.buffer)
-                         if epoch_graphs_enabled() and hasattr(self.sampler, "draw_epochs") else None)
-                if drawn is not None and self._graphed_epochs is None:
-                    from cusrl_amd.template.graphs import GraphedEpochs
-
-                    self._graphed_epochs = GraphedEpochs(self)
-                if drawn is None or not self._graphed_epochs.run(drawn):
-                    for metadata, indices in (self._iter_drawn(drawn) if drawn is not None else self.sampler.iter_indices(self.buffer)):
-                        # (opt-in) index slices at addresses that repeat from update to update — the sampler's persistent
-                        # buffers — read in place by the captured step: one capture per address, no copy into a static buffer
-                        in_place = self.index_slices_in_place and getattr(self.sampler, "persistent_indices", False)
-                        key = self._step_key(metadata, indices.numel(), indices.data_ptr() if in_place else 0)
-                        if (step := self._graphed_steps.get(key)) is None:
-                            if self._graph_key_reads != len(self._metadata_reads):
-                                # the set of metadata keys hooks read has grown: graphs keyed on the shorter signature can
-                                # never be looked up again — release them (and their static buffers)
-                                self._graph_key_reads = len(self._metadata_reads)
-                                width = len(key)
-                                for stale in [k for k in self._graphed_steps if len(k) != width]:
-                                    self._graphed_steps.pop(stale).flush_metrics()
-                            step = self._graphed_steps[key] = GraphedTrainStep(self, key[0], key[1])
-                            budget = self.sampler.num_epochs * (self.sampler.num_mini_batches if isinstance(self.sampler.num_mini_batches, int)
-                                                                else max(self.sampler.num_mini_batches)) if hasattr(self.sampler, "num_epochs") else 0
-                            if budget and len(self._graphed_steps) > budget and not self._graph_budget_warned:
-                                self._graph_budget_warned = True
-                                self.warn(f"{len(self._graphed_steps)} minibatch-step graphs for {budget} steps per update: a hook reads "
-                                          f"metadata whose values keep changing ({sorted(self._metadata_reads)}); every distinct value is "
-                                          "its own capture")
-                        step.run(metadata, indices, in_place)
+                drawn = None
+                if epoch_graphs_enabled() and hasattr(self.sampler, "draw_epochs"):
+                    if self._graphed_epochs is None:
+                        self._graphed_epochs = GraphedEpochs(self)
+                    # (the draw only has to wait for the previous update's readers of the index rows — not for pre_update's
+                    # kernels the main stream has just been given: the permutations are drawn while those run)
+                    drawn = self.sampler.draw_epochs(self.buffer, after=self._minibatches_done)
+                steps = () if drawn is not None and self._graphed_epochs.run(drawn) else (
+                    self._iter_drawn(drawn) if drawn is not None else self.sampler.iter_indices(self.buffer))
+                for metadata, indices in steps:
+                    key = self._step_key(metadata, indices.numel())
+                    if (step := self._graphed_steps.get(key)) is None:
+                        if self._graph_key_reads != len(self._metadata_reads):
+                            # the set of metadata keys hooks read has grown: graphs keyed on the shorter signature can
+                            # never be looked up again — release them (and their static buffers)
+                            self._graph_key_reads = len(self._metadata_reads)
+                            width = len(key)
+                            for stale in [k for k in self._graphed_steps if len(k) != width]:
+                                self._graphed_steps.pop(stale).flush_metrics()
+                        step = self._graphed_steps[key] = GraphedTrainStep(self, key[0], key[1])
+                        budget = self.sampler.num_epochs * (self.sampler.num_mini_batches if isinstance(self.sampler.num_mini_batches, int)
+                                                            else max(self.sampler.num_mini_batches)) if hasattr(self.sampler, "num_epochs") else 0
+                        if budget and len(self._graphed_steps) > budget and not self._graph_budget_warned:
+                            self._graph_budget_warned = True
+                            self.warn(f"{len(self._graphed_steps)} minibatch-step graphs for {budget} steps per update: a hook reads "
+                                      f"metadata whose values keep changing ({sorted(self._metadata_reads)}); every distinct value is "
+                                      "its own capture")
+                    step.run(metadata, indices)
+                if drawn is not None:
+                    if self._minibatches_done is None:
+                        self._minibatches_done = torch.cuda.Event()
+                    self._minibatches_done.record(torch.cuda.current_stream())
                 deferred: list = []
                 for step in self._graphed_steps.values():
                     step.flush_metrics(deferred)
@@ -338,10 +344,10 @@ class ActorCritic(Agent):
         self.hook.apply_schedule(self.iteration + 1)
         return super().update()
 
-    def _step_key(self, metadata, numel: int, address: int) -> tuple:
-        """Key of the captured minibatch step that serves ``metadata``: slot, sampling form, batch size, (in-place) index
-        address, and the value of every metadata key a hook ever read (steps whose values differ are different captures)."""
-        key = (metadata["mini_batch_index"], metadata["temporal"], numel, address)
+    def _step_key(self, metadata, numel: int) -> tuple:
+        """Key of the captured minibatch step that serves ``metadata``: slot, sampling form, batch size and the value of every
+        metadata key a hook ever read (steps whose values differ are different captures)."""
+        key = (metadata["mini_batch_index"], metadata["temporal"], numel)
         if self._metadata_reads:
             key += tuple((name, _hashable(metadata.get(name))) for name in sorted(self._metadata_reads)
                          if name not in ("mini_batch_index", "temporal"))
@@ -381,13 +387,40 @@ class ActorCritic(Agent):
                 total = total + term
             self.grad_scaler.scale(total).backward()
             return
-        first = roots[0]
-        if self._unit_grad is None or self._unit_grad.dtype != first.dtype:
-            # persistent (no ones_like per step) and registered: custom backwards recognise it by address (nn/module.py)
-            self._unit_grad = register_unit_gradient(torch.ones((), dtype=first.dtype, device=first.device))
-        units = [self._unit_grad if term.dtype == first.dtype else torch.ones((), dtype=term.dtype, device=term.device)
-                 for term in roots]
+        units = [self._unit_gradient(term) for term in roots]
         plan = self._split_backward_plan()
+        # a summand evaluated on the critic's stream (hook/on_policy/value.py: the value term of the stock composition)
+        branch_root = getattr(loss, "branch", None)
+        networks = self._network_windows() if branch_root is not None else None
+        if branch_root is not None and (networks is None or len(roots) != len(loss)):
+            # not differentiable network by network (shared parameters, or a summand was dropped above): join first
+            torch.cuda.current_stream().wait_stream(branch_root[1])
+            branch_root = None
+        if plan is None and branch_root is not None:
+            # The critic's backward where its forward and its loss ran, the other summands' on the main stream, both issued from
+            # here back to back: neither pass waits for the other (the engine would order a one-pass backward behind the stream
+            # this call is made from), the two streams meet ONCE, in front of the assembly.
+            value_root, branch = branch_root
+            critic_ids, other_ids = networks
+            position = next(i for i, term in enumerate(roots) if term is value_root)
+            others = [term for i, term in enumerate(roots) if i != position]
+            other_units = [unit for i, unit in enumerate(units) if i != position]
+            with torch.cuda.stream(branch):
+                with collect_split_weight_grads() as critic_slabs:
+                    critic_grads = torch.autograd.grad([value_root], [flat.params[i] for i in critic_ids],
+                                                       grad_outputs=[units[position]], allow_unused=True)
+            with collect_split_weight_grads() as split_slabs:
+                other_grads = torch.autograd.grad(others, [flat.params[i] for i in other_ids], grad_outputs=other_units,
+                                                  allow_unused=True)
+            torch.cuda.current_stream().wait_stream(branch)  # the step's one join
+            grads: list = [None] * len(flat.params)
+            for i, grad in zip(critic_ids, critic_grads):
+                grads[i] = grad
+            for i, grad in zip(other_ids, other_grads):
+                grads[i] = grad
+            split_slabs.update(critic_slabs)
+            flat.assemble(grads, split_slabs)
+            return
         if plan is None:
             with collect_split_weight_grads() as split_slabs:
                 grads = torch.autograd.grad(roots, flat.params, grad_outputs=units, allow_unused=True)
@@ -409,11 +442,18 @@ class ActorCritic(Agent):
         # the stream whose allocator pool they came from.  Only the all-reduce, which touches nothing but the persistent flat
         # buffer, always goes to the branch stream.
         on_branch = getattr(self, "_critic_backward_stream", None) is branch
+        critic_roots, critic_units, other_roots, other_units = roots, units, roots, units
+        if branch_root is not None:  # the value term is a root of its own (evaluated on `branch`): each pass takes its summands
+            position = next(i for i, term in enumerate(roots) if term is branch_root[0])
+            critic_roots, critic_units = [roots[position]], [units[position]]
+            other_roots = [term for i, term in enumerate(roots) if i != position]
+            other_units = [unit for i, unit in enumerate(units) if i != position]
+            on_branch = True
 
         def critic_pass():
             with collect_split_weight_grads() as slabs:
-                grads = torch.autograd.grad(roots, [flat.params[i] for i in critic_ids], grad_outputs=units, allow_unused=True,
-                                            retain_graph=True)
+                grads = torch.autograd.grad(critic_roots, [flat.params[i] for i in critic_ids], grad_outputs=critic_units,
+                                            allow_unused=True, retain_graph=branch_root is None)
             flat.assemble(grads, slabs, subset=critic_ids)
 
         def critic_reduce():
@@ -435,13 +475,44 @@ class ActorCritic(Agent):
             with torch.cuda.stream(branch):
                 critic_reduce()
         with collect_split_weight_grads() as slabs:
-            grads = torch.autograd.grad(roots, [flat.params[i] for i in other_ids], grad_outputs=units, allow_unused=True)
+            grads = torch.autograd.grad(other_roots, [flat.params[i] for i in other_ids], grad_outputs=other_units, allow_unused=True)
         flat.assemble(grads, slabs, subset=other_ids)
         if inline:
             for window in windows[1:]:
                 distributed.reduce_mean_(window)
         main.wait_stream(branch)
         flat.reduced = inline
+
+    def _unit_gradient(self, term: torch.Tensor) -> torch.Tensor:
+        """The persistent, registered ones-scalar of ``term``'s dtype and device (no ones_like per step; custom backwards
+        recognise a registered scalar by identity, nn/module.py) — one per (dtype, device), for every root of a step."""
+        key = (term.dtype, term.device)
+        unit = self._unit_grads.get(key)
+        if unit is None:
+            unit = self._unit_grads[key] = register_unit_gradient(torch.ones((), dtype=term.dtype, device=term.device))
+        return unit
+
+    def _network_windows(self):
+        """``(critic parameter indices, the others' indices)`` of the flat gradient buffer when the critic shares no parameter
+        with anything else the optimizer steps (then a summand that reaches the critic alone can be differentiated on its own),
+        else None.  Computed once."""
+        if self._networks is not False:
+            return self._networks
+        self._networks = None
+        flat = self.flat_gradients
+        if flat is None:
+            return None
+        critic = {id(p) for p in self.critic.parameters()}
+        outside = {id(p) for p in self.actor.parameters()} | {id(p) for p in self.hook.parameters()}
+        critic_ids = [i for i, p in enumerate(flat.params) if id(p) in critic]
+        if critic_ids and not (critic & outside):
+            self._networks = (critic_ids, [i for i, p in enumerate(flat.params) if id(p) not in critic])
+        return self._networks
+
+    @property
+    def separate_value_root(self) -> bool:
+        """May ``ValueLoss`` evaluate its term by its own launch on the critic's stream (a root of its own in ``_backward``)?"""
+        return self._separate_value_term and self._network_windows() is not None
 
     def _split_backward_plan(self):
         """``(critic parameter indices, the others' indices, [critic window, other windows ...])`` of the flat gradient buffer

@@ -53,7 +53,7 @@ class LazyBatch(dict):
     __slots__ = ("_buffer", "_indices", "_temporal", "_pending", "_hot", "_expired", "_own", "_lead_shape")
 
     def __init__(self, buffer: "Buffer", indices: torch.Tensor, temporal: bool, hot: set | None,
-                 lead_shape: tuple[int, ...] | None = None):
+                 lead_shape: tuple[int, ...] | None = None, preloaded: dict | None = None):
         super().__init__()
         self._buffer, self._indices, self._temporal = buffer, indices, temporal
         self._lead_shape = lead_shape
@@ -61,6 +61,12 @@ class LazyBatch(dict):
         self._expired = False
         self._own: set = set()  # keys the consumer wrote itself: reading them back says nothing about the buffer
         names = list(buffer.schema)
+        if preloaded is not None:
+            # fields somebody already gathered for exactly these indices (a captured step's prefetch, template/graphs.py):
+            # they are simply there; every other field of the buffer stays available on first access
+            dict.update(self, preloaded)
+            self._pending = dict.fromkeys(name for name in names if name not in preloaded)
+            return
         first = not self._hot
         eager = names if first else [name for name in names if name in self._hot]
         self._pending = dict.fromkeys(name for name in names if name not in eager)
@@ -491,9 +497,10 @@ class Buffer(MutableMapping):
         batch = {key: sampler(key, tensor) for key, tensor in self.storage.items()}
         return reconstruct_nested(batch, self.schema)
 
-    def prepare_sampling(self, hot_fields=None) -> None:
+    def prepare_sampling(self, hot_fields=None) -> bool:
         """Refresh the per-slot record (``cusrl_pack_rows``) if anything could have written to its leaves since it was
-        built.  The samplers call this once per pass before the first minibatch; it is a flag check when nothing changed.
+        built; True when that launched something (on the current stream).  The samplers call this once per pass before the
+        first minibatch; it is a flag check when nothing changed.
         ``hot_fields``: the top-level fields the consumer is known to read (a sampler's ``hot_fields``); once known, the
         record holds exactly their leaves — wide ones included — so a sampled slot is two memory lines; before that
         (first pass) it holds the narrow leaves.  Must run OUTSIDE hipGraph capture (captured steps only *read* it)."""
@@ -514,7 +521,7 @@ class Buffer(MutableMapping):
                 self._record_clean.clear()
         if not self.pack_narrow_leaves or self.device.type != "cuda":
             self._pack = None
-            return
+            return False
         pack = self._pack
         key = self._pack_plan_key()
         if key != self._pack_key:  # leaves were (re)allocated or the plan changed: plan again
@@ -526,7 +533,7 @@ class Buffer(MutableMapping):
                     self.layout_version += 1
                 self._pack = None
                 self._record_clean.clear()
-                return
+                return False
             wanted = tuple((name, self.storage[name].data_ptr(), ops._row_bytes(self.storage[name], 2)) for name in names)
             if pack is None or set(pack.key) != set(wanted):
                 pack = self._pack = ops.RecordPack({name: self.storage[name] for name in names})
@@ -534,13 +541,14 @@ class Buffer(MutableMapping):
                 self._through = None
                 self.layout_version += 1
         if pack is None:
-            return
+            return False
         clean, storage = self._record_clean, self.storage
         stale = [name for name in pack.leaves if clean.get(name) != storage[name]._version]
         if stale:
             pack.build(None if len(stale) == len(pack.leaves) else stale)
             for name in stale:
                 clean[name] = storage[name]._version
+        return bool(stale)
 
     def _pack_plan_key(self):
         return (self._pack_hot, self.record_threshold_bytes, self._storage_epoch)
@@ -556,35 +564,47 @@ class Buffer(MutableMapping):
         return key in pack.offsets and self._record_clean.get(key) == self.storage[key]._version
 
     def gather(self, indices: torch.Tensor, temporal: bool = False, fields: Sequence[str] | None = None,
-               lead_shape: tuple[int, ...] | None = None) -> dict[str, Any]:
+               lead_shape: tuple[int, ...] | None = None, out: dict[str, torch.Tensor] | None = None) -> dict[str, Any]:
         """``flatten(0, 1)[indices]`` (or ``[:, indices]`` when ``temporal``) of every leaf — or of the leaves of the
         top-level ``fields`` only — in one launch; narrow leaves come through the packed record while it is current.
         ``lead_shape``: view the gathered rows as ``[*lead_shape, ...]`` (the ``[sequence_len, batch]`` windows of the
-        temporal random sampler, whose flat slot list is ``sequence_len * batch`` long)."""
+        temporal random sampler, whose flat slot list is ``sequence_len * batch`` long).  ``out``: destinations by leaf key the
+        caller keeps from call to call (a captured step's persistent batch tensors): a leaf found there is gathered into that
+        tensor, a leaf missing there gets a fresh tensor which is left in ``out``."""
         if fields is None:
             keys, schema = list(self.storage), self.schema
         else:
             schema = {name: self.schema[name] for name in fields}
             keys = [key for name in fields for _, key in iterate_nested(self.schema[name])]
+        if out is not None:
+            batch = indices.numel()
+            lead = (self.capacity, batch) if temporal else (batch,)
+            for key in keys:
+                if key not in out:
+                    leaf = self.storage[key]
+                    out[key] = torch.empty(lead + tuple(leaf.shape[2:]), dtype=leaf.dtype, device=leaf.device)
         pack = self._pack
         packed = [key for key in keys if pack is not None and self._mirrored(pack, key)]
         plain = [key for key in keys if key not in packed] if packed else keys
         if packed and len(plain) <= _native_max_fields():
             outputs, packed_outputs = ops.gather_rows_packed(
-                [self.storage[k] for k in plain], pack, packed, indices, self.capacity, self.parallelism, temporal)
+                [self.storage[k] for k in plain], pack, packed, indices, self.capacity, self.parallelism, temporal,
+                out=None if out is None else [out[k] for k in plain], packed_out=None if out is None else [out[k] for k in packed])
             gathered = dict(zip(plain, outputs))
             gathered.update(zip(packed, packed_outputs))
         else:
-            outputs = ops.gather_rows([self.storage[k] for k in keys], indices, self.capacity, self.parallelism, temporal)
+            outputs = ops.gather_rows([self.storage[k] for k in keys], indices, self.capacity, self.parallelism, temporal,
+                                      out=None if out is None else [out[k] for k in keys])
             gathered = dict(zip(keys, outputs))
         if lead_shape is not None:
             gathered = {key: rows.view(tuple(lead_shape) + tuple(rows.shape[1:])) for key, rows in gathered.items()}
         return reconstruct_nested(gathered, schema)
 
     def gather_lazy(self, indices: torch.Tensor, temporal: bool = False, hot: set | None = None,
-                    lead_shape: tuple[int, ...] | None = None) -> LazyBatch:
-        """The minibatch as a :class:`LazyBatch`: the ``hot`` fields now (one launch), the rest on first access."""
-        return LazyBatch(self, indices, temporal, hot, lead_shape)
+                    lead_shape: tuple[int, ...] | None = None, preloaded: dict | None = None) -> LazyBatch:
+        """The minibatch as a :class:`LazyBatch`: the ``hot`` fields now (one launch) — or the ``preloaded`` ones as they are,
+        no launch — the rest on first access."""
+        return LazyBatch(self, indices, temporal, hot, lead_shape, preloaded)
 
     # ------------------------------------------------------------------ validation (messages as in the reference)
     def _as_tensor(self, data) -> torch.Tensor:

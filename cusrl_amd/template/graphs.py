@@ -12,10 +12,13 @@ tracing compiler the same knob captures them into HIP graphs and replays them:
 * :class:`GraphedAct` — ``pre_act`` → ``actor.explore`` (sampling included: torch's graph-safe Philox state) →
   ``post_act`` for envs that are not capturable (the env step then stays host-driven).
 * :class:`GraphedTrainStep` — one per minibatch slot (and per value of every ``metadata`` key a hook reads,
-  :class:`TrackedMetadata`): gather of the fields the step's hooks read (``LazyBatch``; plain leaves while the buffer is
-  cache-resident, the per-slot record beyond) → critic forward on a second stream ‖ actor forward → fused PPO objective
-  WITHOUT its finalize launch (loss values as running block sums, ``ops.DeferredLoss``) → backward (critic's on its own
-  branch) → one-launch gradient assembly (+ the squared-norm partials of the clip) → gradient all-reduce → Adam.
+  :class:`TrackedMetadata`).  The gather of the fields the step's hooks read (``LazyBatch``; plain leaves while the buffer is
+  cache-resident, the per-slot record beyond) is NOT part of the graph (round 6): it depends on nothing the previous step
+  computes, so it runs ahead on the agent's gather stream into the step's persistent batch tensors while that step is still
+  in its backward.  The graph: critic forward → value term → critic backward on a second stream ‖ actor forward →
+  surrogate + entropy terms → actor backward (ONE fork, ONE join; loss values as running block sums without a finalize
+  launch, ``ops.DeferredLoss``) → one-launch gradient assembly (+ the squared-norm partials of the clip) → gradient
+  all-reduce → Adam.
   One process, or RCCL through the C ABI (``cusrl_allreduce_mean`` enqueued on the step's stream — the default route of
   an RCCL job): ONE graph; torch.distributed's collectives (gloo, or the fallback route): two graphs with the eager
   all-reduce between them.
@@ -159,10 +162,10 @@ class _Capture:
     censuses: list[dict] = []  # node census of the most recent captures of the process (tests, scripts/graph_census.py)
 
     def capture(self, fn, stream: torch.cuda.Stream, pool=None):
-        tap = MetricTap()
-        self.agent.metrics.tap(tap)
         # persistent (allocated outside the capture, so replays do not re-zero it); taps accumulate into it in-graph
         self.accumulator = torch.zeros(self.MAX_TAPS, dtype=torch.float32, device=self.agent.device)
+        tap = MetricTap(self.accumulator)
+        self.agent.metrics.tap(tap)
         graph = torch.cuda.CUDAGraph(keep_graph=True)  # kept for the node census below; instantiated right behind it
         # Python's cyclic collector must not run inside the capture: finalisers of unrelated garbage (an old agent's
         # pinned host buffers, events, graphs) issue stream operations that are illegal while capturing and abort
@@ -184,7 +187,14 @@ class _Capture:
                         raise RuntimeError(f"more than {self.MAX_TAPS} metrics recorded inside one captured phase")
                     from cusrl_amd import ops
 
-                    ops.accumulate_scalars_(self.accumulator, tap.values)  # one launch (torch: stack + add_)
+                    # one launch per run of slots whose producer did not add its value itself (torch: stack + add_); the stock
+                    # step's only tap — the gradient norm — is added by the Adam launch: no launch here
+                    pending = [i for i in range(len(tap.values)) if i not in tap.produced]
+                    while pending:
+                        run = [pending.pop(0)]
+                        while pending and pending[0] == run[-1] + 1:
+                            run.append(pending.pop(0))
+                        ops.accumulate_scalars_(self.accumulator[run[0]:], [tap.values[i] for i in run])
         finally:
             if gc_was_enabled:
                 gc.enable()
@@ -252,6 +262,9 @@ class GraphedTrainStep:
         # running block sums of the fused objective (ops.DeferredLoss): the captured step runs the loss kernel without its
         # finalize launch; created by the eager warm-up, read and reset by flush_metrics
         self.deferred_loss = None
+        # fields of the step's minibatch that somebody gathered AHEAD of the step (a whole-epoch graph forks the next step's
+        # gather off while this step runs, GraphedEpochs): the step's LazyBatch takes them as they are
+        self.preloaded: dict[str, Any] | None = None
         # replays of this step's body from a whole-epoch graph (GraphedEpochs): counted here so that the running loss sums
         # are divided by the right number of evaluations
         self.extra_replays = 0
@@ -299,7 +312,7 @@ class GraphedTrainStep:
     # the two phases, written once and used for the eager warm-up, the capture and (implicitly) the replays
     def _phase_a(self):
         agent = self.agent
-        batch = agent.buffer.gather_lazy(self.static_indices, self.temporal, self.hot_fields)
+        batch = agent.buffer.gather_lazy(self.static_indices, self.temporal, self.hot_fields, preloaded=self.preloaded)
         agent.actor.clear_intermediate_repr()
         agent.critic.clear_intermediate_repr()
         agent.hook.pre_objective(self.metadata, batch)
@@ -330,21 +343,15 @@ class GraphedTrainStep:
             agent.record(**objectives)
         agent.hook.post_objective(self.metadata, batch)
 
-    def run(self, metadata: dict[str, Any], indices: torch.Tensor, in_place: bool = False):
-        """``in_place``: ``indices`` lives at an address the caller keys this step on (a slice of the sampler's persistent
-        index buffers): the capture reads it where it is; otherwise it is copied into the step's static buffer."""
+    def run(self, metadata: dict[str, Any], indices: torch.Tensor):
+        """One minibatch step on the index slice ``indices`` (copied into the step's static index buffer)."""
         from cusrl_amd.utils.distributed import reduce_gradients
 
         agent = self.agent
-        if in_place:
-            if self.static_indices is None or self.static_indices.data_ptr() != indices.data_ptr() or self.static_indices.shape != indices.shape:
-                self.static_indices = indices
-                self.state = 0
-        else:
-            if self.static_indices is None or self.static_indices.shape != indices.shape:
-                self.static_indices = torch.empty_like(indices)
-                self.state = 0
-            self.static_indices.copy_(indices)
+        if self.static_indices is None or self.static_indices.shape != indices.shape:
+            self.static_indices = torch.empty_like(indices)
+            self.state = 0
+        self.static_indices.copy_(indices)
         self.metadata = TrackedMetadata(metadata, agent._metadata_reads)
         # the captured gather reads the per-slot record: keep it current (flag check); once the warm-up has learned which
         # fields the step reads, the record holds exactly those (two memory lines per sampled slot)
@@ -354,14 +361,10 @@ class GraphedTrainStep:
         signature = (capture_signature(agent), agent.buffer.layout_version)
         if self.state == 2 and signature != self.signature:
             self.flush_metrics()
+            if self.deferred_loss is not None:
+                self.deferred_loss.armed = self.deferred_loss.value_armed = False  # the new capture records its own launches
             self.state = 1  # a host-side value the capture froze has changed: capture again (the warm-up is still valid)
         self.signature = signature
-        if self.state == 2:
-            self.forward_backward.replay()
-            if not self.single_graph:
-                reduce_gradients(agent.optimizer, agent.flat_gradients)
-                self.optimize.replay()
-            return
         if self.state == 0:  # eager on the capture stream: warms rocBLAS / allocator and performs this real step
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
@@ -372,17 +375,18 @@ class GraphedTrainStep:
             self.carry = {}
             self.state = 1
             return
-        if self.single_graph:
-            self.forward_backward.capture(self._whole_step, self.stream, pool=agent._graph_pool)
+        if self.state == 1:
+            if self.single_graph:
+                self.forward_backward.capture(self._whole_step, self.stream, pool=agent._graph_pool)
+            else:
+                self.forward_backward.capture(self._phase_a, self.stream, pool=agent._graph_pool)
+                self.optimize.capture(self._phase_b, self.stream, pool=agent._graph_pool)
+            self.carry = {}
             self.state = 2
-            self.forward_backward.replay()
-            return
-        self.forward_backward.capture(self._phase_a, self.stream, pool=agent._graph_pool)
-        self.optimize.capture(self._phase_b, self.stream, pool=agent._graph_pool)
-        self.state = 2
         self.forward_backward.replay()
-        reduce_gradients(agent.optimizer, agent.flat_gradients)
-        self.optimize.replay()
+        if not self.single_graph:
+            reduce_gradients(agent.optimizer, agent.flat_gradients)
+            self.optimize.replay()
 
     def flush_metrics(self, deferred: list | None = None):
         """Fold what the replays accumulated on the device into the agent's metrics.  ``deferred`` (a list the caller
@@ -411,21 +415,27 @@ class GraphedTrainStep:
 
 
 def epoch_graphs_enabled() -> bool:
-    """Opt-in (``CUSRL_EPOCH_GRAPHS=1``): measured neutral on config 2 (update 5.82 vs 5.84 ms over 14 interleaved runs on two
-    boxes, profiles/r04/bench_epoch_graphs_ab.txt) — the copy and the replay boundary it removes per step are hidden behind
-    the device-bound GEMM chain — so the default stays one graph per minibatch step."""
-    return os.environ.get("CUSRL_EPOCH_GRAPHS", "0") == "1"
+    """On by default since round 6 (``CUSRL_EPOCH_GRAPHS=0`` keeps one graph per minibatch step): round 4 measured this form
+    neutral (profiles/r04/bench_epoch_graphs_ab.txt) because the step-by-step loop was device-bound then; with one fork and one
+    join per step and the gather off the critical path the device needs less time per step than the HOST needs to issue one
+    (the replay of a two-branch 22-node graph costs the host ~80 us, the Python around it as much again:
+    profiles/r06/host_vs_device.txt), and what the device gained was lost to replays that arrive late."""
+    return os.environ.get("CUSRL_EPOCH_GRAPHS", "1") != "0"
 
 
 class GraphedEpochs:
-    """The minibatch steps of ONE epoch back to back as one hipGraph (round 4) — built on top of the per-step graphs once
-    every step of an update replays from its own graph, like the whole-rollout graph on top of the per-step env graphs.
+    """The minibatch steps of ONE epoch back to back as one hipGraph — built on top of the per-step graphs once every step
+    of an update replays from its own graph, like the whole-rollout graph on top of the per-step env graphs.
 
-    What it removes per minibatch step is what sits BETWEEN two step graphs: the copy of the index slice into the step's
+    What it removes per minibatch step is what sits BETWEEN two step graphs — the copy of the index slice into the step's
     static buffer (the slices are read in place from the sampler's persistent ``[E, S]`` permutation buffer,
-    ``MiniBatchSampler.draw_epochs``) and a replay boundary.  An epoch's graph may start as soon as its permutation's
-    event has fired; the later epochs' permutations keep being drawn on the side stream meanwhile.  One graph per epoch
-    (not one per update): a captured graph cannot wait for an event recorded outside of it.
+    ``MiniBatchSampler.draw_epochs``), a replay boundary and ~150 us of host work — and what it adds (round 6) is the
+    gather AHEAD of the step: the rows of step k + 1 depend on nothing step k computes, so body k forks their gather off to
+    the agent's gather stream before it starts and body k + 1 joins it — inside one graph a fork and a join are edges, not
+    host calls.  The gathered leaves live in two persistent sets of batch tensors used in turn (the set body k reads was
+    written while body k - 1 ran; the one gather k + 1 writes was last read by body k - 1).  An epoch's graph may start
+    as soon as its permutation's event has fired; the later epochs' permutations keep being drawn on the side stream
+    meanwhile.  One graph per epoch (not one per update): a captured graph cannot wait for an event recorded outside of it.
 
     Only with ONE graph per step (single process or the C-ABI collectives) and steps that are all captured under the
     current signature; anything else keeps stepping graph by graph."""
@@ -437,12 +447,16 @@ class GraphedEpochs:
         self.signature: tuple | None = None
         self.enabled = epoch_graphs_enabled()
         self.replays = 0
+        # the gather of the next step's rows as a second branch of the running step (CUSRL_PREFETCH_GATHER=0: inside the step)
+        self.prefetch = os.environ.get("CUSRL_PREFETCH_GATHER", "1") != "0"
+        self.gather_stream = torch.cuda.Stream(device=agent.device) if self.prefetch else None
+        self.stores: dict[tuple, dict[str, torch.Tensor]] = {}
 
     def _steps_of(self, plan_row, permutations, epoch):
         """The (warm, captured) GraphedTrainStep of every minibatch of this epoch, or None if one is missing."""
         agent, found = self.agent, []
         for metadata, lo, hi in plan_row:
-            step = agent._graphed_steps.get(agent._step_key(metadata, hi - lo, 0))
+            step = agent._graphed_steps.get(agent._step_key(metadata, hi - lo))
             if step is None or step.state != 2 or not step.single_graph or step.signature != self.signature:
                 return None
             found.append((step, metadata, permutations[epoch, lo:hi]))
@@ -452,7 +466,7 @@ class GraphedEpochs:
         """One update from per-epoch graphs; False = conditions not met (the caller steps graph by graph — and must do so
         WITHOUT consuming the generator again: it iterates the same ``drawn`` permutations)."""
         agent = self.agent
-        if not self.enabled or agent.index_slices_in_place:
+        if not self.enabled:
             return False
         permutations, events, plan = drawn
         signature = (capture_signature(agent), agent.buffer.layout_version)
@@ -473,6 +487,7 @@ class GraphedEpochs:
             entry = self.epochs.get(key)
             main.wait_event(events[epoch])  # this epoch's permutation has been drawn
             if entry is None:
+                self._allocate([row])
                 entry = self.epochs[key] = {"capture": _Capture(agent)}
                 entry["capture"].capture(lambda row=row: self._body(row), self.stream, pool=agent._graph_pool)
             entry["capture"].replay()
@@ -481,17 +496,45 @@ class GraphedEpochs:
         self.replays += 1
         return True
 
+    def _gather(self, step, indices, parity: int):
+        """The fields ``step`` is known to read, for the rows ``indices`` names, into the persistent batch tensors of ``parity``."""
+        buffer = self.agent.buffer
+        names = tuple(name for name in buffer.schema if name in step.hot_fields)
+        store = self.stores.setdefault((parity, indices.numel(), step.temporal, names), {})
+        return buffer.gather(indices, step.temporal, fields=names, out=store)
+
     def _body(self, row):
         agent = self.agent
-        for step, metadata, indices in row:
-            saved = step.static_indices, step.metadata
+        main, side = torch.cuda.current_stream(), self.gather_stream
+        # (the persistent batch tensors exist by now: `_allocate` ran outside the capture)
+        ahead = self._gather(row[0][0], row[0][2], 0) if side is not None else None
+        for k, (step, metadata, indices) in enumerate(row):
+            saved = step.static_indices, step.metadata, step.preloaded
             step.static_indices = indices  # read in place
             step.metadata = TrackedMetadata(metadata, agent._metadata_reads)
+            step.preloaded, following = ahead, None
+            if side is not None and k + 1 < len(row):
+                # fork: the next step's rows, while this step runs (they depend on the buffer and the permutation only)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    following = self._gather(row[k + 1][0], row[k + 1][2], (k + 1) % 2)
             try:
                 step._whole_step()
             finally:
-                step.static_indices, step.metadata = saved
+                step.static_indices, step.metadata, step.preloaded = saved
             step.carry = {}
+            if following is not None:
+                main.wait_stream(side)  # join, in front of the step that reads them
+            ahead = following
+
+    def _allocate(self, rows):
+        """The persistent batch tensors of both parities, created OUTSIDE the capture (one throw-away gather per set: an
+        allocation made while capturing would belong to the graph's private pool)."""
+        if self.gather_stream is None:
+            return
+        for row in rows:
+            for k, (step, _, indices) in enumerate(row):
+                self._gather(step, indices, k % 2)
 
     def flush_metrics(self):
         for entry in self.epochs.values():

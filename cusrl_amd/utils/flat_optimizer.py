@@ -61,6 +61,7 @@ class FlatAdam:
         self._lr_value: float | None = None
         self.ticket = torch.zeros(1, dtype=torch.int32, device=device)
         self._pending_clip: tuple[torch.Tensor, float | None, torch.Tensor] | None = None
+        self.metrics = None  # the agent's Metrics (set by the agent): a captured step's tap may take the norm straight from the launch
         self._views: list[tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []
         with torch.no_grad():
             for p, offset in zip(self.params, flat_gradients.offsets):  # the same 16-byte-aligned windows as the gradients
@@ -141,10 +142,13 @@ class FlatAdam:
         # ahead of torch's per-parameter counter.)
         kept = [(view, view.clone(), m, m.clone(), v, v.clone())
                 for view, m, v in (self._views[i] for i in self.gradients.absent)]
+        # a captured step whose metric tap holds this step's norm: the launch adds it to the tap's running sum itself
+        tap = getattr(self.metrics, "_tap", None) if norm is not None else None
+        slot = tap.slot_of(norm) if tap is not None else None
         ops.adam_step(self.param_buffer, self.gradients.buffer, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
                       self.ticket, betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"],
                       decoupled=decoupled, maximize=bool(group.get("maximize", False)), clip_partials=partials,
-                      max_norm=max_norm, norm_out=norm)
+                      max_norm=max_norm, norm_out=norm, norm_accumulator=slot)
         for view, view0, m, m0, v, v0 in kept:
             view.copy_(view0), m.copy_(m0), v.copy_(v0)
         return loss

@@ -35,15 +35,30 @@ class Metric:
 class MetricTap:
     """Receives ``(name, 0-d tensor, count)`` while a step is being captured into a hipGraph."""
 
-    def __init__(self):
+    def __init__(self, accumulator: torch.Tensor | None = None):
         self.names: list[str] = []
         self.values: list[torch.Tensor] = []
         self.counts: list[int] = []
+        # the persistent running sums of the capture (slot i belongs to values[i]) and the slots whose value is added by the
+        # launch that PRODUCES it (the flat Adam step adds its gradient norm itself): no accumulate launch for those
+        self.accumulator = accumulator
+        self.produced: set[int] = set()
 
     def add(self, name: str, value: torch.Tensor, count: int):
         self.names.append(name)
         self.values.append(value)
         self.counts.append(count)
+
+    def slot_of(self, value: torch.Tensor) -> torch.Tensor | None:
+        """The accumulator slot of a tapped value, handed to its producer: the producer adds the value itself (and the capture
+        skips it).  None when the value is not tapped (or there is no accumulator)."""
+        if self.accumulator is None:
+            return None
+        for index, held in enumerate(self.values):
+            if held.data_ptr() == value.data_ptr() and index < self.accumulator.numel() and index not in self.produced:
+                self.produced.add(index)
+                return self.accumulator[index : index + 1]
+        return None
 
 
 class Metrics:

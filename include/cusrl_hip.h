@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CUSRL_ABI_VERSION 5
+#define CUSRL_ABI_VERSION 6
 #define CUSRL_MAX_FIELDS 24 /* leaves per push / gather launch; larger tables are split by the host */
 #define CUSRL_MAX_PACKED 16 /* 1-8 byte entries of the per-slot record (cusrl_pack_rows); wide fields count as leaves */
 #define CUSRL_MAX_RECORD_BYTES 1024
@@ -51,8 +51,10 @@ const char *cusrl_error_string(int code);
  * what a captured step is made of is checkable: type_counts[k] (HOST, n_types entries) = number of nodes of
  * hipGraphNodeType k (0 kernel, 1 memcpy, 2 memset, ...); `names` (HOST, `capacity` bytes, may be NULL with capacity 0)
  * receives the mangled names of the kernel nodes in node order, '\n'-terminated, truncated at capacity;
- * *names_len = bytes the full list needs.  The host refuses to replay a captured minibatch step that contains memset
- * nodes or ATen global-reduce kernels (template/graphs.py: they do not replay reliably on this stack). */
+ * *names_len = bytes the full list needs.  The host (template/graphs.py `_Capture.capture`) walks every captured region with
+ * this before it instantiates it and rewrites the region's memset nodes (cusrl_graph_replace_memsets below: they do not
+ * replay reliably on this stack); ATen global-reduce kernels are allowed (their semaphore memsets are what gets rewritten),
+ * the tests assert that the stock compositions contain none. */
 int cusrl_graph_census(void *graph, int64_t *type_counts, int n_types, char *names, int64_t capacity, int64_t *names_len);
 
 /* Replace every memset node of a captured, not yet instantiated hipGraph by a kernel node (a plain fill kernel) with the
@@ -228,6 +230,24 @@ int64_t cusrl_ppo_loss_num_partials(int64_t B);
 int64_t cusrl_ppo_loss_std_partial_rows(int64_t B);
 int64_t cusrl_ppo_loss_blocks(int64_t B, int64_t A);
 
+/* D == 0 in cusrl_ppo_loss_fwd_bwd / cusrl_ppo_loss_categorical_fwd_bwd (ABI 6): the launch carries NO value term — ret,
+ * curr_value, old_value, d_value may be NULL, losses_out[0] = losses_out[5] = 0 and losses_out[6] = surrogate + entropy.
+ * The value term then comes from the launch below.
+ *
+ * ValueLoss.objective on its own — cusrl/hook/on_policy/value.py:121-137 (`mse_loss(return, curr_value) * weight`) and the
+ * clipped form `_clipped_value_loss` value.py:85-89 — forward AND backward in one pass over ret / curr_value / old_value
+ * [B, D]: d_value [B, D] = d(value_loss)/d(curr_value) (optional), losses_out[0] = the weighted loss, losses_out[1] = mean of
+ * curr_value.sum(-1) (the `value` metric, value.py:139-141).  The sum `value + surrogate + entropy` the agent differentiates
+ * with a unit gradient (cusrl/template/actor_critic.py:309-312) splits into its summands; the host evaluates this one on the
+ * stream the critic runs on, so that critic forward -> value term -> critic backward is one branch of the captured
+ * minibatch step.  Same per-element arithmetic as the one-launch objective (d_value bit-identical).
+ * partials: double[cusrl_value_loss_blocks(B, D)][2]; flags: 0 or CUSRL_LOSS_DEFER (every block ADDS {sum sq. error, sum value}
+ * to its row; losses_out may be NULL). */
+int cusrl_value_loss_fwd_bwd(const float *ret, const float *curr_value, const float *old_value, int64_t B, int64_t D,
+                             double value_clip, double w_val, float *losses_out, float *d_value, double *partials, int flags,
+                             void *stream);
+int64_t cusrl_value_loss_blocks(int64_t B, int64_t D);
+
 /* The same objective for one-hot categorical policies (discrete action spaces) —
  * cusrl/nn/module/distribution.py:332-366 over torch.distributions.OneHotCategorical: action [B,A] one-hot (the taken
  * action is its first arg-max), logits [B,A] unnormalised; logp = log_softmax(logits)[taken],
@@ -393,6 +413,23 @@ int cusrl_relu_bwd_colsum(const float *grad, const float *output, float *grad_in
                           int64_t rows, int64_t H, void *stream);
 int64_t cusrl_colsum_num_partials(int64_t rows, int64_t H);
 
+/* ---- backward of the FIRST layer of an MLP (ABI 6): y = relu(x W^T + b) whose input needs no gradient — the observation layer
+ * of the actor / critic backbones (cusrl/nn/module/mlp.py:89-90; what autograd runs there: threshold_backward, sum(0), the
+ * weight-gradient GEMM).  ONE pass over grad_out [rows, H], output [rows, H] (the ReLU's output: grad is masked by output > 0;
+ * NULL: no activation) and input [rows, K] produces dW [H, K] = masked^T x and db [H] = column sums of masked — nothing is
+ * written back per row (no masked-gradient matrix: dX is not needed).  The products run on v_mfma_f32_16x16x4_f32 (exact f32,
+ * the column of ones of db included); the kernel is bound by the 4 (2 H + K) bytes per row it streams.
+ * Result: grads float[H * K + H] = dW (row-major) | db — what cusrl_assemble_gradients copies into the two parameters' slots
+ * (offset 0 / numel H*K and offset H*K / numel H).  Two launches on `stream`: the pass (per block one [64, K + 1] piece of a
+ * partial row) and a small fixed-order sum of the partial rows (a kernel boundary is the cheap cross-XCD fence here).
+ * partials: float[cusrl_input_layer_row_blocks(rows, H)][H * K + H] workspace.
+ * Supported (cusrl_input_layer_supported): K % 4 == 0, K <= 60, H % 64 == 0, H <= 4096; all pointers 16-byte aligned.
+ * Deterministic (fixed summation order). */
+int cusrl_input_layer_bwd(const float *grad_out, const float *output, const float *input, int64_t rows, int64_t in_features,
+                          int64_t out_features, float *partials, float *grads, void *stream);
+int cusrl_input_layer_supported(int64_t in_features, int64_t out_features);
+int64_t cusrl_input_layer_row_blocks(int64_t rows, int64_t out_features);
+
 /* ---- backward of a narrow linear layer (policy-mean / value heads; torch.nn.Linear backward with out_features <= 16)
  * One pass over the minibatch produces all three gradients of y = x W^T + b:
  *   grad_input [rows, K] = grad_out W   (skipped when NULL),   dW [O, K] = grad_out^T x,   db [O] = sum_rows grad_out.
@@ -456,11 +493,13 @@ int cusrl_grad_sumsq(const float *grad, int64_t n, double *partials, void *strea
  * Hyper-parameters are doubles like torch's: 1 - beta and the bias corrections are formed in double, then rounded.
  * param / grad / exp_avg / exp_avg_sq: float[n], 16-byte aligned; step, lr: device float[1] (hipGraph replays see
  * schedule changes); norm_out: device float[1] or NULL (receives ||grad||, the `grad_norm` metric);
+ * norm_accumulator (ABI 6): device float[1] or NULL — ||grad|| is ADDED to it (the running sum a captured step keeps of the
+ * metric over its replays, cusrl_accumulate_scalars' job without its launch);
  * ticket: device uint32[1], zero-initialised once by the caller and owned by this entry point afterwards. */
 int cusrl_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, const float *lr,
                     int64_t n, double beta1, double beta2, double eps, double weight_decay, int decoupled_weight_decay,
                     int maximize, const double *clip_partials, int64_t num_clip_partials, float max_norm,
-                    float *norm_out, uint32_t *ticket, void *stream);
+                    float *norm_out, float *norm_accumulator, uint32_t *ticket, void *stream);
 
 /* ---- running observation statistics ----
  * cusrl/nn/utils/normalization.py:15-50 `mean_var_count` of x [rows, C] restricted to rows with mask != 0 (mask may

@@ -2,11 +2,23 @@ import os
 import sys
 from pathlib import Path
 
-# the host-logic tests and the gloo workers exercise hook bookkeeping in processes without a GPU: opt in to the hooks' torch-op
-# (host) forms, which the product refuses otherwise (cusrl_amd/utils/misc.py host_form)
-os.environ.setdefault("CUSRL_HOST_FORMS", "1")
-
 import pytest
+
+HOST_FORMS = "CUSRL_HOST_FORMS"
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_runtest_setup(item):
+    """The host-logic tests and the gloo workers exercise hook bookkeeping in processes without a GPU: THEY — the tests that are
+    not marked ``gpu`` — opt in to the hooks' torch-op (host) forms, which the product refuses otherwise
+    (cusrl_amd/utils/misc.py host_form).  A ``gpu`` test runs with the gate shut, exactly like a user's process: a hook that
+    is handed a CPU tensor there raises instead of quietly taking the reference's torch-op chain
+    (tests/test_auxiliary_rewards.py::test_host_forms_are_refused_in_gpu_tests).  Set before any fixture of the test is built;
+    the workers the CPU tests spawn inherit it."""
+    if item.get_closest_marker("gpu") is None:
+        os.environ[HOST_FORMS] = "1"
+    else:
+        os.environ.pop(HOST_FORMS, None)
 
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:

@@ -81,6 +81,39 @@ def test_rnd_and_amp_with_hip_reward_epilogues_match_reference(golden):
 
 
 @pytest.mark.gpu
+def test_host_forms_are_refused_in_gpu_tests(golden):
+    """In a process that runs ``gpu`` tests the gate in front of the hooks' torch-op (host) forms is SHUT (tests/conftest.py):
+    each of the four places where a CPU tensor could otherwise quietly take the reference's op chain raises — the same
+    behaviour a user's process gets (cusrl_amd/utils/misc.py host_form)."""
+    import os
+
+    assert os.environ.get("CUSRL_HOST_FORMS") != "1"
+    g = golden("aux_rewards")
+    with pytest.raises(RuntimeError, match="RandomNetworkDistillation.pre_update received CPU tensors"):
+        run_rnd(g, "cpu")
+    with pytest.raises(RuntimeError, match="received CPU tensors"):  # (its running statistics come first: RunningMeanStd)
+        run_amp(g, "cpu")
+    shaping = cusrl.hook.RewardShaping(scale=2.0, shift=0.5)
+    with pytest.raises(RuntimeError, match="RewardShaping.post_step received CPU tensors"):
+        shaping.post_step({"reward": torch.ones(4, 1)})
+    from cusrl_amd.nn.rms import mean_var_count
+
+    with pytest.raises(RuntimeError, match="RunningMeanStd .mean_var_count. received CPU tensors"):
+        mean_var_count(torch.ones(4, 3))
+    # AMP's own site, reached with the statistics switched off the host path: the style reward of CPU logits
+    amp = cusrl.hook.AdversarialMotionPrior(cusrl.Mlp.Factory([16, 8]), dataset_source=g["amp_dataset"].copy(), state_indices=slice(1, 5),
+                                            batch_size=None, reward_scale=0.5, loss_weight=2.0, grad_penalty_weight=5.0)
+    amp.pre_init(fake_agent("cpu", {}))
+    amp.init()
+    amp.transition_rms.update = lambda *a, **k: None
+    amp.transition_rms.normalize = lambda x: x
+    amp._sample_demonstration = lambda n: amp.dataset[:7]
+    with pytest.raises(RuntimeError, match="AdversarialMotionPrior.post_step received CPU tensors"):
+        amp.post_step({"observation": torch.from_numpy(g["amp_obs_0"].copy()), "next_observation": torch.from_numpy(g["amp_next_obs_0"].copy()),
+                       "reward": torch.from_numpy(g["amp_reward_in_0"].copy())})
+
+
+@pytest.mark.gpu
 def test_reward_epilogue_kernels_vs_formula():
     from cusrl_amd import ops
 

@@ -134,9 +134,13 @@ def _reference_gradients(agent, names, params_before, indices, kind):
 
 @pytest.mark.parametrize("rows", [1024, 4096, 24576])
 @pytest.mark.parametrize("kind", ["stock", "amp", "split", "hook_by_hook"])
-def test_every_replay_of_a_captured_step_matches_float64_autograd(cusrl, kind, rows, gradient_parity):
+def test_every_replay_of_a_captured_step_matches_float64_autograd(cusrl, kind, rows, gradient_parity, monkeypatch):
     from cusrl_amd.hook.on_policy.fused import FusedPpoObjective
     from cusrl_amd.template import graphs
+
+    # one graph per minibatch step, so that every replay's gradient can be looked at (the default since round 6 replays a whole
+    # epoch's steps from one graph; that form is held to THIS one bit for bit: test_epoch_graphs_change_no_bit below)
+    monkeypatch.setenv("CUSRL_EPOCH_GRAPHS", "0")
 
     N, T, minibatches, epochs, obs_dim, act_dim, soak_iterations = SIZES[rows]
     assert N * T // minibatches == rows
@@ -248,4 +252,39 @@ def test_two_seeded_runs_of_the_captured_loop_are_bit_identical(cusrl, kind, con
         state["grad"] = agent.flat_gradients.buffer.clone()
         finals.append(state)
     differing = [key for key in finals[0] if not torch.equal(finals[0][key], finals[1][key])]
+    assert not differing, differing[:8]
+
+
+@pytest.mark.parametrize("rows", [1024, 24576])
+@pytest.mark.parametrize("kind", ["stock", "amp", "split"])
+def test_epoch_graphs_change_no_bit(cusrl, kind, rows, monkeypatch):
+    """The default captured form (round 6): one hipGraph per EPOCH whose step bodies read their index slices in place and whose
+    gathers run one step ahead on a second stream (template/graphs.py GraphedEpochs).  It is the step-by-step form above —
+    float64-checked replay by replay — with another issue order and nothing else: same seed, 8 iterations, every parameter,
+    every buffer leaf and the last flat gradient bit-identical between the two; and the epoch graphs really ran."""
+    N, T, minibatches, epochs, obs_dim, act_dim, _ = SIZES[rows]
+    finals = []
+    for epoch_graphs in ("1", "0"):
+        monkeypatch.setenv("CUSRL_EPOCH_GRAPHS", epoch_graphs)
+        cusrl.set_global_seed(57)
+        env = cusrl.testing.DummyTorchEnvironment(num_instances=N, observation_dim=obs_dim, action_dim=act_dim, device=DEV)
+        trainer = cusrl.Trainer(env, _factory(cusrl, kind, T, minibatches, epochs), num_iterations=8, verbose=False)
+        trainer.run_training_loop()
+        torch.cuda.synchronize()
+        agent = trainer.agent
+        graphed = agent._graphed_epochs
+        if epoch_graphs == "1" and not any(h.objective_draws_random for h in agent.hook if h.active):
+            # (AMP draws random numbers inside its objective: the sampler then keeps the reference's interleaving of draws, no
+            # up-front permutations, and the update steps graph by graph)
+            assert graphed is not None and graphed.replays >= 4 and len(graphed.epochs) == epochs, (graphed and graphed.replays)
+            for entry in graphed.epochs.values():
+                assert entry["capture"].census["memset"] == 0
+        if epoch_graphs == "0":
+            assert graphed is None or graphed.replays == 0
+        state = {f"param/{name}": p.detach().clone() for name, p in agent.named_parameters()}
+        state.update({f"buffer/{key}": leaf.clone() for key, leaf in agent.buffer.storage.items()})
+        state["grad"] = agent.flat_gradients.buffer.clone()
+        state["metrics"] = {}
+        finals.append(state)
+    differing = [key for key in finals[0] if key != "metrics" and not torch.equal(finals[0][key], finals[1][key])]
     assert not differing, differing[:8]

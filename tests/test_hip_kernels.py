@@ -1373,6 +1373,85 @@ def test_ppo_loss_deferred_finalize_accumulates_block_rows(ops, form):
         torch.testing.assert_close(flat[4:], plain["d_std"], rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("B,A,D", [(24576, 12, 1), (1000, 7, 1), (513, 32, 2), (3, 40, 1), (255, 4, 3), (70001, 12, 1)])
+@pytest.mark.parametrize("vclip", [None, 0.2])
+@pytest.mark.parametrize("form", ["std_matrix", "std_vector", "categorical"])
+def test_value_term_alone_plus_policy_terms_equal_the_one_launch_objective(ops, B, A, D, vclip, form):
+    """Round 6: inside a captured step with the critic on its own stream the value term is ONE launch there
+    (``cusrl_value_loss_fwd_bwd``) and the surrogate + entropy terms another on the actor's stream (``D = 0`` form of
+    ``cusrl_ppo_loss_fwd_bwd``).  Together they must be the one-launch objective: d_value, d_mean / d_logits, d_std and every
+    per-sample output BIT-identical (same per-element arithmetic), the three losses and the metric means to fp32 rounding of
+    a different summation order — and against the oracle (value.py:85-89,121-137)."""
+    if form == "std_vector" and not ops.ppo_loss_accepts_std_vector(A):
+        pytest.skip("the std-vector form exists for action widths that are a multiple of 4 up to 32")
+    rng = np.random.default_rng(B + A + D)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    adv, ret = f(B, 1), f(B, D)
+    curr_value, old_value = ret + 0.3 * f(B, D), ret + 0.3 * f(B, D)
+    kw = dict(clip=0.2, value_clip=vclip, w_sur=1.0, w_val=0.5, w_ent=0.01)
+    if form == "categorical":
+        logits = 2.0 * f(B, A)
+        action = np.eye(A, dtype=np.float32)[rng.integers(0, A, B)]
+        old_logp = oracle.categorical_ppo_loss(adv, np.zeros((B, 1), np.float32), action, logits + 0.05 * f(B, A), ret, curr_value)["logp"]
+        head = tuple(dev(x) for x in (adv, old_logp, action, logits))
+        call, grads = ops.ppo_loss_categorical_fwd_bwd, ("d_logits",)
+    else:
+        mean = f(B, A)
+        vector = (rng.random(A) + 0.5).astype(np.float32)
+        std = vector if form == "std_vector" else np.repeat(vector[None], B, 0)
+        action = (mean + vector * f(B, A)).astype(np.float32)
+        old_logp, _ = oracle.normal_logp_entropy(action, mean + 0.02 * f(B, A), np.repeat(vector[None], B, 0))
+        head = tuple(dev(x) for x in (adv, old_logp, action, mean, std))
+        call, grads = ops.ppo_loss_fwd_bwd, ("d_mean", "d_std")
+    value_args = tuple(dev(x) for x in (ret, curr_value, old_value))
+    whole = call(*head, *value_args, **kw)
+    policy = call(*head, None, None, None, **kw)
+    value = ops.value_loss_fwd_bwd(*value_args, value_clip=vclip, w_val=0.5)
+    assert "d_value" not in policy
+    assert torch.equal(value["d_value"], whole["d_value"])
+    for key in ("logp", "entropy", "logp_ratio", "ratio") + grads:
+        assert torch.equal(policy[key], whole[key]), key
+    w, p, v = host(whole["losses"]), host(policy["losses"]), host(value["losses"])
+    assert p[0] == 0.0 and p[5] == 0.0 and p[6] == np.float32(p[1] + p[2])
+    np.testing.assert_array_equal(p[1:5], w[1:5])
+    np.testing.assert_allclose(v[0], w[0], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(v[1], w[5], rtol=2e-6, atol=1e-7)
+    err = curr_value.astype(np.float64) - ret
+    if vclip is None:
+        want = (err ** 2).mean() * 0.5
+    else:
+        clipped = old_value.astype(np.float64) + np.clip(curr_value.astype(np.float64) - old_value, -vclip, vclip)
+        want = np.maximum(err ** 2, (clipped - ret) ** 2).mean() * 0.5
+    np.testing.assert_allclose(v[0], want, rtol=1e-5)
+    # the deferred-finalize forms of both launches: their sums land in separate rows and drain to the same six metrics
+    rows = ops.DeferredLoss(B, A, D, torch.device(DEV), categorical=form == "categorical")
+    for _ in range(2):
+        deferred_policy = call(*head, None, None, None, deferred=rows, **kw)
+        deferred_value = ops.value_loss_fwd_bwd(*value_args, value_clip=vclip, w_val=0.5, deferred=rows)
+    assert "losses" not in deferred_value and torch.equal(deferred_value["d_value"], whole["d_value"])
+    drained = rows.drain(2)
+    for name, index in (("value_loss", 0), ("surrogate_loss", 1), ("entropy_loss", 2), ("ratio", 3), ("entropy", 4), ("value", 5)):
+        total, count = drained[name]
+        assert count == (1 if index < 3 else B)
+        np.testing.assert_allclose(total / 2, w[index], rtol=2e-6, atol=1e-7, err_msg=name)
+    assert float(rows.rows.abs().sum()) == 0.0 and float(rows.value_rows.abs().sum()) == 0.0
+    if form == "std_vector":
+        torch.testing.assert_close(deferred_policy["d_std"].materialize(), whole["d_std"], rtol=1e-5, atol=1e-9)
+
+
+def test_value_term_argument_errors(ops):
+    from cusrl_amd import _native
+
+    lib = _native.lib()
+    x = torch.zeros(8, 1, device=DEV)
+    rows = torch.zeros(1, 2, dtype=torch.float64, device=DEV)
+    out = torch.zeros(2, device=DEV)
+    assert lib.cusrl_value_loss_fwd_bwd(x.data_ptr(), x.data_ptr(), None, 8, 1, 0.2, 0.5, out.data_ptr(), None, rows.data_ptr(), 0, None) == -1
+    assert lib.cusrl_value_loss_fwd_bwd(x.data_ptr(), x.data_ptr(), None, 0, 1, -1.0, 0.5, out.data_ptr(), None, rows.data_ptr(), 0, None) == -1
+    assert lib.cusrl_value_loss_fwd_bwd(x.data_ptr(), x.data_ptr(), None, 8, 1, -1.0, 0.5, None, None, rows.data_ptr(), 0, None) == -1
+    assert lib.cusrl_value_loss_blocks(24576, 1) == 24 and lib.cusrl_value_loss_blocks(0, 1) == 0
+
+
 @pytest.mark.parametrize("B,A,D", [(98304, 12, 1), (1000, 7, 1), (3, 40, 2), (257, 4, 3)])
 def test_policy_stats_vs_oracle(ops, B, A, D):
     rng = np.random.default_rng(B + A + D)
@@ -1424,6 +1503,46 @@ def test_assemble_gradients_reduces_deferred_column_windows(ops):
     torch.testing.assert_close(pieces[1][0].materialize().double(), torch.from_numpy(want[1536:1548]).to(DEV), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("rows,K,H", [(24576, 48, 256), (1000, 12, 64), (37, 60, 128), (4097, 4, 320), (8, 48, 256), (98304, 48, 256)])
+@pytest.mark.parametrize("mask", [True, False])
+def test_input_layer_backward_matches_float64(ops, rows, K, H, mask, gradient_parity):
+    """``cusrl_input_layer_bwd`` (round 6): ReLU mask + bias gradient + weight gradient of the bottom layer from ONE pass,
+    against float64 ``(g * (y > 0)).T @ x`` / ``.sum(0)`` (what autograd's threshold_backward, sum and mm compute,
+    cusrl/nn/module/mlp.py:89-90) to 1e-5 of each gradient's largest entry; a second launch is bit-identical."""
+    torch.manual_seed(rows + K + H)
+    g = torch.randn(rows, H, device=DEV)
+    y = torch.relu(torch.randn(rows, H, device=DEV)) if mask else None
+    x = torch.randn(rows, K, device=DEV)
+    weight = torch.empty(H, K, device=DEV)
+    assert ops.input_layer_supported(g, y, x, weight)
+    first = ops.input_layer_backward(g, y, x)
+    second = ops.input_layer_backward(g, y, x)
+    masked = (g * (y > 0) if mask else g).double()
+    want_w, want_b = masked.t() @ x.double(), masked.sum(0)
+    assert first[0].shape == (H, K) and first[1].shape == (H,)
+    gradient_parity(f"input_layer.dW[{rows},{K},{H},{mask}]", host(first[0]), host(want_w), 1e-5)
+    # a bias gradient is a sum of `rows` signed terms that cancel: its yardstick is the sum of their magnitudes per column
+    scale = float(masked.abs().sum(0).max())
+    assert float((first[1].double() - want_b).abs().max()) <= 1e-6 * scale
+    assert torch.equal(first[0], second[0]) and torch.equal(first[1], second[1])  # fixed summation order
+
+
+def test_input_layer_argument_errors(ops):
+    from cusrl_amd import _native
+
+    lib = _native.lib()
+    assert not lib.cusrl_input_layer_supported(50, 256) and not lib.cusrl_input_layer_supported(64, 256)
+    assert not lib.cusrl_input_layer_supported(48, 100) and lib.cusrl_input_layer_supported(48, 256)
+    g, x = torch.zeros(8, 256, device=DEV), torch.zeros(8, 48, device=DEV)
+    ws = torch.zeros(16, 256 * 49, device=DEV)
+    call = lambda *a: lib.cusrl_input_layer_bwd(*a, None)  # noqa: E731
+    assert call(None, None, x.data_ptr(), 8, 48, 256, ws.data_ptr(), ws.data_ptr()) == -1
+    assert call(g.data_ptr(), None, x.data_ptr(), 0, 48, 256, ws.data_ptr(), ws.data_ptr()) == -1
+    assert call(g.data_ptr(), None, x.data_ptr(), 8, 50, 256, ws.data_ptr(), ws.data_ptr()) == -3
+    assert call(g.data_ptr() + 4, None, x.data_ptr(), 8, 48, 256, ws.data_ptr(), ws.data_ptr()) == -3
+    assert lib.cusrl_input_layer_row_blocks(24576, 256) == 64 and lib.cusrl_input_layer_row_blocks(0, 256) == 0
+
+
 def test_flat_backward_with_deferred_sums_matches_plain_autograd():
     """The agent's backward: split-GEMM slabs, deferred bias / head column sums, all summed by the assembly launch."""
     from cusrl_amd.nn.module import Linear, Mlp, collect_split_weight_grads
@@ -1448,7 +1567,10 @@ def test_flat_backward_with_deferred_sums_matches_plain_autograd():
 
     with collect_split_weight_grads() as sink:
         grads = torch.autograd.grad(loss_of(False), flat.params, allow_unused=True)
-    assert sum(g is None for g in grads) == len(flat.params)  # every gradient took the deferred route
+    # every gradient took the deferred route — but the two bottom layers' (round 6: their weight and bias gradients come
+    # finished out of cusrl_input_layer_bwd)
+    assert sum(g is None for g in grads) == len(flat.params) - 4
+    assert all(g is not None for g, p in zip(grads, flat.params) if p.shape in ((256, 48), (256,)))
     flat.assemble(grads, sink)
     want = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss_of(True), flat.params)])
     torch.testing.assert_close(flat.packed(), want, rtol=2e-4, atol=1e-4 * float(want.abs().max()))

@@ -88,8 +88,8 @@ def test_every_negative_return_code_of_the_c_abi_is_reachable_without_a_launch()
     assert lib.cusrl_gather_memory(None, p, p, p, 4, 64, None) == -1
     assert lib.cusrl_scatter_rows(p, None, p, 4, 16, None, None) == -1
     assert lib.cusrl_window_indices(p, p, p, 4, 2, 8, 3, 8, None) == -1   # cursor outside the ring
-    assert lib.cusrl_adam_step(p, p, p, p, p, p, 100, 0.9, 0.999, 1e-8, 0.0, 0, 0, None, 0, -1.0, None, None, None) == -1
-    assert lib.cusrl_adam_step(odd, p, p, p, p, p, 100, 0.9, 0.999, 1e-8, 0.0, 0, 0, None, 0, -1.0, None, p, None) == -3
+    assert lib.cusrl_adam_step(p, p, p, p, p, p, 100, 0.9, 0.999, 1e-8, 0.0, 0, 0, None, 0, -1.0, None, None, None, None) == -1
+    assert lib.cusrl_adam_step(odd, p, p, p, p, p, 100, 0.9, 0.999, 1e-8, 0.0, 0, 0, None, 0, -1.0, None, None, p, None) == -3
     assert lib.cusrl_categorical_sample_logp(p, None, p, p, 8, 3, None) == -1
     assert lib.cusrl_categorical_sample_logp(p, p, p, p, 8, 0, None) == -1
     assert lib.cusrl_categorical_sample_logp(None, None, None, None, 0, 3, None) == 0   # an empty step is not an error
