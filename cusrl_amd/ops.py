@@ -777,14 +777,18 @@ class DeferredLoss:
     critic's stream (:func:`value_loss_fwd_bwd`) keeps its two sums in ``value_rows``: two launches on two streams must not
     read-modify-write the same words."""
 
-    __slots__ = ("rows", "value_rows", "value_armed", "value_weight", "policy_has_value", "B", "A", "D", "weights", "blocks", "armed")
+    __slots__ = ("storage", "rows", "value_rows", "value_armed", "value_weight", "policy_has_value", "B", "A", "D", "weights", "blocks",
+                 "armed")
 
     def __init__(self, B: int, A: int, D: int, device, categorical: bool):
         self.B, self.A, self.D = B, A, D
         lib = _native.lib()
         self.blocks = int(lib.cusrl_ppo_loss_blocks(B, 0 if categorical else A))
-        self.rows = torch.zeros((max(int(lib.cusrl_ppo_loss_num_partials(B)), 1), 5), dtype=torch.float64, device=device)
-        self.value_rows = torch.zeros((max(int(lib.cusrl_value_loss_blocks(B, D)), 1), 2), dtype=torch.float64, device=device)
+        # (both sets of rows are windows of ONE tensor: staged for the host and reset as one piece)
+        policy, value = max(int(lib.cusrl_ppo_loss_num_partials(B)), 1), max(int(lib.cusrl_value_loss_blocks(B, D)), 1)
+        self.storage = torch.zeros(policy * 5 + value * 2, dtype=torch.float64, device=device)
+        self.rows = self.storage[: policy * 5].view(policy, 5)
+        self.value_rows = self.storage[policy * 5 :].view(value, 2)
         self.weights: tuple[float, float, float] | None = None
         self.value_weight: float | None = None
         self.armed = False  # a launch of the (policy / whole) objective has been recorded against `rows`
@@ -805,6 +809,26 @@ class DeferredLoss:
             total = torch.stack((value[0], total[1], total[2], total[3], value[1]))
         return total
 
+    def stage(self):
+        """``(storage, decode)`` for a batched host read (``Metrics._stage_pending`` snapshots and zeroes ``storage``):
+        ``decode(host values of storage)`` gives what :meth:`metrics` gives, under the flags and weights in force NOW."""
+        if not (self.armed or self.value_armed):
+            return None
+        policy_rows, blocks = self.rows.shape[0], self.blocks
+        frozen = (self.armed, self.value_armed, self.policy_has_value, self.weights, self.value_weight)
+
+        def decode(host):
+            import numpy as np
+
+            flat = np.asarray(host, dtype=np.float64)
+            sums = flat[: policy_rows * 5].reshape(policy_rows, 5)[:blocks].sum(0)
+            if frozen[1]:
+                value = flat[policy_rows * 5 :].reshape(-1, 2).sum(0)
+                sums[0], sums[4] = value[0], value[1]
+            return self._metrics(sums.tolist(), *frozen)
+
+        return self.storage, decode
+
     def drain(self, replays: int) -> dict[str, tuple[float, int]] | None:
         """``{metric: (sum over replays of the per-step mean, samples per step)}`` and a reset of the rows."""
         if replays <= 0 or (total := self.sums()) is None:
@@ -812,13 +836,16 @@ class DeferredLoss:
         return self.metrics(total.tolist())
 
     def metrics(self, sums: Sequence[float]) -> dict[str, tuple[float, int]]:
+        return self._metrics(sums, self.armed, self.value_armed, self.policy_has_value, self.weights, self.value_weight)
+
+    def _metrics(self, sums, armed, value_armed, policy_has_value, weights, value_weight) -> dict[str, tuple[float, int]]:
         B, D = self.B, self.D
         out: dict[str, tuple[float, int]] = {}
-        if self.value_armed or (self.armed and self.policy_has_value):
-            w_val = self.value_weight if self.value_armed else self.weights[0]
+        if value_armed or (armed and policy_has_value):
+            w_val = value_weight if value_armed else weights[0]
             out["value_loss"] = (sums[0] / (B * D) * w_val, 1)
-        if self.armed:
-            _, w_sur, w_ent = self.weights
+        if armed:
+            _, w_sur, w_ent = weights
             out["surrogate_loss"] = (-sums[1] / B * w_sur, 1)
             out["entropy_loss"] = (-sums[2] / B * w_ent, 1)
             out["ratio"] = (sums[3] / B, B)

@@ -283,29 +283,28 @@ class ActorCritic(Agent):
             self._sampler_prefetch_checked = self.sampler
             if self._steps_draw_random():
                 self.sampler.prefetch = False  # keep the reference's interleaving of permutation and in-step draws
+        # The first epoch's permutation depends on nothing pre_update computes: drawn NOW (side stream), it runs under
+        # pre_update's kernels instead of between them and the first minibatch step.  Only when no hook this package does not
+        # know could draw from the generator inside pre_update (the reference draws the permutation behind it,
+        # cusrl/sampler/mini_batch_sampler.py:56): none of this package's hooks does.
+        early = self._draw_epochs(prepare=False) if self._draws_early() else None
         self.hook.pre_update(self.buffer)  # a3-a6: next_value, GAE, advantage normalisation
         with self._training_mode():
-            recurrent = self.actor.is_recurrent or self.critic.is_recurrent  # dynamic sequence counts: not capturable
-            graphed = self.compile and hasattr(self.sampler, "iter_indices") and not recurrent
+            # (recurrent networks: dynamic sequence counts, not capturable; a hook's collective / host read-back stays out of capture)
+            graphed = self._graphable()
             if graphed:
-                from cusrl_amd.template.graphs import GraphedTrainStep, eager_phases
+                from cusrl_amd.template.graphs import GraphedTrainStep
 
-                graphed = "objective" not in eager_phases(self)  # a hook's collective / host read-back stays out of capture
-            if graphed:
                 # every epoch's permutation drawn up front on the draw-ahead stream (same generator calls, same order):
                 # once every step replays from its own graph, a whole epoch's steps replay from ONE graph that reads its
                 # index slices in place and gathers each step's rows while the step before it runs (template/graphs.py
                 # GraphedEpochs); until then — and whenever a condition does not hold — the steps run graph by graph over
                 # the very same permutations
-                from cusrl_amd.template.graphs import GraphedEpochs, epoch_graphs_enabled
+                from cusrl_amd.template.graphs import GraphedEpochs
 
-                drawn = None
-                if epoch_graphs_enabled() and hasattr(self.sampler, "draw_epochs"):
-                    if self._graphed_epochs is None:
-                        self._graphed_epochs = GraphedEpochs(self)
-                    # (the draw only has to wait for the previous update's readers of the index rows — not for pre_update's
-                    # kernels the main stream has just been given: the permutations are drawn while those run)
-                    drawn = self.sampler.draw_epochs(self.buffer, after=self._minibatches_done)
+                drawn = early if early is not None else self._draw_epochs()
+                if drawn is not None and self._graphed_epochs is None:
+                    self._graphed_epochs = GraphedEpochs(self)
                 steps = () if drawn is not None and self._graphed_epochs.run(drawn) else (
                     self._iter_drawn(drawn) if drawn is not None else self.sampler.iter_indices(self.buffer))
                 for metadata, indices in steps:
@@ -331,18 +330,40 @@ class ActorCritic(Agent):
                     if self._minibatches_done is None:
                         self._minibatches_done = torch.cuda.Event()
                     self._minibatches_done.record(torch.cuda.current_stream())
-                deferred: list = []
+                # what the replays accumulated on the device (metric taps, loss sums): handed to the metrics, read in ONE host
+                # copy together with everything else this update recorded (Agent.update -> Metrics.summary)
                 for step in self._graphed_steps.values():
-                    step.flush_metrics(deferred)
+                    step.flush_metrics()
                 if self._graphed_epochs is not None:
                     self._graphed_epochs.flush_metrics()
-                GraphedTrainStep.resolve_deferred(deferred)  # the loss sums of every step: one host read
             else:
                 for metadata, batch in self.sampler(self.buffer):  # a7/a8
                     self._train_step(metadata, batch)
         self.hook.post_update()
         self.hook.apply_schedule(self.iteration + 1)
         return super().update()
+
+    def _graphable(self) -> bool:
+        """Does this update's minibatch loop go through captured steps (``compile=True``, an index-yielding sampler, feed-forward
+        networks, no hook that keeps its objective phase out of capture)?"""
+        if not (self.compile and hasattr(self.sampler, "iter_indices")) or self.actor.is_recurrent or self.critic.is_recurrent:
+            return False
+        from cusrl_amd.template.graphs import eager_phases
+
+        return "objective" not in eager_phases(self)
+
+    def _draws_early(self) -> bool:
+        return self._graphable() and all(type(hook).__module__.startswith("cusrl_amd.") for hook in self.hook if hook.active)
+
+    def _draw_epochs(self, prepare: bool = True):
+        """The sampler's up-front permutations (``DrawnEpochs``) when whole-epoch graphs are on and the sampler offers them."""
+        from cusrl_amd.template.graphs import epoch_graphs_enabled
+
+        if not (epoch_graphs_enabled() and hasattr(self.sampler, "draw_epochs")):
+            return None
+        # (the draw only has to wait for the previous update's readers of the index rows — not for whatever the main stream has
+        # been given since)
+        return self.sampler.draw_epochs(self.buffer, after=self._minibatches_done, prepare=prepare)
 
     def _step_key(self, metadata, numel: int) -> tuple:
         """Key of the captured minibatch step that serves ``metadata``: slot, sampling form, batch size and the value of every
@@ -357,12 +378,10 @@ class ActorCritic(Agent):
     def _iter_drawn(drawn):
         """``(metadata, index slice)`` of every minibatch of permutations drawn by ``sampler.draw_epochs`` — each epoch after
         its permutation's event."""
-        permutations, events, plan = drawn
-        main = torch.cuda.current_stream()
-        for epoch, row in enumerate(plan):
-            main.wait_event(events[epoch])
+        for epoch, row in enumerate(drawn.plan):
+            drawn.wait(epoch)
             for metadata, lo, hi in row:
-                yield dict(metadata), permutations[epoch, lo:hi]
+                yield dict(metadata), drawn.permutations[epoch, lo:hi]
 
     def _zero_grad(self):
         if self.flat_optimizer is not None:

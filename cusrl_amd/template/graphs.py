@@ -162,6 +162,8 @@ class _Capture:
     censuses: list[dict] = []  # node census of the most recent captures of the process (tests, scripts/graph_census.py)
 
     def capture(self, fn, stream: torch.cuda.Stream, pool=None):
+        for values, _, record in self.stage_metrics(self.agent.metrics):  # an earlier capture's sums: its accumulator goes away
+            self.agent.metrics.defer(values.clone(), record)
         # persistent (allocated outside the capture, so replays do not re-zero it); taps accumulate into it in-graph
         self.accumulator = torch.zeros(self.MAX_TAPS, dtype=torch.float32, device=self.agent.device)
         tap = MetricTap(self.accumulator)
@@ -224,15 +226,26 @@ class _Capture:
         self.replays += 1
 
     def flush_metrics(self):
-        """Fold the accumulated taps into the agent's metrics (one host copy) and reset."""
+        """Hand the accumulated taps over to the agent's metrics: they are read — together with every other capture's, in ONE host
+        copy — when the metrics are (``Metrics._stage_pending``); nothing is launched or synchronised here."""
         if self.accumulator is None or self.replays == 0 or not self.tap_names:
             self.replays = 0
             return
-        sums = self.accumulator.tolist()
-        self.accumulator.zero_()
-        for name, count, total in zip(self.tap_names, self.tap_counts, sums):
-            self.agent.metrics.add_resolved(name, total * count, count * self.replays)
+        self.agent.metrics.pending(self)
+
+    def stage_metrics(self, metrics):
+        """``[(values, tensor to reset, callback)]`` for :meth:`Metrics._stage_pending`: this capture's running sums as of now."""
+        if self.accumulator is None or self.replays == 0 or not self.tap_names:
+            self.replays = 0
+            return []
+        names, counts, replays = list(self.tap_names), list(self.tap_counts), self.replays
         self.replays = 0
+
+        def record(sums):
+            for name, count, total in zip(names, counts, sums):
+                metrics.add_resolved(name, total * count, count * replays)
+
+        return [(self.accumulator[: len(names)], self.accumulator, record)]
 
 
 class GraphedTrainStep:
@@ -360,7 +373,9 @@ class GraphedTrainStep:
             agent.flat_optimizer.refresh()  # learning-rate changes reach the captured step through device memory
         signature = (capture_signature(agent), agent.buffer.layout_version)
         if self.state == 2 and signature != self.signature:
-            self.flush_metrics()
+            for values, reset, record in self.stage_metrics(agent.metrics):  # (now: the flags below describe the NEXT capture)
+                agent.metrics.defer(values.clone(), record)
+                reset.zero_()
             if self.deferred_loss is not None:
                 self.deferred_loss.armed = self.deferred_loss.value_armed = False  # the new capture records its own launches
             self.state = 1  # a host-side value the capture froze has changed: capture again (the warm-up is still valid)
@@ -389,29 +404,23 @@ class GraphedTrainStep:
             self.optimize.replay()
 
     def flush_metrics(self, deferred: list | None = None):
-        """Fold what the replays accumulated on the device into the agent's metrics.  ``deferred`` (a list the caller
-        resolves with :meth:`resolve_deferred`): the loss sums are only ENQUEUED here, so that all steps of an update
-        share one host read."""
+        """Hand what the replays accumulated on the device — the captures' metric taps and the objective's running loss sums —
+        over to the agent's metrics; read with everything else in one host copy (``Metrics._stage_pending``)."""
+        self.agent.metrics.pending(self)
+
+    def stage_metrics(self, metrics):
         replays = self.forward_backward.replays + self.extra_replays
         self.extra_replays = 0
-        self.forward_backward.flush_metrics()
-        self.optimize.flush_metrics()
-        if self.deferred_loss is None or replays <= 0 or (sums := self.deferred_loss.sums()) is None:
-            return
-        if deferred is None:
-            self._record_deferred(sums.tolist(), replays)
-        else:
-            deferred.append((self, sums, replays))
+        entries = self.forward_backward.stage_metrics(metrics) + self.optimize.stage_metrics(metrics)
+        if self.deferred_loss is not None and replays > 0 and (staged := self.deferred_loss.stage()) is not None:
+            values, decode = staged
 
-    def _record_deferred(self, sums, replays: int):
-        for name, (total, count) in self.deferred_loss.metrics(sums).items():  # total = sum over the replays of the step's mean
-            self.agent.metrics.add_resolved(name, total * count, count * replays)
+            def record(host, decode=decode, replays=replays):
+                for name, (total, count) in decode(host).items():  # total = sum over the replays of the step's mean
+                    metrics.add_resolved(name, total * count, count * replays)
 
-    @staticmethod
-    def resolve_deferred(deferred: list):
-        if deferred:
-            for (step, _, replays), sums in zip(deferred, torch.stack([entry[1] for entry in deferred]).tolist()):
-                step._record_deferred(sums, replays)
+            entries.append((values, values, record))
+        return entries
 
 
 def epoch_graphs_enabled() -> bool:
@@ -468,7 +477,7 @@ class GraphedEpochs:
         agent = self.agent
         if not self.enabled:
             return False
-        permutations, events, plan = drawn
+        permutations, plan = drawn.permutations, drawn.plan
         signature = (capture_signature(agent), agent.buffer.layout_version)
         if signature != self.signature:
             self.flush_metrics()
@@ -481,16 +490,18 @@ class GraphedEpochs:
         agent.buffer.prepare_sampling(hot)
         if agent.flat_optimizer is not None:
             agent.flat_optimizer.refresh()  # learning-rate changes reach the captured steps through device memory
-        main = torch.cuda.current_stream()
         for epoch, row in enumerate(rows):
             key = (epoch, permutations.data_ptr(), tuple(id(step) for step, _, _ in row))
             entry = self.epochs.get(key)
-            main.wait_event(events[epoch])  # this epoch's permutation has been drawn
+            drawn.wait(epoch)  # this epoch's permutation has been drawn
             if entry is None:
                 self._allocate([row])
                 entry = self.epochs[key] = {"capture": _Capture(agent)}
                 entry["capture"].capture(lambda row=row: self._body(row), self.stream, pool=agent._graph_pool)
             entry["capture"].replay()
+            # the next epoch's permutation: issued behind this epoch's launch, so that the draw's dozen small launches run
+            # under these steps (the host is free now) instead of in front of the update's first step
+            drawn.draw(epoch + 1)
             for step, _, _ in row:
                 step.extra_replays += 1
         self.replays += 1

@@ -104,6 +104,29 @@ class EnvironmentStats:
             self._reward_sum.zero_()
         self.num_steps = 0
 
+    def means(self):
+        """``(mean_episode_length, mean_episode_reward, mean_step_reward)`` — what the three properties below give — from ONE
+        host copy when the statistics live on the device (the properties cost a reduction launch and a synchronising ``item()``
+        each, the episode count two more: five host round trips at the end of every iteration with an idle device behind them)."""
+        if not self.on_device:
+            return self.mean_episode_length, self.mean_episode_reward, self.mean_step_reward
+        import numpy as np
+
+        D, R = self.reward_dim, self.buffer_size
+        flat = torch.cat((self._episodes_dev[self._parity].reshape(1).double(), self._reward_sum,
+                          self.rew_buffer.reshape(-1).double(), self.len_buffer.reshape(-1).double())).tolist()
+        count = min(int(flat[0]), R)
+        step = np.asarray(flat[1 : 1 + D], dtype=np.float64) / self.num_envs
+        step = (step.astype(np.float32) / np.float32(self.num_steps)) if self.num_steps else step.astype(np.float32)
+        rewards = np.asarray(flat[1 + D : 1 + D + R * D], dtype=np.float32).reshape(R, D)
+        lengths = np.asarray(flat[1 + D + R * D :], dtype=np.float32)
+        if count == 0:
+            episode_length, episode_reward = 0.0, np.zeros(D, dtype=np.float32)
+        else:
+            episode_length, episode_reward = float(lengths[:count].mean()), rewards[:count].mean(axis=0)
+        scalar = (lambda v: float(v[0])) if D == 1 else (lambda v: tuple(float(x) for x in v))
+        return episode_length, scalar(episode_reward), scalar(step)
+
     @property
     def mean_step_reward(self):
         if self.on_device:
@@ -422,8 +445,7 @@ class Trainer:
     def _log_info(self, info: dict[str, float]):
         for key, value in self.environment.get_metrics().items():
             info[f"Environment/{key}"] = value
-        info["Metric/episode_length"] = self.stats.mean_episode_length
-        episode_reward, step_reward = self.stats.mean_episode_reward, self.stats.mean_step_reward
+        info["Metric/episode_length"], episode_reward, step_reward = self.stats.means()
         if isinstance(episode_reward, tuple):
             info.update({f"Metric/episode_reward.{i}": v for i, v in enumerate(episode_reward)})
             info.update({f"Metric/reward.{i}": v for i, v in enumerate(step_reward)})

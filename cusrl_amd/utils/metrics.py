@@ -65,6 +65,12 @@ class Metrics:
     def __init__(self):
         self._queue: dict[str, list[tuple[torch.Tensor | float, int]]] = {}
         self._tap: MetricTap | None = None
+        # device tensors of any length whose host values a callback turns into resolved contributions (the running sums the
+        # captured hipGraphs keep): they travel to the host in the SAME copy as the queued scalars
+        self._lazy: list[tuple[torch.Tensor, Any]] = []
+        # objects with a `stage_metrics(metrics)` method that still hold un-staged device sums (captures that replayed since the
+        # last read): asked right before the one host copy
+        self._pending: list[Any] = []
 
     # ------------------------------------------------------------------ recording
     @torch.no_grad()
@@ -110,26 +116,73 @@ class Metrics:
     def tap(self, tap: MetricTap | None):
         self._tap = tap
 
+    def defer(self, values: torch.Tensor, callback) -> None:
+        """``callback(list of floats)`` is called with the host values of the device tensor ``values`` when the metrics are next
+        read; it records them with :meth:`add_resolved`."""
+        self._lazy.append((values.reshape(-1), callback))
+
+    def pending(self, source) -> None:
+        """``source.stage_metrics(self)`` will be called before the next read (once)."""
+        if not any(held is source for held in self._pending):
+            self._pending.append(source)
+
     def clear(self):
         self._queue.clear()
+        self._lazy.clear()
 
     # ------------------------------------------------------------------ reading
     def _resolve(self) -> dict[str, Metric]:
-        tensors: dict[torch.device, list[torch.Tensor]] = {}
+        self._stage_pending()
+        lazy, self._lazy = self._lazy, []
+        tensors: dict[tuple, list[torch.Tensor]] = {}
         for entries in self._queue.values():
             for value, _ in entries:
                 if isinstance(value, torch.Tensor):
-                    tensors.setdefault(value.device, []).append(value)
-        host: dict[int, float] = {}
-        for group in tensors.values():  # one stack + one host copy per device
-            for tensor, scalar in zip(group, torch.stack(group).tolist()):
-                host[id(tensor)] = scalar
+                    tensors.setdefault((value.device, value.dtype), []).append(value)
+        for values, _ in lazy:
+            tensors.setdefault((values.device, values.dtype), []).append(values)
+        host: dict[int, Any] = {}
+        for group in tensors.values():  # ONE concatenation + ONE host copy per (device, dtype), whatever was recorded
+            flat = torch.cat([tensor.reshape(-1) for tensor in group]).tolist() if len(group) > 1 else group[0].reshape(-1).tolist()
+            offset = 0
+            for tensor in group:
+                n = tensor.numel()
+                host[id(tensor)] = flat[offset] if tensor.dim() == 0 else flat[offset : offset + n]
+                offset += n
+        for values, callback in lazy:
+            callback(host[id(values)])
         resolved = {}
         for name, entries in self._queue.items():
             total = sum(count for _, count in entries)
             mean = sum((host[id(v)] if isinstance(v, torch.Tensor) else v) * (count / total) for v, count in entries)
             resolved[name] = Metric(torch.tensor(mean, dtype=torch.float32), total)
         return resolved
+
+    def _stage_pending(self):
+        """Snapshot (ONE concatenation) and reset (ONE multi-tensor fill) the device-side running sums of every capture that
+        replayed since the last read, whatever their number — the per-capture ``tolist`` of rounds 2-5 was one host
+        synchronisation per captured graph and update (nine for the ``ppo`` preset)."""
+        sources, self._pending = self._pending, []
+        staged = []
+        for source in sources:
+            staged.extend(source.stage_metrics(self) or ())
+        staged = [(tensor, reset, callback) for tensor, reset, callback in staged if tensor.numel()]
+        by_type: dict[tuple, list] = {}
+        for entry in staged:
+            by_type.setdefault((entry[0].device, entry[0].dtype), []).append(entry)
+        for group in by_type.values():
+            snapshot = torch.cat([tensor.reshape(-1) for tensor, _, _ in group])
+            torch._foreach_zero_([reset for _, reset, _ in group])
+            sizes = [tensor.numel() for tensor, _, _ in group]
+            callbacks = [callback for _, _, callback in group]
+
+            def scatter(values, sizes=sizes, callbacks=callbacks):
+                offset = 0
+                for size, callback in zip(sizes, callbacks):
+                    callback(values[offset : offset + size])
+                    offset += size
+
+            self.defer(snapshot, scatter)
 
     def summary(self, prefix: str = "") -> dict[str, float]:
         if prefix and not prefix.endswith("/"):

@@ -10,5 +10,6 @@ for cfg in "$@"; do
   CUSRL_EPOCH_GRAPHS=$1 CUSRL_SEPARATE_VALUE_TERM=$2 CUSRL_PREFETCH_GATHER=$3 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o bench -- python $R/bench.py --no-cpu-baseline --no-kernel-pass --no-scale-pass --no-env-ab --steps 6 --warmup 6 > /tmp/seq.log 2>&1 < /dev/null
   grep "^{" /tmp/seq.log | cut -c1-200
   T=$(find $OUT -name "*kernel_trace.csv" | head -1)
-  python $R/scripts/step_timeline.py $T "ppo_loss_rowgroup" --nth -7 --steps 3 > $R/gpurun_out/$TAG/timeline_epochs$1_value$2_prefetch$3.txt
+  python $R/scripts/step_timeline.py $T "ppo_loss_rowgroup" --nth -7 --steps 3 --periods 45 > $R/gpurun_out/$TAG/timeline_epochs$1_value$2_prefetch$3.txt
+  python $R/scripts/idle_gaps.py $T --min-us 10 > $R/gpurun_out/$TAG/idle_gaps_epochs$1_value$2_prefetch$3.txt
 done

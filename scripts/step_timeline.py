@@ -37,6 +37,10 @@ def main():
     if periods:
         print(f"anchor-to-anchor period over {len(periods)} in-update pairs: median {statistics.median(periods):.1f} us, "
               f"mean {statistics.mean(periods):.1f} us, min {min(periods):.1f}, max {max(periods):.1f}")
+    if "--periods" in sys.argv:  # the periods of the last `count` anchor pairs in order (an update's steps: where do the long ones sit?)
+        count = int(sys.argv[sys.argv.index("--periods") + 1])
+        tail = starts[-(count + 1):]
+        print("last periods (us): " + " ".join(f"{(b - a) / 1e3:.0f}" for a, b in zip(tail, tail[1:])))
     a = anchors[nth]
     b = anchors[nth + steps] if nth + steps < 0 or nth + steps < len(anchors) else len(rows)
     t0 = int(rows[a]["Start_Timestamp"])
