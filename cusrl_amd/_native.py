@@ -46,6 +46,8 @@ _P = c_void_p
 _SIGNATURES = {
     "cusrl_abi_version": (c_int, []),
     "cusrl_error_string": (c_char_p, [c_int]),
+    "cusrl_set_option": (c_int, [c_char_p, c_int64]),
+    "cusrl_get_option": (c_int, [c_char_p, POINTER(c_int64)]),
     "cusrl_buffer_push": (c_int, [POINTER(Field), c_int, c_int64, c_int64, _P]),
     "cusrl_buffer_push_through": (c_int, [POINTER(Field), c_int, c_int64, c_int64, _P, c_int64, POINTER(ctypes.c_int32), _P]),
     "cusrl_next_value": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, c_int64, c_int64, c_int64, _P]),
@@ -172,7 +174,46 @@ def lib() -> ctypes.CDLL:
         if handle.cusrl_abi_version() != ABI_VERSION:
             raise NativeError(f"ABI mismatch: library {handle.cusrl_abi_version()}, binding {ABI_VERSION}; rebuild")
         _lib = handle
+        _options_from_environment()
     return _lib
+
+
+# The A/B scripts of rounds 2-5 drive the kernels' launch-shape / cache-policy overrides through CUSRL_* environment variables.
+# The library no longer reads the environment in its launch entry points (cusrl_set_option, ABI 6): the HOST translates them,
+# once, when it loads the library.  {environment variable: (option, {text: value})}; None = the integer as it stands.
+_ENVIRONMENT_OPTIONS = {
+    "CUSRL_GAE_POLICY": ("gae_policy", {"0": 1, "5": 6, "7": 8}),
+    "CUSRL_GAE_BLOCK": ("gae_block", None),
+    "CUSRL_LOSS_POLICY": ("loss_policy", {"0": 1, "1": 2}),
+    "CUSRL_PUSH_POLICY": ("push_policy", {"0": 1, "3": 2}),
+    "CUSRL_COLSUM_ROWS": ("colsum_rows", None),
+    "CUSRL_HEAD_ROWS": ("head_rows", None),
+    "CUSRL_GRU_BIAS_ROWS": ("gru_bias_rows", None),
+}
+
+
+def set_option(key: str, value: int) -> None:
+    """``cusrl_set_option``: force a kernel's launch shape / cache policy (0: back to its own rule); include/cusrl_hip.h."""
+    check(lib().cusrl_set_option(key.encode(), int(value)), f"cusrl_set_option({key!r}, {value})")
+
+
+def get_option(key: str) -> int:
+    value = c_int64()
+    check(lib().cusrl_get_option(key.encode(), ctypes.byref(value)), f"cusrl_get_option({key!r})")
+    return int(value.value)
+
+
+def _options_from_environment() -> None:
+    for variable, (key, mapping) in _ENVIRONMENT_OPTIONS.items():
+        text = os.environ.get(variable)
+        if text is None or text == "":
+            continue
+        try:
+            value = mapping[text] if mapping is not None else int(text)
+        except (KeyError, ValueError):
+            continue  # (an unknown value meant "the kernel's own rule" to the library, too)
+        if _lib.cusrl_set_option(key.encode(), value) != 0:
+            continue
 
 
 # Launch census: how often each C-ABI entry point was called through ``check`` (every ``ops`` function reports its

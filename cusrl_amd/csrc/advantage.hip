@@ -477,24 +477,21 @@ static bool gae_vec4(const float *reward, const float *value, const float *next_
 }
 
 // ---- launch shape of the at-scale scan (measured: profiles/r04/gae_policy.md)
-static int env_int(const char *name, int fallback) {
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : fallback;
-}
 // Cache policy by footprint.  While the six streams (21 B/slot) fit the 256 MB Infinity Cache the default policy is the
 // fastest; beyond it the inputs and `return` stream past the caches, and `advantage` — which the normalisation pass reads
 // right back — stays cached while it fits half of the Infinity Cache, else it streams too.
-// CUSRL_GAE_POLICY = 0 | 5 | 7 forces one of the three instantiated policies (A/B measurements, scripts/pmc_r04_cases.py).
+// cusrl_set_option("gae_policy", 1 + {0, 5, 7}) forces one of the three instantiated policies (A/B measurements,
+// scripts/pmc_r04_cases.py).
 static int gae_policy(int64_t slots) {
-    const int forced = env_int("CUSRL_GAE_POLICY", -1);
+    const int forced = int(option(kOptGaePolicy)) - 1;
     if (forced == 0 || forced == (kNtLoad | kNtRet) || forced == (kNtLoad | kNtAdv | kNtRet)) return forced;
     if (slots * 21 < (int64_t(256) << 20)) return 0;
     return slots * 4 <= (int64_t(128) << 20) ? (kNtLoad | kNtRet) : (kNtLoad | kNtAdv | kNtRet);
 }
 // 256-thread blocks while ONE resident wave of blocks covers the columns (<= 5 blocks per CU at ~100 VGPRs); beyond
-// that 128-thread blocks backfill at a finer grain (+8 % at 4 M envs).  CUSRL_GAE_BLOCK = 128 | 256 forces one.
+// that 128-thread blocks backfill at a finer grain (+8 % at 4 M envs).  cusrl_set_option("gae_block", 128 | 256) forces one.
 static int gae_block(int64_t columns) {
-    const int forced = env_int("CUSRL_GAE_BLOCK", 0);
+    const int forced = int(option(kOptGaeBlock));
     if (forced == 128 || forced == 256) return forced;
     return ceil_div(columns / 4, 256) <= 5 * 256 ? 256 : 128;
 }

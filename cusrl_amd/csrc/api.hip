@@ -1,7 +1,53 @@
 // ABI bookkeeping for libcusrl_hip.so.
 #include "common.hpp"
 
+#include <atomic>
+#include <string.h>
+
 extern "C" int cusrl_abi_version(void) { return CUSRL_ABI_VERSION; }
+
+// ---- options: what rounds 2-5 read from CUSRL_* environment variables INSIDE the launch entry points ----------------------
+namespace cusrl {
+static std::atomic<int64_t> g_options[kNumOptions];
+static const char *const kOptionNames[kNumOptions] = {"gae_policy", "gae_block", "loss_policy", "push_policy",
+                                                      "colsum_rows", "head_rows", "gru_bias_rows"};
+int64_t option(Option which) { return g_options[which].load(std::memory_order_relaxed); }
+
+static bool option_accepts(int which, int64_t value) {
+    if (value == 0) return true;  // back to the kernel's own rule
+    switch (which) {
+        case kOptGaePolicy: return value == 1 || value == 6 || value == 8;  // 1 + {0, 5, 7}
+        case kOptGaeBlock: return value == 128 || value == 256;
+        case kOptLossPolicy:
+        case kOptPushPolicy: return value == 1 || value == 2;
+        case kOptColsumRows: return value >= 4 && value <= 4096;
+        case kOptHeadRows: return value >= 8 && value <= 4096;
+        case kOptGruBiasRows: return value == 4 || value == 8 || value == 16 || value == 32;
+        default: return false;
+    }
+}
+}  // namespace cusrl
+
+extern "C" int cusrl_set_option(const char *key, int64_t value) {
+    if (!key) return CUSRL_E_INVALID;
+    for (int k = 0; k < cusrl::kNumOptions; ++k)
+        if (strcmp(key, cusrl::kOptionNames[k]) == 0) {
+            if (!cusrl::option_accepts(k, value)) return CUSRL_E_UNSUPPORTED;
+            cusrl::g_options[k].store(value, std::memory_order_relaxed);
+            return 0;
+        }
+    return CUSRL_E_INVALID;
+}
+
+extern "C" int cusrl_get_option(const char *key, int64_t *value_out) {
+    if (!key || !value_out) return CUSRL_E_INVALID;
+    for (int k = 0; k < cusrl::kNumOptions; ++k)
+        if (strcmp(key, cusrl::kOptionNames[k]) == 0) {
+            *value_out = cusrl::option(cusrl::Option(k));
+            return 0;
+        }
+    return CUSRL_E_INVALID;
+}
 
 extern "C" const char *cusrl_error_string(int code) {
     switch (code) {

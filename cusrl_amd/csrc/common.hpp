@@ -12,6 +12,20 @@ constexpr int kWave = 64;      // CDNA wavefront
 constexpr int kBlock = 256;    // 4 waves = one wave per SIMD of a CU
 constexpr int kWavesPerBlock = kBlock / kWave;
 
+// Launch-shape / cache-policy overrides (cusrl_set_option, include/cusrl_hip.h): 0 everywhere = every kernel chooses by its
+// own measured rule.  Set by the host through the C ABI — never read from the process environment inside a launch entry point.
+enum Option {
+    kOptGaePolicy,    // gae_policy    1 + {0, 5, 7}: force that cache policy of the scan (0: by footprint)
+    kOptGaeBlock,     // gae_block     128 | 256 threads per block (0: by column count)
+    kOptLossPolicy,   // loss_policy   1: default cache policy, 2: non-temporal [B, A] streams (0: by footprint)
+    kOptPushPolicy,   // push_policy   1: default cache policy, 2: streaming (0: by footprint)
+    kOptColsumRows,   // colsum_rows   rows per block of the mask + column-sum pass (0: 64)
+    kOptHeadRows,     // head_rows     rows per block of the narrow-head backward (0: 96)
+    kOptGruBiasRows,  // gru_bias_rows rows per partial row of the GRU bias gradients, 4 | 8 | 16 | 32 (0: 16)
+    kNumOptions
+};
+int64_t option(Option which);  // api.hip
+
 inline int launch_status() {
     hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : static_cast<int>(err);

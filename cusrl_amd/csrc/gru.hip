@@ -162,12 +162,8 @@ __global__ __launch_bounds__(kBlock) void gru_gates_bwd_kernel(float *__restrict
 // iteration) by 2 x 17 MB of partial rows.  Fixed summation order (deterministic).
 constexpr int kBiasRowsDefault = 16;
 static int bias_rows() {
-    static const int rows = [] {
-        const char *v = getenv("CUSRL_GRU_BIAS_ROWS");
-        const int r = v && *v ? atoi(v) : kBiasRowsDefault;
-        return (r == 4 || r == 8 || r == 16 || r == 32) ? r : kBiasRowsDefault;
-    }();
-    return rows;
+    const int r = int(option(kOptGruBiasRows));  // cusrl_set_option("gru_bias_rows", 4 | 8 | 16 | 32)
+    return (r == 4 || r == 8 || r == 16 || r == 32) ? r : kBiasRowsDefault;
 }
 
 template <typename V>

@@ -7,14 +7,10 @@
 
 namespace cusrl {
 
-// rows of the matrix one block reduces (64: 24576 rows -> 384 blocks); CUSRL_COLSUM_ROWS overrides it for sweeps
+// rows of the matrix one block reduces (64: 24576 rows -> 384 blocks); cusrl_set_option("colsum_rows", n) overrides it for sweeps
 static int col_rows_per_block() {
-    static const int rows = [] {
-        const char *e = getenv("CUSRL_COLSUM_ROWS");
-        const int v = e ? atoi(e) : 0;
-        return v >= 4 && v <= 4096 ? v : 64;
-    }();
-    return rows;
+    const int v = int(option(kOptColsumRows));
+    return v >= 4 && v <= 4096 ? v : 64;
 }
 constexpr int kColBatch = 4;          // row passes whose loads are issued together
 

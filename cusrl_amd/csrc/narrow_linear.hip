@@ -11,15 +11,11 @@
 
 namespace cusrl {
 
-// rows of the minibatch one block reduces: 96 -> a 24576-row minibatch is 256 blocks, one per CU (CUSRL_HEAD_ROWS overrides
-// it for sweeps: profiles/r04/narrow_head_rows.txt)
+// rows of the minibatch one block reduces: 96 -> a 24576-row minibatch is 256 blocks, one per CU (cusrl_set_option("head_rows", n)
+// overrides it for sweeps: profiles/r04/narrow_head_rows.txt)
 static int head_rows_per_block() {
-    static const int rows = [] {
-        const char *e = getenv("CUSRL_HEAD_ROWS");
-        const int v = e ? atoi(e) : 0;
-        return v >= 8 && v <= 4096 ? v : 96;
-    }();
-    return rows;
+    const int v = int(option(kOptHeadRows));
+    return v >= 8 && v <= 4096 ? v : 96;
 }
 constexpr int head_batch(int O) { return O > 8 ? 2 : 4; }  // X rows in flight per lane (VGPR budget: O x 12 + ...)
 constexpr int kHeadBiasPad = 16;  // db rides behind dW in the same partial row, padded to keep float4 alignment

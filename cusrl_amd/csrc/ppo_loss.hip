@@ -806,39 +806,28 @@ extern "C" int cusrl_ppo_loss_categorical_fwd_bwd(const float *advantage, const 
     return launch_finalize(partials, blocks, B, A, D, p, losses_out, nullptr, nullptr, s);
 }
 
-#define CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, FULL, WAVE_ROWS, STREAM)                                                     \
-    hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, VEC, FULL, WAVE_ROWS, STREAM>), dim3(uint32_t(blocks)), dim3(kBlock), \
-                       0, s, advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out,     \
-                       entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials,            \
-                       int(defer))
-// (the streaming policy exists for the training step's launch, kFull)
-#define CUSRL_LAUNCH_ROWGROUP_FULL(LPR, VEC, WAVE_ROWS)                                                                \
-    if (full && streaming) CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, true, WAVE_ROWS, true);                                  \
-    else if (full) CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, true, WAVE_ROWS, false);                                         \
-    else CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, false, WAVE_ROWS, false)
+// The instantiated forms (round 6: what measured slower or neutral in rounds 4-5 is no longer compiled — the per-round scalar
+// streams, kWaveRows = false, profiles/r05/loss_layout_ab.txt): the scalar streams of a wave's rows always move as one access
+// per stream; the training step's launch (kFull) exists with and without the non-temporal [B, A] streams.
+#define CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, FULL, STREAM)                                                                \
+    hipLaunchKernelGGL((ppo_loss_rowgroup_kernel<LPR, VEC, FULL, true, STREAM>), dim3(uint32_t(blocks)), dim3(kBlock), 0, s, \
+                       advantage, old_logp, action, mean, std, ret, curr_value, old_value, B, int(D), p, logp_out,          \
+                       entropy_out, logp_ratio_out, ratio_out, d_mean, d_std, d_value, partials, d_std_partials, int(defer))
+#define CUSRL_LAUNCH_ROWGROUP_FULL(LPR, VEC)                                                                            \
+    if (full && streaming) CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, true, true);                                              \
+    else if (full) CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, true, false);                                                     \
+    else CUSRL_LAUNCH_ROWGROUP_AS(LPR, VEC, false, false)
 #define CUSRL_LAUNCH_ROWGROUP(LPR)                                                                                     \
-    if (std_vector && wave_rows) { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, true, true); }                                      \
-    else if (std_vector) { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, true, false); }                                             \
-    else if (wave_rows) { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, false, true); }                                              \
-    else { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, false, false); }
+    if (std_vector) { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, true); }                                                         \
+    else { CUSRL_LAUNCH_ROWGROUP_FULL(LPR, false); }
 
 // Cache policy by footprint, like the GAE scan's (advantage.hip): while the launch's bytes fit the 256 MB Infinity Cache the
 // default policy is the fastest (config 2's in-step launch moves 4.4 MB out of L2); beyond it the [B, A] streams go past the
-// caches.  CUSRL_LOSS_POLICY = 0 | 1 forces one (A/B measurements).
+// caches.  cusrl_set_option("loss_policy", 1 | 2) forces the default / the streaming form (A/B measurements).
 static bool loss_streaming(int64_t B, int64_t A, int64_t D, bool std_vector) {
-    if (const char *e = getenv("CUSRL_LOSS_POLICY")) {
-        if (e[0] == '0') return false;
-        if (e[0] == '1') return true;
-    }
+    if (const int64_t forced = option(kOptLossPolicy)) return forced == 2;
     const int64_t per_row = 8 + (std_vector ? 8 : 12) * A + 8 * D + (std_vector ? 4 : 8) * A + 4 * D + 16;
     return B * per_row > (int64_t(256) << 20);
-}
-
-// the scalar streams of a wave's rows as one access per stream (kWaveRows); CUSRL_LOSS_WAVE_ROWS=0 keeps round 3's
-// one-access-per-round form for A/B runs
-static bool loss_wave_rows() {
-    const char *e = getenv("CUSRL_LOSS_WAVE_ROWS");  // (read per call: the A/B scripts flip it inside one process)
-    return !(e && e[0] == '0');
 }
 
 extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_logp, const float *action,
@@ -868,7 +857,6 @@ extern "C" int cusrl_ppo_loss_fwd_bwd(const float *advantage, const float *old_l
     if (blocks > INT32_MAX) return CUSRL_E_UNSUPPORTED;
     // the training step wants every output: that variant carries no per-store pointer tests
     const bool full = logp_out && entropy_out && logp_ratio_out && ratio_out && d_mean && (d_value || D == 0) && (std_vector || d_std);
-    const bool wave_rows = loss_wave_rows();
     const bool streaming = loss_streaming(B, A, D, std_vector);
     if (chunked) {
         switch (A / 4) {

@@ -106,10 +106,11 @@ __global__ __launch_bounds__(kBlock) void push_kernel(const PushTable tab) {
 }
 
 // a step whose read + written bytes do not fit the 256 MB Infinity Cache streams past the caches (0.72 -> 0.79 of the
-// roofline at 1 M envs, profiles/r04/push_policy.txt); CUSRL_PUSH_POLICY = 0 | 3 forces one form (A/B measurements)
+// roofline at 1 M envs, profiles/r04/push_policy.txt); cusrl_set_option("push_policy", 1 | 2) forces the default / the
+// streaming form (A/B measurements)
 inline bool push_streams(int64_t step_bytes) {
-    const char *forced = getenv("CUSRL_PUSH_POLICY");
-    return forced && *forced ? atoi(forced) == 3 : 2 * step_bytes >= (int64_t(256) << 20);
+    const int64_t forced = option(kOptPushPolicy);
+    return forced ? forced == 2 : 2 * step_bytes >= (int64_t(256) << 20);
 }
 
 // Fills `tab` from the caller's field list (validation included); `skip` = index of a field that is NOT to be copied (the

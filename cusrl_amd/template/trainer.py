@@ -104,20 +104,37 @@ class EnvironmentStats:
             self._reward_sum.zero_()
         self.num_steps = 0
 
+    def stage_means(self, metrics) -> None:
+        """Have the device-side statistics travel to the host in the copy ``metrics`` makes when it is next read
+        (``Metrics.defer``): :meth:`means` then costs no host round trip of its own.  Call when the rollout's launches are in."""
+        if self.on_device:
+            self._staged = None
+            steps = self.num_steps
+
+            def keep(values):
+                self._staged = (values, steps)
+
+            metrics.defer(self._snapshot(), keep)
+
+    def _snapshot(self) -> torch.Tensor:
+        return torch.cat((self._episodes_dev[self._parity].reshape(1).double(), self._reward_sum,
+                          self.rew_buffer.reshape(-1).double(), self.len_buffer.reshape(-1).double()))
+
     def means(self):
         """``(mean_episode_length, mean_episode_reward, mean_step_reward)`` — what the three properties below give — from ONE
         host copy when the statistics live on the device (the properties cost a reduction launch and a synchronising ``item()``
-        each, the episode count two more: five host round trips at the end of every iteration with an idle device behind them)."""
+        each, the episode count two more: five host round trips at the end of every iteration with an idle device behind them);
+        from no copy of its own when :meth:`stage_means` sent the values along with the agent's metrics."""
         if not self.on_device:
             return self.mean_episode_length, self.mean_episode_reward, self.mean_step_reward
         import numpy as np
 
         D, R = self.reward_dim, self.buffer_size
-        flat = torch.cat((self._episodes_dev[self._parity].reshape(1).double(), self._reward_sum,
-                          self.rew_buffer.reshape(-1).double(), self.len_buffer.reshape(-1).double())).tolist()
+        staged, self._staged = getattr(self, "_staged", None), None
+        flat, num_steps = staged if staged is not None else (self._snapshot().tolist(), self.num_steps)
         count = min(int(flat[0]), R)
         step = np.asarray(flat[1 : 1 + D], dtype=np.float64) / self.num_envs
-        step = (step.astype(np.float32) / np.float32(self.num_steps)) if self.num_steps else step.astype(np.float32)
+        step = (step.astype(np.float32) / np.float32(num_steps)) if num_steps else step.astype(np.float32)
         rewards = np.asarray(flat[1 + D : 1 + D + R * D], dtype=np.float32).reshape(R, D)
         lengths = np.asarray(flat[1 + D + R * D :], dtype=np.float32)
         if count == 0:
@@ -245,6 +262,8 @@ class Trainer:
             observation, state = self._rollout_captured(graphed, observation, state)
         else:
             observation, state = self._rollout_eager(observation, state)
+        if hasattr(agent, "metrics"):
+            self.stats.stage_means(agent.metrics)  # read with the update's metrics: one host copy for both
         with timer.record("agent"):
             agent_info = agent.update()
         self._log_info(agent_info)

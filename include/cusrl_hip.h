@@ -46,6 +46,24 @@ int cusrl_abi_version(void);
 /* Human-readable text for a return code (host string, static storage). */
 const char *cusrl_error_string(int code);
 
+/* Launch-shape and cache-policy overrides (ABI 6).  Every kernel chooses its launch shape and cache policy by a measured rule
+ * of its own (footprint against the 256 MB Infinity Cache, rows per block); these exist for A/B measurements and sweeps.  Up
+ * to ABI 5 the library read them from CUSRL_* environment variables inside the launch entry points — invisible to a caller
+ * binding this header; now they are part of it, and the only environment variable the library itself reads is
+ * CUSRL_RCCL_LIBRARY (where to find RCCL, cusrl_comm_*).  value 0 = back to the kernel's own rule.
+ *   "gae_policy"    1 + {0, 5, 7}: cache policy of cusrl_gae's scan (bit 0 non-temporal loads, bit 1 `advantage`, bit 2 `return`)
+ *   "gae_block"     128 | 256 threads per block of the scan
+ *   "loss_policy"   1 default policy | 2 non-temporal [B, A] streams in cusrl_ppo_loss_fwd_bwd
+ *   "push_policy"   1 default policy | 2 streaming in cusrl_buffer_push*
+ *   "colsum_rows"   rows per block of cusrl_relu_bwd_colsum (4 .. 4096)
+ *   "head_rows"     rows per block of cusrl_narrow_linear_bwd (8 .. 4096)
+ *   "gru_bias_rows" rows per partial row of cusrl_gru_gates_bwd_bias (4 | 8 | 16 | 32)
+ * Returns 0, CUSRL_E_INVALID for an unknown key, CUSRL_E_UNSUPPORTED for a value outside the list.  Host-side, thread-safe
+ * (relaxed atomics); takes effect at the next launch.  Every setting changes how bytes move, never a result bit
+ * (tests/test_hip_kernels.py: *_every_cache_policy_*, *_cache_policies_change_no_bit). */
+int cusrl_set_option(const char *key, int64_t value);
+int cusrl_get_option(const char *key, int64_t *value_out);
+
 /* Node census of a captured hipGraph (`graph` = hipGraph_t): a host-side walk, no launch, no stream.  The reference's
  * `compile=True` (cusrl/template/actor_critic.py:217-220) hands its loops to torch.compile; here they are hipGraphs, and
  * what a captured step is made of is checkable: type_counts[k] (HOST, n_types entries) = number of nodes of

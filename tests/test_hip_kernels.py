@@ -23,6 +23,24 @@ def ops():
     return _ops
 
 
+@pytest.fixture
+def option():
+    """``option(key, value)``: ``cusrl_set_option`` for the duration of the test (every key it touched goes back to 0 — the kernel's
+    own rule — afterwards)."""
+    from cusrl_amd import _native
+
+    touched = []
+
+    def set_(key, value):
+        touched.append(key)
+        _native.set_option(key, value)
+        assert _native.get_option(key) == value
+
+    yield set_
+    for key in touched:
+        _native.set_option(key, 0)
+
+
 def dev(x):
     return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
 
@@ -519,15 +537,15 @@ def test_gae_bit_exact_vs_oracle(ops, T, N, D, lamda_value):
 
 @pytest.mark.parametrize("policy,block", [("0", "256"), ("5", "256"), ("7", "128"), ("5", "128"), ("7", "256")])
 @pytest.mark.parametrize("lamda_value", [None, 0.9])
-def test_gae_every_cache_policy_and_block_size_is_bit_exact(ops, monkeypatch, policy, block, lamda_value):
+def test_gae_every_cache_policy_and_block_size_is_bit_exact(ops, option, policy, block, lamda_value):
     """The at-scale launch shapes of round 4 (cusrl_gae: cache policy per stream x block size, profiles/r04/gae_policy.md)
     forced one by one on a rollout large enough to take the 4-columns-per-lane path: a cache policy must not change a bit."""
     T, N = 6, 262144 + 4 * 37  # >= 4 * 256 * 256 columns, not a multiple of a block
     rng = np.random.default_rng(int(policy) * 7 + int(block))
     reward, value, nv = (rng.standard_normal((T, N, 1)).astype(np.float32) for _ in range(3))
     done = rng.random((T, N, 1)) < 0.05
-    monkeypatch.setenv("CUSRL_GAE_POLICY", policy)
-    monkeypatch.setenv("CUSRL_GAE_BLOCK", block)
+    option("gae_policy", 1 + int(policy))  # (through the C ABI: cusrl_set_option — the library reads no environment variable)
+    option("gae_block", int(block))
     adv, ret, partials = ops.gae(dev(reward), dev(value), dev(nv), dev(done), 0.99, 0.95, lamda_value)
     oadv, oret = oracle.gae(reward, done, value, nv, 0.99, 0.95, lamda_value)
     assert np.array_equal(host(adv), oadv) and np.array_equal(host(ret), oret)
@@ -549,10 +567,10 @@ def test_gae_beyond_the_infinity_cache_takes_the_streaming_policy_and_stays_bit_
 
 
 @pytest.mark.parametrize("policy", ["0", "3"])
-def test_push_streaming_policy_moves_the_same_bytes(ops, monkeypatch, policy):
+def test_push_streaming_policy_moves_the_same_bytes(ops, option, policy):
     """cusrl_buffer_push with the non-temporal form forced (it is chosen by footprint beyond the Infinity Cache) against the
     oracle's slab assignment: every leaf, mixed widths, an unaligned one."""
-    monkeypatch.setenv("CUSRL_PUSH_POLICY", policy)
+    option("push_policy", 2 if policy == "3" else 1)
     rng = np.random.default_rng(int(policy))
     N, T = 5000, 3
     steps = {"observation": rng.standard_normal((N, 48)).astype(np.float32), "action": rng.standard_normal((N, 12)).astype(np.float32),
@@ -1287,13 +1305,12 @@ def test_ppo_loss_std_vector_equals_repeated_matrix(ops, B, A, D, vclip):
 
 @pytest.mark.parametrize("A", [4, 12, 16, 32])
 @pytest.mark.parametrize("form", ["std_vector", "std_matrix"])
-def test_ppo_loss_layouts_and_cache_policies_change_no_bit(ops, form, A, monkeypatch):
-    """The objective's launch variants of round 5 — per-row scalar streams moved once per wave or once per round
-    (CUSRL_LOSS_WAVE_ROWS), the [B, A] streams with the non-temporal hint (the footprint policy's choice beyond the Infinity
-    Cache, forced here with CUSRL_LOSS_POLICY=1) — move the same bytes through the same arithmetic: every per-sample output and
-    gradient bit-identical across the four combinations at a ragged batch size (a partial last block, a partial last wave);
-    the two scalar-stream layouts sum the loss terms in different lane orders, so the seven loss scalars agree to fp32
-    rounding.  (The default combination is what the golden / oracle tests above hold to the reference.)"""
+def test_ppo_loss_cache_policies_change_no_bit(ops, form, A, option):
+    """The objective's two shipped launch forms — default cache policy, and the [B, A] streams with the non-temporal hint (the
+    footprint rule's choice beyond the Infinity Cache, forced here through ``cusrl_set_option("loss_policy", ...)``) — move the
+    same bytes through the same arithmetic: every output bit-identical at a ragged batch size (a partial last block, a partial
+    last wave).  (Round 5's second scalar-stream layout, measured neutral, is no longer compiled; the default form is what the
+    golden / oracle tests above hold to the reference.)"""
     rng = np.random.default_rng(31 + A)
     B, D = 24576 + 37, 1
     f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
@@ -1307,20 +1324,26 @@ def test_ppo_loss_layouts_and_cache_policies_change_no_bit(ops, form, A, monkeyp
     args = tuple(dev(x) for x in (adv, old_logp, action, mean, std, ret, curr_value, old_value))
     kw = dict(clip=0.2, value_clip=0.2, w_sur=1.0, w_val=0.5, w_ent=0.01)
     results = {}
-    for wave_rows in ("1", "0"):
-        for policy in ("0", "1"):
-            monkeypatch.setenv("CUSRL_LOSS_WAVE_ROWS", wave_rows)
-            monkeypatch.setenv("CUSRL_LOSS_POLICY", policy)
-            results[wave_rows, policy] = ops.ppo_loss_fwd_bwd(*args, **kw)
-    base = results["1", "0"]
-    for key, other in results.items():
-        for name in ("logp", "entropy", "ratio", "logp_ratio", "d_mean", "d_value") + (("d_std",) if form == "std_matrix" else ()):
-            assert torch.equal(other[name], base[name]), (key, name)
-        if key[0] == "1":  # same lane order of the sums: bit-identical scalars and std-vector gradient
-            assert torch.equal(other["losses"], base["losses"]) and torch.equal(other["d_std"], base["d_std"]), key
-        else:
-            torch.testing.assert_close(other["losses"], base["losses"], rtol=2e-6, atol=1e-7)
-            torch.testing.assert_close(other["d_std"], base["d_std"], rtol=1e-5, atol=1e-5 * float(base["d_std"].abs().max()))
+    for policy in (1, 2):
+        option("loss_policy", policy)
+        results[policy] = ops.ppo_loss_fwd_bwd(*args, **kw)
+    for name in ("logp", "entropy", "ratio", "logp_ratio", "d_mean", "d_value", "d_std", "losses"):
+        assert torch.equal(results[2][name], results[1][name]), name
+
+
+def test_options_are_validated_and_readable(ops):
+    from cusrl_amd import _native
+
+    lib = _native.lib()
+    assert lib.cusrl_set_option(b"no_such_option", 1) == -1 and lib.cusrl_set_option(None, 1) == -1
+    assert lib.cusrl_set_option(b"gae_block", 100) == -3 and lib.cusrl_set_option(b"loss_policy", 3) == -3
+    assert lib.cusrl_set_option(b"gru_bias_rows", 5) == -3 and lib.cusrl_set_option(b"colsum_rows", 2) == -3
+    for key, value in (("gae_policy", 6), ("gae_block", 128), ("loss_policy", 2), ("push_policy", 1), ("colsum_rows", 32),
+                       ("head_rows", 64), ("gru_bias_rows", 8)):
+        _native.set_option(key, value)
+        assert _native.get_option(key) == value
+        _native.set_option(key, 0)
+        assert _native.get_option(key) == 0
 
 
 @pytest.mark.parametrize("form", ["std_vector", "std_matrix", "categorical"])
