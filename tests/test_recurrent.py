@@ -494,3 +494,116 @@ def test_fused_rnn_matches_nn_rnn_forward_and_backward(nonlinearity, L, B, I, H,
                                              None if lengths is None else lengths.numpy(), relu=nonlinearity == "relu")
         np.testing.assert_allclose(results[1][0].cpu().numpy(), ref_out, rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(results[1][1].cpu().numpy(), ref_h, rtol=1e-5, atol=2e-6)
+
+
+def _gru_float64(x, done, memory0, params, prefix, layers, hidden):
+    """A stacked GRU over ``x [T, n, C]`` in float64 with torch.nn.GRU's cell equations (gate rows r, z, n), one env column at a
+    time step: the memory ``[n, layers * hidden]`` of an env restarts from zero behind every step at which its episode ended
+    (cusrl/nn/module/rnn.py:206-253: the done-split layout gives every later segment a zero memory).  Returns the top layer's
+    outputs ``[T, n, hidden]``."""
+    T, n = x.shape[:2]
+    state = [memory0[:, k * hidden:(k + 1) * hidden] for k in range(layers)]
+    outputs = []
+    for t in range(T):
+        below = x[t]
+        for k in range(layers):
+            w_ih, w_hh = params[f"{prefix}.weight_ih_l{k}"], params[f"{prefix}.weight_hh_l{k}"]
+            gi = below @ w_ih.t() + params[f"{prefix}.bias_ih_l{k}"]
+            gh = state[k] @ w_hh.t() + params[f"{prefix}.bias_hh_l{k}"]
+            r = torch.sigmoid(gi[:, :hidden] + gh[:, :hidden])
+            z = torch.sigmoid(gi[:, hidden:2 * hidden] + gh[:, hidden:2 * hidden])
+            cand = torch.tanh(gi[:, 2 * hidden:] + r * gh[:, 2 * hidden:])
+            below = state[k] = (1 - z) * cand + z * state[k]
+        outputs.append(below)
+        keep = (~done[t]).to(x.dtype)  # [n, 1]
+        state = [s * keep for s in state]
+    return torch.stack(outputs)
+
+
+@pytest.mark.gpu
+def test_recurrent_minibatch_steps_match_float64_autograd(gradient_parity):
+    """The BPTT minibatch step of a GRU agent (BASELINE config 4's path: temporal minibatches, done-split sequences, the fused GRU
+    cores, the one-launch objective, the flat gradient assembly) against an INDEPENDENT float64 evaluation, on every optimizer
+    step of 10 iterations (>= 32 steps): the flat gradient buffer behind each step is d(value + surrogate + entropy loss) /
+    d(parameters) at the parameters the step started from, recomputed here with a hand-written float64 GRU (torch.nn.GRU's
+    equations, memories restarting at episode ends), the formulas of cusrl/hook/on_policy/ppo.py:10-18, value.py:121-137,
+    nn/module/distribution.py:207-213 and plain autograd.  Weights: 1e-5 of the tensor's largest entry; biases / the std vector:
+    1e-5 of the summed magnitudes of each element's own per-row terms.  (Recurrent minibatch steps are not captured — dynamic
+    sequence counts — so this is a correctness soak of the eager path, the recurrent twin of tests/test_captured_step_soak.py.)"""
+    import math
+
+    from cusrl_amd.template.actor_critic import ActorCritic
+
+    cusrl.config.set_device(DEV)
+    cusrl.set_global_seed(9)
+    N, T, H, actor_layers, critic_layers = 64, 8, 32, 2, 1
+    factory = cusrl.preset.RecurrentPpoAgentFactory(
+        rnn_type="GRU", actor_num_layers=actor_layers, actor_hidden_size=H, critic_num_layers=critic_layers, critic_hidden_size=H,
+        num_steps_per_update=T, sampler_epochs=2, sampler_mini_batches=2, optimizer_kwargs={"capturable": True, "fused": True})
+    env = cusrl.testing.DummyTorchEnvironment(num_instances=N, observation_dim=10, action_dim=4, device=DEV)
+    trainer = cusrl.Trainer(env, factory, num_iterations=10, verbose=False)
+    agent = trainer.agent
+    flat = agent.flat_gradients
+    assert flat is not None and agent.flat_optimizer is not None
+    names = {id(p): name for name, p in agent.named_parameters()}
+    windows = [(names[id(p)], offset, p.numel()) for p, offset in zip(flat.params, flat.offsets)]
+    record = {"steps": 0, "worst": {}, "segments": 0, "near_clip": 0}
+    original = ActorCritic._train_step
+
+    def train_step(self, metadata, batch):
+        assert metadata["temporal"] is True
+        before = {name: p.detach().double().clone().requires_grad_(True) for name, p in self.named_parameters()}
+        f64 = lambda key: batch[key].double()  # noqa: E731
+        obs, action, old_logp, advantage, ret = f64("observation"), f64("action"), f64("action_logp"), f64("advantage"), f64("return")
+        done = batch["done"].clone()
+        actor_memory, critic_memory = batch["actor_memory"][0].double(), batch["critic_memory"][0].double()
+        record["segments"] += int(done[:-1].sum())
+        original(self, metadata, batch)
+        torch.cuda.synchronize()
+        mine = flat.buffer.clone()
+        summed = {}
+        latent = _gru_float64(obs, done, actor_memory, before, "actor.backbone.rnn", actor_layers, H)
+        mean = summed["actor.distribution.mean_head.bias"] = (
+            latent @ before["actor.distribution.mean_head.weight"].t() + before["actor.distribution.mean_head.bias"])
+        std = summed["actor.distribution.std.param"] = before["actor.distribution.std.param"].expand_as(mean)
+        logp = (-((action - mean) ** 2) / (2 * std**2) - std.log() - math.log(math.sqrt(2 * math.pi))).sum(-1, keepdim=True)
+        entropy = (0.5 + 0.5 * math.log(2 * math.pi) + std.log()).sum(-1, keepdim=True)
+        ratio = (logp - old_logp).exp()
+        hooks = self.hook
+        surrogate, value_hook, entropy_hook = hooks["ppo_surrogate_loss"], hooks["value_loss"], hooks["entropy_loss"]
+        lo = float(torch.tensor(1.0 - surrogate.clip_ratio, dtype=torch.float32))
+        hi = float(torch.tensor(1.0 + surrogate.clip_ratio, dtype=torch.float32))
+        loss = -torch.min(advantage * ratio, advantage * ratio.clamp(lo, hi)).mean() * surrogate.weight
+        value_latent = _gru_float64(obs, done, critic_memory, before, "critic.backbone.rnn", critic_layers, H)
+        value = summed["critic.value_head.bias"] = value_latent @ before["critic.value_head.weight"].t() + before["critic.value_head.bias"]
+        loss = loss + (value - ret).square().mean() * value_hook.weight - entropy.mean() * entropy_hook.weight
+        wanted = list(before)
+        grads = torch.autograd.grad(loss, [before[name] for name in wanted] + list(summed.values()), allow_unused=True)
+        reference = {name: (g if g is not None else torch.zeros_like(before[name])) for name, g in zip(wanted, grads)}
+        magnitudes = {name: terms.abs().sum((0, 1)) for name, terms in zip(summed, grads[len(wanted):])}
+        margin = float(torch.minimum((ratio - lo).abs(), (ratio - hi).abs()).min().detach())
+        record["near_clip"] += margin < 1e-6
+        for name, offset, numel in windows:
+            got, want = mine[offset:offset + numel].double(), reference[name].reshape(-1)
+            if name in magnitudes:
+                error = float(((got - want).abs() / magnitudes[name].reshape(-1).clamp_min(1e-30)).max())
+            else:
+                error = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+            bound = 1e-5 if margin >= 1e-6 else 0.1  # (a ratio within fp32 noise of a clip bound may fall on either side)
+            assert error <= bound, f"step {record['steps']}: {name} off by {error:.3e}"
+            if margin >= 1e-6:
+                record["worst"][name] = max(record["worst"].get(name, 0.0), error)
+        record["steps"] += 1
+
+    ActorCritic._train_step = train_step
+    try:
+        trainer.run_training_loop()
+    finally:
+        ActorCritic._train_step = original
+    assert record["steps"] >= 32, record["steps"]
+    assert record["segments"] > 0  # episodes ended inside the minibatches: the memory restarts were exercised
+    assert record["near_clip"] <= 2
+    for name, error in record["worst"].items():
+        gradient_parity(f"recurrent_step_soak[{name}]", [1.0 + error], [1.0], 1e-5)
+    print(f"recurrent step soak: {record['steps']} optimizer steps, {record['segments']} episode ends inside minibatches, worst "
+          f"error {max(record['worst'].values()):.2e}")
