@@ -151,6 +151,7 @@ class ActorCritic(Agent):
         self._graphed_act = None
         self._graphed_steps: dict[tuple, Any] = {}
         self._graphed_epochs = None
+        self._branch_tail = None  # a callable GraphedEpochs wants issued at the tail of the running step's critic branch
         self._minibatches_done = None  # event behind the last minibatch step of the previous update (its index rows may be redrawn)
         self._graph_key_reads = 0
         self._graph_budget_warned = False
@@ -428,6 +429,11 @@ class ActorCritic(Agent):
                 with collect_split_weight_grads() as critic_slabs:
                     critic_grads = torch.autograd.grad([value_root], [flat.params[i] for i in critic_ids],
                                                        grad_outputs=[units[position]], allow_unused=True)
+                # the critic's branch ends before the actor's: work that depends on neither — the gather of the NEXT minibatch
+                # step's rows (template/graphs.py GraphedEpochs) — rides at its tail
+                tail, self._branch_tail = self._branch_tail, None
+                if tail is not None:
+                    tail()
             with collect_split_weight_grads() as split_slabs:
                 other_grads = torch.autograd.grad(others, [flat.params[i] for i in other_ids], grad_outputs=other_units,
                                                   allow_unused=True)

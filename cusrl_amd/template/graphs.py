@@ -456,9 +456,11 @@ class GraphedEpochs:
         self.signature: tuple | None = None
         self.enabled = epoch_graphs_enabled()
         self.replays = 0
-        # the gather of the next step's rows as a second branch of the running step (CUSRL_PREFETCH_GATHER=0: inside the step)
-        self.prefetch = os.environ.get("CUSRL_PREFETCH_GATHER", "1") != "0"
-        self.gather_stream = torch.cuda.Stream(device=agent.device) if self.prefetch else None
+        # the gather of the next step's rows ahead of that step.  CUSRL_PREFETCH_GATHER: "tail" (default) — at the tail of the
+        # running step's critic branch, which ends before the actor's (no third stream; compositions without the branch issue it
+        # behind the step); "side" — forked to a stream of its own at the start of the running step; "0" — inside the step
+        self.prefetch = os.environ.get("CUSRL_PREFETCH_GATHER", "tail")
+        self.gather_stream = torch.cuda.Stream(device=agent.device) if self.prefetch == "side" else None
         self.stores: dict[tuple, dict[str, torch.Tensor]] = {}
 
     def _steps_of(self, plan_row, permutations, epoch):
@@ -517,31 +519,40 @@ class GraphedEpochs:
     def _body(self, row):
         agent = self.agent
         main, side = torch.cuda.current_stream(), self.gather_stream
+        ahead_of_step = self.prefetch in ("side", "tail")
         # (the persistent batch tensors exist by now: `_allocate` ran outside the capture)
-        ahead = self._gather(row[0][0], row[0][2], 0) if side is not None else None
+        ahead = self._gather(row[0][0], row[0][2], 0) if ahead_of_step else None
         for k, (step, metadata, indices) in enumerate(row):
             saved = step.static_indices, step.metadata, step.preloaded
             step.static_indices = indices  # read in place
             step.metadata = TrackedMetadata(metadata, agent._metadata_reads)
-            step.preloaded, following = ahead, None
-            if side is not None and k + 1 < len(row):
-                # fork: the next step's rows, while this step runs (they depend on the buffer and the permutation only)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    following = self._gather(row[k + 1][0], row[k + 1][2], (k + 1) % 2)
+            step.preloaded = ahead
+            following: list = []
+            if ahead_of_step and k + 1 < len(row):
+                # the next step's rows depend on the buffer and the permutation only
+                fetch = lambda k=k: following.append(self._gather(row[k + 1][0], row[k + 1][2], (k + 1) % 2))  # noqa: E731
+                if side is not None:  # fork: on a stream of their own while this step runs
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        fetch()
+                else:  # at the tail of this step's critic branch (ActorCritic._backward calls it there, on that stream)
+                    agent._branch_tail = fetch
             try:
                 step._whole_step()
             finally:
                 step.static_indices, step.metadata, step.preloaded = saved
+                pending, agent._branch_tail = agent._branch_tail, None
             step.carry = {}
-            if following is not None:
+            if pending is not None:
+                pending()  # no critic branch in this composition: behind the step, on its stream
+            elif side is not None and following:
                 main.wait_stream(side)  # join, in front of the step that reads them
-            ahead = following
+            ahead = following[0] if following else None
 
     def _allocate(self, rows):
         """The persistent batch tensors of both parities, created OUTSIDE the capture (one throw-away gather per set: an
         allocation made while capturing would belong to the graph's private pool)."""
-        if self.gather_stream is None:
+        if self.prefetch not in ("side", "tail"):
             return
         for row in rows:
             for k, (step, _, indices) in enumerate(row):
