@@ -449,8 +449,8 @@ def _average_same_keys(info: dict[str, float]) -> dict[str, float] | None:
 
 def average_dict(info: dict[str, float]) -> dict[str, float]:
     """Rank-average every key that at least one rank reported (trainer.py:387)."""
-    if not configure_distributed():
-        return info
+    if not configure_distributed() or world_size() == 1:
+        return info  # (a process group of one: the mean over the ranks is the rank's own value — no collective, no host copy)
     if (averaged := _average_same_keys(info)) is not None:
         return averaged
     gathered = gather_obj(info)

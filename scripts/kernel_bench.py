@@ -167,9 +167,22 @@ def bench_size(N, T=24, obs=48, act=12, mbs=4, only=None, iters=None):
         v = dict(a, std=torch.rand(act, device=DEV) + 0.5)
         rows.measure(f"ppo loss fwd+bwd, std vector (B={B})", lambda: ops.ppo_loss_fwd_bwd(*v.values(), **kw), loss_bytes - B * 8 * act)
 
+        # round 6: what a captured step with the critic on its own stream launches instead — the surrogate + entropy terms
+        # without the value term (actor's stream) and the value term alone (critic's stream)
+        policy_only = dict(v, ret=None, curr_value=None, old_value=None)
+        rows.measure(f"ppo loss fwd+bwd, std vector, no value term (B={B})", lambda: ops.ppo_loss_fwd_bwd(*policy_only.values(), **kw),
+                     loss_bytes - B * 8 * act - B * 12)
+    rows.measure(f"value term fwd+bwd (B={B})",
+                 lambda: ops.value_loss_fwd_bwd(a["ret"], a["curr_value"], None, value_clip=None, w_val=0.5), B * 12)
+
     # ---- MLP backward epilogues and the optimizer-side kernels of one minibatch step
     g256, y256 = f(B, 256), torch.relu(f(B, 256))
     rows.measure(f"relu bwd + bias grad [B,256] (B={B})", lambda: ops.relu_backward_bias(g256, y256), B * 256 * 12)
+    # round 6: the bottom layer's whole backward (mask + bias gradient + weight gradient, nothing written back per row)
+    x_obs = f(B, obs)
+    if ops.input_layer_supported(g256, y256, x_obs, torch.empty(256, obs, device=DEV)):
+        rows.measure(f"input layer bwd [B,{obs}]x[B,256] (B={B})", lambda: ops.input_layer_backward(g256, y256, x_obs),
+                     B * 4 * (2 * 256 + obs))
     gm, gv, h2 = f(B, act), f(B, 1), f(B, 128)
     wm, wv = f(act, 128), f(1, 128)
     rows.measure(f"narrow head bwd 128->{act} (B={B})", lambda: ops.narrow_linear_backward(gm, h2, wm), B * 4 * (act + 256))
