@@ -173,6 +173,8 @@ class ValueComputation(Hook):
         scratch["head"].run(self.bootstrap_truncated_states, self.termination_value)
         if not self.bootstrap_truncated_states:
             return
+        if (idle := getattr(self.agent, "run_while_waiting", None)) is not None:
+            idle()  # (the region above is running: whatever the agent wants issued meanwhile goes out before the host blocks)
         k = counter.wait()
         if k == 0:
             return

@@ -152,6 +152,7 @@ class ActorCritic(Agent):
         self._graphed_steps: dict[tuple, Any] = {}
         self._graphed_epochs = None
         self._branch_tail = None  # a callable GraphedEpochs wants issued at the tail of the running step's critic branch
+        self._while_waiting = None  # host work to issue while a pre_update hook waits for the device (run_while_waiting)
         self._minibatches_done = None  # event behind the last minibatch step of the previous update (its index rows may be redrawn)
         self._graph_key_reads = 0
         self._graph_budget_warned = False
@@ -289,7 +290,18 @@ class ActorCritic(Agent):
         # know could draw from the generator inside pre_update (the reference draws the permutation behind it,
         # cusrl/sampler/mini_batch_sampler.py:56): none of this package's hooks does.
         early = self._draw_epochs(prepare=False) if self._draws_early() else None
-        self.hook.pre_update(self.buffer)  # a3-a6: next_value, GAE, advantage normalisation
+        if early is not None:
+            from cusrl_amd.template.graphs import epoch_graphs_mode
+
+            if epoch_graphs_mode() == "update":
+                # the whole-update graph needs EVERY epoch's permutation before it starts: the remaining draws are issued while
+                # the host has nothing to do — ValueComputation.pre_update waits for the truncated count of a region it has
+                # just launched (`run_while_waiting`) — and run under that region on the side stream
+                self._while_waiting = lambda: early.draw(len(early) - 1)
+        try:
+            self.hook.pre_update(self.buffer)  # a3-a6: next_value, GAE, advantage normalisation
+        finally:
+            self._while_waiting = None
         with self._training_mode():
             # (recurrent networks: dynamic sequence counts, not capturable; a hook's collective / host read-back stays out of capture)
             graphed = self._graphable()
@@ -343,6 +355,13 @@ class ActorCritic(Agent):
         self.hook.post_update()
         self.hook.apply_schedule(self.iteration + 1)
         return super().update()
+
+    def run_while_waiting(self) -> None:
+        """Called by a hook right before it blocks on a device result it has just launched the work for: host work that depends
+        on neither (here: drawing the later epochs' permutations) is issued now instead of behind the wait."""
+        pending, self._while_waiting = self._while_waiting, None
+        if pending is not None:
+            pending()
 
     def _graphable(self) -> bool:
         """Does this update's minibatch loop go through captured steps (``compile=True``, an index-yielding sampler, feed-forward

@@ -423,13 +423,19 @@ class GraphedTrainStep:
         return entries
 
 
-def epoch_graphs_enabled() -> bool:
-    """On by default since round 6 (``CUSRL_EPOCH_GRAPHS=0`` keeps one graph per minibatch step): round 4 measured this form
-    neutral (profiles/r04/bench_epoch_graphs_ab.txt) because the step-by-step loop was device-bound then; with one fork and one
-    join per step and the gather off the critical path the device needs less time per step than the HOST needs to issue one
+def epoch_graphs_mode() -> str:
+    """``"update"`` (default since round 6): ALL minibatch steps of an update replay from one hipGraph; ``"epoch"``
+    (``CUSRL_EPOCH_GRAPHS=1``): one graph per epoch; ``"off"`` (``=0``): one graph per minibatch step.  Round 4 measured the epoch
+    form neutral (profiles/r04/bench_epoch_graphs_ab.txt) because the step-by-step loop was device-bound then; with one fork and
+    one join per step and the gather off the critical path the device needs less time per step than the HOST needs to issue one
     (the replay of a two-branch 22-node graph costs the host ~80 us, the Python around it as much again:
-    profiles/r06/host_vs_device.txt), and what the device gained was lost to replays that arrive late."""
-    return os.environ.get("CUSRL_EPOCH_GRAPHS", "1") != "0"
+    profiles/r06/experiments/), and what the device gained was lost to replays that arrive late."""
+    value = os.environ.get("CUSRL_EPOCH_GRAPHS", "update")
+    return {"0": "off", "1": "epoch", "epoch": "epoch"}.get(value, "update")
+
+
+def epoch_graphs_enabled() -> bool:
+    return epoch_graphs_mode() != "off"
 
 
 class GraphedEpochs:
@@ -454,7 +460,8 @@ class GraphedEpochs:
         self.stream: torch.cuda.Stream = agent._graph_stream
         self.epochs: dict[tuple, dict] = {}
         self.signature: tuple | None = None
-        self.enabled = epoch_graphs_enabled()
+        self.mode = epoch_graphs_mode()
+        self.enabled = self.mode != "off"
         self.replays = 0
         # the gather of the next step's rows ahead of that step.  CUSRL_PREFETCH_GATHER: "tail" (default) — at the tail of the
         # running step's critic branch, which ends before the actor's (no third stream; compositions without the branch issue it
@@ -492,10 +499,19 @@ class GraphedEpochs:
         agent.buffer.prepare_sampling(hot)
         if agent.flat_optimizer is not None:
             agent.flat_optimizer.refresh()  # learning-rate changes reach the captured steps through device memory
-        for epoch, row in enumerate(rows):
-            key = (epoch, permutations.data_ptr(), tuple(id(step) for step, _, _ in row))
+        if self.mode == "update":
+            # ONE graph for the whole update: a replay boundary costs the device the time the host needs to enqueue the next
+            # graph's first packets (the first step of every epoch graph ran with its second branch tens of microseconds late),
+            # and with every permutation at hand the gather ahead of a step also crosses the epoch boundaries.  All permutations
+            # must have been drawn: they are issued while the host waits for pre_update's truncated count
+            # (ActorCritic._while_waiting), i.e. they run under pre_update's kernels.
+            groups = [(len(rows) - 1, [entry for row in rows for entry in row])]
+        else:
+            groups = list(enumerate(rows))
+        for last_epoch, row in groups:
+            key = (last_epoch, len(groups), permutations.data_ptr(), tuple(id(step) for step, _, _ in row))
             entry = self.epochs.get(key)
-            drawn.wait(epoch)  # this epoch's permutation has been drawn
+            drawn.wait(last_epoch)  # the permutations these steps read have been drawn
             if entry is None:
                 self._allocate([row])
                 entry = self.epochs[key] = {"capture": _Capture(agent)}
@@ -503,7 +519,7 @@ class GraphedEpochs:
             entry["capture"].replay()
             # the next epoch's permutation: issued behind this epoch's launch, so that the draw's dozen small launches run
             # under these steps (the host is free now) instead of in front of the update's first step
-            drawn.draw(epoch + 1)
+            drawn.draw(last_epoch + 1)
             for step, _, _ in row:
                 step.extra_replays += 1
         self.replays += 1

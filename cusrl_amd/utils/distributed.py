@@ -592,7 +592,10 @@ class FlatGradients:
         else:
             params, offsets = [self.params[i] for i in subset], [self.offsets[i] for i in subset]
             mine = {p.data_ptr() for p in params}
-            for key in [key for key in (split_slabs or {}) if key not in mine]:
+            others = {p.data_ptr() for p in self.params} - mine
+            # slabs of the OTHER windows' parameters (a loss node both passes share hands the std vector's over in each) are
+            # that pass's business; a key that belongs to no optimizer parameter at all stays and raises below
+            for key in [key for key in (split_slabs or {}) if key in others]:
                 del split_slabs[key]
         # parameters autograd returned no gradient for (unused this step): torch's optimizers skip them; the flat Adam
         # step reads this list and leaves their windows untouched (utils/flat_optimizer.py)

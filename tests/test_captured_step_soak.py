@@ -333,7 +333,7 @@ def test_epoch_graphs_change_no_bit(cusrl, kind, rows, monkeypatch):
     every buffer leaf and the last flat gradient bit-identical between the two; and the epoch graphs really ran."""
     N, T, minibatches, epochs, obs_dim, act_dim, _ = SIZES[rows]
     finals = []
-    for epoch_graphs in ("1", "0"):
+    for epoch_graphs in ("update", "1", "0"):
         monkeypatch.setenv("CUSRL_EPOCH_GRAPHS", epoch_graphs)
         cusrl.set_global_seed(57)
         env = cusrl.testing.DummyTorchEnvironment(num_instances=N, observation_dim=obs_dim, action_dim=act_dim, device=DEV)
@@ -342,10 +342,11 @@ def test_epoch_graphs_change_no_bit(cusrl, kind, rows, monkeypatch):
         torch.cuda.synchronize()
         agent = trainer.agent
         graphed = agent._graphed_epochs
-        if epoch_graphs == "1" and not any(h.objective_draws_random for h in agent.hook if h.active):
+        if epoch_graphs != "0" and not any(h.objective_draws_random for h in agent.hook if h.active):
             # (AMP draws random numbers inside its objective: the sampler then keeps the reference's interleaving of draws, no
             # up-front permutations, and the update steps graph by graph)
-            assert graphed is not None and graphed.replays >= 4 and len(graphed.epochs) == epochs, (graphed and graphed.replays)
+            # (one graph per update by default, one per epoch with CUSRL_EPOCH_GRAPHS=1)
+            assert graphed is not None and graphed.replays >= 4 and len(graphed.epochs) in (1, epochs), (graphed and graphed.replays)
             for entry in graphed.epochs.values():
                 assert entry["capture"].census["memset"] == 0
         if epoch_graphs == "0":
@@ -355,5 +356,6 @@ def test_epoch_graphs_change_no_bit(cusrl, kind, rows, monkeypatch):
         state["grad"] = agent.flat_gradients.buffer.clone()
         state["metrics"] = {}
         finals.append(state)
-    differing = [key for key in finals[0] if key != "metrics" and not torch.equal(finals[0][key], finals[1][key])]
-    assert not differing, differing[:8]
+    for other in finals[1:]:
+        differing = [key for key in finals[0] if key != "metrics" and not torch.equal(finals[0][key], other[key])]
+        assert not differing, differing[:8]
