@@ -35,7 +35,8 @@ bench)
   # the round's switches, one at a time against the default, interleaved
   for i in 1 2; do
     python bench.py $B 2>/dev/null | tail -1 | brief "default"
-    CUSRL_EPOCH_GRAPHS=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_EPOCH_GRAPHS=0"
+    CUSRL_EPOCH_GRAPHS=1 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_EPOCH_GRAPHS=1 (one graph per epoch)"
+    CUSRL_EPOCH_GRAPHS=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_EPOCH_GRAPHS=0 (one graph per step)"
     CUSRL_SEPARATE_VALUE_TERM=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_SEPARATE_VALUE_TERM=0"
     CUSRL_PREFETCH_GATHER=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_PREFETCH_GATHER=0"
     CUSRL_PREFETCH_GATHER=side python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_PREFETCH_GATHER=side"
@@ -50,7 +51,7 @@ profile)
   bash scripts/gpu_pmc.sh r06final/pmc_gather > "$O/gpu_pmc.log" 2>&1; tail -2 "$O/gpu_pmc.log"
   bash scripts/gpu_profile.sh r06final/prof --steps 20 --warmup 6 > "$O/gpu_profile.log" 2>&1
   tail -8 "$O/gpu_profile.log"
-  bash scripts/gpu_r06_timeline.sh r06final/timeline "1 1 tail" > "$O/timeline.log" 2>&1
+  bash scripts/gpu_r06_timeline.sh r06final/timeline "update 1 tail" > "$O/timeline.log" 2>&1
   python scripts/kernel_bench.py --envs 4096 1048576 --json "$O/kernel_bench_graph_timed.json" 2>/dev/null | grep -v amdgpu > "$O/kernel_bench_graph_timed.txt"
   tail -5 "$O/kernel_bench_graph_timed.txt"
   ;;
