@@ -315,6 +315,105 @@ def test_metrics_weighted_mean():
     assert metrics.summary() == {}
 
 
+def test_metrics_read_staged_device_sums_and_lazy_tensors_in_one_pass():
+    """Round 6: what captured graphs accumulate on the device reaches the metrics through ``pending`` sources (snapshot + reset,
+    batched per dtype) and ``defer``-red tensors of any length — resolved together with the queued scalars by ONE read."""
+    metrics = cusrl.utils.Metrics()
+    accumulator = torch.tensor([6.0, 9.0, 0.0, 0.0])   # two tapped metrics summed over 3 replays
+    rows = torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=torch.float64)
+    calls = []
+
+    class Capture:
+        def stage_metrics(self, m):
+            calls.append("staged")
+            return [(accumulator[:2], accumulator, lambda sums: [m.add_resolved(name, total * 1, 1 * 3) for name, total in zip(("a", "b"), sums)]),
+                    (rows, rows, lambda values: m.add_resolved("rows", sum(values), 1))]
+
+    source = Capture()
+    metrics.pending(source)
+    metrics.pending(source)  # registered once
+    metrics.defer(torch.tensor([[2.0, 4.0]]), lambda values: metrics.add_resolved("lazy", sum(values), 2))
+    metrics.record(plain=torch.tensor([5.0, 7.0]))
+    summary = metrics.summary("Agent")
+    assert calls == ["staged"]
+    assert summary == {"Agent/plain": pytest.approx(6.0), "Agent/a": pytest.approx(2.0), "Agent/b": pytest.approx(3.0),
+                       "Agent/rows": pytest.approx(10.0), "Agent/lazy": pytest.approx(3.0)}
+    assert float(accumulator.abs().sum()) == 0.0 and float(rows.abs().sum()) == 0.0  # snapshot taken, sources reset
+    metrics.clear()
+    assert metrics.summary() == {}
+
+
+def test_precision_resolves_the_autocast_argument():
+    """``Agent(autocast=...)``: False / None = fp32 without autocast, True = fp16 autocast (needs a GradScaler), a dtype or its
+    name = autocast to it (cusrl/template/agent.py:101-109)."""
+    from cusrl_amd.template.agent import Precision
+
+    assert Precision.resolve(False) == (torch.float32, False) and Precision.resolve(None) == (torch.float32, False)
+    assert Precision.resolve(True) == (torch.float16, True) and Precision.resolve(True).needs_grad_scaler
+    assert Precision.resolve("bfloat16") == (torch.bfloat16, True) and not Precision.resolve("torch.bf16").needs_grad_scaler
+    assert Precision.resolve(torch.float16).needs_grad_scaler and not Precision.resolve("fp32").needs_grad_scaler
+    with pytest.raises(ValueError, match="Unknown autocast dtype"):
+        Precision.resolve("float8")
+
+
+def test_objectives_hand_out_the_branch_root_as_a_root_of_its_own():
+    """``Objectives.terms()`` (round 6): the fused total, the non-fused terms, and — when the value term was evaluated by its own
+    launch on the critic's stream — that term as one more root, marked as the branch (``Roots.branch``)."""
+    from cusrl_amd.template.hook import Objectives, Roots
+
+    total, value, extra = (torch.tensor(float(v), requires_grad=True) for v in (1.0, 2.0, 3.0))
+    objectives = Objectives(value_loss=None, surrogate_loss=None, entropy_loss=None, extra_loss=extra)
+    objectives.total, objectives.fused_keys = total, ("value_loss", "surrogate_loss", "entropy_loss")
+    plain = objectives.terms()
+    assert isinstance(plain, Roots) and plain.branch is None and [t is x for t, x in zip(plain, (total, extra))] == [True, True]
+    objectives.branch_root = (value, "stream")
+    roots = objectives.terms()
+    assert len(roots) == 3 and roots[-1] is value and roots.branch == (value, "stream")
+    unfused = Objectives(a=total, b=None, c=extra)
+    assert [t is x for t, x in zip(unfused.terms(), (total, extra))] == [True, True] and len(unfused.terms()) == 2  # None entries skipped
+
+
+def test_options_of_the_c_abi_without_a_gpu(monkeypatch):
+    """``cusrl_set_option`` / ``cusrl_get_option`` are host functions: keys, accepted values, error codes — and the host's one-time
+    translation of the A/B scripts' CUSRL_* variables (the library itself reads no environment variable in a launch entry point)."""
+    from cusrl_amd import _native
+
+    lib = _native.lib()
+    assert lib.cusrl_set_option(b"unknown", 1) == -1 and lib.cusrl_set_option(b"gae_block", 64) == -3
+    for key, value in (("gae_policy", 8), ("gae_block", 256), ("loss_policy", 1), ("push_policy", 2), ("colsum_rows", 128),
+                       ("head_rows", 96), ("gru_bias_rows", 32)):
+        _native.set_option(key, value)
+        assert _native.get_option(key) == value
+    monkeypatch.setenv("CUSRL_GAE_POLICY", "5")
+    monkeypatch.setenv("CUSRL_LOSS_POLICY", "1")
+    monkeypatch.setenv("CUSRL_PUSH_POLICY", "bogus")  # (an unknown value meant "the kernel's own rule" to the library, too)
+    for key in ("gae_policy", "loss_policy", "push_policy"):
+        _native.set_option(key, 0)
+    _native._options_from_environment()
+    assert (_native.get_option("gae_policy"), _native.get_option("loss_policy"), _native.get_option("push_policy")) == (6, 2, 0)
+    for key in _native._ENVIRONMENT_OPTIONS.values():
+        _native.set_option(key[0], 0)
+    sources = "".join(path.read_text() for path in (ROOT / "cusrl_amd" / "csrc").iterdir())
+    assert sources.count("getenv(") == 1 and 'getenv("CUSRL_RCCL_LIBRARY")' in sources
+
+
+def test_size_helpers_of_the_round_6_entry_points():
+    from cusrl_amd import _native
+
+    import ctypes
+
+    lib = _native.lib()
+    assert lib.cusrl_value_loss_blocks(24576, 1) == 24 and lib.cusrl_value_loss_blocks(1000, 3) == 3 and lib.cusrl_value_loss_blocks(0, 1) == 0
+    assert lib.cusrl_input_layer_supported(48, 256) and lib.cusrl_input_layer_supported(12, 64)
+    assert not lib.cusrl_input_layer_supported(64, 256) and not lib.cusrl_input_layer_supported(48, 96)
+    assert lib.cusrl_input_layer_row_blocks(24576, 256) == 64 and lib.cusrl_input_layer_row_blocks(8, 256) == 1
+    p = ctypes.c_void_p(16)
+    assert lib.cusrl_value_loss_fwd_bwd(p, p, None, 8, 1, 0.2, 0.5, p, None, p, 0, None) == -1   # clipped form without the old value
+    assert lib.cusrl_input_layer_bwd(p, None, p, 8, 50, 256, p, p, None) == -3                     # K not a multiple of 4
+    assert lib.cusrl_ppo_loss_fwd_bwd(p, p, p, p, p, None, None, None, 8, 4, 0, 0.2, -1.0, 1.0, 0.5, 0.0, None, None, None, None, None,
+                                      None, None, None, None, 8, None, 0, None) == -1             # D = 0 still needs losses / partials
+
+
 def test_timer_sections_accumulate():
     timer = cusrl.utils.Timer("cpu")
     with timer.record("agent"):
@@ -534,6 +633,9 @@ def test_flat_gradient_assembly_by_window_for_the_split_backward(monkeypatch):
     assert flat.window([0, 1]).numel() == 20
     with pytest.raises(ValueError, match="consecutive"):
         flat.window([0, 2])
+    # (round 6) a slab keyed by something that is NO optimizer parameter at all is still an error, subset or not
+    with pytest.raises(RuntimeError, match="not optimizer parameters"):
+        flat.assemble([g2, None], {123456789: torch.randn(3, 5)}, subset=critic)
 
 
 def test_graph_census_families():
