@@ -192,6 +192,7 @@ def torch_generator_env_ms(args, device):
     for _ in range(steps):
         observation, state = trainer._rollout_and_update(observation, state)
         trainer.iteration += 1
+    trainer.flush()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     env.close()
@@ -259,6 +260,7 @@ def run_gpu(args, rank, world):
     for _ in range(args.steps):
         observation, state = trainer._rollout_and_update(observation, state)
         trainer.iteration += 1
+    trainer.flush()  # the last iteration's log (the trainer reads an iteration's log behind the next rollout's launch) is timed too
     barrier()
     elapsed = time.perf_counter() - t0
     update_ms = sum(s.elapsed_time(e) for s, e in update_events) / max(len(update_events), 1)

@@ -127,10 +127,11 @@ class ValueComputation(Hook):
     # Eagerly the block above is ~25 dependent launches (two critic passes, the shift kernel, the compaction, a gather,
     # a scatter) whose device time is a quarter of their host launch time.  With a deferred feed-forward critic every
     # shape in it is static except the number k of truncated slots, so it becomes
-    #   head  : value pass over [T*N], last_value, next_value, compaction (k stored straight into pinned host memory)
+    #   head  : compaction of the truncated flags (k stored straight into pinned host memory), value pass over [T*N],
+    #           last_value, next_value
     #   tail_b: gather of the first b slots, critic on b rows, scatter limited to k ON THE DEVICE (b = a power-of-two
     #           capacity >= 2k that only ever grows; slots past k are stale but valid rows, computed and dropped)
-    # The host polls k between the two replays (no stream synchronisation) and picks the bucket.
+    # The host polls k (no stream synchronisation) — it is there a few microseconds into the head — and picks the bucket.
     _MIN_BUCKET = 256
 
     def _replayable(self, buffer: Buffer) -> bool:
@@ -154,18 +155,29 @@ class ValueComputation(Hook):
             scratch = self._replay_scratch = {"key": key, "slots": torch.zeros(T * N, dtype=torch.int64, device=value.device),
                                               "counter": ops.HostCounter(), "head": None, "tails": {}}
         slots, counter = scratch["slots"], scratch["counter"]
+        compaction = scratch.get("compaction")
+        if compaction is None:
+            from cusrl_amd import _native
+
+            blocks = max(int(_native.lib().cusrl_flag_blocks(T * N)), 1)
+            compaction = scratch["compaction"] = {"n": T * N, "device": truncated.device, "indices": slots,
+                                                  "counts": torch.empty(blocks, dtype=torch.int32, device=truncated.device)}
         critic, autocast = self.agent.critic, self.agent.autocast
 
         def head():
+            if self.bootstrap_truncated_states:
+                # FIRST: the truncated slots and their number k depend on the buffer's flags alone, and k is the one value the
+                # host waits for (it picks the tail's capacity) — published a few microseconds into the region, the host issues
+                # the tail, the hooks behind this one and the update's graph while the critic pass below keeps the device busy
+                # (up to round 5 the compaction came last and took the shift kernel's block counts: the device then sat idle
+                # for as long as the host needed to issue all of that)
+                ops.compact_flags(truncated, None, counter.tensor, scratch=compaction)
             with autocast():
                 flat_value = critic.evaluate(state.flatten(0, 1))
                 last_value = critic.evaluate(next_state[-1])
             value.copy_(flat_value.float().view(T, N, -1))
-            counts = ops.next_value(value, terminated, truncated, last_value.float(), self.termination_value,
-                                    truncated_uses_own_value=not self.bootstrap_truncated_states, out=next_value)
-            if self.bootstrap_truncated_states:
-                ops.compact_flags(truncated, counts, counter.tensor,
-                                  scratch={"n": T * N, "device": truncated.device, "indices": slots, "counts": None})
+            ops.next_value(value, terminated, truncated, last_value.float(), self.termination_value,
+                           truncated_uses_own_value=not self.bootstrap_truncated_states, out=next_value)
 
         if scratch["head"] is None:
             scratch["head"] = GraphedRegion(self.agent, head)

@@ -181,9 +181,12 @@ class Agent(ABC):
         (one host copy, utils/metrics.py) and an empty metric store."""
         self.step_index = 0
         self.iteration += 1
-        summary = self.metrics.summary(self.name)
+        # `deferred_summary` (set by a Trainer that pipelines its logging, template/trainer.py): the copy to the host is issued
+        # here, the values are formed when the caller asks for them — `StagedSummary.resolve()` — and the caller may enqueue
+        # the next rollout in between instead of leaving the device idle behind a blocking read
+        staged = self.metrics.staged_summary(self.name)
         self.metrics.clear()
-        return summary
+        return staged if getattr(self, "deferred_summary", False) else staged.resolve()
 
     def set_inference_mode(self, mode: bool = True, deterministic: bool | None = True):
         """Inference: no buffer writes, no updates; ``deterministic`` (None: leave as it is) only ever holds while inferring."""

@@ -104,17 +104,21 @@ class EnvironmentStats:
             self._reward_sum.zero_()
         self.num_steps = 0
 
-    def stage_means(self, metrics) -> None:
-        """Have the device-side statistics travel to the host in the copy ``metrics`` makes when it is next read
-        (``Metrics.defer``): :meth:`means` then costs no host round trip of its own.  Call when the rollout's launches are in."""
-        if self.on_device:
-            self._staged = None
-            steps = self.num_steps
-
-            def keep(values):
-                self._staged = (values, steps)
-
-            metrics.defer(self._snapshot(), keep)
+    def freeze(self, metrics=None) -> "StatsFrame":
+        """Close the statistics of the rollout that has just been issued: a :class:`StatsFrame` that will give its three means
+        and carries its step counters, and the per-rollout accumulators back at zero (``clear_step_info``) — in stream order,
+        so the next rollout may be enqueued before anybody has read the frame.  With device-resident statistics and a
+        ``metrics`` store the values travel to the host in the ONE copy the store makes when it is next read
+        (``Metrics.defer``); otherwise they are read right here (five host round trips on a GPU, none on the CPU)."""
+        frame = StatsFrame(self.num_steps, self.total_steps, self.num_envs, self.reward_dim, self.buffer_size)
+        if self.on_device and metrics is not None:
+            metrics.defer(self._snapshot(), frame.receive)
+        elif self.on_device:
+            frame.receive(self._snapshot().tolist())
+        else:
+            frame.means = (self.mean_episode_length, self.mean_episode_reward, self.mean_step_reward)
+        self.clear_step_info()
+        return frame
 
     def _snapshot(self) -> torch.Tensor:
         return torch.cat((self._episodes_dev[self._parity].reshape(1).double(), self._reward_sum,
@@ -123,26 +127,12 @@ class EnvironmentStats:
     def means(self):
         """``(mean_episode_length, mean_episode_reward, mean_step_reward)`` — what the three properties below give — from ONE
         host copy when the statistics live on the device (the properties cost a reduction launch and a synchronising ``item()``
-        each, the episode count two more: five host round trips at the end of every iteration with an idle device behind them);
-        from no copy of its own when :meth:`stage_means` sent the values along with the agent's metrics."""
+        each, the episode count two more)."""
         if not self.on_device:
             return self.mean_episode_length, self.mean_episode_reward, self.mean_step_reward
-        import numpy as np
-
-        D, R = self.reward_dim, self.buffer_size
-        staged, self._staged = getattr(self, "_staged", None), None
-        flat, num_steps = staged if staged is not None else (self._snapshot().tolist(), self.num_steps)
-        count = min(int(flat[0]), R)
-        step = np.asarray(flat[1 : 1 + D], dtype=np.float64) / self.num_envs
-        step = (step.astype(np.float32) / np.float32(num_steps)) if num_steps else step.astype(np.float32)
-        rewards = np.asarray(flat[1 + D : 1 + D + R * D], dtype=np.float32).reshape(R, D)
-        lengths = np.asarray(flat[1 + D + R * D :], dtype=np.float32)
-        if count == 0:
-            episode_length, episode_reward = 0.0, np.zeros(D, dtype=np.float32)
-        else:
-            episode_length, episode_reward = float(lengths[:count].mean()), rewards[:count].mean(axis=0)
-        scalar = (lambda v: float(v[0])) if D == 1 else (lambda v: tuple(float(x) for x in v))
-        return episode_length, scalar(episode_reward), scalar(step)
+        frame = StatsFrame(self.num_steps, self.total_steps, self.num_envs, self.reward_dim, self.buffer_size)
+        frame.receive(self._snapshot().tolist())
+        return frame.means
 
     @property
     def mean_step_reward(self):
@@ -172,6 +162,35 @@ class EnvironmentStats:
     def load_state_dict(self, state_dict: dict):
         if state_dict:
             self.total_steps = state_dict["total_steps"]
+
+
+class StatsFrame:
+    """The episode statistics of ONE rollout as its log will report them (``EnvironmentStats.freeze``): the host counters at the
+    moment the rollout was closed and — once ``receive`` has been given the device snapshot — the three means."""
+
+    __slots__ = ("num_steps", "total_steps", "num_envs", "reward_dim", "buffer_size", "means")
+
+    def __init__(self, num_steps: int, total_steps: int, num_envs: int, reward_dim: int, buffer_size: int):
+        self.num_steps, self.total_steps, self.num_envs = num_steps, total_steps, num_envs
+        self.reward_dim, self.buffer_size = reward_dim, buffer_size
+        self.means = None
+
+    def receive(self, flat) -> None:
+        """``flat`` = host values of ``EnvironmentStats._snapshot()``: episode count, reward sums, the ring of finished episodes."""
+        import numpy as np
+
+        D, R, num_steps = self.reward_dim, self.buffer_size, self.num_steps
+        count = min(int(flat[0]), R)
+        step = np.asarray(flat[1 : 1 + D], dtype=np.float64) / self.num_envs
+        step = (step.astype(np.float32) / np.float32(num_steps)) if num_steps else step.astype(np.float32)
+        rewards = np.asarray(flat[1 + D : 1 + D + R * D], dtype=np.float32).reshape(R, D)
+        lengths = np.asarray(flat[1 + D + R * D :], dtype=np.float32)
+        if count == 0:
+            episode_length, episode_reward = 0.0, np.zeros(D, dtype=np.float32)
+        else:
+            episode_length, episode_reward = float(lengths[:count].mean()), rewards[:count].mean(axis=0)
+        scalar = (lambda v: float(v[0])) if D == 1 else (lambda v: tuple(float(x) for x in v))
+        self.means = (episode_length, scalar(episode_reward), scalar(step))
 
 
 class TrainerHook:
@@ -218,7 +237,10 @@ class Trainer:
         self.timer = Timer(self.agent.device)
         # Perf/*_time come from HIP events; on a GPU every 8th env step is bracketed and scaled (utils/timing.py)
         self.timer_sampling = 8 if self.agent.device.type == "cuda" else 1
-        self.last_info: dict[str, float] = {}
+        self._last_info: dict[str, float] = {}
+        self._pending_log: tuple | None = None
+        # the log of an iteration is read, averaged and written AFTER the next rollout has been launched (A/B switch)
+        self.pipeline_logs = os.environ.get("CUSRL_PIPELINE_LOGS", "1") != "0"
         self.host_thread_cpus: list[int] = []
         if pin_host_thread and self.agent.device.type == "cuda":  # extension: NUMA-local placement of the driving thread
             from cusrl_amd.utils.affinity import pin_host_thread as pin
@@ -249,10 +271,13 @@ class Trainer:
                 observation, state = self._rollout_and_update(observation, state)
                 self.iteration += 1
                 if self.iteration % self.checkpoint_interval == 0:
+                    self.flush()
                     self._save_checkpoint()
+            self.flush()
             if self.iteration != self._last_checkpoint_iteration:
                 self._save_checkpoint()
         finally:
+            self._pending_log = None
             self.environment.close()
 
     def _rollout_and_update(self, observation, state):
@@ -262,14 +287,41 @@ class Trainer:
             observation, state = self._rollout_captured(graphed, observation, state)
         else:
             observation, state = self._rollout_eager(observation, state)
-        if hasattr(agent, "metrics"):
-            self.stats.stage_means(agent.metrics)  # read with the update's metrics: one host copy for both
+        # The log of the PREVIOUS iteration, when it was left pending (below): its values are read now, with this rollout
+        # already enqueued behind that iteration's update — the device goes from one to the other without waiting for the host
+        # to read, average and print.
+        self.flush()
+        metrics = getattr(agent, "metrics", None)
+        frame = self.stats.freeze(metrics)  # (device statistics: read with the update's metrics, one host copy for both)
+        # Pipelined logging: only around captured rollouts (a host-driven rollout keeps the device waiting anyway), without
+        # trainer hooks (their `post_update` follows the log and may read anything) and for agents that stage their summary.
+        pipelined = self.pipeline_logs and graphed is not None and not self.hooks and metrics is not None
+        if metrics is not None:
+            agent.deferred_summary = pipelined
         with timer.record("agent"):
             agent_info = agent.update()
-        self._log_info(agent_info)
+        self._pending_log = (agent_info, frame, timer.detach(), self.iteration)
+        if not pipelined:
+            self.flush()
+        return observation, state
+
+    def flush(self) -> None:
+        """Write the log an iteration left pending (no-op when there is none): ``_rollout_and_update`` calls it behind the next
+        rollout's launch; the training loop before a checkpoint and at its end; ``last_info`` before it answers."""
+        pending, self._pending_log = self._pending_log, None
+        if pending is None:
+            return
+        agent_info, frame, timer, iteration = pending
+        if hasattr(agent_info, "resolve"):  # a staged summary (utils/metrics.py): wait for its copy, not for the stream
+            agent_info = agent_info.resolve()
+        self._log_info(agent_info, frame, timer, iteration)
         for hook in self.hooks:
             hook.post_update()
-        return observation, state
+
+    @property
+    def last_info(self) -> dict[str, float]:
+        self.flush()
+        return self._last_info
 
     def _rollout_graphs(self, observation, state):
         """The captured-step driver when this rollout can go through it (template/graphs.py GraphedRolloutStep): a
@@ -461,33 +513,33 @@ class Trainer:
              "iteration": self.iteration, "stats": self.stats.state_dict()}, iteration=self.iteration)
         self._last_checkpoint_iteration = self.iteration
 
-    def _log_info(self, info: dict[str, float]):
+    def _log_info(self, info: dict[str, float], frame: StatsFrame, timer: Timer, iteration: int):
+        """The log of iteration ``iteration`` (trainer.py:370-416) from what that iteration left behind: its agent metrics, the
+        frame of its rollout's statistics and the timer sections recorded during it."""
         for key, value in self.environment.get_metrics().items():
             info[f"Environment/{key}"] = value
-        info["Metric/episode_length"], episode_reward, step_reward = self.stats.means()
+        info["Metric/episode_length"], episode_reward, step_reward = frame.means
         if isinstance(episode_reward, tuple):
             info.update({f"Metric/episode_reward.{i}": v for i, v in enumerate(episode_reward)})
             info.update({f"Metric/reward.{i}": v for i, v in enumerate(step_reward)})
         else:
             info["Metric/episode_reward"], info["Metric/reward"] = episode_reward, step_reward
-        rollout = self.timer["rollout"]  # captured rollouts: one bracket, split as measured on the host-driven iteration
+        rollout = timer["rollout"]  # captured rollouts: one bracket, split as measured on the host-driven iteration
         split = self._rollout_split or (0.5, 0.5)
-        info["Perf/environment_time"] = self.timer["environment"] + rollout * split[1]
-        info["Perf/agent_time"] = self.timer["agent"] + rollout * split[0]
+        info["Perf/environment_time"] = timer["environment"] + rollout * split[1]
+        info["Perf/agent_time"] = timer["agent"] + rollout * split[0]
         info = distributed.average_dict(info)
         world = distributed.world_size()
-        steps = self.stats.num_steps * self.environment.num_instances * world
-        info["Perf/environment_step"] = self.stats.total_steps * world
+        steps = frame.num_steps * self.environment.num_instances * world
+        info["Perf/environment_step"] = frame.total_steps * world
         info["Perf/environment_fps"] = steps / max(info["Perf/environment_time"], 1e-12)
         info["Perf/agent_fps"] = steps / max(info["Perf/agent_time"], 1e-12)
         for hook in self.hooks:
             hook.pre_log_info(info)
         if self.logger is not None:
-            self.logger.log(info, self.iteration + 1)
+            self.logger.log(info, iteration + 1)
         if self.verbose:
-            print(f"[iteration {self.iteration + 1}/{self.num_iterations}] episode_len={info['Metric/episode_length']:.2f} "
+            print(f"[iteration {iteration + 1}/{self.num_iterations}] episode_len={info['Metric/episode_length']:.2f} "
                   f"reward={info['Metric/reward'] if 'Metric/reward' in info else float('nan'):.4f} "
                   f"env_time={info['Perf/environment_time']:.4f}s agent_time={info['Perf/agent_time']:.4f}s")
-        self.last_info = info
-        self.timer.clear()
-        self.stats.clear_step_info()
+        self._last_info = info

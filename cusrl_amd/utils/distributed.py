@@ -76,7 +76,7 @@ _pg_stream: "torch.cuda.Stream | None" = None
 
 
 @contextmanager
-def _process_group_stream(device=None):
+def _process_group_stream(device=None, join: bool = True):
     """Issue a ``torch.distributed`` collective of an RCCL job on a dedicated stream that NEVER captures.
 
     ProcessGroupNCCL records a collective's completion event on the stream the call is issued on, and its watchdog thread
@@ -86,7 +86,10 @@ def _process_group_stream(device=None):
     capturing stream" and the watchdog aborts the process (seen as a sporadic SIGABRT of one-rank RCCL test jobs on the
     torch.distributed route, round 5).  So the process-group collectives of this package hop to their own stream: the
     caller's stream is joined before and after, i.e. the collective stays ordered exactly where it was issued.  Operands
-    must be allocated by the caller (outside this context); what is allocated inside is consumed inside."""
+    must be allocated by the caller (outside this context); what is allocated inside is consumed inside.  ``join=False``: a
+    collective whose operands come from the HOST and go back to it (the trainer's log average) — allocated, reduced and read
+    inside the context, ordered against nothing the caller's stream holds: it does not queue behind the rollout the trainer
+    has already launched there (template/trainer.py pipelines its logs), and the caller's stream does not wait for it."""
     device = torch.device(CONFIG.device if device is None else device)
     if (device.type != "cuda" or torch.distributed.get_backend() != torch.distributed.Backend.NCCL
             or torch.cuda.is_current_stream_capturing()):
@@ -96,10 +99,12 @@ def _process_group_stream(device=None):
     if _pg_stream is None or _pg_stream.device != device:
         _pg_stream = torch.cuda.Stream(device=device)
     current = torch.cuda.current_stream(device)
-    _pg_stream.wait_stream(current)
+    if join:
+        _pg_stream.wait_stream(current)
     with torch.cuda.stream(_pg_stream):
         yield
-    current.wait_stream(_pg_stream)
+    if join:
+        current.wait_stream(_pg_stream)
 
 
 def barrier():
@@ -434,11 +439,11 @@ def _average_same_keys(info: dict[str, float]) -> dict[str, float] | None:
     head = [low, high, low * low, high * high, float(len(keys)), 1.0 if plain else 0.0]
     body = [float(v) for v in values] if plain else []
     device = "cpu" if torch.distributed.get_backend() == torch.distributed.Backend.GLOO else CONFIG.device
-    packed = torch.tensor(head + body + [0.0] * (_LOG_SLOTS - len(body)), dtype=torch.float64, device=device)
-    with _process_group_stream(packed.device):
+    with _process_group_stream(device, join=False):  # host values in, host values out: nothing of the caller's stream is touched
+        packed = torch.tensor(head + body + [0.0] * (_LOG_SLOTS - len(body)), dtype=torch.float64, device=device)
         torch.distributed.all_reduce(packed, op=torch.distributed.ReduceOp.SUM)
+        summed = packed.tolist()
     world = CONFIG.world_size
-    summed = packed.tolist()
     s_low, s_high, q_low, q_high, count, all_plain = summed[:6]
     same = (all_plain == world and s_low == world * low and s_high == world * high and q_low == world * low * low
             and q_high == world * high * high and count == world * len(keys))

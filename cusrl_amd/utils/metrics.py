@@ -19,7 +19,7 @@ from typing import Any
 
 import torch
 
-__all__ = ["Metric", "MetricTap", "Metrics"]
+__all__ = ["Metric", "MetricTap", "Metrics", "StagedSummary"]
 
 
 class Metric:
@@ -61,6 +61,22 @@ class MetricTap:
         return None
 
 
+class StagedSummary:
+    """A metric summary whose values are on their way to the host (``Metrics.staged_summary``): ``resolve()`` waits for the copy
+    and returns the ``{prefix + name: value}`` dict; until then the device may be given more work."""
+
+    __slots__ = ("_finish", "_prefix", "_values")
+
+    def __init__(self, finish, prefix: str):
+        self._finish, self._prefix, self._values = finish, prefix, None
+
+    def resolve(self) -> dict[str, float]:
+        if self._values is None:
+            self._values = {f"{self._prefix}{name}": metric.mean.item() for name, metric in self._finish().items()}
+            self._finish = None
+        return self._values
+
+
 class Metrics:
     def __init__(self):
         self._queue: dict[str, list[tuple[torch.Tensor | float, int]]] = {}
@@ -71,6 +87,7 @@ class Metrics:
         # objects with a `stage_metrics(metrics)` method that still hold un-staged device sums (captures that replayed since the
         # last read): asked right before the one host copy
         self._pending: list[Any] = []
+        self._landings: dict[tuple, list] = {}  # pinned host buffers of the staged reads (_landing)
 
     # ------------------------------------------------------------------ recording
     @torch.no_grad()
@@ -132,31 +149,72 @@ class Metrics:
 
     # ------------------------------------------------------------------ reading
     def _resolve(self) -> dict[str, Metric]:
+        return self._stage()()
+
+    def _stage(self):
+        """The device half of a read: everything recorded so far is concatenated ONCE per (device, dtype) and sent to the host in
+        ONE copy each — into pinned memory, without waiting for it.  Returns the host half: a callable that waits for the copies
+        (an event, not a stream synchronisation), runs the deferred callbacks and forms the count-weighted means.  Between the
+        two the caller may enqueue whatever it likes (the trainer launches the next rollout, template/trainer.py): the store
+        itself can be cleared and recorded into again, the staged read keeps its own references."""
         self._stage_pending()
         lazy, self._lazy = self._lazy, []
+        queue = {name: list(entries) for name, entries in self._queue.items()}
         tensors: dict[tuple, list[torch.Tensor]] = {}
-        for entries in self._queue.values():
+        for entries in queue.values():
             for value, _ in entries:
                 if isinstance(value, torch.Tensor):
                     tensors.setdefault((value.device, value.dtype), []).append(value)
         for values, _ in lazy:
             tensors.setdefault((values.device, values.dtype), []).append(values)
-        host: dict[int, Any] = {}
-        for group in tensors.values():  # ONE concatenation + ONE host copy per (device, dtype), whatever was recorded
-            flat = torch.cat([tensor.reshape(-1) for tensor in group]).tolist() if len(group) > 1 else group[0].reshape(-1).tolist()
-            offset = 0
-            for tensor in group:
-                n = tensor.numel()
-                host[id(tensor)] = flat[offset] if tensor.dim() == 0 else flat[offset : offset + n]
-                offset += n
-        for values, callback in lazy:
-            callback(host[id(values)])
-        resolved = {}
-        for name, entries in self._queue.items():
-            total = sum(count for _, count in entries)
-            mean = sum((host[id(v)] if isinstance(v, torch.Tensor) else v) * (count / total) for v, count in entries)
-            resolved[name] = Metric(torch.tensor(mean, dtype=torch.float32), total)
-        return resolved
+        copies, events = [], []
+        for (device, dtype), group in tensors.items():  # ONE concatenation + ONE host copy per (device, dtype), whatever was recorded
+            flat = torch.cat([tensor.reshape(-1) for tensor in group]) if len(group) > 1 else group[0].reshape(-1)
+            if device.type == "cuda":
+                landing = self._landing(device, dtype, flat.numel())
+                landing.copy_(flat, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record(torch.cuda.current_stream(device))
+                events.append(event)
+                flat = landing
+            copies.append((group, flat))
+
+        def finish() -> dict[str, Metric]:
+            for event in events:
+                event.synchronize()
+            host: dict[int, Any] = {}
+            for group, flat in copies:
+                values = flat.tolist()
+                offset = 0
+                for tensor in group:
+                    n = tensor.numel()
+                    host[id(tensor)] = values[offset] if tensor.dim() == 0 else values[offset : offset + n]
+                    offset += n
+            # (the callbacks record what they decode with `add_resolved`: into THIS read's entries — the store may have been
+            # cleared and recorded into again since the read was staged)
+            live, self._queue = self._queue, queue
+            try:
+                for values, callback in lazy:
+                    callback(host[id(values)])
+            finally:
+                self._queue = live
+            resolved = {}
+            for name, entries in queue.items():
+                total = sum(count for _, count in entries)
+                mean = sum((host[id(v)] if isinstance(v, torch.Tensor) else v) * (count / total) for v, count in entries)
+                resolved[name] = Metric(torch.tensor(mean, dtype=torch.float32), total)
+            return resolved
+
+        return finish
+
+    def _landing(self, device, dtype, numel: int) -> torch.Tensor:
+        """Pinned host memory for one staged copy: two buffers per (device, dtype) used in turn, so that a read staged while the
+        previous one has not been finished yet lands somewhere else."""
+        ring = self._landings.setdefault((device, dtype), [None, None, 0])
+        slot = ring[2] = ring[2] ^ 1
+        if ring[slot] is None or ring[slot].numel() < numel:
+            ring[slot] = torch.empty(max(numel, 256), dtype=dtype).pin_memory()
+        return ring[slot][:numel]
 
     def _stage_pending(self):
         """Snapshot (ONE concatenation) and reset (ONE multi-tensor fill) the device-side running sums of every capture that
@@ -185,9 +243,13 @@ class Metrics:
             self.defer(snapshot, scatter)
 
     def summary(self, prefix: str = "") -> dict[str, float]:
+        return self.staged_summary(prefix).resolve()
+
+    def staged_summary(self, prefix: str = "") -> "StagedSummary":
+        """:meth:`summary` in two halves: the device copies are issued now, the host values are formed by ``.resolve()``."""
         if prefix and not prefix.endswith("/"):
             prefix += "/"
-        return {f"{prefix}{name}": metric.mean.item() for name, metric in self._resolve().items()}
+        return StagedSummary(self._stage(), prefix)
 
     def __getitem__(self, name: str) -> Metric:
         return self._resolve()[name]

@@ -75,6 +75,20 @@ class Timer:
                 total += self._total[key] * (seen / self._timed[key])
         return total
 
+    def detach(self) -> "Timer":
+        """What this timer has accumulated so far, as a timer of its own (to be read later — e.g. after sections of the NEXT
+        iteration have already been recorded into this one, template/trainer.py); this timer starts again from zero."""
+        if self._open:
+            raise RuntimeError(f"Timer sections still open: {sorted(map(str, self._open))}")
+        frozen = Timer.__new__(Timer)
+        frozen.device, frozen._gpu = self.device, self._gpu
+        frozen._open, frozen._boundary, frozen._boundary_time = {}, None, 0.0
+        frozen._total, frozen._pending, frozen._seen, frozen._timed = self._total, self._pending, self._seen, self._timed
+        self._total, self._pending = defaultdict(float), defaultdict(list)
+        self._seen, self._timed = defaultdict(int), defaultdict(int)
+        self._boundary = None
+        return frozen
+
     def clear(self):
         self._pending.clear()
         self._boundary = None
