@@ -111,6 +111,8 @@ _SIGNATURES = {
     "cusrl_narrow_linear_num_partials": (c_int64, [c_int64]),
     "cusrl_narrow_linear_supported": (c_int, [c_int64, c_int64]),
     "cusrl_narrow_linear_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int64, _P]),
+    "cusrl_mlp2_forward": (c_int, [_P, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "cusrl_mlp2_forward_supported": (c_int, [c_int64, c_int64, c_int64, c_int64]),
     "cusrl_clip_grad_norm": (c_int, [_P, c_int64, c_float, _P, _P, _P]),
     "cusrl_clip_grad_norm_num_partials": (c_int64, [c_int64]),
     "cusrl_assemble_gradients": (c_int, [POINTER(GradPiece), c_int64, _P, _P, _P]),

@@ -9,8 +9,8 @@ from typing import Any, Callable
 import torch
 from torch import Tensor, nn
 
-from cusrl_amd.nn.distribution import Distribution
-from cusrl_amd.nn.module import Linear, Module, ModuleFactory
+from cusrl_amd.nn.distribution import Distribution, NormalDist
+from cusrl_amd.nn.module import Linear, Module, ModuleFactory, fused_inference_layers
 
 __all__ = ["Actor", "Value"]
 
@@ -36,6 +36,15 @@ class Actor(Module):
         self.latent_dim = self.backbone.output_dim
         self.backbone_kwargs: dict[str, Any] = {}
         self.distribution_kwargs: dict[str, Any] = {}
+        # the no-grad pass (acting, statistics) of an Mlp backbone + Normal head as one launch; it leaves no "backbone.output"
+        # in `intermediate_repr` — a hook that reads the latent of a no-grad pass switches this off
+        self.fused_inference = True
+
+    def _fused_layers(self, observation, memory, backbone_kwargs, distribution_kwargs):
+        if (not self.fused_inference or type(self.distribution) is not NormalDist or self.backbone_kwargs or self.distribution_kwargs
+                or distribution_kwargs or any(key != "sequential" for key in (backbone_kwargs or ()))):
+            return None
+        return fused_inference_layers(self.backbone, self.distribution.mean_head, observation, memory)
 
     def clear_intermediate_repr(self):
         super().clear_intermediate_repr()
@@ -55,6 +64,12 @@ class Actor(Module):
         """``forward_type``: "forward" -> (dist_params, memory); "explore" -> (dist_params, (action, logp), memory);
         "act" / "act_deterministic" -> (action, memory)  (actor.py:69-92)."""
         if forward_type == "forward":
+            if (layers := self._fused_layers(observation, memory, backbone_kwargs, distribution_kwargs)) is not None:
+                from cusrl_amd import ops
+
+                self.intermediate_repr.pop("backbone.output", None)
+                mean = ops.mlp2_forward(observation, layers)
+                return {"mean": mean, "std": self.distribution.std(mean)}, memory
             latent, memory = self._encode(observation, memory, done, backbone_kwargs)
             dist_kwargs = {**self.distribution_kwargs, **(distribution_kwargs or {})}
             return self.distribution(latent, observation=observation, **dist_kwargs), memory
@@ -62,6 +77,18 @@ class Actor(Module):
             forward_type, deterministic = "act", True
         if forward_type not in ("explore", "act"):
             raise ValueError(f"Unsupported 'forward_type' value: {forward_type!r}")
+        if not deterministic and (layers := self._fused_layers(observation, memory, backbone_kwargs, distribution_kwargs)) is not None:
+            # acting: backbone, mean head, Normal.rsample and its log-prob from ONE launch; eps from torch's generator exactly
+            # as the unfused path draws it (distribution.py NormalDist.sample)
+            from cusrl_amd import ops
+
+            self.intermediate_repr.pop("backbone.output", None)
+            vector = self.distribution.std_vector()
+            eps = torch.empty((observation.shape[0], vector.numel()), dtype=torch.float32, device=observation.device).normal_()
+            action, logp, mean, repeated = ops.mlp2_forward(observation, layers, std=vector, eps=eps)
+            if forward_type == "act":
+                return action, memory
+            return {"mean": mean, "std": repeated}, (action, logp), memory
         latent, memory = self._encode(observation, memory, None, backbone_kwargs)
         dist_kwargs = {**self.distribution_kwargs, **(distribution_kwargs or {})}
         if deterministic:
@@ -121,12 +148,19 @@ class Value(Module):
         self.value_head = value_head
         self.action_aware = action_aware
         self.backbone_kwargs: dict[str, Any] = {}
+        self.fused_inference = True  # (as for Actor)
 
     def forward(self, state: Tensor, *, action: Tensor | None = None, memory=None, done: Tensor | None = None, **kwargs):
         if self.action_aware:
             if action is None:
                 raise ValueError("Action must be provided when 'action_aware' is True")
             state = torch.cat([state, action], dim=-1)
+        if (self.fused_inference and not self.backbone_kwargs and not kwargs
+                and (layers := fused_inference_layers(self.backbone, self.value_head, state, memory)) is not None):
+            from cusrl_amd import ops
+
+            self.intermediate_repr.pop("backbone.output", None)
+            return ops.mlp2_forward(state, layers), memory  # the no-grad pass (value targets) as one launch
         kwargs = {**self.backbone_kwargs, **kwargs}
         if done is not None:
             kwargs["done"] = done

@@ -227,6 +227,11 @@ class NormalDist(_Normal):
     def forward(self, backbone_feat: Tensor, **kwargs):
         return {"mean": self.mean_head(backbone_feat), "std": self.std(backbone_feat)}
 
+    def std_vector(self) -> Tensor:
+        """The fp32 ``[A]`` std behind the bijector, detached (what every row of the ``std`` parameter repeats)."""
+        with disable_autocast(self.std.param.device.type):
+            return self.std.bijector(self.std.param.detach().float()).float()
+
     def sample(self, backbone_feat: Tensor, **kwargs):
         if not (backbone_feat.is_cuda and not torch.is_grad_enabled()):
             return super().sample(backbone_feat, **kwargs)

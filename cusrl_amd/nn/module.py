@@ -17,8 +17,8 @@ from torch.nn.functional import linear
 
 from cusrl_amd.utils.nest import iterate_nested
 
-__all__ = ["Linear", "LinearFp32", "linear_act", "Mlp", "Module", "ModuleFactory", "disable_autocast", "double_differentiable",
-           "is_unit_gradient", "register_unit_gradient", "resolve_activation_fn"]
+__all__ = ["Linear", "LinearFp32", "fused_inference_layers", "linear_act", "Mlp", "Module", "ModuleFactory", "disable_autocast",
+           "double_differentiable", "is_unit_gradient", "register_unit_gradient", "resolve_activation_fn"]
 
 
 def disable_autocast(device_type: str):
@@ -280,6 +280,28 @@ class LinearFp32(nn.Linear):
             return linear(input.float(), self.weight.float(), None if self.bias is None else self.bias.float())
 
 
+# The no-grad pass of backbone + head as ONE launch (round 6, ops.mlp2_forward; CUSRL_FUSED_INFERENCE=0: the library GEMM chain,
+# A/B switch).  Acting on 4096 envs is three launch-bound GEMMs + the sampling launch: 24 of the 37 us a captured env step takes.
+_FUSED_INFERENCE = os.environ.get("CUSRL_FUSED_INFERENCE", "1") != "0"
+
+
+def fused_inference_layers(backbone, head: nn.Linear, input, memory=None):
+    """``(w1, b1, w2, b2, w3, b3)`` when ``head(backbone(input))`` can be evaluated by ``ops.mlp2_forward`` right now: no gradient
+    asked for, a feed-forward Linear / ReLU / Linear / ReLU backbone (``Mlp.inference_stack``) in front of a linear head, a
+    contiguous fp32 ``[B, K]`` device input outside autocast, shapes the kernel takes; else None."""
+    if (not _FUSED_INFERENCE or torch.is_grad_enabled() or memory is not None or not isinstance(backbone, Mlp)
+            or not isinstance(head, nn.Linear) or not isinstance(input, torch.Tensor) or not input.is_cuda or input.dim() != 2
+            or input.dtype != torch.float32 or torch.is_autocast_enabled("cuda")):
+        return None
+    stack = backbone.inference_stack()
+    if stack is None:
+        return None
+    from cusrl_amd import ops
+
+    layers = (*stack, head.weight, head.bias)
+    return layers if ops.mlp2_forward_supported(input, layers) else None
+
+
 class ModuleFactory:
     def __call__(self, input_dim: int | None = None, output_dim: int | None = None) -> "Module":
         raise NotImplementedError
@@ -413,3 +435,13 @@ class Mlp(Module):
 
     def __getitem__(self, index: int) -> nn.Module:
         return self.layers[index]
+
+    def inference_stack(self):
+        """``(w1, b1, w2, b2)`` when this is exactly Linear / ReLU / Linear / ReLU with biases (the preset's backbone,
+        ``ends_with_activation=True``): the shape ``ops.mlp2_forward`` evaluates — together with the head behind it — in one
+        launch when no gradient is asked for; None for anything else."""
+        layers = self.layers
+        if (len(layers) == 4 and type(layers[0]) is Linear and type(layers[1]) is nn.ReLU and type(layers[2]) is Linear
+                and type(layers[3]) is nn.ReLU and layers[0].bias is not None and layers[2].bias is not None):
+            return layers[0].weight, layers[0].bias, layers[2].weight, layers[2].bias
+        return None

@@ -1542,6 +1542,54 @@ def narrow_linear_forward(input: torch.Tensor, weight: torch.Tensor, bias: torch
     return out
 
 
+def mlp2_forward_supported(input: torch.Tensor, layers) -> bool:
+    """``layers`` = ``(w1, b1, w2, b2, w3, b3)`` (``b3`` may be None) of a Linear / ReLU / Linear / ReLU / Linear stack whose shapes
+    the one-launch inference pass takes (``cusrl_mlp2_forward_supported``), over a contiguous fp32 ``[B, K]`` device matrix."""
+    w1, b1, w2, b2, w3, b3 = layers
+    tensors = [input, w1, b1, w2, b2, w3] + ([b3] if b3 is not None else [])
+    if input.dim() != 2 or input.shape[0] == 0 or any(
+            (not t.is_cuda) or t.dtype != torch.float32 or (not t.is_contiguous()) or t.data_ptr() % 16 for t in tensors):
+        return False
+    if w1.dim() != 2 or w2.dim() != 2 or w3.dim() != 2 or w1.shape[1] != input.shape[1] or w2.shape[1] != w1.shape[0] \
+            or w3.shape[1] != w2.shape[0] or b1.numel() != w1.shape[0] or b2.numel() != w2.shape[0] \
+            or (b3 is not None and b3.numel() != w3.shape[0]):
+        return False
+    return bool(_native.lib().cusrl_mlp2_forward_supported(w1.shape[1], w1.shape[0], w2.shape[0], w3.shape[0]))
+
+
+def mlp2_forward(input: torch.Tensor, layers, std: torch.Tensor | None = None, eps: torch.Tensor | None = None,
+                 repeat_std: bool = True):
+    """``w3 relu(w2 relu(w1 x + b1) + b2) + b3`` in ONE launch (``cusrl_mlp2_forward``), no autograd: the head's output
+    ``[B, out]``; with ``std`` (``[out]`` vector) and ``eps`` (``[B, out]``) the acting path's ``(action, logp [B, 1], mean,
+    repeated std or None)`` — ``action = mean + eps * std`` and its log-prob as ``normal_sample_logp`` evaluates them."""
+    w1, b1, w2, b2, w3, b3 = layers
+    input = _f32(input, "input")
+    rows, K = input.shape
+    out_features = w3.shape[0]
+    out = torch.empty((rows, out_features), dtype=torch.float32, device=input.device)
+    sampling = eps is not None
+    action = logp = repeated = None
+    if sampling:
+        std, eps = _f32(std, "std"), _f32(eps, "eps")
+        if std.numel() != out_features or eps.shape != out.shape:
+            raise ValueError("mlp2_forward: one std per output and one eps per output element are required")
+        action = torch.empty_like(out)
+        logp = torch.empty((rows, 1), dtype=torch.float32, device=input.device)
+        repeated = torch.empty_like(out) if repeat_std else None
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    _observed(
+        "cusrl_mlp2_forward",
+        lambda: rows * 4 * (K + out_features * (4 if sampling else 1)) + 4 * (w1.numel() + w2.numel() + w3.numel()),
+        lambda: _native.lib().cusrl_mlp2_forward(input.data_ptr(), rows, K, w1.data_ptr(), b1.data_ptr(), w1.shape[0], w2.data_ptr(),
+                                                 b2.data_ptr(), w2.shape[0], w3.data_ptr(), ptr(b3), out_features, out.data_ptr(),
+                                                 ptr(std) if sampling else None, ptr(eps), ptr(action), ptr(logp), ptr(repeated),
+                                                 _stream()),
+    )
+    if sampling:
+        return action, logp, out, repeated
+    return out
+
+
 def narrow_linear_backward(grad_output: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
                            need_input_grad: bool = True, relu_input: bool = False, defer: bool = False):
     """``(grad_output @ weight, grad_output.T @ input, grad_output.sum(0))`` of a linear layer with at most 16

@@ -470,6 +470,25 @@ int cusrl_narrow_linear_supported(int64_t in_features, int64_t out_features);
 int cusrl_narrow_linear_fwd(const float *input, const float *weight, const float *bias, float *output, int64_t rows,
                             int64_t in_features, int64_t out_features, void *stream);
 
+/* ---- inference pass of a two-hidden-layer ReLU MLP + head, one launch (csrc/mlp_forward.hip) ----
+ * output[b, :] = w3 relu(w2 relu(w1 input[b, :] + b1) + b2) + b3 — the Linear / ReLU stack of cusrl/nn/module/mlp.py:74-93
+ * behind the policy-mean head (cusrl/nn/module/actor.py:69-92, distribution.py:256-262) or the value head
+ * (cusrl/nn/module/critic.py:87-88), evaluated WITHOUT autograd: acting (ActorCritic.act, actor_critic.py:226-244), the value
+ * targets (hook/on_policy/value.py:58-79), the post-update statistics (hook/on_policy/stats.py:29-40).  Replaces three library
+ * GEMMs (+ the sampling launch): every intermediate stays on chip, a workgroup keeps its weight slices in registers and walks
+ * 16-row tiles.  fp32 MFMA accumulation; agrees with the library GEMMs to a few ulp of the accumulated magnitude.
+ * Weights are torch.nn.Linear's: w1 [hidden1, in], w2 [hidden2, hidden1], w3 [out, hidden2], row-major; b3 may be NULL.
+ * Sampling epilogue (eps != NULL; std [out] vector, eps [rows, out]): action = mean + eps * std, logp[b] = sum_a log N(action |
+ * mean, std) with the expressions and the summation order of cusrl_normal_sample_logp, std_out (optional) = std repeated per
+ * row; `output` (optional then) receives the mean.  Without eps: std / action / logp / std_out must be NULL and output given.
+ * Supported (cusrl_mlp2_forward_supported): in % 4 == 0, 4 <= in <= 64; hidden1 in {128, 256}; hidden2 in {64, 128};
+ * 1 <= out <= 16; input / weights / biases 16-byte aligned (output too when out % 4 == 0). */
+int cusrl_mlp2_forward(const float *input, int64_t rows, int64_t in_features, const float *w1, const float *b1, int64_t hidden1,
+                       const float *w2, const float *b2, int64_t hidden2, const float *w3, const float *b3, int64_t out_features,
+                       float *output, const float *std, const float *eps, float *action, float *logp, float *std_out,
+                       void *stream);
+int cusrl_mlp2_forward_supported(int64_t in_features, int64_t hidden1, int64_t hidden2, int64_t out_features);
+
 /* ---- gradient-norm clipping (hook/on_policy/gradient_clipping.py:67-83 -> torch.nn.utils.clip_grad_norm_) ----
  * norm_out[0] = ||grad||_2 (pre-clip, the `grad_norm/default` metric); grad *= min(max_norm / (norm + 1e-6), 1).
  * max_norm < 0: measure only.  grad: float[n], 16-byte aligned (the flat gradient buffer every .grad aliases);
