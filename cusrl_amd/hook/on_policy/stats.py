@@ -81,9 +81,17 @@ class OnPolicyStatistics(Hook):
             return False
         from cusrl_amd.template.graphs import GraphedRegion
 
+        # The reference draws one permutation here (stats.py:29-32 -> mini_batch_sampler.py:56): so do we — the generator must see it
+        # — but the in-place pass never reads its values, so the draw's dozen launches (~80 us of sort) go to the samplers'
+        # draw-ahead stream instead of sitting between the last minibatch step and this pass.  (The per-slot record is current
+        # here: `prepare_sampling` inside the iteration launches nothing; it is asked first, on this stream, should it ever.)
+        from cusrl_amd.sampler.mini_batch_sampler import _prefetch_stream
+
+        buffer.prepare_sampling(self.sampler.hot_fields if getattr(self.sampler, "lazy", False) else None)
         metadata = None
-        for metadata, _indices in self.sampler.iter_indices(buffer):  # the reference draws one permutation here: so do we
-            pass
+        with torch.cuda.stream(_prefetch_stream(agent.device)):
+            for metadata, _indices in self.sampler.iter_indices(buffer):
+                pass
         if metadata is None or metadata["temporal"]:
             return False
         flat = buffer.sample(lambda _name, tensor: tensor.flatten(0, 1))
