@@ -297,7 +297,12 @@ class ActorCritic(Agent):
                 # the whole-update graph needs EVERY epoch's permutation before it starts: the remaining draws are issued while
                 # the host has nothing to do — ValueComputation.pre_update waits for the truncated count of a region it has
                 # just launched (`run_while_waiting`) — and run under that region on the side stream
-                self._while_waiting = lambda: early.draw(len(early) - 1)
+                def while_waiting():
+                    early.draw(len(early) - 1)
+                    if self._graphed_epochs is not None:  # ... and the host half of the update graph's launch (GraphedEpochs.prepare)
+                        self._graphed_epochs.prepare(early)
+
+                self._while_waiting = while_waiting
         try:
             self.hook.pre_update(self.buffer)  # a3-a6: next_value, GAE, advantage normalisation
         finally:

@@ -36,9 +36,13 @@ class EnvironmentStats:
         self.total_steps = self.num_steps = 0
         self._num_episodes = 0
         if self.on_device:
-            self._episodes_dev = zeros(2, dtype=torch.int64)  # double-buffered: see cusrl_episode_stats
+            # one block of 8-byte slots: [episode counter x 2 (uint64, double-buffered: see cusrl_episode_stats) | reward sums
+            # (fp64)] — it travels to the host as ONE piece of the metrics' staged read, the counters as bit patterns
+            self._block = zeros(2 + reward_dim, dtype=torch.float64)
+            self._episodes_dev = self._block[:2].view(torch.int64)
             self._parity = 0
-            self._reward_sum = zeros(reward_dim, dtype=torch.float64)
+            self._reward_sum = self._block[2:]
+            self._frame: StatsFrame | None = None
 
     # ---- device path: one launch per env step
     def track(self, reward: torch.Tensor, done: torch.Tensor):
@@ -99,26 +103,64 @@ class EnvironmentStats:
         self.episode_len[indices] = 0.0
 
     def clear_step_info(self):
-        self.reward.zero_()
         if self.on_device:
             self._reward_sum.zero_()
+        else:
+            self.reward.zero_()
         self.num_steps = 0
 
     def freeze(self, metrics=None) -> "StatsFrame":
         """Close the statistics of the rollout that has just been issued: a :class:`StatsFrame` that will give its three means
-        and carries its step counters, and the per-rollout accumulators back at zero (``clear_step_info``) — in stream order,
-        so the next rollout may be enqueued before anybody has read the frame.  With device-resident statistics and a
-        ``metrics`` store the values travel to the host in the ONE copy the store makes when it is next read
-        (``Metrics.defer``); otherwise they are read right here (five host round trips on a GPU, none on the CPU)."""
+        and carries its step counters, with the per-rollout accumulators back at zero before the next rollout touches them.
+        With device-resident statistics and a ``metrics`` store NOTHING is launched here: the store takes the values along — and
+        zeroes the reward sums — when it is next read (``Metrics.pending`` -> :meth:`stage_metrics`: the one snapshot / one
+        reset / one host copy per dtype that every captured graph's running sums share), which must happen before the next
+        rollout is issued (``agent.update()`` reads the store when it closes; ``Trainer`` checks).  Otherwise the values are
+        read right here (a host round trip on a GPU, none on the CPU)."""
         frame = StatsFrame(self.num_steps, self.total_steps, self.num_envs, self.reward_dim, self.buffer_size)
         if self.on_device and metrics is not None:
-            metrics.defer(self._snapshot(), frame.receive)
-        elif self.on_device:
+            frame.parity, self._frame = self._parity, frame
+            metrics.pending(self)
+            self.num_steps = 0
+            return frame
+        if self.on_device:
             frame.receive(self._snapshot().tolist())
         else:
             frame.means = (self.mean_episode_length, self.mean_episode_reward, self.mean_step_reward)
         self.clear_step_info()
         return frame
+
+    def stage_metrics(self, metrics):
+        """``[(values, tensor to reset or None, callback)]`` for ``Metrics._stage_pending``: the 8-byte block (reset: the reward
+        sums), the two rings of finished episodes (no reset) — handed to the frame :meth:`freeze` left waiting."""
+        frame, self._frame = self._frame, None
+        if frame is None:
+            return []
+        parts: dict[str, list] = {}
+
+        def collect(name):
+            def keep(values):
+                parts[name] = values
+                if len(parts) == 3:
+                    import struct
+
+                    block = parts["block"]
+                    episodes = struct.unpack("<q", struct.pack("<d", block[frame.parity]))[0]  # the uint64 counter's bits
+                    frame.receive([float(episodes), *block[2:], *parts["rewards"], *parts["lengths"]])
+            return keep
+
+        frame.staged = True
+        return [(self._block, self._reward_sum, collect("block")), (self.rew_buffer.reshape(-1), None, collect("rewards")),
+                (self.len_buffer.reshape(-1), None, collect("lengths"))]
+
+    def close_frame(self, frame: "StatsFrame") -> None:
+        """A frame nobody staged (the agent's ``update()`` did not read its metrics): read it now, synchronously — the values
+        must leave before the next rollout moves them."""
+        if self.on_device and not frame.staged and frame.means is None:
+            self._frame = None
+            frame.parity = None
+            frame.receive(self._snapshot().tolist())
+            self._reward_sum.zero_()
 
     def _snapshot(self) -> torch.Tensor:
         return torch.cat((self._episodes_dev[self._parity].reshape(1).double(), self._reward_sum,
@@ -168,12 +210,13 @@ class StatsFrame:
     """The episode statistics of ONE rollout as its log will report them (``EnvironmentStats.freeze``): the host counters at the
     moment the rollout was closed and — once ``receive`` has been given the device snapshot — the three means."""
 
-    __slots__ = ("num_steps", "total_steps", "num_envs", "reward_dim", "buffer_size", "means")
+    __slots__ = ("num_steps", "total_steps", "num_envs", "reward_dim", "buffer_size", "means", "parity", "staged")
 
     def __init__(self, num_steps: int, total_steps: int, num_envs: int, reward_dim: int, buffer_size: int):
         self.num_steps, self.total_steps, self.num_envs = num_steps, total_steps, num_envs
         self.reward_dim, self.buffer_size = reward_dim, buffer_size
         self.means = None
+        self.parity, self.staged = None, False  # device statistics: which episode counter is current; taken along by a staged read
 
     def receive(self, flat) -> None:
         """``flat`` = host values of ``EnvironmentStats._snapshot()``: episode count, reward sums, the ring of finished episodes."""
@@ -300,6 +343,7 @@ class Trainer:
             agent.deferred_summary = pipelined
         with timer.record("agent"):
             agent_info = agent.update()
+        self.stats.close_frame(frame)  # (no-op when the update's staged read took the statistics along)
         self._pending_log = (agent_info, frame, timer.detach(), self.iteration)
         if not pipelined:
             self.flush()

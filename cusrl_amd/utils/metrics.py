@@ -230,7 +230,9 @@ class Metrics:
             by_type.setdefault((entry[0].device, entry[0].dtype), []).append(entry)
         for group in by_type.values():
             snapshot = torch.cat([tensor.reshape(-1) for tensor, _, _ in group])
-            torch._foreach_zero_([reset for _, reset, _ in group])
+            resets = [reset for _, reset, _ in group if reset is not None]  # (None: a piece that is only read)
+            if resets:
+                torch._foreach_zero_(resets)
             sizes = [tensor.numel() for tensor, _, _ in group]
             callbacks = [callback for _, _, callback in group]
 

@@ -250,3 +250,63 @@ def test_fused_synthetic_env_step_draws_the_documented_distributions(cusrl):
     graph.replay()
     torch.cuda.synchronize()
     assert not torch.equal(first, captured) and abs(captured.var().item() - 1.0) < 0.01
+
+
+class _ListLogger:
+    """Collects every ``log(info, iteration)`` call (the trainer's logger protocol)."""
+
+    def __init__(self):
+        self.entries = []
+
+    def log(self, info, iteration):
+        self.entries.append((iteration, dict(info)))
+
+    def save_checkpoint(self, checkpoint, iteration):
+        self.entries.append(("checkpoint", iteration))
+
+
+@pytest.mark.parametrize("kind", ["continuous", "amp"])
+def test_pipelined_logging_reports_every_iteration_once_with_the_same_values(cusrl, kind):
+    """Round 6: the trainer reads an iteration's log AFTER the next rollout has been launched (`Trainer.pipeline_logs`).  Against
+    the unpipelined loop from the same seed: the same iterations in the same order, every value of every log equal — the timing
+    keys aside —, checkpoints behind the log of their iteration, parameters bit-identical."""
+    runs = {}
+    for pipelined in (True, False):
+        cusrl.set_global_seed(33)
+        env = cusrl.testing.DummyTorchEnvironment(num_instances=256, observation_dim=12, action_dim=4, device=DEV)
+        logger = _ListLogger()
+        trainer = cusrl.Trainer(env, _factory(cusrl, kind, 8), logger_factory=lambda logger=logger: logger, num_iterations=9,
+                                checkpoint_interval=4, verbose=False)
+        trainer.pipeline_logs = pipelined
+        trainer.run_training_loop()
+        assert trainer._pending_log is None
+        runs[pipelined] = (logger.entries, [p.detach().clone() for p in trainer.agent.parameters()], trainer)
+    piped, plain = runs[True][0], runs[False][0]
+    order = [entry[0] if entry[0] != "checkpoint" else ("checkpoint", entry[1]) for entry in piped]
+    assert order == [entry[0] if entry[0] != "checkpoint" else ("checkpoint", entry[1]) for entry in plain]
+    assert order == [("checkpoint", 0), 1, 2, 3, 4, ("checkpoint", 4), 5, 6, 7, 8, ("checkpoint", 8), 9, ("checkpoint", 9)]
+    assert runs[True][2]._graphed_rollout is not None and runs[True][2]._graphed_rollout.rollout_replays > 0  # (it did pipeline)
+    for (it_a, a), (it_b, b) in zip([e for e in piped if e[0] != "checkpoint"], [e for e in plain if e[0] != "checkpoint"]):
+        assert it_a == it_b and a.keys() == b.keys()
+        for key in a:
+            if key.startswith("Perf/") and key != "Perf/environment_step":
+                assert a[key] > 0
+            else:
+                assert a[key] == b[key], (it_a, key)
+    for p, q in zip(runs[True][1], runs[False][1]):
+        assert torch.equal(p, q)
+
+
+def test_direct_agent_update_still_returns_plain_floats(cusrl):
+    """``agent.update()`` hands out a staged summary only to a trainer that asked for it (`deferred_summary`)."""
+    cusrl.set_global_seed(5)
+    env = cusrl.testing.DummyTorchEnvironment(num_instances=64, observation_dim=12, action_dim=4, device=DEV)
+    agent = _factory(cusrl, "continuous", 4).from_environment(env)
+    observation, state, _ = env.reset()
+    for _ in range(4):
+        action = agent.act(observation, state)
+        observation, state, reward, terminated, truncated, info = env.step(action)
+        ready = agent.step(observation, reward, terminated, truncated, state, **info)
+    assert ready
+    summary = agent.update()
+    assert isinstance(summary, dict) and summary and all(isinstance(v, float) for v in summary.values())

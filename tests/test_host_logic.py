@@ -959,3 +959,102 @@ def test_every_script_and_package_module_compiles():
     assert len(files) > 40
     for file in files:
         compile(file.read_text(), str(file), "exec")  # SyntaxError names the file
+
+
+def test_staged_summary_keeps_its_own_entries_while_the_store_moves_on():
+    """Round 6: ``Metrics.staged_summary`` issues the copy and returns; the store may be cleared and recorded into again before
+    ``resolve()`` — deferred callbacks record into the STAGED read, not into whatever the store holds by then."""
+    metrics = cusrl.utils.Metrics()
+    metrics.record(loss=torch.tensor([1.0, 3.0]))
+    metrics.defer(torch.tensor([4.0, 6.0]), lambda values: metrics.add_resolved("late", sum(values), 2))
+    staged = metrics.staged_summary("Agent")
+    metrics.clear()
+    metrics.record(loss=torch.tensor([100.0]))              # the next iteration's recording
+    assert staged.resolve() == {"Agent/loss": pytest.approx(2.0), "Agent/late": pytest.approx(5.0)}
+    assert staged.resolve() is staged.resolve()             # resolved once
+    assert metrics.summary("Agent") == {"Agent/loss": pytest.approx(100.0)}   # nothing of the staged read leaked into the store
+
+
+def test_timer_detach_hands_the_sections_over_and_starts_from_zero():
+    from cusrl_amd.utils.timing import Timer
+
+    timer = Timer("cpu")
+    with timer.record("agent"):
+        pass
+    for _ in range(3):
+        with timer.record("environment", 2):
+            pass
+    frozen = timer.detach()
+    assert frozen["agent"] >= 0.0 and frozen["environment"] >= 0.0 and set(frozen._seen) == {("environment", 2)}
+    assert not timer._total and not timer._seen and timer["agent"] == 0.0
+    with timer.record("agent"):
+        with pytest.raises(RuntimeError, match="still open"):
+            timer.detach()
+
+
+def test_environment_stats_freeze_snapshots_the_rollout_and_resets_the_step_accumulators():
+    from cusrl_amd.template.trainer import EnvironmentStats
+
+    stats = EnvironmentStats(num_envs=4, reward_dim=1, buffer_size=8)
+    for step in range(3):
+        stats.track_step(torch.full((4, 1), float(step + 1)))
+    stats.track_episode(torch.tensor([1, 3]))
+    frame = stats.freeze()
+    assert (frame.num_steps, frame.total_steps) == (3, 12) and stats.num_steps == 0 and stats.total_steps == 12
+    length, reward, step_reward = frame.means
+    assert length == pytest.approx(3.0) and reward == pytest.approx(6.0) and step_reward == pytest.approx(2.0)
+    assert float(stats.reward.abs().sum()) == 0.0
+    # the device form's decode, from a host list shaped like `_snapshot()`: count, reward sum, the ring of rewards, of lengths
+    from cusrl_amd.template.trainer import StatsFrame
+
+    decoded = StatsFrame(num_steps=2, total_steps=8, num_envs=4, reward_dim=1, buffer_size=3)
+    decoded.receive([2.0, 16.0, 5.0, 7.0, 0.0, 10.0, 20.0, 0.0])
+    assert decoded.means == (pytest.approx(15.0), pytest.approx(6.0), pytest.approx(2.0))
+
+
+def test_trainer_flushes_a_pending_log_before_last_info_answers():
+    """The trainer's loop with a stand-in agent on the CPU (the product agent only runs on a GPU): a host-driven rollout logs right
+    away; a log left pending — what a captured rollout does — is written by ``flush()`` / by whoever asks for ``last_info`` first,
+    under the iteration it belongs to; the training loop leaves nothing pending and checkpoints behind the log."""
+    from cusrl_amd.template.agent import Agent, AgentFactory
+
+    class CountingAgent(Agent):
+        def act(self, observation, state=None):
+            return torch.zeros(observation.shape[0], 2)
+
+        def step(self, next_observation, reward, terminated, truncated, next_state=None, **kwargs):
+            return super().step(next_observation, reward, terminated, truncated, next_state, **kwargs)
+
+        def update(self):
+            self.metrics.record(updates=torch.tensor(float(self.iteration + 1)))
+            return super().update()
+
+    class Factory(AgentFactory):
+        def __call__(self, environment_spec):
+            return CountingAgent(environment_spec, num_steps_per_update=4, name="Agent", device="cpu")
+
+    class Logger:
+        def __init__(self):
+            self.entries = []
+
+        def log(self, info, iteration):
+            self.entries.append((iteration, info["Agent/updates"], info["Perf/environment_step"]))
+
+        def save_checkpoint(self, checkpoint, iteration):
+            self.entries.append(("checkpoint", iteration))
+
+    env = cusrl.testing.DummyTorchEnvironment(num_instances=8, observation_dim=6, action_dim=2, device="cpu")
+    logger = Logger()
+    trainer = cusrl.Trainer(env, Factory(num_steps_per_update=4), logger_factory=lambda: logger, num_iterations=3, checkpoint_interval=2,
+                            verbose=False)
+    observation, state, _ = env.reset()
+    observation, state = trainer._rollout_and_update(observation, state)
+    assert trainer._pending_log is None and logger.entries == [(1, 1.0, 32)]   # a host-driven rollout logs right away
+    assert trainer.last_info["Agent/updates"] == 1.0 and trainer.agent.deferred_summary is False
+    trainer._pending_log = ({"Agent/updates": 9.0}, trainer.stats.freeze(), trainer.timer.detach(), 7)
+    assert trainer.last_info["Agent/updates"] == 9.0 and trainer._pending_log is None and logger.entries[-1][:2] == (8, 9.0)
+    logger.entries.clear()
+    trainer.iteration = 0
+    trainer.agent.iteration = 0
+    trainer.run_training_loop()
+    assert logger.entries == [("checkpoint", 0), (1, 1.0, 64), (2, 2.0, 96), ("checkpoint", 2), (3, 3.0, 128), ("checkpoint", 3)]
