@@ -119,6 +119,8 @@ _SIGNATURES = {
     "cusrl_assemble_gradients_blocks": (c_int64, [POINTER(GradPiece), c_int64]),
     "cusrl_grad_sumsq": (c_int, [_P, c_int64, _P, _P]),
     "cusrl_adam_step": (c_int, [_P] * 6 + [c_int64, c_double, c_double, c_double, c_double, c_int, c_int, _P, c_int64, c_float, _P, _P, _P, _P]),
+    "cusrl_adam_step_window": (c_int, [_P] * 6 + [c_int64, c_double, c_double, c_double, c_double, c_int, c_int, _P, c_int64, _P, c_int64,
+                                       c_float, _P, _P, _P, _P, _P]),
     "cusrl_masked_col_stats": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, _P]),
     "cusrl_masked_stats_num_partials": (c_int64, [c_int64, c_int64]),
     "cusrl_rms_merge": (c_int, [_P] * 7 + [c_float, c_double, c_int64, _P]),

@@ -99,8 +99,10 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float *__restrict__ p
                                                            float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
                                                            float *__restrict__ step, const float *__restrict__ lr,
                                                            const double *__restrict__ clip_partials,
+                                                           const double *__restrict__ clip_partials_b, int num_b,
                                                            float *__restrict__ norm_out, float *__restrict__ norm_accumulator,
-                                                           unsigned int *__restrict__ ticket, int64_t n, AdamParams a) {
+                                                           float *__restrict__ step_mirror, unsigned int *__restrict__ ticket,
+                                                           int64_t n, AdamParams a) {
     __shared__ float shared[4];  // clip coefficient, step size, sqrt(bias_correction2), new step count
     // The four streams of this thread's FIRST float4 are requested before anything else: they do not depend on the clipping
     // coefficient, and the chain partial rows -> norm -> coefficient below is a memory round trip of its own (round 6: the
@@ -115,8 +117,11 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float *__restrict__ p
     if (threadIdx.x < kWave) {
         float coef = 1.0f;
         if (clip_partials) {  // uniform branch; the partials of cusrl_grad_sumsq (<= 64) or of the gradient assembly
+            // (a second array continues the first: the partial rows of two gradient assemblies — one per network window,
+            // cusrl_adam_step_window — are summed exactly as ONE assembly's rows would be)
             double p = 0.0;
-            for (int i = threadIdx.x; i < a.num_clip_partials; i += kWave) p += clip_partials[i];
+            const int first = a.num_clip_partials, total = first + num_b;
+            for (int i = threadIdx.x; i < total; i += kWave) p += i < first ? clip_partials[i] : clip_partials_b[i - first];
             p = wave_sum(p);
             const float norm = float(sqrt(p));
             if (a.max_norm >= 0.0f) {
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float *__restrict__ p
     if (threadIdx.x == 0) {
         if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
             step[0] = t;
+            if (step_mirror) step_mirror[0] = t;  // a second counter kept equal (the other window's, cusrl_adam_step_window)
             *ticket = 0u;
         }
     }
@@ -203,7 +209,27 @@ extern "C" int cusrl_adam_step(float *param, const float *grad, float *exp_avg, 
                  int(num_clip_partials)};
     const int64_t blocks = ceil_div(n / 4 > 0 ? n / 4 : 1, kBlock);
     adam_step_kernel<<<int(blocks > 1024 ? 1024 : blocks), kBlock, 0, as_stream(stream)>>>(
-        param, grad, exp_avg, exp_avg_sq, step, lr, clip_partials, norm_out, norm_accumulator, ticket, n, a);
+        param, grad, exp_avg, exp_avg_sq, step, lr, clip_partials, nullptr, 0, norm_out, norm_accumulator, nullptr, ticket, n, a);
+    return launch_status();
+}
+
+extern "C" int cusrl_adam_step_window(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step,
+                                      const float *lr, int64_t n, double beta1, double beta2, double eps, double weight_decay,
+                                      int decoupled_weight_decay, int maximize, const double *clip_partials_a, int64_t num_a,
+                                      const double *clip_partials_b, int64_t num_b, float max_norm, float *norm_out,
+                                      float *norm_accumulator, float *step_mirror, uint32_t *ticket, void *stream) {
+    using namespace cusrl;
+    if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !step || !lr || !ticket) return CUSRL_E_INVALID;
+    if (num_a < 0 || num_b < 0 || (num_a > 0 && !clip_partials_a) || (num_b > 0 && !clip_partials_b)) return CUSRL_E_INVALID;
+    if (num_b > 0 && num_a == 0) return CUSRL_E_INVALID;  // (the second array continues the first)
+    if (num_a + num_b > kMaxClipPartials) return CUSRL_E_INVALID;
+    if (!aligned(param, 16) || !aligned(grad, 16) || !aligned(exp_avg, 16) || !aligned(exp_avg_sq, 16))
+        return CUSRL_E_UNSUPPORTED;
+    AdamParams a{beta1, beta2, float(eps), float(weight_decay), max_norm, decoupled_weight_decay, maximize, int(num_a)};
+    const int64_t blocks = ceil_div(n / 4 > 0 ? n / 4 : 1, kBlock);
+    adam_step_kernel<<<int(blocks > 1024 ? 1024 : blocks), kBlock, 0, as_stream(stream)>>>(
+        param, grad, exp_avg, exp_avg_sq, step, lr, num_a > 0 ? clip_partials_a : nullptr, clip_partials_b, int(num_b), norm_out,
+        norm_accumulator, step_mirror, ticket, n, a);
     return launch_status();
 }
 

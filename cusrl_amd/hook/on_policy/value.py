@@ -238,7 +238,10 @@ class ValueLoss(Hook):
             separate = getattr(self.agent, "separate_value_root", False) and fused.unit_grad
             if separate:  # (read on the main stream, in front of the fork: a lazy batch gathers a field where it is first touched)
                 ret, old_value = batch["return"], (batch["value"] if self.loss_clip is not None else None)
-            branch.wait_stream(main)  # the gather of `state` was issued on `main`
+            if not (separate and getattr(self.agent, "_batch_on_branch", False)):
+                branch.wait_stream(main)  # the gather of `state` was issued on `main`
+            # (else: a step inside a whole-update graph whose predecessor left the streams unjoined — the critic's parameters were
+            # stepped, and this step's rows gathered, on `branch` itself: it carries on without meeting the main stream)
             with torch.cuda.stream(branch):
                 curr_value = self.agent.critic.evaluate(state, memory=memory, done=done)
                 if separate:

@@ -1741,6 +1741,37 @@ def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, ex
     )
 
 
+def adam_step_window(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+                     step: torch.Tensor, lr: torch.Tensor, ticket: torch.Tensor, *, betas: tuple[float, float], eps: float,
+                     weight_decay: float, decoupled: bool, maximize: bool = False,
+                     clip_partials: tuple[torch.Tensor | None, torch.Tensor | None] = (None, None), max_norm: float | None = None,
+                     norm_out: torch.Tensor | None = None, norm_accumulator: torch.Tensor | None = None,
+                     step_mirror: torch.Tensor | None = None):
+    """:func:`adam_step` over one window of the flat buffers (``cusrl_adam_step_window``): ``clip_partials`` = the squared-norm
+    partial rows of up to two gradient assemblies, summed as one array; ``step_mirror``: a second counter set to the new count."""
+    for tensor, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (step, "step"), (lr, "lr")):
+        _f32(tensor, name)
+    require_device(ticket, "ticket")
+    if ticket.dtype != torch.int32 or ticket.numel() != 1:
+        raise TypeError("'ticket' must be a 1-element int32 device tensor")
+    n = param.numel()
+    if not (grad.numel() == exp_avg.numel() == exp_avg_sq.numel() == n) or not all(t.is_contiguous() for t in (param, grad, exp_avg, exp_avg_sq)):
+        raise ValueError("a window of the flat optimizer buffers: four contiguous stretches of the same length")
+    first, second = clip_partials
+    if any(t is not None and (t.dtype != torch.float64 or not t.is_cuda) for t in (first, second)):
+        raise TypeError("'clip_partials' are fp64 device tensors")
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    check(
+        _native.lib().cusrl_adam_step_window(
+            param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), step.data_ptr(), lr.data_ptr(), n,
+            float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(decoupled), int(maximize),
+            ptr(first), 0 if first is None else first.numel(), ptr(second), 0 if second is None else second.numel(),
+            -1.0 if max_norm is None else float(max_norm), ptr(norm_out), ptr(norm_accumulator), ptr(step_mirror), ticket.data_ptr(),
+            _stream()),
+        "cusrl_adam_step_window",
+    )
+
+
 # ------------------------------------------------------------------------------------------------ running statistics
 def masked_col_stats(x: torch.Tensor, mask: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``mean_var_count`` (population variance) of the rows of ``x [rows, C]`` whose ``mask`` byte is set

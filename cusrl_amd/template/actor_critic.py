@@ -152,6 +152,10 @@ class ActorCritic(Agent):
         self._graphed_steps: dict[tuple, Any] = {}
         self._graphed_epochs = None
         self._branch_tail = None  # a callable GraphedEpochs wants issued at the tail of the running step's critic branch
+        # set by GraphedEpochs around the step bodies of a whole-update / whole-epoch capture: a step may leave its two streams
+        # unjoined (they meet behind the LAST body); `_batch_on_branch`: the running step's rows were gathered on the critic's stream
+        self._unjoined_steps = False
+        self._batch_on_branch = False
         self._while_waiting = None  # host work to issue while a pre_update hook waits for the device (run_while_waiting)
         self._minibatches_done = None  # event behind the last minibatch step of the previous update (its index rows may be redrawn)
         self._graph_key_reads = 0
@@ -449,6 +453,37 @@ class ActorCritic(Agent):
             position = next(i for i, term in enumerate(roots) if term is value_root)
             others = [term for i, term in enumerate(roots) if i != position]
             other_units = [unit for i, unit in enumerate(units) if i != position]
+            ranges = self._two_window_ranges() if self._unjoined_steps else None
+            if ranges is not None:
+                # Round 6, inside a whole-update / whole-epoch graph: each network's window of the flat buffer is assembled on the
+                # stream its backward ran on, and the streams do NOT meet — the optimizer steps the two windows where they are
+                # (FlatAdam.step: each behind the other window's assembly, the clipping coefficient needs both).  The rows of the
+                # NEXT minibatch step are gathered in front of the critic's assembly, so the one event the main stream waits for
+                # covers them too.
+                main = torch.cuda.current_stream()
+                flat.absent = []
+                with torch.cuda.stream(branch):
+                    with collect_split_weight_grads() as critic_slabs:
+                        critic_grads = torch.autograd.grad([value_root], [flat.params[i] for i in critic_ids],
+                                                           grad_outputs=[units[position]], allow_unused=True)
+                    tail, self._branch_tail = self._branch_tail, None
+                    if tail is not None:
+                        tail()
+                    branch_sumsq = flat.assemble(critic_grads, critic_slabs, subset=critic_ids, want_sumsq=True)
+                    branch_assembled = torch.cuda.Event()
+                    branch_assembled.record(branch)
+                with collect_split_weight_grads() as split_slabs:
+                    other_grads = torch.autograd.grad(others, [flat.params[i] for i in other_ids], grad_outputs=other_units,
+                                                      allow_unused=True)
+                main_sumsq = flat.assemble(other_grads, split_slabs, subset=other_ids, want_sumsq=True)
+                main_assembled = torch.cuda.Event()
+                main_assembled.record(main)
+                main_range, branch_range = ranges
+                # (the rows in parameter order: summed as ONE assembly's rows would be — the same norm to the bit)
+                sumsq = (main_sumsq, branch_sumsq) if main_range[0] < branch_range[0] else (branch_sumsq, main_sumsq)
+                flat.split_tail = {"branch": branch, "branch_assembled": branch_assembled, "main_assembled": main_assembled,
+                                   "sumsq": sumsq, "main_range": main_range, "branch_range": branch_range}
+                return
             with torch.cuda.stream(branch):
                 with collect_split_weight_grads() as critic_slabs:
                     critic_grads = torch.autograd.grad([value_root], [flat.params[i] for i in critic_ids],
@@ -557,6 +592,35 @@ class ActorCritic(Agent):
         if critic_ids and not (critic & outside):
             self._networks = (critic_ids, [i for i, p in enumerate(flat.params) if id(p) not in critic])
         return self._networks
+
+    def _two_window_ranges(self):
+        """``(element range of the others' window, of the critic's window)`` of the flat buffers when a minibatch step may leave
+        its two streams unjoined (``_backward`` / ``FlatAdam.step``): one process, the flat Adam step, critic and others each one
+        run of consecutive parameters, nobody but the stock gradient clipping between backward and step (a ``pre_optim`` of
+        another hook could read gradients of the window that lives on the other stream); else None.  Computed once."""
+        cached = getattr(self, "_two_windows", False)
+        if cached is not False:
+            return cached
+        self._two_windows = None
+        from cusrl_amd.hook.on_policy.gradient_clipping import GradientClipping
+        from cusrl_amd.template.hook import Hook
+        from cusrl_amd.utils.config import configure_distributed
+
+        networks, flat = self._network_windows(), self.flat_gradients
+        if networks is None or flat is None or self.flat_optimizer is None or configure_distributed():
+            return None
+        if os.environ.get("CUSRL_TWO_WINDOW_STEP", "1") == "0":  # A/B switch
+            return None
+        for hook in self.hook:
+            stock = type(hook).pre_optim is Hook.pre_optim and type(hook).post_optim is Hook.post_optim
+            if hook._active and not stock and not (isinstance(hook, GradientClipping) and not hook.groups
+                                                   and type(hook).post_optim is Hook.post_optim):
+                return None
+        try:
+            self._two_windows = (flat.element_range(networks[1]), flat.element_range(networks[0]))
+        except ValueError:
+            self._two_windows = None
+        return self._two_windows
 
     @property
     def separate_value_root(self) -> bool:

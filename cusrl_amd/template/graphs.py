@@ -561,6 +561,7 @@ class GraphedEpochs:
         ahead_of_step = self.prefetch in ("side", "tail")
         # (the persistent batch tensors exist by now: `_allocate` ran outside the capture)
         ahead = self._gather(row[0][0], row[0][2], 0) if ahead_of_step else None
+        on_branch = branch_open = False
         for k, (step, metadata, indices) in enumerate(row):
             saved = step.static_indices, step.metadata, step.preloaded
             step.static_indices = indices  # read in place
@@ -576,17 +577,33 @@ class GraphedEpochs:
                         fetch()
                 else:  # at the tail of this step's critic branch (ActorCritic._backward calls it there, on that stream)
                     agent._branch_tail = fetch
+            optimizer = agent.flat_optimizer
+            two_window_before = optimizer.two_window_steps if optimizer is not None else 0
+            agent._unjoined_steps = self.prefetch == "tail"  # (the step may leave its streams unjoined: ActorCritic._backward)
+            agent._batch_on_branch = on_branch
             try:
                 step._whole_step()
             finally:
                 step.static_indices, step.metadata, step.preloaded = saved
                 pending, agent._branch_tail = agent._branch_tail, None
+                agent._unjoined_steps = agent._batch_on_branch = False
             step.carry = {}
+            unjoined = optimizer is not None and optimizer.two_window_steps != two_window_before
+            if agent.flat_gradients is not None and agent.flat_gradients.split_tail is not None:
+                # (a backward left its streams unjoined and nobody stepped the optimizer: meet here)
+                main.wait_stream(agent.flat_gradients.split_tail["branch"])
+                agent.flat_gradients.split_tail, unjoined = None, False
             if pending is not None:
                 pending()  # no critic branch in this composition: behind the step, on its stream
             elif side is not None and following:
                 main.wait_stream(side)  # join, in front of the step that reads them
             ahead = following[0] if following else None
+            # the next step's rows were gathered at the tail of this step's critic branch, which then stepped the critic's window
+            # itself: the next step's critic forward need not meet the main stream (hook/on_policy/value.py)
+            on_branch = unjoined and pending is None and side is None and bool(following)
+            branch_open = unjoined
+        if branch_open:
+            main.wait_stream(agent._branch_stream)  # the streams of the last body meet before the capture ends
 
     def _allocate(self, rows):
         """The persistent batch tensors of both parities, created OUTSIDE the capture (one throw-away gather per set: an

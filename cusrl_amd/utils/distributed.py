@@ -558,6 +558,9 @@ class FlatGradients:
         # the per-network split of the backward (ActorCritic._backward): the windows it reduces, and whether it already did
         self.split_windows: list[torch.Tensor] | None = None
         self.reduced = False
+        # a backward that assembled the critic's window on the critic's stream and the others' on the main stream WITHOUT joining
+        # them (ActorCritic._backward, round 6): events, squared-norm rows and element ranges for the two-window optimizer step
+        self.split_tail: dict | None = None
         self._sumsq: torch.Tensor | None = None
         self._sumsq_version = -1
         for p, offset in zip(self.params, self.offsets):
@@ -582,13 +585,15 @@ class FlatGradients:
             self.attach()
         self.buffer.zero_()
 
-    def assemble(self, grads, split_slabs: dict[int, torch.Tensor] | None = None, subset: Sequence[int] | None = None):
+    def assemble(self, grads, split_slabs: dict[int, torch.Tensor] | None = None, subset: Sequence[int] | None = None,
+                 want_sumsq: bool | None = None):
         """Write every parameter's gradient into its slot with ONE launch (``cusrl_assemble_gradients``).
         ``grads[i]`` is parameter i's gradient or None; ``split_slabs`` maps a parameter's storage address to the
         unsummed ``[S, ...]`` partial gradients its split-batch GEMM left behind (cusrl_amd/nn/module.py).
         ``subset`` (indices into ``params``, ``grads`` aligned with it): only those parameters' windows are written — the
         per-network split of the backward (``ActorCritic._backward``) assembles critic and actor windows separately; slabs
-        of parameters outside the subset (the shared loss node hands the std vector's over in both passes) are dropped."""
+        of parameters outside the subset (the shared loss node hands the std vector's over in both passes) are dropped.
+        ``want_sumsq`` (default: a single process assembling everything): also return the blocks' partial sums of squares."""
         from cusrl_amd import ops
 
         pieces = []
@@ -624,8 +629,19 @@ class FlatGradients:
             raise RuntimeError("split weight gradients were produced for tensors that are not optimizer parameters")
         # single process: nothing changes the gradients between here and the clipping, so the assembly also leaves the
         # partial sums of squares the clipping coefficient needs (with several ranks the all-reduce comes in between)
-        self._sumsq = ops.assemble_gradients(pieces, self.buffer, want_sumsq=not configure_distributed() and subset is None)
+        if want_sumsq is None:
+            want_sumsq = not configure_distributed() and subset is None
+        sumsq = ops.assemble_gradients(pieces, self.buffer, want_sumsq=want_sumsq)
+        self._sumsq = sumsq if subset is None else None
         self._sumsq_version = self.buffer._version
+        return sumsq
+
+    def element_range(self, indices: Sequence[int]) -> tuple[int, int]:
+        """``(first, end)`` element offsets of the run of consecutive parameters ``indices`` (padding included)."""
+        first, last = indices[0], indices[-1]
+        if list(indices) != list(range(first, last + 1)):
+            raise ValueError("a gradient window is a run of consecutive parameters")
+        return self.offsets[first], (self.offsets[last + 1] if last + 1 < len(self.offsets) else self.buffer.numel())
 
     def window(self, indices: Sequence[int]) -> torch.Tensor:
         """The contiguous stretch of the buffer that holds the (consecutive) parameters ``indices``, padding included."""

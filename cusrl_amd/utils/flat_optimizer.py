@@ -60,6 +60,11 @@ class FlatAdam:
         self.lr = torch.zeros(1, dtype=torch.float32, device=device)
         self._lr_value: float | None = None
         self.ticket = torch.zeros(1, dtype=torch.int32, device=device)
+        # the two-window step (ActorCritic._backward left the streams unjoined, FlatGradients.split_tail): the critic's window is
+        # stepped on the critic's stream with a counter and a ticket of its own; every launch keeps the two counters equal
+        self.branch_step_count = torch.zeros(1, dtype=torch.float32, device=device)
+        self.branch_ticket = torch.zeros(1, dtype=torch.int32, device=device)
+        self.two_window_steps = 0
         self._pending_clip: tuple[torch.Tensor, float | None, torch.Tensor] | None = None
         self.metrics = None  # the agent's Metrics (set by the agent): a captured step's tap may take the norm straight from the launch
         self._views: list[tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []
@@ -81,6 +86,7 @@ class FlatAdam:
         steps = [float(state[p]["step"]) for p in self.params if p in state and "step" in state[p]]
         with torch.no_grad():
             self.step_count.fill_(max(steps) if steps else 0.0)
+            self.branch_step_count.fill_(max(steps) if steps else 0.0)
             for p, (_, exp_avg, exp_avg_sq) in zip(self.params, self._views):
                 held = state.get(p, {})
                 if "exp_avg" in held and held["exp_avg"] is not exp_avg:
@@ -99,6 +105,10 @@ class FlatAdam:
         """Take over gradient clipping: launches only the squared-norm partials now; the coefficient is applied by
         the next :meth:`step`.  Returns the device scalar that will hold the pre-clip norm after that step."""
         norm = torch.empty(1, dtype=torch.float32, device=self.lr.device)  # one per step: metrics keep a reference
+        tail = self.gradients.split_tail
+        if tail is not None:  # two unjoined window assemblies: their rows, in parameter order (summed as one array by both launches)
+            self._pending_clip = (tail["sumsq"], max_norm, norm)
+            return norm[0]
         partials = self.gradients.take_sumsq()  # left behind by the gradient assembly when nothing touched them since
         if partials is None:
             partials = ops.grad_sumsq(self.gradients.buffer)
@@ -145,10 +155,35 @@ class FlatAdam:
         # a captured step whose metric tap holds this step's norm: the launch adds it to the tap's running sum itself
         tap = getattr(self.metrics, "_tap", None) if norm is not None else None
         slot = tap.slot_of(norm) if tap is not None else None
-        ops.adam_step(self.param_buffer, self.gradients.buffer, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                      self.ticket, betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"],
-                      decoupled=decoupled, maximize=bool(group.get("maximize", False)), clip_partials=partials,
-                      max_norm=max_norm, norm_out=norm, norm_accumulator=slot)
+        hyper = dict(betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"], decoupled=decoupled,
+                     maximize=bool(group.get("maximize", False)), max_norm=max_norm)
+        tail, self.gradients.split_tail = self.gradients.split_tail, None
+        if tail is not None and not kept:
+            # The backward left the critic's window assembled on the critic's stream and the others' on this one, unjoined: each
+            # window is stepped where its gradients are, behind the OTHER window's assembly (an event edge — the clipping
+            # coefficient needs both windows' rows).  No join, no fork: the critic's next forward follows its own step on its own
+            # stream, and a stream only ever waits for the other's assembly — a fork / join pair per minibatch step costs
+            # ~18 us on this stack, two late-bound event edges ~11 (scripts/probe_graph_fork.py).
+            pair = partials if isinstance(partials, tuple) else (partials, None)
+            main, branch = torch.cuda.current_stream(), tail["branch"]
+            (lo, hi), (blo, bhi) = tail["main_range"], tail["branch_range"]
+            with torch.cuda.stream(branch):
+                branch.wait_event(tail["main_assembled"])
+                ops.adam_step_window(self.param_buffer[blo:bhi], self.gradients.buffer[blo:bhi], self.exp_avg[blo:bhi],
+                                     self.exp_avg_sq[blo:bhi], self.branch_step_count, self.lr, self.branch_ticket,
+                                     clip_partials=pair, **hyper)
+            main.wait_event(tail["branch_assembled"])
+            ops.adam_step_window(self.param_buffer[lo:hi], self.gradients.buffer[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                                 self.step_count, self.lr, self.ticket, clip_partials=pair, norm_out=norm, norm_accumulator=slot,
+                                 **hyper)
+            self.two_window_steps += 1
+            return loss
+        if tail is not None:  # (parameters without a gradient are put back below: one launch over everything, behind a join)
+            torch.cuda.current_stream().wait_stream(tail["branch"])
+        pair = partials if isinstance(partials, tuple) else (partials, None)
+        ops.adam_step_window(self.param_buffer, self.gradients.buffer, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+                             self.ticket, clip_partials=pair, norm_out=norm, norm_accumulator=slot,
+                             step_mirror=self.branch_step_count, **hyper)
         for view, view0, m, m0, v, v0 in kept:
             view.copy_(view0), m.copy_(m0), v.copy_(v0)
         return loss

@@ -538,6 +538,21 @@ int cusrl_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
                     int maximize, const double *clip_partials, int64_t num_clip_partials, float max_norm,
                     float *norm_out, float *norm_accumulator, uint32_t *ticket, void *stream);
 
+/* cusrl_adam_step over ONE WINDOW of the flat buffers (round 6): the optimizer step of the parameters of one network, issued on
+ * the stream that produced their gradients — the critic's on the critic's branch of a captured minibatch step, the others' on
+ * the main stream — so that the two branches of the step never join (actor_critic.py:311-320 runs clip + step once, behind one
+ * backward).  The clipping coefficient is the GLOBAL one (gradient_clipping.py:74): the squared norm is the sum of
+ * clip_partials_a[0 .. num_a) followed by clip_partials_b[0 .. num_b) — the partial rows of the two windows' gradient
+ * assemblies, in the order ONE assembly of all parameters would have left them; both launches of a step are handed the same
+ * two arrays and compute the same norm to the bit.  param / grad / exp_avg / exp_avg_sq point at the window's first element
+ * (16-byte aligned), n is its length; every window has its own `step` counter and `ticket`; step_mirror (optional): a second
+ * device float[1] that receives the new step count too (the other window's counter, when a launch covers both windows). */
+int cusrl_adam_step_window(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, const float *lr,
+                           int64_t n, double beta1, double beta2, double eps, double weight_decay, int decoupled_weight_decay,
+                           int maximize, const double *clip_partials_a, int64_t num_a, const double *clip_partials_b,
+                           int64_t num_b, float max_norm, float *norm_out, float *norm_accumulator, float *step_mirror,
+                           uint32_t *ticket, void *stream);
+
 /* ---- running observation statistics ----
  * cusrl/nn/utils/normalization.py:15-50 `mean_var_count` of x [rows, C] restricted to rows with mask != 0 (mask may
  * be NULL = all rows; replaces the host-synchronising boolean-mask select of hook/mdp/observation.py:206-208):

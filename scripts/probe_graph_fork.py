@@ -91,6 +91,44 @@ def main():
             s1.wait_stream(s3)
         return body
 
+    def leapfrog(branch, piece):
+        """no join: each stream runs its branch, a short piece (its half of the gradient assembly), waits for the OTHER stream's
+        piece (an event edge), runs a second short piece (its half of the optimizer step) and goes on with its next branch"""
+        state = {}
+
+        def body():
+            first = "e1" not in state
+            if first:
+                s2.wait_stream(s1)
+            with torch.cuda.stream(s2):
+                spin(branch)
+                spin(piece)
+                e2 = torch.cuda.Event()
+                e2.record(s2)
+            spin(branch)
+            spin(piece)
+            e1 = torch.cuda.Event()
+            e1.record(s1)
+            s1.wait_event(e2)
+            spin(piece)
+            with torch.cuda.stream(s2):
+                s2.wait_event(e1)
+                spin(piece)
+            state["e1"] = e1
+        return body, state
+
+    def capture_leapfrog(branch, piece, reps=20):
+        body, state = leapfrog(branch, piece)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s1):
+            for _ in range(reps):
+                body()
+            s1.wait_stream(s2)
+        return graph
+
+    for branch in (100, 30):
+        print(f"leapfrog (no join; two event edges per repetition), branches {branch} us + 2 x 5 us pieces per stream: "
+              f"{time_graph(capture_leapfrog(branch, 5)):8.1f} us per repetition (ideal {branch + 10})")
     for head, branch in ((15, 100), (15, 30), (5, 100)):
         print(f"head {head} us, branches {branch} us each:")
         print(f"  serial (head + 2 branches on one stream)      {time_graph(capture(serial(head, branch))):8.1f} us per repetition (ideal {head + 2 * branch})")
