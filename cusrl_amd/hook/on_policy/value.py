@@ -152,9 +152,14 @@ class ValueComputation(Hook):
         scratch = self._replay_scratch
         key = (buffer.layout_version, state.data_ptr(), next_state.data_ptr(), T, N)
         if scratch is None or scratch["key"] != key:  # the regions below close over these very tensors
+            # TWO pinned counters used in turn: the host may run up to one iteration ahead of the device (the trainer does not
+            # wait for an update to finish before it issues the next rollout and this hook), and the tail of iteration i reads
+            # ITS counter on the device when it executes — `arm()` of iteration i + 1 must not touch that one.  The host cannot
+            # get two iterations ahead: `wait()` below returns only once the device has reached this iteration's head.
             scratch = self._replay_scratch = {"key": key, "slots": torch.zeros(T * N, dtype=torch.int64, device=value.device),
-                                              "counter": ops.HostCounter(), "head": None, "tails": {}}
-        slots, counter = scratch["slots"], scratch["counter"]
+                                              "counters": (ops.HostCounter(), ops.HostCounter()), "parity": 0, "heads": {}, "tails": {}}
+        parity = scratch["parity"] = scratch["parity"] ^ 1
+        slots, counter = scratch["slots"], scratch["counters"][parity]
         compaction = scratch.get("compaction")
         if compaction is None:
             from cusrl_amd import _native
@@ -179,10 +184,10 @@ class ValueComputation(Hook):
             ops.next_value(value, terminated, truncated, last_value.float(), self.termination_value,
                            truncated_uses_own_value=not self.bootstrap_truncated_states, out=next_value)
 
-        if scratch["head"] is None:
-            scratch["head"] = GraphedRegion(self.agent, head)
+        if parity not in scratch["heads"]:  # (one captured head per counter: its address is baked into the compaction launch)
+            scratch["heads"][parity] = GraphedRegion(self.agent, head)
         counter.arm()
-        scratch["head"].run(self.bootstrap_truncated_states, self.termination_value)
+        scratch["heads"][parity].run(self.bootstrap_truncated_states, self.termination_value)
         if not self.bootstrap_truncated_states:
             return
         if (idle := getattr(self.agent, "run_while_waiting", None)) is not None:
@@ -200,9 +205,9 @@ class ValueComputation(Hook):
                 bootstrap = critic.evaluate(rows)
             ops.scatter_rows(bootstrap.float(), slots[:bucket], next_value, counter.tensor)
 
-        region = scratch["tails"].get(bucket)
+        region = scratch["tails"].get((bucket, parity))
         if region is None:
-            region = scratch["tails"][bucket] = GraphedRegion(self.agent, tail)
+            region = scratch["tails"][(bucket, parity)] = GraphedRegion(self.agent, tail)
         region.run(bucket)
 
 

@@ -284,11 +284,14 @@ class ActorCritic(Agent):
         return any(isinstance(layer, torch.nn.modules.dropout._DropoutNd) and layer.p > 0
                    for module in modules for layer in module.modules())
 
-    def update(self):
+    def _check_sampler_prefetch(self):
         if hasattr(self.sampler, "prefetch") and getattr(self, "_sampler_prefetch_checked", None) is not self.sampler:
             self._sampler_prefetch_checked = self.sampler
             if self._steps_draw_random():
                 self.sampler.prefetch = False  # keep the reference's interleaving of permutation and in-step draws
+
+    def update(self):
+        self._check_sampler_prefetch()
         # The first epoch's permutation depends on nothing pre_update computes: drawn NOW (side stream), it runs under
         # pre_update's kernels instead of between them and the first minibatch step.  Only when no hook this package does not
         # know could draw from the generator inside pre_update (the reference draws the permutation behind it,

@@ -284,6 +284,9 @@ class Trainer:
         self._pending_log: tuple | None = None
         # the log of an iteration is read, averaged and written AFTER the next rollout has been launched (A/B switch)
         self.pipeline_logs = os.environ.get("CUSRL_PIPELINE_LOGS", "1") != "0"
+        # "late" (A/B; measured 0.12 ms SLOWER): the pending log is written behind the update's launches instead of between the
+        # rollout's launch and the update's — the host then issues the next rollout while the update still runs
+        self._late_flush = os.environ.get("CUSRL_PIPELINE_LOGS") == "late"
         self.host_thread_cpus: list[int] = []
         if pin_host_thread and self.agent.device.type == "cuda":  # extension: NUMA-local placement of the driving thread
             from cusrl_amd.utils.affinity import pin_host_thread as pin
@@ -330,10 +333,14 @@ class Trainer:
             observation, state = self._rollout_captured(graphed, observation, state)
         else:
             observation, state = self._rollout_eager(observation, state)
-        # The log of the PREVIOUS iteration, when it was left pending (below): its values are read now, with this rollout
-        # already enqueued behind that iteration's update — the device goes from one to the other without waiting for the host
-        # to read, average and print.
-        self.flush()
+        if graphed is not None and self._pending_log is not None and not self._late_flush:
+            # The log of the PREVIOUS iteration, left pending: read, averaged and written now — with this rollout already enqueued
+            # behind that iteration's update, the device goes from one into the other without waiting for the host to read and
+            # print.  (Two other placements measured slower on one box, 4.75-4.80 ms this way: behind this iteration's update
+            # launches — the host then issues the next rollout and its side-stream draws while the update still runs, 4.88-4.91
+            # — and here but with the coming update's permutation draws issued in front of the read, 4.86-4.88: work parked on
+            # another hardware queue behind an event costs the running graph time.)
+            self.flush()
         metrics = getattr(agent, "metrics", None)
         frame = self.stats.freeze(metrics)  # (device statistics: read with the update's metrics, one host copy for both)
         # Pipelined logging: only around captured rollouts (a host-driven rollout keeps the device waiting anyway), without
@@ -344,6 +351,7 @@ class Trainer:
         with timer.record("agent"):
             agent_info = agent.update()
         self.stats.close_frame(frame)  # (no-op when the update's staged read took the statistics along)
+        self.flush()  # (a log still pending here: `CUSRL_PIPELINE_LOGS=late` — written behind this iteration's launches, A/B)
         self._pending_log = (agent_info, frame, timer.detach(), self.iteration)
         if not pipelined:
             self.flush()

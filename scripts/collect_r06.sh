@@ -35,17 +35,22 @@ bench)
   # the round's switches, one at a time against the default, interleaved
   for i in 1 2; do
     python bench.py $B 2>/dev/null | tail -1 | brief "default"
+    CUSRL_PIPELINE_LOGS=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_PIPELINE_LOGS=0 (log read before the next rollout is launched)"
+    CUSRL_FUSED_INFERENCE=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_FUSED_INFERENCE=0 (library GEMM chain for the no-grad passes)"
+    CUSRL_TWO_WINDOW_STEP=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_TWO_WINDOW_STEP=0 (join + one Adam launch per step)"
     CUSRL_EPOCH_GRAPHS=1 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_EPOCH_GRAPHS=1 (one graph per epoch)"
     CUSRL_EPOCH_GRAPHS=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_EPOCH_GRAPHS=0 (one graph per step)"
     CUSRL_SEPARATE_VALUE_TERM=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_SEPARATE_VALUE_TERM=0"
     CUSRL_PREFETCH_GATHER=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_PREFETCH_GATHER=0"
-    CUSRL_PREFETCH_GATHER=side python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_PREFETCH_GATHER=side"
     CUSRL_INPUT_LAYER_KERNEL=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_INPUT_LAYER_KERNEL=0"
     CUSRL_CONCURRENT_CRITIC=0 python bench.py $B 2>/dev/null | tail -1 | brief "CUSRL_CONCURRENT_CRITIC=0"
   done | tee "$O/switches_ab.txt"
   bash scripts/gpu_r06_one_rank.sh > "$O/one_rank.log" 2>&1; cp gpurun_out/r06_one_rank/* "$O/" 2>/dev/null; tail -6 "$O/bench_one_rank.txt"
   python scripts/input_layer_bench.py 2>&1 | grep -v amdgpu.ids | tee "$O/input_layer_bench.txt"
   python scripts/host_vs_device.py --iterations 40 2>&1 | grep -v amdgpu.ids | head -3 | cut -c1-400 | tee "$O/host_vs_device.txt"
+  python scripts/graph_floor.py 2>&1 | grep -v amdgpu.ids | tee "$O/graph_floor.txt"
+  python scripts/mlp_forward_bench.py 2>&1 | grep -v amdgpu.ids | tee "$O/mlp_forward_bench.txt"
+  python scripts/probe_graph_fork.py 2>&1 | grep -v amdgpu.ids | tee "$O/probe_graph_fork.txt"
   ;;
 profile)
   bash scripts/gpu_pmc.sh r06final/pmc_gather > "$O/gpu_pmc.log" 2>&1; tail -2 "$O/gpu_pmc.log"

@@ -63,26 +63,27 @@ def main():
     for hook in agent.hook:
         scratch = getattr(hook, "_replay_scratch", None)
         if scratch:
-            regions["pre_update head"] = scratch["head"].capture
-            for bucket, region in scratch["tails"].items():
-                regions[f"pre_update tail (bucket {bucket})"] = region.capture
+            for parity, region in scratch["heads"].items():  # (one per pinned counter, used in turn)
+                regions[f"pre_update head (counter {parity})"] = region.capture
+            for (bucket, parity), region in scratch["tails"].items():
+                regions[f"pre_update tail (bucket {bucket}, counter {parity})"] = region.capture
         replay = getattr(hook, "_replay", None)
         if isinstance(replay, dict) and "region" in replay:
             regions["statistics pass"] = replay["region"].capture
     for key, entry in agent._graphed_epochs.epochs.items():
         regions[f"update ({key[1]} graph(s), last epoch {key[0]})"] = entry["capture"]
     total = 0.0
-    seen_rollout = False
+    seen = set()
     for name, capture in regions.items():
         if capture.graph is None:
             continue
         us = timed(capture.graph.replay, args.replays)
         nodes = capture.census.get("kernel", "?") if capture.census else "?"
         print(f"{us:9.1f} us  {name}  ({nodes} kernel nodes)")
-        if name.startswith("rollout"):
-            if seen_rollout:
-                continue  # (two parities of the statistics ring: one of them runs per iteration)
-            seen_rollout = True
+        family = name.split(" (")[0]  # (rollout: two parities of the statistics ring; head / tail: two counters — one of each per iteration)
+        if family in seen:
+            continue
+        seen.add(family)
         total += us
     # the eager launches between the regions: GAE + normalisation (two hooks' pre_update) and the draw of the permutations
     print(f"{total:9.1f} us  sum of the regions one iteration replays")

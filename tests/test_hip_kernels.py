@@ -1242,6 +1242,60 @@ def test_adam_step_vs_oracle(ops, n, decoupled, weight_decay, max_norm):
         np.testing.assert_allclose(host(d_v), exp_avg_sq, rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize("max_norm", [None, 0.5])
+def test_adam_step_window_pair_equals_one_launch_over_everything(ops, max_norm):
+    """Round 6: the optimizer step of two windows — each its own launch, counter and ticket, both handed BOTH windows' squared-norm
+    rows — leaves parameters, moments and norm bit-identical to ONE launch over the whole buffers whose rows are the two arrays in
+    order (what one gradient assembly of all parameters leaves); a launch over everything keeps the second counter equal."""
+    n, cut = 92_584, 46_600  # (both windows start on a 16-byte boundary)
+    g = torch.Generator().manual_seed(3)
+    make = lambda scale: (torch.randn(n, generator=g) * scale).to(DEV)  # noqa: E731
+    joint = [make(1.0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)]
+    split = [t.clone() for t in joint]
+    lr = torch.full((1,), 2e-4, device=DEV)
+    step_j, step_mirror, ticket_j = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    steps = [torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)]
+    tickets = [torch.zeros(1, dtype=torch.int32, device=DEV) for _ in range(2)]
+    hyper = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, decoupled=True, max_norm=max_norm)
+    for _ in range(3):
+        grad = make(0.02)
+        rows = (ops.grad_sumsq(grad[:cut].contiguous()), ops.grad_sumsq(grad[cut:].contiguous())) if max_norm is not None else (None, None)
+        norm_j, norm_s = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+        ops.adam_step_window(joint[0], grad, joint[1], joint[2], step_j, lr, ticket_j, clip_partials=rows,
+                             norm_out=norm_j if max_norm is not None else None, step_mirror=step_mirror, **hyper)
+        for w, (lo, hi) in enumerate(((0, cut), (cut, n))):
+            ops.adam_step_window(split[0][lo:hi], grad[lo:hi], split[1][lo:hi], split[2][lo:hi], steps[w], lr, tickets[w],
+                                 clip_partials=rows, norm_out=norm_s if (w == 0 and max_norm is not None) else None, **hyper)
+        for a, b in zip(joint, split):
+            assert torch.equal(a, b)
+        assert torch.equal(norm_j, norm_s) and (max_norm is None or float(norm_j) > max_norm)  # (the clip is active)
+        assert step_j.item() == step_mirror.item() == steps[0].item() == steps[1].item()
+        assert ticket_j.item() == tickets[0].item() == tickets[1].item() == 0
+    # the rows continue each other: (a, b) sums like the one array [a | b]
+    if max_norm is not None:
+        single = [t.clone() for t in joint]
+        step_1, ticket_1 = step_j.clone(), torch.zeros(1, dtype=torch.int32, device=DEV)
+        grad = make(0.02)
+        a, b = ops.grad_sumsq(grad[:cut].contiguous()), ops.grad_sumsq(grad[cut:].contiguous())
+        ops.adam_step_window(joint[0], grad, joint[1], joint[2], step_j, lr, ticket_j, clip_partials=(a, b), **hyper)
+        ops.adam_step(single[0], grad, single[1], single[2], step_1, lr, ticket_1, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
+                      decoupled=True, clip_partials=torch.cat((a, b)), max_norm=max_norm)
+        for x, y in zip(joint, single):
+            assert torch.equal(x, y)
+    # refusals of the raw entry point: rows without a first array, too many rows
+    from cusrl_amd import _native
+
+    lib = _native.lib()
+    args = lambda a_ptr, na, b_ptr, nb: (joint[0].data_ptr(), grad.data_ptr(), joint[1].data_ptr(), joint[2].data_ptr(), step_j.data_ptr(),  # noqa: E731
+                                         lr.data_ptr(), n, 0.9, 0.999, 1e-8, 0.0, 0, 0, a_ptr, na, b_ptr, nb, 1.0, None, None, None,
+                                         ticket_j.data_ptr(), None)
+    dummy = torch.zeros(4, dtype=torch.float64, device=DEV)
+    assert lib.cusrl_adam_step_window(*args(None, 0, dummy.data_ptr(), 4)) == -1
+    assert lib.cusrl_adam_step_window(*args(dummy.data_ptr(), 4, None, 2)) == -1
+    assert lib.cusrl_adam_step_window(*args(dummy.data_ptr(), 1 << 16, dummy.data_ptr(), 1)) == -1
+    torch.cuda.synchronize()
+
+
 def test_assemble_gradients_sums_slabs_into_slots(ops):
     rng = np.random.default_rng(3)
     shapes = [(16, 128 * 256), (1, 256), (16, 256 * 48), (1, 12), (0, 7), (3, 5), (1, 1)] * 5  # 35 pieces: two launches
