@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the device idles during one training iteration, from a rocprofv3 kernel trace:
 
-    python scripts/idle_gaps.py <kernel_trace.csv> [--anchor normal_sample_logp] [--min-us 12]
+    python scripts/idle_gaps.py <kernel_trace.csv> [--anchor <kernel name part>] [--min-us 12]
 
 takes the LAST full iteration (from the first dispatch of the anchor kernel's last-but-one burst to the next burst), forms the
 union of all queues' busy intervals and prints every idle gap longer than --min-us with the kernels on either side — host
@@ -22,11 +22,19 @@ def short(name: str) -> str:
 
 def main():
     path = sys.argv[1]
-    anchor = sys.argv[sys.argv.index("--anchor") + 1] if "--anchor" in sys.argv else "normal_sample_logp"
+    anchor = sys.argv[sys.argv.index("--anchor") + 1] if "--anchor" in sys.argv else None
     min_us = float(sys.argv[sys.argv.index("--min-us") + 1]) if "--min-us" in sys.argv else 12.0
     with open(path) as fh:
         rows = sorted(csv.DictReader(fh), key=lambda r: int(r["Start_Timestamp"]))
-    hits = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
+    # a kernel that only the rollout launches, once per env step (since round 6's second part acting is cusrl_mlp2_forward, which
+    # the value and statistics passes launch too: the env's own step kernel / the step epilogue mark the rollout)
+    for candidate in ([anchor] if anchor else ["normal_sample_logp", "synthetic_env_step", "step_epilogue"]):
+        hits = [i for i, r in enumerate(rows) if candidate in r["Kernel_Name"]]
+        if hits:
+            break
+    if not hits:
+        print("no anchor kernel in the trace")
+        return
     # bursts of the anchor (one per rollout): split where consecutive hits are > 2 ms apart
     bursts = [hits[0]]
     for a, b in zip(hits, hits[1:]):
