@@ -88,6 +88,9 @@ def configure_distributed(backend: str | None = None, **kwargs) -> bool:
             if backend == "nccl":
                 kwargs.setdefault("device_id", CONFIG.device)
         torch.distributed.init_process_group(backend=backend, world_size=CONFIG.world_size, rank=CONFIG.rank, **kwargs)
+        from cusrl_amd.utils.distributed import host_group
+
+        host_group()  # the gloo group of an RCCL job's host values (the trainer's log): created where every rank passes together
     return True
 
 

@@ -76,7 +76,7 @@ _pg_stream: "torch.cuda.Stream | None" = None
 
 
 @contextmanager
-def _process_group_stream(device=None, join: bool = True):
+def _process_group_stream(device=None):
     """Issue a ``torch.distributed`` collective of an RCCL job on a dedicated stream that NEVER captures.
 
     ProcessGroupNCCL records a collective's completion event on the stream the call is issued on, and its watchdog thread
@@ -86,10 +86,7 @@ def _process_group_stream(device=None, join: bool = True):
     capturing stream" and the watchdog aborts the process (seen as a sporadic SIGABRT of one-rank RCCL test jobs on the
     torch.distributed route, round 5).  So the process-group collectives of this package hop to their own stream: the
     caller's stream is joined before and after, i.e. the collective stays ordered exactly where it was issued.  Operands
-    must be allocated by the caller (outside this context); what is allocated inside is consumed inside.  ``join=False``: a
-    collective whose operands come from the HOST and go back to it (the trainer's log average) — allocated, reduced and read
-    inside the context, ordered against nothing the caller's stream holds: it does not queue behind the rollout the trainer
-    has already launched there (template/trainer.py pipelines its logs), and the caller's stream does not wait for it."""
+    must be allocated by the caller (outside this context); what is allocated inside is consumed inside."""
     device = torch.device(CONFIG.device if device is None else device)
     if (device.type != "cuda" or torch.distributed.get_backend() != torch.distributed.Backend.NCCL
             or torch.cuda.is_current_stream_capturing()):
@@ -99,12 +96,10 @@ def _process_group_stream(device=None, join: bool = True):
     if _pg_stream is None or _pg_stream.device != device:
         _pg_stream = torch.cuda.Stream(device=device)
     current = torch.cuda.current_stream(device)
-    if join:
-        _pg_stream.wait_stream(current)
+    _pg_stream.wait_stream(current)
     with torch.cuda.stream(_pg_stream):
         yield
-    if join:
-        current.wait_stream(_pg_stream)
+    current.wait_stream(_pg_stream)
 
 
 def barrier():
@@ -410,12 +405,29 @@ def collective_route() -> str:
     return f"torch.distributed {backend} (host-staged; eager all-reduce between two graphs per step)"
 
 
+_host_pg = None
+
+
+def host_group():
+    """The process group HOST values travel through (the trainer's per-iteration log, gathered Python objects): the default group
+    when that is gloo, else a gloo group next to the RCCL one — created on first use, which every rank reaches at the same point
+    (``configure_distributed`` calls it right behind ``init_process_group``).  Why not RCCL: a device collective of host scalars
+    needs an upload, a kernel and a read-back, and on this stack anything a host thread WAITS for on a side stream queues behind
+    the work parked on the default stream (`scripts/probe_pg_stream.py`: 83 ms behind an 83 ms kernel, whichever stream or
+    priority) — the pipelined trainer reads a log while the next rollout runs there."""
+    global _host_pg
+    if torch.distributed.get_backend() == torch.distributed.Backend.GLOO:
+        return None
+    if _host_pg is None:
+        _host_pg = torch.distributed.new_group(backend="gloo")
+    return _host_pg
+
+
 def gather_obj(obj: _T) -> list[_T]:
     if not configure_distributed():
         return [obj]
     out: list[Any] = [None] * CONFIG.world_size
-    with _process_group_stream():
-        torch.distributed.all_gather_object(out, obj)
+    torch.distributed.all_gather_object(out, obj, group=host_group())
     return out
 
 
@@ -438,11 +450,9 @@ def _average_same_keys(info: dict[str, float]) -> dict[str, float] | None:
     low, high = float(digest & 0xFFFF), float(digest >> 16)
     head = [low, high, low * low, high * high, float(len(keys)), 1.0 if plain else 0.0]
     body = [float(v) for v in values] if plain else []
-    device = "cpu" if torch.distributed.get_backend() == torch.distributed.Backend.GLOO else CONFIG.device
-    with _process_group_stream(device, join=False):  # host values in, host values out: nothing of the caller's stream is touched
-        packed = torch.tensor(head + body + [0.0] * (_LOG_SLOTS - len(body)), dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(packed, op=torch.distributed.ReduceOp.SUM)
-        summed = packed.tolist()
+    packed = torch.tensor(head + body + [0.0] * (_LOG_SLOTS - len(body)), dtype=torch.float64)  # host values: a host collective
+    torch.distributed.all_reduce(packed, op=torch.distributed.ReduceOp.SUM, group=host_group())
+    summed = packed.tolist()
     world = CONFIG.world_size
     s_low, s_high, q_low, q_high, count, all_plain = summed[:6]
     same = (all_plain == world and s_low == world * low and s_high == world * high and q_low == world * low * low

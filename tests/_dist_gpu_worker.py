@@ -40,6 +40,17 @@ def main(out_dir: str, compile_: str, native: str):
     flat = torch.full((1000,), float(rank + 1), device="cuda")
     distributed.reduce_mean_(flat)
     info = {k: v for k, v in trainer.last_info.items() if k.startswith("Agent/")}
+    # the trainer's log average as a multi-rank job issues it (`average_dict` answers a group of one without a collective): host
+    # values through the job's gloo group (`distributed.host_group`) — with a long kernel parked on the device's default stream, as
+    # the next rollout is when the pipelined trainer reads a log (round 6): it must not wait for the device
+    torch.cuda._sleep(200_000_000)  # ~80 ms on the current stream
+    probe = {"Agent/a": 1.5 + rank, "Metric/b": -2.0, "Perf/c": 3}
+    began = __import__("time").perf_counter()
+    averaged = distributed._average_same_keys(dict(probe))
+    log_average_s = __import__("time").perf_counter() - began
+    expected = {"Agent/a": 1.5 + (world - 1) / 2, "Metric/b": -2.0, "Perf/c": 3.0}
+    assert averaged is not None and all(abs(averaged[k] - expected[k]) < 1e-12 for k in expected), averaged
+    torch.cuda.synchronize()
     graphs = [step.single_graph for step in getattr(trainer.agent, "_graphed_steps", {}).values()]
     Path(out_dir, f"rank{rank}.json").write_text(json.dumps({
         "info": info, "world": world, "rank": rank, "first_perm": first_perm,
@@ -52,6 +63,7 @@ def main(out_dir: str, compile_: str, native: str):
         "split_backward": bool(trainer.agent._split_plan),
         "allreduce_calls": _native.launch_counts.get("cusrl_allreduce_mean", 0),
         "allgather_calls": _native.launch_counts.get("cusrl_allgather", 0),
+        "log_average_s": log_average_s,
     }))
     distributed.barrier()
     torch.cuda.synchronize()

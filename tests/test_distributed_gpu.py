@@ -50,6 +50,9 @@ def test_ppo_preset_over_rccl_single_rank(tmp_path, compile_, native):
     for key in ("Agent/value_loss", "Agent/surrogate_loss", "Agent/entropy_loss", "Agent/kl_divergence"):
         assert math.isfinite(result["info"][key]), key
     assert result["native"] == (native == "1")
+    # the log average ran over RCCL on the process-group stream and did NOT queue behind the ~80 ms kernel parked on the caller's
+    # stream (the worker asserts its values): the pipelined trainer reads a log while the next rollout runs
+    assert result["log_average_s"] < 0.05, result["log_average_s"]
     if native == "1":  # the C-ABI entry points really carried the collectives
         assert result["allreduce_calls"] > 0 and result["allgather_calls"] > 0
         if compile_ == "1":
