@@ -167,6 +167,50 @@ def dominant_kernel(agent):
             "bytes_per_launch": nbytes, "avg_us": round(us, 3), "achieved_GBps": round(nbytes / us / 1e3, 1)}
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak: 256 CUs x 4 SIMDs x 64 flop / clk x 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def mlp_forward_roofline(agent):
+    """``cusrl_mlp2_forward`` with the agent's own actor (48 -> 256 -> 128 -> 12) at the statistics pass's size (98 304 rows) and at
+    1 048 576 rows, graph-timed like the dominant kernel: flop / duration against the fp32 MFMA peak.  The PMC side (MFMA
+    instructions issued = required, matrix-pipe busy share, memory traffic) is quoted from the committed passes while the kernel
+    source is the one they were taken from (profiles/r06/pmc_mlp_forward_summary.json)."""
+    import hashlib
+
+    from cusrl_amd import ops
+    from cusrl_amd.nn.module import fused_inference_layers
+
+    actor = agent.actor
+    probe = torch.randn(16, actor.input_dim, device=agent.device)
+    with torch.no_grad():
+        layers = fused_inference_layers(actor.backbone, actor.distribution.mean_head, probe)
+    if layers is None:
+        return None
+    w1, _, w2, _, w3, _ = layers
+    per_row = 2 * (w1.numel() + w2.numel() + w3.numel())
+    out = {"kernel": "cusrl::mlp2_forward_kernel (acting, value targets, statistics pass: backbone + head without autograd)",
+           "bound": "mfma", "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "timing": "hipGraph of 10 launches between one HIP-event pair"}
+    for rows in (98304, 1 << 20):
+        x = torch.randn(rows, actor.input_dim, device=agent.device)
+        with torch.no_grad():
+            us = graph_time(lambda: ops.mlp2_forward(x, layers), launches=10, replays=10)
+        key = "achieved" if rows == 98304 else "achieved_at_scale"
+        out[key] = round(per_row * rows / us / 1e6, 1)
+        out["avg_us" if rows == 98304 else "avg_us_at_scale"] = round(us, 2)
+        out["frac" if rows == 98304 else "frac_at_scale"] = round(per_row * rows / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 4)
+        del x
+    out["rows"], out["rows_at_scale"], out["flop_per_row"] = 98304, 1 << 20, per_row
+    path = ROOT / "profiles" / "r06" / "pmc_mlp_forward_summary.json"
+    if path.exists():
+        summary = json.loads(path.read_text())
+        source = hashlib.sha256((ROOT / "cusrl_amd" / "csrc" / "mlp_forward.hip").read_bytes()).hexdigest()[:16]
+        if summary.get("mlp_forward_hip_sha256_16") == source:
+            out["pmc"] = {name: {k: entry.get(k) for k in ("mfma_issued_over_required", "mfma_pipe_utilisation", "traffic_over_algorithmic")}
+                          for name, entry in summary["cases"].items() if name != "stream_16B"}
+            out["pmc_source"] = "quoted: rocprofv3 PMC passes of this kernel source, profiles/r06/pmc_mlp_forward_summary.json"
+    return out
+
+
 def cusrl_iterate(schema):
     from cusrl_amd.utils.nest import iterate_nested
 
@@ -359,6 +403,14 @@ def run_gpu(args, rank, world):
                                   "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
         torch.cuda.empty_cache()
 
+    mfma = None
+    if not args.no_scale_pass and rank == 0 and world == 1:
+        try:
+            mfma = mlp_forward_roofline(agent)
+        except Exception as error:  # an extra beside the headline must never cost the line itself
+            print(f"bench: cusrl_mlp2_forward roofline skipped ({type(error).__name__}: {error})", file=sys.stderr)
+        torch.cuda.empty_cache()
+
     steps_per_iteration = args.envs_per_gpu * HORIZON * world
     traffic, traffic_source = pmc_traffic(args.envs_per_gpu)
     profile = rocprof_gather(dominant["bytes_per_launch"]) if dominant and args.envs_per_gpu == NUM_ENVS else None
@@ -448,6 +500,8 @@ def run_gpu(args, rank, world):
                          **scale},
             # ... and flat, for consumers that keep scalars only
             **{f"at_scale_{key}_frac": entry["frac"] for key, entry in scale.items()},
+            # the one kernel of the path bound by the matrix cores, not by bytes (round 6): the no-grad MLP pass
+            **({"mfma_kernel": mfma} if mfma else {}),
         },
         "kernels": kernels,
     }
