@@ -63,6 +63,7 @@ _SIGNATURES = {
     "cusrl_normalize": (c_int, [_P, _P, _P, c_float, c_int64, c_int64, _P]),
     "cusrl_normalize_from_partials": (c_int, [_P, _P, c_int64, c_int64, c_float, c_int64, c_int64, _P, _P, _P]),
     "cusrl_merge_mean_var": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
+    "cusrl_normalize_from_gathered": (c_int, [_P, _P, c_int64, c_float, c_int64, c_int64, _P, _P, _P]),
     "cusrl_gather_rows": (c_int, [POINTER(Field), c_int, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "cusrl_pack_rows": (c_int, [POINTER(PackedField), c_int, _P, c_int64, c_int64, _P]),
     "cusrl_pack_rows_owned": (c_int, [POINTER(PackedField), c_int, _P, c_int64, c_int64, c_int, c_int, _P]),
@@ -121,6 +122,9 @@ _SIGNATURES = {
     "cusrl_adam_step": (c_int, [_P] * 6 + [c_int64, c_double, c_double, c_double, c_double, c_int, c_int, _P, c_int64, c_float, _P, _P, _P, _P]),
     "cusrl_adam_step_window": (c_int, [_P] * 6 + [c_int64, c_double, c_double, c_double, c_double, c_int, c_int, _P, c_int64, _P, c_int64,
                                        c_float, _P, _P, _P, _P, _P]),
+    "cusrl_adam_step_normed": (c_int, [_P] * 6 + [c_int64, c_double, c_double, c_double, c_double, c_int, c_int, _P, c_int64, _P,
+                                       c_float, _P, _P, _P, _P, _P]),
+    "cusrl_adam_step_normed_workspace_bytes": (c_int64, []),
     "cusrl_masked_col_stats": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, _P]),
     "cusrl_masked_stats_num_partials": (c_int64, [c_int64, c_int64]),
     "cusrl_rms_merge": (c_int, [_P] * 7 + [c_float, c_double, c_int64, _P]),

@@ -443,6 +443,56 @@ __global__ void merge_mean_var_kernel(const float *__restrict__ gathered, int W,
     var[d] = __fdiv_rn(q, float(W));
 }
 
+// Merge + normalise in one launch (a job with several ranks: the all-gathered [W, 2D] rows of every rank's mean | var sit
+// between the statistics and their use): every block re-derives the merged statistics with merge_mean_var_kernel's operations in
+// its order (W x 2D floats, L2-resident), then normalises its share like normalize_kernel; block 0 publishes mean / var.
+__global__ __launch_bounds__(kBlock) void normalize_from_gathered_kernel(float *__restrict__ x, const float *__restrict__ gathered,
+                                                                         int W, float eps, int64_t E, int D, int vec4,
+                                                                         float *__restrict__ mean_out, float *__restrict__ var_out) {
+    __shared__ float s_mean[kBlock], s_sd[kBlock];
+    if (threadIdx.x < D) {
+        const int d = threadIdx.x;
+        float s = 0.0f;
+        for (int r = 0; r < W; ++r) s = __fadd_rn(s, gathered[int64_t(r) * 2 * D + d]);
+        const float m = __fdiv_rn(s, float(W));
+        float q = 0.0f;
+        for (int r = 0; r < W; ++r) {
+            const float e = __fsub_rn(gathered[int64_t(r) * 2 * D + d], m);
+            q = __fadd_rn(q, __fadd_rn(gathered[int64_t(r) * 2 * D + D + d], __fmul_rn(e, e)));
+        }
+        const float var = __fdiv_rn(q, float(W));
+        s_mean[d] = m;
+        s_sd[d] = sqrtf(__fadd_rn(var, eps));
+        if (blockIdx.x == 0) mean_out[d] = m, var_out[d] = var;
+    }
+    __syncthreads();
+    const int64_t tid = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    if (D == 1) {
+        const float m = s_mean[0], sd = s_sd[0];
+        if (vec4) {
+            const int64_t n4 = E / 4;
+            for (int64_t i = tid; i < n4; i += stride) {
+                float4 v = reinterpret_cast<float4 *>(x)[i];
+                v.x = __fdiv_rn(__fsub_rn(v.x, m), sd);
+                v.y = __fdiv_rn(__fsub_rn(v.y, m), sd);
+                v.z = __fdiv_rn(__fsub_rn(v.z, m), sd);
+                v.w = __fdiv_rn(__fsub_rn(v.w, m), sd);
+                reinterpret_cast<float4 *>(x)[i] = v;
+            }
+            if (tid == 0)
+                for (int64_t i = n4 * 4; i < E; ++i) x[i] = __fdiv_rn(__fsub_rn(x[i], m), sd);
+        } else {
+            for (int64_t i = tid; i < E; i += stride) x[i] = __fdiv_rn(__fsub_rn(x[i], m), sd);
+        }
+    } else {
+        for (int64_t i = tid; i < E; i += stride) {
+            const int d = int(i % D);
+            x[i] = __fdiv_rn(__fsub_rn(x[i], s_mean[d]), s_sd[d]);
+        }
+    }
+}
+
 }  // namespace cusrl
 
 using namespace cusrl;
@@ -667,5 +717,20 @@ extern "C" int cusrl_merge_mean_var(const float *gathered, int64_t W, int64_t D,
     if (!gathered || !mean || !var) return CUSRL_E_INVALID;
     hipLaunchKernelGGL(merge_mean_var_kernel, dim3(uint32_t(ceil_div(D, 64))), dim3(64), 0, as_stream(stream),
                        gathered, int(W), int(D), mean, var);
+    return launch_status();
+}
+
+extern "C" int cusrl_normalize_from_gathered(float *x, const float *gathered, int64_t W, float eps, int64_t rows, int64_t D,
+                                             float *mean_out, float *var_out, void *stream) {
+    if (rows < 0 || D < 0 || W <= 0) return CUSRL_E_INVALID;
+    if (rows == 0 || D == 0) return 0;
+    if (!x || !gathered || !mean_out || !var_out) return CUSRL_E_INVALID;
+    if (D > kBlock) return CUSRL_E_UNSUPPORTED;
+    const int64_t E = rows * D;
+    const int vec4 = D == 1 && aligned(x, 16);
+    int64_t blocks = ceil_div(vec4 ? E / 4 + 1 : E, kBlock);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(normalize_from_gathered_kernel, dim3(uint32_t(blocks)), dim3(kBlock), 0, as_stream(stream), x, gathered,
+                       int(W), eps, E, int(D), vec4, mean_out, var_out);
     return launch_status();
 }

@@ -185,6 +185,141 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float *__restrict__ p
     }
 }
 
+
+// ---- the Adam step that measures the gradient norm ITSELF (multi-rank steps: the all-reduce sits between the gradient
+// assembly, whose free partial sums are of the un-averaged gradients, and the clipping — so the norm used to be a launch of
+// its own on the serial tail of every minibatch step, gradient_clipping.py:74 behind distributed.py:145-172).  One launch: every
+// block sums the squares of its share of `norm_grad` (the WHOLE flat gradient buffer, also when the launch steps one window),
+// publishes the partial sum in a slot of the workspace, waits until every slot of the launch is filled, and derives the — to the
+// bit identical — coefficient from the slots in fixed order.  A grid-wide meeting inside a plain launch: the grid is at most one
+// block per CU (kNormedMaxBlocks), so every block is resident, or becomes resident as unrelated work drains, while the others
+// wait; two such launches side by side (the two windows of an unjoined step) are 2 x 91 blocks of the ppo preset's networks.
+// No fence anywhere: a slot IS its own flag (device-scope read-modify-writes on one 8-byte word; "empty" is a bit pattern no
+// sum of squares has), the slots of the NEXT launch are re-armed by this one (two sets, chosen by a launch counter the last
+// block to finish bumps), so the entry point stays self-resetting and graph-safe like the ticket.
+constexpr int kNormedMaxBlocks = 256;
+constexpr unsigned long long kSlotEmpty = ~0ull;                     // (the workspace starts as 0xFF bytes)
+constexpr unsigned long long kCanonicalNan = 0x7ff8000000000000ull;
+constexpr int kNormedSpinLimit = 1 << 20;  // a slot that never fills (cannot happen while the grid is resident): NaN, loudly
+
+struct NormedWorkspace {
+    unsigned long long slots[2][kNormedMaxBlocks];
+    unsigned int launches;  // parity = the set this launch publishes into
+    unsigned int pad[3];
+};
+static_assert(kNormedMaxBlocks == kBlock, "block 0 re-arms one slot per thread");
+
+__global__ __launch_bounds__(kBlock) void adam_step_normed_kernel(float *__restrict__ param, const float *__restrict__ grad,
+                                                                  float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
+                                                                  float *__restrict__ step, const float *__restrict__ lr,
+                                                                  const float *__restrict__ norm_grad, int64_t norm_n,
+                                                                  NormedWorkspace *__restrict__ ws, float *__restrict__ norm_out,
+                                                                  float *__restrict__ norm_accumulator,
+                                                                  float *__restrict__ step_mirror, unsigned int *__restrict__ ticket,
+                                                                  int64_t n, AdamParams a) {
+    __shared__ float shared[4];  // clip coefficient, step size, sqrt(bias_correction2), new step count
+    __shared__ double scratch[kWavesPerBlock];
+    // (as in adam_step_kernel: the window's first float4s are requested before anything else)
+    const int64_t n4 = n / 4;
+    float4 *p4 = reinterpret_cast<float4 *>(param), *m4 = reinterpret_cast<float4 *>(exp_avg),
+           *v4 = reinterpret_cast<float4 *>(exp_avg_sq);
+    const float4 *g4 = reinterpret_cast<const float4 *>(grad);
+    const int64_t i0 = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), m0 = p0, v0 = p0, g0 = p0;
+    if (i0 < n4) p0 = p4[i0], m0 = m4[i0], v0 = v4[i0], g0 = g4[i0];
+    // every block reads the launch counter here, before the LAST block to finish bumps it (behind the meeting below)
+    const unsigned int set = ws->launches & 1u;
+    unsigned long long *mine = ws->slots[set];
+    if (blockIdx.x == 0) atomicExch(&ws->slots[set ^ 1u][threadIdx.x], kSlotEmpty);  // the next launch's set (the previous
+                                                                                      // launch, its last user, is complete)
+    double acc = 0.0;
+    const int64_t nn4 = norm_n / 4;
+    const float4 *__restrict__ ng4 = reinterpret_cast<const float4 *>(norm_grad);
+    for (int64_t i = i0; i < nn4; i += int64_t(gridDim.x) * kBlock) {
+        const float4 v = ng4[i];
+        acc += double(v.x * v.x + v.y * v.y) + double(v.z * v.z + v.w * v.w);  // (sumsq_partials_kernel's terms)
+    }
+    if (blockIdx.x == 0 && threadIdx.x < norm_n - nn4 * 4) {
+        const float v = norm_grad[nn4 * 4 + threadIdx.x];
+        acc += double(v * v);
+    }
+    const double total = block_sum(acc, scratch);
+    if (threadIdx.x < kWave) {
+        if (threadIdx.x == 0) {
+            unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(total));
+            atomicExch(&mine[blockIdx.x], bits == kSlotEmpty ? kCanonicalNan : bits);
+        }
+        double p = 0.0;
+        for (int i = threadIdx.x; i < int(gridDim.x); i += kWave) {
+            unsigned long long bits;
+            int spins = 0;
+            while ((bits = atomicAdd(&mine[i], 0ull)) == kSlotEmpty) {
+                if (++spins > kNormedSpinLimit) {
+                    bits = kCanonicalNan;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            p += __longlong_as_double(static_cast<long long>(bits));
+        }
+        p = wave_sum(p);
+        if (threadIdx.x == 0) {
+            const float norm = float(sqrt(p));
+            float coef = 1.0f;
+            if (a.max_norm >= 0.0f) {
+                const float c = a.max_norm / (norm + 1e-6f);  // clip_grad_norm_: max_norm / (total_norm + 1e-6)
+                coef = c < 1.0f ? c : (c != c ? c : 1.0f);
+            }
+            if (blockIdx.x == 0) {
+                if (norm_out) norm_out[0] = norm;
+                if (norm_accumulator) norm_accumulator[0] += norm;
+            }
+            const float t = step[0] + 1.0f;
+            const double bc1 = 1.0 - pow(a.beta1, double(t)), bc2 = 1.0 - pow(a.beta2, double(t));
+            shared[0] = coef;
+            shared[1] = float(double(lr[0]) / bc1);
+            shared[2] = float(sqrt(bc2));
+            shared[3] = t;
+        }
+    }
+    __syncthreads();
+    const float coef = shared[0], step_size = shared[1], bc2_sqrt = shared[2], t = shared[3];
+    const float beta2 = float(a.beta2), omb1 = float(1.0 - a.beta1), omb2 = float(1.0 - a.beta2);
+    const float decay = a.decoupled ? 1.0f - lr[0] * a.weight_decay : 1.0f;
+    const float l2 = a.decoupled ? 0.0f : a.weight_decay;
+    const float sign = a.maximize ? -coef : coef;
+
+    auto update = [&](float &p, float g, float &m, float &v) {  // (adam_step_kernel's, operation for operation)
+        g *= sign;
+        p *= decay;
+        g += l2 * p;
+        m += (g - m) * omb1;
+        v = beta2 * v + omb2 * (g * g);
+        p -= step_size * (m / (sqrtf(v) / bc2_sqrt + a.eps));
+    };
+    for (int64_t i = i0; i < n4; i += int64_t(gridDim.x) * kBlock) {
+        float4 p = p0, m = m0, v = v0;
+        const float4 g = g0;
+        const int64_t next = i + int64_t(gridDim.x) * kBlock;
+        if (next < n4) p0 = p4[next], m0 = m4[next], v0 = v4[next], g0 = g4[next];
+        update(p.x, g.x, m.x, v.x), update(p.y, g.y, m.y, v.y), update(p.z, g.z, m.z, v.z), update(p.w, g.w, m.w, v.w);
+        p4[i] = p, m4[i] = m, v4[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        update(param[i], grad[i], exp_avg[i], exp_avg_sq[i]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {  // (every block has read step[0] and the launch counter by now)
+            step[0] = t;
+            if (step_mirror) step_mirror[0] = t;
+            ws->launches += 1u;
+            *ticket = 0u;
+        }
+    }
+}
+
 }  // namespace cusrl
 
 extern "C" int cusrl_grad_sumsq(const float *grad, int64_t n, double *partials, void *stream) {
@@ -367,4 +502,26 @@ extern "C" int cusrl_assemble_gradients(const cusrl_grad_piece_t *pieces, int64_
         sumsq_base += blocks;
     }
     return 0;
+}
+
+extern "C" int64_t cusrl_adam_step_normed_workspace_bytes(void) { return int64_t(sizeof(cusrl::NormedWorkspace)); }
+
+extern "C" int cusrl_adam_step_normed(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step,
+                                      const float *lr, int64_t n, double beta1, double beta2, double eps, double weight_decay,
+                                      int decoupled_weight_decay, int maximize, const float *norm_grad, int64_t norm_n,
+                                      void *workspace, float max_norm, float *norm_out, float *norm_accumulator,
+                                      float *step_mirror, uint32_t *ticket, void *stream) {
+    using namespace cusrl;
+    if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !step || !lr || !ticket) return CUSRL_E_INVALID;
+    if (norm_n <= 0 || !norm_grad || !workspace) return CUSRL_E_INVALID;
+    if (!aligned(param, 16) || !aligned(grad, 16) || !aligned(exp_avg, 16) || !aligned(exp_avg_sq, 16) ||
+        !aligned(norm_grad, 16) || !aligned(workspace, 8))
+        return CUSRL_E_UNSUPPORTED;
+    AdamParams a{beta1, beta2, float(eps), float(weight_decay), max_norm, decoupled_weight_decay, maximize, 0};
+    // the grid follows the NORM's buffer alone: the launches of a step's windows split it alike and find the same norm, bit for bit
+    const int64_t blocks = ceil_div(norm_n / 4 > 0 ? norm_n / 4 : 1, kBlock);
+    adam_step_normed_kernel<<<int(blocks > kNormedMaxBlocks ? kNormedMaxBlocks : blocks), kBlock, 0, as_stream(stream)>>>(
+        param, grad, exp_avg, exp_avg_sq, step, lr, norm_grad, norm_n, static_cast<NormedWorkspace *>(workspace), norm_out,
+        norm_accumulator, step_mirror, ticket, n, a);
+    return launch_status();
 }

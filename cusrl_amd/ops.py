@@ -701,10 +701,11 @@ def col_stats(x: torch.Tensor) -> torch.Tensor:
 
 
 def adv_stats_finalize(partials: torch.Tensor, count: int) -> tuple[torch.Tensor, torch.Tensor]:
-    """``var, mean`` (unbiased) from block partials, fixed summation order."""
+    """``var, mean`` (unbiased) from block partials, fixed summation order.  The two are the halves of ONE ``[2 D]`` row
+    (``mean | var`` — what a cross-rank merge gathers: ``packed_mean_var`` hands it over without a ``torch.cat``)."""
     P, D, _ = partials.shape
-    mean = torch.empty(D, dtype=torch.float32, device=partials.device)
-    var = torch.empty(D, dtype=torch.float32, device=partials.device)
+    row = torch.empty(2 * D, dtype=torch.float32, device=partials.device)
+    mean, var = row[:D], row[D:]
     check(
         _native.lib().cusrl_stats_finalize(partials.data_ptr(), P, D, count, mean.data_ptr(), var.data_ptr(), _stream()),
         "cusrl_stats_finalize",
@@ -749,6 +750,39 @@ def normalize_from_partials_(x: torch.Tensor, partials: torch.Tensor, count: int
         lambda: x.numel() * 8,
         lambda: _native.lib().cusrl_normalize_from_partials(x.data_ptr(), partials.data_ptr(), P, count, eps, x.numel() // max(D, 1), D,
                                                             mean.data_ptr(), var.data_ptr(), _stream()),
+    )
+    _modified_in_place(x)
+    return var, mean
+
+
+def packed_mean_var(mean: torch.Tensor, var: torch.Tensor) -> torch.Tensor:
+    """``[mean | var]`` as one contiguous row: the halves of :func:`adv_stats_finalize`'s row as they are (no launch), else a
+    ``torch.cat``."""
+    D = mean.numel()
+    if (mean.dim() == var.dim() == 1 and var.numel() == D and mean.is_contiguous() and var.is_contiguous()
+            and mean.untyped_storage().data_ptr() == var.untyped_storage().data_ptr()
+            and var.storage_offset() == mean.storage_offset() + D):
+        return mean.as_strided((2 * D,), (1,), mean.storage_offset())
+    return torch.cat((mean, var), dim=0)
+
+
+def normalize_from_gathered_(x: torch.Tensor, gathered: torch.Tensor, eps: float = 1e-8) -> tuple[torch.Tensor, torch.Tensor]:
+    """:func:`merge_mean_var` + :func:`normalize_` as ONE launch: ``gathered [W, 2 D]`` holds every rank's ``mean | var``;
+    returns the merged ``(var, mean)``."""
+    require_device(x, "x")
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise TypeError("normalize_from_gathered_: expected a contiguous float32 tensor")
+    gathered = _f32(gathered, "gathered")
+    D = x.shape[-1]
+    if gathered.dim() != 2 or gathered.shape[1] != 2 * D:
+        raise ValueError("normalize_from_gathered_: expected [W, 2 D] rows of mean | var")
+    mean = torch.empty(D, dtype=torch.float32, device=x.device)
+    var = torch.empty(D, dtype=torch.float32, device=x.device)
+    _observed(
+        "cusrl_normalize_from_gathered",
+        lambda: x.numel() * 8,
+        lambda: _native.lib().cusrl_normalize_from_gathered(x.data_ptr(), gathered.data_ptr(), gathered.shape[0], eps,
+                                                            x.numel() // max(D, 1), D, mean.data_ptr(), var.data_ptr(), _stream()),
     )
     _modified_in_place(x)
     return var, mean
@@ -1769,6 +1803,43 @@ def adam_step_window(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Ten
             -1.0 if max_norm is None else float(max_norm), ptr(norm_out), ptr(norm_accumulator), ptr(step_mirror), ticket.data_ptr(),
             _stream()),
         "cusrl_adam_step_window",
+    )
+
+
+def adam_norm_workspace(device) -> torch.Tensor:
+    """A workspace of :func:`adam_step_normed` (0xFF bytes; one per launch that may run beside another one)."""
+    return torch.full((int(_native.lib().cusrl_adam_step_normed_workspace_bytes()),), 0xFF, dtype=torch.uint8, device=device)
+
+
+def adam_step_normed(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+                     step: torch.Tensor, lr: torch.Tensor, ticket: torch.Tensor, *, norm_grad: torch.Tensor, workspace: torch.Tensor,
+                     betas: tuple[float, float], eps: float, weight_decay: float, decoupled: bool, maximize: bool = False,
+                     max_norm: float | None = None, norm_out: torch.Tensor | None = None,
+                     norm_accumulator: torch.Tensor | None = None, step_mirror: torch.Tensor | None = None):
+    """:func:`adam_step_window` whose launch measures ``||norm_grad||`` itself (``cusrl_adam_step_normed``): the clipping
+    coefficient of a step whose gradients were averaged over the ranks after their assembly — no squared-norm launch in between."""
+    for tensor, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (step, "step"), (lr, "lr"),
+                         (norm_grad, "norm_grad")):
+        _f32(tensor, name)
+    require_device(ticket, "ticket")
+    require_device(workspace, "workspace")
+    if ticket.dtype != torch.int32 or ticket.numel() != 1:
+        raise TypeError("'ticket' must be a 1-element int32 device tensor")
+    lib = _native.lib()
+    if workspace.dtype != torch.uint8 or workspace.numel() < int(lib.cusrl_adam_step_normed_workspace_bytes()):
+        raise TypeError("'workspace' comes from ops.adam_norm_workspace")
+    n = param.numel()
+    if not (grad.numel() == exp_avg.numel() == exp_avg_sq.numel() == n) or not all(
+            t.is_contiguous() for t in (param, grad, exp_avg, exp_avg_sq, norm_grad)):
+        raise ValueError("a window of the flat optimizer buffers: four contiguous stretches of the same length")
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    check(
+        lib.cusrl_adam_step_normed(
+            param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), step.data_ptr(), lr.data_ptr(), n,
+            float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(decoupled), int(maximize),
+            norm_grad.data_ptr(), norm_grad.numel(), workspace.data_ptr(), -1.0 if max_norm is None else float(max_norm),
+            ptr(norm_out), ptr(norm_accumulator), ptr(step_mirror), ticket.data_ptr(), _stream()),
+        "cusrl_adam_step_normed",
     )
 
 

@@ -27,7 +27,10 @@ _PREFETCH_STREAMS: dict[torch.device, torch.cuda.Stream] = {}
 def _prefetch_stream(device: torch.device) -> torch.cuda.Stream:
     stream = _PREFETCH_STREAMS.get(device)
     if stream is None:
-        stream = _PREFETCH_STREAMS[device] = torch.cuda.Stream(device=device)
+        # (a stream that demonstrably runs beside the stream the loop issues on: utils/streams.py)
+        from cusrl_amd.utils.streams import side_stream
+
+        stream = _PREFETCH_STREAMS[device] = side_stream(device)
     return stream
 
 

@@ -465,6 +465,11 @@ class ActorCritic(Agent):
                 # covers them too.
                 main = torch.cuda.current_stream()
                 flat.absent = []
+                # (several ranks: the rows would be of the un-averaged gradients — reduce_gradients averages the buffer behind
+                # both assemblies, the step launches measure its norm themselves)
+                from cusrl_amd.utils.config import configure_distributed
+
+                multi_rank = configure_distributed()
                 with torch.cuda.stream(branch):
                     with collect_split_weight_grads() as critic_slabs:
                         critic_grads = torch.autograd.grad([value_root], [flat.params[i] for i in critic_ids],
@@ -472,20 +477,20 @@ class ActorCritic(Agent):
                     tail, self._branch_tail = self._branch_tail, None
                     if tail is not None:
                         tail()
-                    branch_sumsq = flat.assemble(critic_grads, critic_slabs, subset=critic_ids, want_sumsq=True)
+                    branch_sumsq = flat.assemble(critic_grads, critic_slabs, subset=critic_ids, want_sumsq=not multi_rank)
                     branch_assembled = torch.cuda.Event()
                     branch_assembled.record(branch)
                 with collect_split_weight_grads() as split_slabs:
                     other_grads = torch.autograd.grad(others, [flat.params[i] for i in other_ids], grad_outputs=other_units,
                                                       allow_unused=True)
-                main_sumsq = flat.assemble(other_grads, split_slabs, subset=other_ids, want_sumsq=True)
+                main_sumsq = flat.assemble(other_grads, split_slabs, subset=other_ids, want_sumsq=not multi_rank)
                 main_assembled = torch.cuda.Event()
                 main_assembled.record(main)
                 main_range, branch_range = ranges
                 # (the rows in parameter order: summed as ONE assembly's rows would be — the same norm to the bit)
                 sumsq = (main_sumsq, branch_sumsq) if main_range[0] < branch_range[0] else (branch_sumsq, main_sumsq)
                 flat.split_tail = {"branch": branch, "branch_assembled": branch_assembled, "main_assembled": main_assembled,
-                                   "sumsq": sumsq, "main_range": main_range, "branch_range": branch_range}
+                                   "sumsq": sumsq, "main_range": main_range, "branch_range": branch_range, "reduce": multi_rank}
                 return
             with torch.cuda.stream(branch):
                 with collect_split_weight_grads() as critic_slabs:
@@ -610,8 +615,17 @@ class ActorCritic(Agent):
         from cusrl_amd.utils.config import configure_distributed
 
         networks, flat = self._network_windows(), self.flat_gradients
-        if networks is None or flat is None or self.flat_optimizer is None or configure_distributed():
+        if networks is None or flat is None or self.flat_optimizer is None:
             return None
+        if configure_distributed():
+            # several ranks: the step stays unjoined when the all-reduce can be captured where it belongs — ONE collective over
+            # the whole buffer through the C-ABI communicator, on the main stream behind both assemblies (reduce_gradients) —
+            # and the step launches measure the averaged gradients' norm themselves (cusrl_adam_step_normed)
+            from cusrl_amd.utils import distributed
+            from cusrl_amd.utils.config import CONFIG
+
+            if CONFIG.split_gradient_allreduce or distributed.native_comm() is None:
+                return None
         if os.environ.get("CUSRL_TWO_WINDOW_STEP", "1") == "0":  # A/B switch
             return None
         for hook in self.hook:

@@ -674,6 +674,19 @@ def reduce_gradients(optimizer: torch.optim.Optimizer, flat: FlatGradients | Non
         return
     if flat is not None and flat.intact():
         flat._sumsq = None  # the averaged gradients have another norm
+        tail = flat.split_tail
+        if tail is not None and tail.get("reduce"):
+            # An unjoined step (ActorCritic._backward): the critic's window was assembled on the critic's stream, the others' on
+            # this one.  ONE collective over the whole buffer, here, behind the critic's assembly; the critic's step launch waits
+            # for it through the event its stream would have waited for anyway (FlatAdam.step: `main_assembled`) — the step still
+            # has two cross-stream edges and no join.
+            main = torch.cuda.current_stream()
+            main.wait_event(tail["branch_assembled"])
+            reduce_mean_(flat.buffer)
+            averaged = torch.cuda.Event()
+            averaged.record(main)
+            tail.update(main_assembled=averaged, main_joined=True, reduced=True, reduce=False)
+            return
         if flat.reduced:  # the split route already averaged both windows inside the backward
             flat.reduced = False
             return

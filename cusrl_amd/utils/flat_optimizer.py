@@ -16,6 +16,9 @@ fused-adam), and the learning rate is read from device memory so hipGraph replay
 
 from __future__ import annotations
 
+import functools
+import os
+
 import torch
 
 from cusrl_amd import ops
@@ -24,6 +27,7 @@ from cusrl_amd.utils.distributed import FlatGradients
 __all__ = ["FlatAdam"]
 
 _SUPPORTED = (torch.optim.Adam, torch.optim.AdamW)
+_OWN_NORM = "own"  # a pending clip without squared-norm rows: the step launch measures the norm of the flat buffer itself
 _GROUP_KEYS = ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize", "decoupled_weight_decay")
 
 
@@ -65,6 +69,8 @@ class FlatAdam:
         self.branch_step_count = torch.zeros(1, dtype=torch.float32, device=device)
         self.branch_ticket = torch.zeros(1, dtype=torch.int32, device=device)
         self.two_window_steps = 0
+        # workspaces of cusrl_adam_step_normed, one per window (allocated here: never inside a capture)
+        self._norm_workspaces = (ops.adam_norm_workspace(device), ops.adam_norm_workspace(device))
         self._pending_clip: tuple[torch.Tensor, float | None, torch.Tensor] | None = None
         self.metrics = None  # the agent's Metrics (set by the agent): a captured step's tap may take the norm straight from the launch
         self._views: list[tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []
@@ -106,12 +112,16 @@ class FlatAdam:
         the next :meth:`step`.  Returns the device scalar that will hold the pre-clip norm after that step."""
         norm = torch.empty(1, dtype=torch.float32, device=self.lr.device)  # one per step: metrics keep a reference
         tail = self.gradients.split_tail
-        if tail is not None:  # two unjoined window assemblies: their rows, in parameter order (summed as one array by both launches)
-            self._pending_clip = (tail["sumsq"], max_norm, norm)
+        if tail is not None:
+            # two unjoined window assemblies: their rows, in parameter order (summed as one array by both launches) — or, when
+            # the gradients were averaged over the ranks behind the assemblies, the norm each step launch measures itself
+            self._pending_clip = (_OWN_NORM if tail.get("reduced") else tail["sumsq"], max_norm, norm)
             return norm[0]
         partials = self.gradients.take_sumsq()  # left behind by the gradient assembly when nothing touched them since
         if partials is None:
-            partials = ops.grad_sumsq(self.gradients.buffer)
+            # (several ranks: the all-reduce came in between; or something edited the gradients) — the step launch measures the
+            # norm itself (cusrl_adam_step_normed) instead of a squared-norm launch in front of it
+            partials = _OWN_NORM
         self._pending_clip = (partials, max_norm, norm)
         return norm[0]
 
@@ -164,26 +174,49 @@ class FlatAdam:
             # coefficient needs both windows' rows).  No join, no fork: the critic's next forward follows its own step on its own
             # stream, and a stream only ever waits for the other's assembly — a fork / join pair per minibatch step costs
             # ~18 us on this stack, two late-bound event edges ~11 (scripts/probe_graph_fork.py).
-            pair = partials if isinstance(partials, tuple) else (partials, None)
             main, branch = torch.cuda.current_stream(), tail["branch"]
             (lo, hi), (blo, bhi) = tail["main_range"], tail["branch_range"]
-            with torch.cuda.stream(branch):
-                branch.wait_event(tail["main_assembled"])
-                ops.adam_step_window(self.param_buffer[blo:bhi], self.gradients.buffer[blo:bhi], self.exp_avg[blo:bhi],
-                                     self.exp_avg_sq[blo:bhi], self.branch_step_count, self.lr, self.branch_ticket,
-                                     clip_partials=pair, **hyper)
-            main.wait_event(tail["branch_assembled"])
-            ops.adam_step_window(self.param_buffer[lo:hi], self.gradients.buffer[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
-                                 self.step_count, self.lr, self.ticket, clip_partials=pair, norm_out=norm, norm_accumulator=slot,
-                                 **hyper)
+            if partials is _OWN_NORM:
+                # several ranks (reduce_gradients averaged the whole buffer on this stream, behind the critic's assembly): both
+                # launches measure the norm of the WHOLE averaged buffer themselves — same split, same norm to the bit
+                work_main, work_branch = self._norm_workspaces
+                stepper = lambda work: functools.partial(ops.adam_step_normed, norm_grad=self.gradients.buffer, workspace=work)  # noqa: E731
+                step_main, step_branch = stepper(work_main), stepper(work_branch)
+            else:
+                pair = partials if isinstance(partials, tuple) else (partials, None)
+                step_main = step_branch = functools.partial(ops.adam_step_window, clip_partials=pair)
+            def critic_window():
+                with torch.cuda.stream(branch):
+                    branch.wait_event(tail["main_assembled"])
+                    step_branch(self.param_buffer[blo:bhi], self.gradients.buffer[blo:bhi], self.exp_avg[blo:bhi],
+                                self.exp_avg_sq[blo:bhi], self.branch_step_count, self.lr, self.branch_ticket, **hyper)
+
+            def main_window():
+                if not tail.get("main_joined"):  # (the all-reduce of a multi-rank step already waited for the critic's assembly)
+                    main.wait_event(tail["branch_assembled"])
+                step_main(self.param_buffer[lo:hi], self.gradients.buffer[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                          self.step_count, self.lr, self.ticket, norm_out=norm, norm_accumulator=slot, **hyper)
+
+            # Which launch is CAPTURED first decides which chain the graph's executor keeps on the hardware queue of the node in
+            # front of them (it follows a node's first edge): behind the all-reduce of a multi-rank step that must be the main
+            # stream's — the longer chain, the actor's — so that its step launch follows the collective without a queue hop.
+            if tail.get("reduced") and os.environ.get("CUSRL_NORMED_MAIN_FIRST", "1") != "0":
+                main_window(), critic_window()
+            else:
+                critic_window(), main_window()
             self.two_window_steps += 1
             return loss
         if tail is not None:  # (parameters without a gradient are put back below: one launch over everything, behind a join)
             torch.cuda.current_stream().wait_stream(tail["branch"])
-        pair = partials if isinstance(partials, tuple) else (partials, None)
-        ops.adam_step_window(self.param_buffer, self.gradients.buffer, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                             self.ticket, clip_partials=pair, norm_out=norm, norm_accumulator=slot,
-                             step_mirror=self.branch_step_count, **hyper)
+        if partials is _OWN_NORM:
+            ops.adam_step_normed(self.param_buffer, self.gradients.buffer, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+                                 self.ticket, norm_grad=self.gradients.buffer, workspace=self._norm_workspaces[0], norm_out=norm,
+                                 norm_accumulator=slot, step_mirror=self.branch_step_count, **hyper)
+        else:
+            pair = partials if isinstance(partials, tuple) else (partials, None)
+            ops.adam_step_window(self.param_buffer, self.gradients.buffer, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+                                 self.ticket, clip_partials=pair, norm_out=norm, norm_accumulator=slot,
+                                 step_mirror=self.branch_step_count, **hyper)
         for view, view0, m, m0, v, v0 in kept:
             view.copy_(view0), m.copy_(m0), v.copy_(v0)
         return loss

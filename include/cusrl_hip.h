@@ -167,6 +167,15 @@ int cusrl_normalize_from_partials(float *x, const double *stat_partials, int64_t
  * mean = avg_r mean_r, var = avg_r (var_r + (mean_r - mean)^2) into mean[D], var[D]. */
 int cusrl_merge_mean_var(const float *gathered, int64_t W, int64_t D, float *mean, float *var, void *stream);
 
+/* cusrl_merge_mean_var + cusrl_normalize as ONE launch (ABI 6, second part of round 6): the advantage normalisation of a job with
+ * several ranks (hook/on_policy/advantage.py:108-115 with `reduce_mean_var_`, distributed.py:175-183, between the statistics and
+ * their use).  gathered: float[W][2 D], every rank's mean | var (cusrl_stats_finalize writes both into one [2 D] row, which
+ * cusrl_allgather collects); every block re-derives the merged statistics — the same operations in the same order as
+ * cusrl_merge_mean_var — and normalises its share of x [rows, D] in place; mean_out / var_out [D] receive the merged statistics.
+ * Bit-identical to cusrl_merge_mean_var + cusrl_normalize.  D <= 256. */
+int cusrl_normalize_from_gathered(float *x, const float *gathered, int64_t W, float eps, int64_t rows, int64_t D,
+                                  float *mean_out, float *var_out, void *stream);
+
 /* ---- a7/a8  minibatch gather — cusrl/sampler/mini_batch_sampler.py:87-89, 113-114; buffer.py:153-162 ----
  * For every leaf i: temporal == 0:  dst_i[b]       = src_i.flatten(0,1)[indices[b]]      b < B
  *                   temporal != 0:  dst_i[t, b]    = src_i[t, indices[b]]                t < T, b < B
@@ -552,6 +561,24 @@ int cusrl_adam_step_window(float *param, const float *grad, float *exp_avg, floa
                            int maximize, const double *clip_partials_a, int64_t num_a, const double *clip_partials_b,
                            int64_t num_b, float max_norm, float *norm_out, float *norm_accumulator, float *step_mirror,
                            uint32_t *ticket, void *stream);
+
+/* cusrl_adam_step_window that measures the gradient norm ITSELF (ABI 6, second part of round 6): the step of a job with several
+ * ranks, where the gradient all-reduce (cusrl/utils/distributed.py:145-172, actor_critic.py:314) sits between the gradient assembly
+ * — whose free partial sums are of the un-averaged gradients — and the clipping (gradient_clipping.py:74), so that the squared
+ * norm used to be a launch of its own (cusrl_grad_sumsq) on the serial tail of every minibatch step.  One launch: every block sums
+ * the squares of its share of norm_grad[0 .. norm_n) (the WHOLE flat gradient buffer, also when the launch steps one window of
+ * it), publishes its partial sum in `workspace`, waits for the launch's other blocks, and derives the coefficient from all
+ * partial sums in fixed order; then the step of cusrl_adam_step_window over param / grad / exp_avg / exp_avg_sq [0 .. n).  The
+ * grid depends on norm_n alone (at most 256 blocks, one per CU: the blocks of a launch meet inside it), so the launches of a
+ * step's windows find the same norm to the bit.  workspace: cusrl_adam_step_normed_workspace_bytes() device bytes, 8-byte
+ * aligned, filled with 0xFF bytes ONCE by the caller and owned by the entry point afterwards (self-re-arming: safe to replay
+ * from a hipGraph); two launches that may run side by side need a workspace each.  norm_grad: 16-byte aligned.  Everything else
+ * as cusrl_adam_step_window; max_norm < 0: measure only. */
+int cusrl_adam_step_normed(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, const float *lr,
+                           int64_t n, double beta1, double beta2, double eps, double weight_decay, int decoupled_weight_decay,
+                           int maximize, const float *norm_grad, int64_t norm_n, void *workspace, float max_norm, float *norm_out,
+                           float *norm_accumulator, float *step_mirror, uint32_t *ticket, void *stream);
+int64_t cusrl_adam_step_normed_workspace_bytes(void);
 
 /* ---- running observation statistics ----
  * cusrl/nn/utils/normalization.py:15-50 `mean_var_count` of x [rows, C] restricted to rows with mask != 0 (mask may

@@ -28,7 +28,7 @@ def main(out_dir: str, compile_: str, native: str):
     env = cusrl.testing.SyntheticEnvironment(256, 20, 6)
     factory = cusrl.preset.PpoAgentFactory(num_steps_per_update=8, sampler_epochs=3, sampler_mini_batches=2,
                                            compile=compile_ == "1")
-    trainer = cusrl.Trainer(env, factory, num_iterations=3, verbose=False)
+    trainer = cusrl.Trainer(env, factory, num_iterations=6, verbose=False)  # (the whole-update graph is captured in the fourth)
     first_perm = torch.randperm(16, device="cuda").tolist()  # per-rank generator streams differ (seed + rank)
     trainer.run_training_loop()
     params = torch.cat([p.detach().reshape(-1) for p in trainer.agent.parameters()])
@@ -64,6 +64,10 @@ def main(out_dir: str, compile_: str, native: str):
         "allreduce_calls": _native.launch_counts.get("cusrl_allreduce_mean", 0),
         "allgather_calls": _native.launch_counts.get("cusrl_allgather", 0),
         "log_average_s": log_average_s,
+        "update_graph_replays": getattr(getattr(trainer.agent, "_graphed_epochs", None), "replays", 0),
+        "two_window_steps": getattr(trainer.agent.flat_optimizer, "two_window_steps", 0),
+        "normed_steps": _native.launch_counts.get("cusrl_adam_step_normed", 0),
+        "sumsq_launches": _native.launch_counts.get("cusrl_grad_sumsq", 0),
     }))
     distributed.barrier()
     torch.cuda.synchronize()

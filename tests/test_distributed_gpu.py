@@ -57,8 +57,31 @@ def test_ppo_preset_over_rccl_single_rank(tmp_path, compile_, native):
         assert result["allreduce_calls"] > 0 and result["allgather_calls"] > 0
         if compile_ == "1":
             assert result["single_graph"] and all(result["single_graph"])  # all-reduce captured inside the step graph
+            assert result["update_graph_replays"] > 0  # ... and the steps replay from ONE graph per update
     elif compile_ == "1":
         assert result["single_graph"] and not any(result["single_graph"])  # eager all-reduce between two graphs
+    # second part of round 6: no route launches a squared-norm pass between the all-reduce and the step — the step launch measures
+    # the averaged gradients' norm itself
+    # (compile=False keeps torch's optimizer and clip_grad_norm_ over the flat buffer)
+    assert result["sumsq_launches"] == 0 and (result["normed_steps"] > 0) == (compile_ == "1")
+
+
+def test_unjoined_step_of_a_multi_rank_job_changes_no_bit_one_rccl_rank(tmp_path):
+    """Second part of round 6: with the critic on its own stream-branch (forced here: the worker's minibatches are below the
+    size where it pays) the step of a multi-rank job stays UNJOINED inside the whole-update graph — the critic's window assembled
+    on the critic's stream, ONE all-reduce over the whole flat buffer on the main stream behind both assemblies, each window
+    stepped on its own stream by a launch that measures the averaged gradients' norm itself (``cusrl_adam_step_normed``).  Against
+    the joined form of the same job (one assembly, the all-reduce, one step launch over everything): the same parameters to the
+    bit — both forms split the norm's sum alike."""
+    (tmp_path / "unjoined").mkdir(), (tmp_path / "joined").mkdir()
+    (unjoined,) = _run(tmp_path / "unjoined", 1, "1", "1", extra_env={"CUSRL_CONCURRENT_CRITIC": "1"})
+    (joined,) = _run(tmp_path / "joined", 1, "1", "1", extra_env={"CUSRL_CONCURRENT_CRITIC": "1", "CUSRL_TWO_WINDOW_STEP": "0"})
+    assert unjoined["native"] and unjoined["update_graph_replays"] > 0 and unjoined["two_window_steps"] > 0, unjoined
+    assert joined["update_graph_replays"] > 0 and joined["two_window_steps"] == 0
+    assert unjoined["sumsq_launches"] == joined["sumsq_launches"] == 0 and unjoined["normed_steps"] > joined["normed_steps"] > 0
+    assert unjoined["param_bytes"] == joined["param_bytes"] and unjoined["param_sum"] == joined["param_sum"]
+    for key in ("Agent/value_loss", "Agent/surrogate_loss", "Agent/kl_divergence"):
+        assert math.isfinite(unjoined["info"][key]) and unjoined["info"][key] == joined["info"][key], key
 
 
 @pytest.mark.parametrize("fault,needle", [

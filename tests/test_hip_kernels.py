@@ -1296,6 +1296,101 @@ def test_adam_step_window_pair_equals_one_launch_over_everything(ops, max_norm):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("n,cut", [(92_584, 46_600), (5, 4), (3_000_003, 1_000_000)])
+@pytest.mark.parametrize("max_norm", [None, 0.5])
+def test_adam_step_normed_measures_the_norm_it_clips_with(ops, n, cut, max_norm):
+    """The step of a multi-rank job (second part of round 6): ``cusrl_adam_step_normed`` sums the squares of the whole gradient
+    buffer inside the step launch (its blocks meet through the workspace) instead of a squared-norm launch in front of it.
+    Against ``cusrl_grad_sumsq`` + ``cusrl_adam_step`` on the same operands: the same fp32 norm (the two routes split the fp64
+    sum differently: the rounded norm may differ in its last bit once in ~1e8 draws — then the comparison loosens), hence the same
+    parameters and moments to the bit; a pair of launches over two windows, side by side on two streams with a workspace each,
+    equals one launch over everything; the workspace re-arms itself (odd and even launches) and survives hipGraph replays."""
+    g = torch.Generator().manual_seed(n)
+    make = lambda scale: (torch.randn(n, generator=g) * scale).to(DEV)  # noqa: E731
+    reference = [make(1.0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)]
+    whole, split = [t.clone() for t in reference], [t.clone() for t in reference]
+    lr = torch.full((1,), 2e-4, device=DEV)
+    counters = lambda: (torch.zeros(1, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV))  # noqa: E731
+    (step_r, ticket_r), (step_w, ticket_w), (step_a, ticket_a), (step_b, ticket_b) = counters(), counters(), counters(), counters()
+    work_w, work_a, work_b = ops.adam_norm_workspace(DEV), ops.adam_norm_workspace(DEV), ops.adam_norm_workspace(DEV)
+    hyper = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, decoupled=True, max_norm=max_norm)
+    side = torch.cuda.Stream()
+    grad = make(0.02)
+    norm_w, norm_s = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+
+    def launches():
+        ops.adam_step_normed(whole[0], grad, whole[1], whole[2], step_w, lr, ticket_w, norm_grad=grad, workspace=work_w,
+                             norm_out=norm_w, **hyper)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.adam_step_normed(split[0][cut:], grad[cut:], split[1][cut:], split[2][cut:], step_b, lr, ticket_b, norm_grad=grad,
+                                 workspace=work_b, **hyper)
+        ops.adam_step_normed(split[0][:cut], grad[:cut], split[1][:cut], split[2][:cut], step_a, lr, ticket_a, norm_grad=grad,
+                             workspace=work_a, norm_out=norm_s, **hyper)
+        main.wait_stream(side)
+
+    def check(exact_norm=None):
+        norm_r = torch.zeros(1, device=DEV)
+        ops.adam_step(reference[0], grad, reference[1], reference[2], step_r, lr, ticket_r, betas=(0.9, 0.999), eps=1e-8,
+                      weight_decay=0.01, decoupled=True, clip_partials=ops.grad_sumsq(grad), max_norm=max_norm, norm_out=norm_r)
+        torch.cuda.synchronize()
+        assert torch.equal(norm_w, norm_s)  # (the grid follows the norm's buffer: every launch splits the sum alike)
+        for a, b in zip(whole, split):
+            assert torch.equal(a, b)
+        np.testing.assert_allclose(float(norm_w), float(grad.double().square().sum().sqrt()), rtol=2e-7)
+        assert max_norm is None or float(norm_w) > max_norm or n < 100
+        if torch.equal(norm_w, norm_r):
+            for a, b in zip(whole, reference):
+                assert torch.equal(a, b)
+        else:
+            assert abs(float(norm_w) - float(norm_r)) <= 1.2e-7 * float(norm_r)
+            for a, b in zip(whole, reference):
+                torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-9)
+                b.copy_(a)
+        assert step_r.item() == step_w.item() == step_a.item() == step_b.item()
+        assert ticket_w.item() == ticket_a.item() == ticket_b.item() == 0
+
+    for _ in range(5):  # odd and even launches: both slot sets, each re-armed by the launch in front of it
+        grad.copy_(make(0.02))
+        launches()
+        check()
+    # a NaN gradient: the norm is NaN like torch's, nothing waits forever
+    if max_norm is not None and n > 100:
+        poisoned = grad.clone()
+        poisoned[7] = float("nan")
+        probe = [t.clone() for t in whole]
+        step_p, ticket_p = step_w.clone(), torch.zeros(1, dtype=torch.int32, device=DEV)
+        norm_p = torch.zeros(1, device=DEV)
+        ops.adam_step_normed(probe[0], poisoned, probe[1], probe[2], step_p, lr, ticket_p, norm_grad=poisoned,
+                             workspace=ops.adam_norm_workspace(DEV), norm_out=norm_p, **hyper)
+        assert torch.isnan(norm_p).all() and torch.isnan(probe[0]).all()
+    # captured: the same three launches replayed from one hipGraph
+    capture_stream = torch.cuda.Stream()
+    capture_stream.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(capture_stream):
+        with torch.cuda.graph(graph, stream=capture_stream):
+            launches()
+    torch.cuda.current_stream().wait_stream(capture_stream)
+    for _ in range(5):
+        grad.copy_(make(0.02))
+        graph.replay()
+        check()
+    # refusals of the raw entry point
+    from cusrl_amd import _native
+
+    lib = _native.lib()
+    args = lambda norm_ptr, norm_n, work: (whole[0].data_ptr(), grad.data_ptr(), whole[1].data_ptr(), whole[2].data_ptr(), step_w.data_ptr(),  # noqa: E731
+                                           lr.data_ptr(), n, 0.9, 0.999, 1e-8, 0.0, 0, 0, norm_ptr, norm_n, work, 1.0, None, None, None,
+                                           ticket_w.data_ptr(), None)
+    assert lib.cusrl_adam_step_normed(*args(None, n, work_w.data_ptr())) == -1
+    assert lib.cusrl_adam_step_normed(*args(grad.data_ptr(), 0, work_w.data_ptr())) == -1
+    assert lib.cusrl_adam_step_normed(*args(grad.data_ptr(), n, None)) == -1
+    assert lib.cusrl_adam_step_normed(*args(grad.data_ptr() + 4, n - 1, work_w.data_ptr())) == -3
+    torch.cuda.synchronize()
+
+
 def test_assemble_gradients_sums_slabs_into_slots(ops):
     rng = np.random.default_rng(3)
     shapes = [(16, 128 * 256), (1, 256), (16, 256 * 48), (1, 12), (0, 7), (3, 5), (1, 1)] * 5  # 35 pieces: two launches
@@ -1671,3 +1766,45 @@ def test_fused_linear_paths_match_plain_autograd():
             torch.testing.assert_close(g, w, rtol=2e-4, atol=1e-4 * float(w.abs().max()))
         with torch.no_grad():
             assert torch.equal(mlp(x), mlp.layers(x))
+
+
+def test_side_stream_runs_beside_the_stream_it_was_made_for():
+    """Second part of round 6: a side stream is chosen by demonstration — work issued to it makes progress while the stream it has
+    to overlap with is busy (HIP maps streams onto a few hardware queues; two streams of one queue run serially, and which queue
+    a new stream gets depends on how many the process created before: the draw-ahead stream of a torchrun rank shared the main
+    stream's).  A stream trivially does not run beside itself."""
+    from cusrl_amd.utils.streams import runs_beside, side_stream
+
+    main = torch.cuda.current_stream()
+    for _ in range(6):  # whatever the process has created so far
+        stream = side_stream(DEV)
+        assert stream != main and runs_beside(stream, [main])
+    assert not runs_beside(main, [main])
+    other = side_stream(DEV, beside=[main, stream])
+    assert runs_beside(other, [main, stream])
+
+
+@pytest.mark.parametrize("W", [1, 2, 8])
+@pytest.mark.parametrize("rows,D", [(98304, 1), (1001, 1), (4099, 3)])
+def test_normalize_from_gathered_equals_merge_then_normalize(ops, W, rows, D):
+    """Second part of round 6: the advantage normalisation of a multi-rank job — ``cusrl_normalize_from_gathered`` (merge of the
+    all-gathered ``mean | var`` rows + normalisation, one launch) against ``cusrl_merge_mean_var`` + ``cusrl_normalize``: the same
+    operations in the same order, bit for bit; the row it gathers is the two halves of ``adv_stats_finalize``'s result as they are."""
+    g = torch.Generator().manual_seed(rows + W)
+    x = (torch.randn(rows, D, generator=g) * 3 + 0.5).to(DEV)
+    var, mean = ops.adv_stats_finalize(ops.col_stats(x), rows)
+    row = ops.packed_mean_var(mean, var)
+    assert row.data_ptr() == mean.data_ptr() and row.shape == (2 * D,) and torch.equal(row, torch.cat((mean, var)))
+    assert torch.equal(ops.packed_mean_var(mean.clone(), var), torch.cat((mean, var)))  # (anything else: a cat)
+    others = [(row + 0.1 * torch.randn(2 * D, generator=g).to(DEV)).abs() for _ in range(W - 1)]
+    gathered = torch.stack([row] + others)
+    expect, merged_mean, merged_var = x.clone(), torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    ops.merge_mean_var(gathered, merged_mean, merged_var)
+    ops.normalize_(expect, merged_mean, merged_var, 1e-8)
+    got = x.clone()
+    got_var, got_mean = ops.normalize_from_gathered_(got, gathered, 1e-8)
+    assert torch.equal(got, expect) and torch.equal(got_mean, merged_mean) and torch.equal(got_var, merged_var)
+    if W == 1:  # one rank: the merge is the identity — the single-process launch's result
+        single = x.clone()
+        ops.normalize_from_partials_(single, ops.col_stats(x), rows, 1e-8)
+        assert torch.equal(got, single)
