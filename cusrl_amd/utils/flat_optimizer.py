@@ -200,7 +200,7 @@ class FlatAdam:
             # Which launch is CAPTURED first decides which chain the graph's executor keeps on the hardware queue of the node in
             # front of them (it follows a node's first edge): behind the all-reduce of a multi-rank step that must be the main
             # stream's — the longer chain, the actor's — so that its step launch follows the collective without a queue hop.
-            if tail.get("reduced") and os.environ.get("CUSRL_NORMED_MAIN_FIRST", "1") != "0":
+            if (tail.get("reduced") and os.environ.get("CUSRL_NORMED_MAIN_FIRST", "1") != "0") or os.environ.get("CUSRL_STEP_MAIN_FIRST") == "1":
                 main_window(), critic_window()
             else:
                 critic_window(), main_window()
