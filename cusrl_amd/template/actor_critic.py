@@ -548,13 +548,14 @@ class ActorCritic(Agent):
                                             allow_unused=True, retain_graph=branch_root is None)
             flat.assemble(grads, slabs, subset=critic_ids)
 
+        # Two collectives in flight on two streams need two communicators: without the second one (it could not be created, or
+        # the route is torch.distributed's) the critic's window is averaged on the MAIN stream behind the join below — one
+        # communicator is only ever used from one stream at a time.
+        on_branch_comm = inline and distributed.branch_comm() is not None
+
         def critic_reduce():
-            if inline:
-                comm = distributed.branch_comm()
-                if comm is not None:
-                    comm.allreduce_mean_(windows[0])
-                else:
-                    distributed.reduce_mean_(windows[0])
+            if on_branch_comm:
+                distributed.branch_comm().allreduce_mean_(windows[0])
 
         if on_branch:
             branch.wait_stream(main)
@@ -573,6 +574,8 @@ class ActorCritic(Agent):
             for window in windows[1:]:
                 distributed.reduce_mean_(window)
         main.wait_stream(branch)
+        if inline and not on_branch_comm:
+            distributed.reduce_mean_(windows[0])
         flat.reduced = inline
 
     def _unit_gradient(self, term: torch.Tensor) -> torch.Tensor:
