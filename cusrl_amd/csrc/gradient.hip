@@ -191,9 +191,10 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float *__restrict__ p
 // its own on the serial tail of every minibatch step, gradient_clipping.py:74 behind distributed.py:145-172).  One launch: every
 // block sums the squares of its share of `norm_grad` (the WHOLE flat gradient buffer, also when the launch steps one window),
 // publishes the partial sum in a slot of the workspace, waits until every slot of the launch is filled, and derives the — to the
-// bit identical — coefficient from the slots in fixed order.  A grid-wide meeting inside a plain launch: the grid is at most one
-// block per CU (kNormedMaxBlocks), so every block is resident, or becomes resident as unrelated work drains, while the others
-// wait; two such launches side by side (the two windows of an unjoined step) are 2 x 91 blocks of the ppo preset's networks.
+// bit identical — coefficient from the slots in fixed order.  A grid-wide meeting inside a plain launch: the grid is at most half
+// a block per CU of the device (and at most kNormedMaxBlocks), so every block is resident, or becomes resident as unrelated work
+// drains, while the others wait; two such launches side by side (the two windows of an unjoined step) are 2 x 91 blocks of the ppo
+// preset's networks on 256 CUs.
 // No fence anywhere: a slot IS its own flag (device-scope read-modify-writes on one 8-byte word; "empty" is a bit pattern no
 // sum of squares has), the slots of the NEXT launch are re-armed by this one (two sets, chosen by a launch counter the last
 // block to finish bumps), so the entry point stays self-resetting and graph-safe like the ticket.
@@ -519,8 +520,17 @@ extern "C" int cusrl_adam_step_normed(float *param, const float *grad, float *ex
         return CUSRL_E_UNSUPPORTED;
     AdamParams a{beta1, beta2, float(eps), float(weight_decay), max_norm, decoupled_weight_decay, maximize, 0};
     // the grid follows the NORM's buffer alone: the launches of a step's windows split it alike and find the same norm, bit for bit
-    const int64_t blocks = ceil_div(norm_n / 4 > 0 ? norm_n / 4 : 1, kBlock);
-    adam_step_normed_kernel<<<int(blocks > kNormedMaxBlocks ? kNormedMaxBlocks : blocks), kBlock, 0, as_stream(stream)>>>(
+    // — and is at most HALF a block per CU of the device this call runs on (a partitioned part has 32 CUs, not 256): the two
+    // launches of an unjoined step meet inside themselves side by side, and every block of both must find a place while the others
+    // wait (a CU holds eight such blocks; unrelated kernels drain, a waiting block does not)
+    int device = 0, cus = 0;
+    if (hipGetDevice(&device) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 2)
+        cus = 2;
+    const int64_t most = cus / 2 < kNormedMaxBlocks ? cus / 2 : kNormedMaxBlocks;
+    int64_t blocks = ceil_div(norm_n / 4 > 0 ? norm_n / 4 : 1, kBlock);
+    if (blocks > most) blocks = most;
+    adam_step_normed_kernel<<<int(blocks), kBlock, 0, as_stream(stream)>>>(
         param, grad, exp_avg, exp_avg_sq, step, lr, norm_grad, norm_n, static_cast<NormedWorkspace *>(workspace), norm_out,
         norm_accumulator, step_mirror, ticket, n, a);
     return launch_status();

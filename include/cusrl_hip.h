@@ -569,7 +569,8 @@ int cusrl_adam_step_window(float *param, const float *grad, float *exp_avg, floa
  * the squares of its share of norm_grad[0 .. norm_n) (the WHOLE flat gradient buffer, also when the launch steps one window of
  * it), publishes its partial sum in `workspace`, waits for the launch's other blocks, and derives the coefficient from all
  * partial sums in fixed order; then the step of cusrl_adam_step_window over param / grad / exp_avg / exp_avg_sq [0 .. n).  The
- * grid depends on norm_n alone (at most 256 blocks, one per CU: the blocks of a launch meet inside it), so the launches of a
+ * grid depends on norm_n and the device alone (at most half a block per CU, <= 256: the blocks of a launch meet inside it, and two
+ * launches may do so side by side), so the launches of a
  * step's windows find the same norm to the bit.  workspace: cusrl_adam_step_normed_workspace_bytes() device bytes, 8-byte
  * aligned, filled with 0xFF bytes ONCE by the caller and owned by the entry point afterwards (self-re-arming: safe to replay
  * from a hipGraph); two launches that may run side by side need a workspace each.  norm_grad: 16-byte aligned.  Everything else
