@@ -456,6 +456,9 @@ def run_gpu(args, rank, world):
             "torch_generator_env_ms_per_step": env_ab_ms,
             "captured_env_steps": (trainer._graphed_rollout.captured if trainer._graphed_rollout is not None else 0),
             "epoch_graph_updates": (agent._graphed_epochs.replays if getattr(agent, "_graphed_epochs", None) is not None else 0),
+            # minibatch steps that left their two streams unjoined (per-network assembly + one step launch per window); with several
+            # ranks: ONE all-reduce on the main stream behind both assemblies, cusrl_adam_step_normed per window
+            "unjoined_steps_captured": int(getattr(getattr(agent, "flat_optimizer", None), "two_window_steps", 0)),
             "autoreset": args.autoreset,
             "host_thread_cpus": pinned,
         },
