@@ -112,6 +112,9 @@ class FlatAdam:
         the next :meth:`step`.  Returns the device scalar that will hold the pre-clip norm after that step."""
         norm = torch.empty(1, dtype=torch.float32, device=self.lr.device)  # one per step: metrics keep a reference
         tail = self.gradients.split_tail
+        if tail is not None and tail.get("reduce"):
+            raise RuntimeError("FlatAdam: the windows of an unjoined multi-rank step reached the clipping without having been "
+                               "averaged over the ranks (reduce_gradients comes between the backward and pre_optim)")
         if tail is not None:
             # two unjoined window assemblies: their rows, in parameter order (summed as one array by both launches) — or, when
             # the gradients were averaged over the ranks behind the assemblies, the norm each step launch measures itself
@@ -185,6 +188,7 @@ class FlatAdam:
             else:
                 pair = partials if isinstance(partials, tuple) else (partials, None)
                 step_main = step_branch = functools.partial(ops.adam_step_window, clip_partials=pair)
+
             def critic_window():
                 with torch.cuda.stream(branch):
                     branch.wait_event(tail["main_assembled"])
@@ -200,7 +204,10 @@ class FlatAdam:
             # Which launch is CAPTURED first decides which chain the graph's executor keeps on the hardware queue of the node in
             # front of them (it follows a node's first edge): behind the all-reduce of a multi-rank step that must be the main
             # stream's — the longer chain, the actor's — so that its step launch follows the collective without a queue hop.
-            if (tail.get("reduced") and os.environ.get("CUSRL_NORMED_MAIN_FIRST", "1") != "0") or os.environ.get("CUSRL_STEP_MAIN_FIRST") == "1":
+            # (a single process: measured neutral, profiles/r06/experiments/step_order_single_process_ab.txt — left as it was)
+            main_first = (tail.get("reduced") and os.environ.get("CUSRL_NORMED_MAIN_FIRST", "1") != "0"
+                          or os.environ.get("CUSRL_STEP_MAIN_FIRST") == "1")
+            if main_first:
                 main_window(), critic_window()
             else:
                 critic_window(), main_window()
