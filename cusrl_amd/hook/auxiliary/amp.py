@@ -171,6 +171,7 @@ class _ReluDiscriminatorObjective(torch.autograd.Function):
 
 class AdversarialMotionPrior(Hook):
     objective_draws_random = True  # torch.randint for the discriminator batch
+    step_draws_random = True  # torch.randint for the step's expert transitions (post_step; the reference's amp.py:161)
     # Extension: a Linear / ReLU discriminator takes the closed-form objective above (CUSRL_AMP_CLOSED_FORM=0 or this
     # attribute restore the autograd double backward, which any other discriminator keeps anyway).
     closed_form_objective: bool = os.environ.get("CUSRL_AMP_CLOSED_FORM", "1") != "0"

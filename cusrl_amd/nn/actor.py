@@ -39,6 +39,10 @@ class Actor(Module):
         # the no-grad pass (acting, statistics) of an Mlp backbone + Normal head as one launch; it leaves no "backbone.output"
         # in `intermediate_repr` — a hook that reads the latent of a no-grad pass switches this off
         self.fused_inference = True
+        # exploration noise drawn ahead of the act step that uses it (template/graphs.py GraphedRolloutStep: the draws of a whole
+        # rollout are issued before it, off its serial chain); taken by the NEXT fused explore pass, once
+        self.pending_noise: Tensor | None = None
+        self.noise_shape: tuple[int, int] | None = None  # of the last fused explore pass (what an ahead-of-time draw must look like)
 
     def _fused_layers(self, observation, memory, backbone_kwargs, distribution_kwargs):
         if (not self.fused_inference or type(self.distribution) is not NormalDist or self.backbone_kwargs or self.distribution_kwargs
@@ -84,7 +88,12 @@ class Actor(Module):
 
             self.intermediate_repr.pop("backbone.output", None)
             vector = self.distribution.std_vector()
-            eps = torch.empty((observation.shape[0], vector.numel()), dtype=torch.float32, device=observation.device).normal_()
+            shape = (observation.shape[0], vector.numel())
+            eps, self.pending_noise, self.noise_shape = self.pending_noise, None, shape
+            if eps is None:
+                eps = torch.empty(shape, dtype=torch.float32, device=observation.device).normal_()
+            elif tuple(eps.shape) != shape or eps.dtype != torch.float32 or eps.device != observation.device or not eps.is_contiguous():
+                raise RuntimeError(f"exploration noise drawn ahead for another pass: {tuple(eps.shape)} vs {shape}")
             action, logp, mean, repeated = ops.mlp2_forward(observation, layers, std=vector, eps=eps)
             if forward_type == "act":
                 return action, memory

@@ -86,6 +86,13 @@ class Environment(ABC):
     then drives such an env without a single host synchronisation per step and, under ``compile=True``, replays a whole
     env step (act -> step -> episode statistics -> post_step hooks -> buffer push -> resets) from ONE hipGraph."""
 
+    generator_free: bool = False
+    """True promises, on top of ``capturable``, that ``step`` and ``reset_static`` draw nothing from torch's global generator
+    (a simulator with a random stream of its own).  The only consumer of that generator inside a captured rollout is then the
+    policy's exploration noise, one draw per env step (cusrl/nn/module/distribution.py:256-262) — and ``GraphedRolloutStep`` issues
+    the T draws of a rollout AHEAD of it, on a side stream while the previous update still runs: the same calls in the same
+    order, hence the same numbers, off the rollout's serial chain of launches."""
+
     def reset_static(self, indices: torch.Tensor, count: torch.Tensor):
         """Fixed-shape form of ``reset(indices=...)`` (environment.py:300-317 of the reference takes a host index list):
         ``indices`` is an int64 device vector of env ids of which only the first ``count`` (1-element int32 device

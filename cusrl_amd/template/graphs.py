@@ -776,6 +776,15 @@ class GraphedRolloutStep:
         self.rollout_replays = 0
         self.whole_rollouts = os.environ.get("CUSRL_WHOLE_ROLLOUT_GRAPH", "1") != "0"
         self.fuse_epilogue_push = os.environ.get("CUSRL_FUSE_EPILOGUE_PUSH", "1") != "0"  # A/B switch
+        # the exploration noise of a whole rollout drawn AHEAD of it (an env that leaves torch's generator alone: the T draws are
+        # the generator's only consumers inside the rollout — issued before its launch, on a side stream, they run while the
+        # previous update does, and the captured env step is one launch shorter); CUSRL_PREDRAW_NOISE=0: drawn inside the step
+        self.predraw_noise = os.environ.get("CUSRL_PREDRAW_NOISE", "1") != "0"
+        self._noise: torch.Tensor | None = None
+        self._noise_stream: torch.cuda.Stream | None = None
+        self._noise_ready: torch.cuda.Event | None = None
+        self._noise_read: torch.cuda.Event | None = None
+        self.noise_draws = 0
 
     # ------------------------------------------------------------------ eligibility
     def supported(self, observation, state) -> bool:
@@ -854,6 +863,7 @@ class GraphedRolloutStep:
                 entry["state"] = min(entry["state"], 1)
             self.rollouts.clear()
             self.signature = signature
+            agent.actor.noise_shape = None  # (set again by the step bodies that take the fused explore pass under these flags)
 
     def run(self, observation, state):
         """One env step; returns ``(next_observation, next_state, ready)`` (the static act inputs of the next step)."""
@@ -925,9 +935,49 @@ class GraphedRolloutStep:
             return None
         return T
 
-    def _rollout_body(self, steps: int):
-        for _ in range(steps):
+    def _rollout_body(self, steps: int, noise: torch.Tensor | None = None):
+        actor = self.agent.actor
+        for t in range(steps):
+            if noise is not None:
+                actor.pending_noise = noise[t]
             self._body()
+            if actor.pending_noise is not None:
+                actor.pending_noise = None
+                raise RuntimeError("a captured env step did not take the exploration noise drawn ahead for it")
+
+    def _noise_plan(self, steps: int) -> torch.Tensor | None:
+        """The persistent ``[T, N, A]`` noise rows of a whole rollout when they may be drawn ahead of it: an env that draws nothing
+        from torch's generator (``generator_free``), a stochastic policy whose act step is the fused explore pass (the step bodies
+        of the current signature recorded its noise shape), hooks of this package only and none of them drawing inside an env step
+        (``Hook.step_draws_random``: AdversarialMotionPrior samples a step's expert transitions in ``post_step``)."""
+        agent, env = self.agent, self.trainer.environment
+        actor = agent.actor
+        shape = getattr(actor, "noise_shape", None)
+        if (not self.predraw_noise or not getattr(env, "generator_free", False) or agent.deterministic or shape is None
+                or not all(type(hook).__module__.startswith("cusrl_amd.") and not (hook._active and hook.step_draws_random)
+                           for hook in agent.hook)):
+            return None
+        if self._noise is None or tuple(self._noise.shape) != (steps, *shape):
+            self._noise = torch.empty((steps, *shape), dtype=torch.float32, device=agent.device)
+            self._noise_ready, self._noise_read = torch.cuda.Event(), None
+            if self._noise_stream is None:
+                from cusrl_amd.utils.streams import side_stream
+
+                self._noise_stream = side_stream(agent.device)
+        return self._noise
+
+    def _draw_noise(self, noise: torch.Tensor):
+        """The T ``normal_()`` calls of this rollout's act steps — the same calls, in the same order, on tensors of the same
+        shape as the steps themselves would issue (nn/actor.py) — on the side stream; the current stream waits for them."""
+        main, side = torch.cuda.current_stream(), self._noise_stream
+        if self._noise_read is not None:
+            side.wait_event(self._noise_read)  # (the previous rollout has read its rows)
+        with torch.cuda.stream(side):
+            for t in range(noise.shape[0]):
+                noise[t].normal_()
+            self._noise_ready.record(side)
+        main.wait_event(self._noise_ready)
+        self.noise_draws += noise.shape[0]
 
     def run_rollout(self, observation, state):
         """The whole rollout from one replay — the T step bodies captured back to back into ONE graph: one launch, one
@@ -942,13 +992,16 @@ class GraphedRolloutStep:
             act.static_observation.copy_(observation)
             if state is not None:
                 act.static_state.copy_(state)
-        key = (trainer.stats._parity, steps)
+        noise = self._noise_plan(steps)
+        key = (trainer.stats._parity, steps, None if noise is None else noise.data_ptr())
         entry = self.rollouts.get(key)
+        if noise is not None:
+            self._draw_noise(noise)
         if entry is None:
             # capture: the bodies' host effects (cursor, counters, hooks' host halves) happen here, once, for this very
             # rollout; the replay right behind the capture performs its device work
             entry = self.rollouts[key] = {"capture": _Capture(agent), "transition": None}
-            entry["capture"].capture(lambda: self._rollout_body(steps), self.stream, pool=agent._graph_pool)
+            entry["capture"].capture(lambda: self._rollout_body(steps, noise), self.stream, pool=agent._graph_pool)
             entry["transition"] = dict(agent.transition)
             entry["capture"].replay()
             ready = self.ready
@@ -961,6 +1014,10 @@ class GraphedRolloutStep:
                 agent.hook.on_replay("act")
                 ready = self._replay_host_effects()
             self.rollout_replays += 1
+        if noise is not None:
+            if self._noise_read is None:
+                self._noise_read = torch.cuda.Event()
+            self._noise_read.record(torch.cuda.current_stream())
         if not ready:
             raise RuntimeError("a whole-rollout graph ended without the agent asking for an update")
         return act.static_observation, act.static_state

@@ -75,6 +75,10 @@ class Hook(Generic[AgentT]):
     # Extension: the hook draws from torch's global generator between pre_objective and post_objective (e.g. AMP samples
     # a discriminator batch).  The sampler then keeps every permutation draw exactly where the reference has it.
     objective_draws_random: bool = False
+    # Extension: the hook draws from torch's generator inside an ENV STEP (``pre_act`` / ``post_act`` / ``post_step``) — then the
+    # exploration noise of a rollout cannot be drawn ahead of it (template/graphs.py GraphedRolloutStep._noise_plan: the draws would
+    # change places with the hook's in the generator's stream).
+    step_draws_random: bool = False
     # Extension: this hook's post_step / should_update only enqueue shape-static device work (no Python state that changes
     # per step, no host read-back), so a whole env step may be replayed from a hipGraph (template/graphs.py
     # GraphedRolloutStep).  Stock hooks qualify; a user-defined hook that overrides either method sets this to opt in.

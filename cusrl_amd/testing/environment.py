@@ -39,6 +39,9 @@ class SyntheticEnvironment(Environment):
         if fused is None:
             fused = os.environ.get("CUSRL_FUSED_ENV", "1") != "0"
         self.fused = bool(fused) and self.device.type == "cuda" and state_dim is None
+        # (the fused step and the reset rows it leaves behind come from the env's own Philox stream: nothing is drawn from torch's
+        # generator while the trainer drives the env — template/environment.py `generator_free`)
+        self.generator_free = self.fused and self.capturable
         if self.fused:
             # follows set_global_seed (seed + rank) without consuming any generator; `seed=` gives an instance its own stream
             base = torch.initial_seed() if seed is None else int(seed)

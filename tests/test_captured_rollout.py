@@ -63,6 +63,14 @@ def test_captured_rollout_is_bit_identical_to_the_host_driven_loop(cusrl, kind):
     # iteration 0 host-driven, 1 eager step bodies, 2 one capture per step (+ the replay behind each), 3 the whole rollout
     # captured as ONE graph (every step was warm), 4-5 one replay per rollout
     assert graphed.replays == 0 and len(graphed.rollouts) == 1 and graphed.rollout_replays == 2
+    # third part of round 6: the env draws nothing from torch's generator (`generator_free`), so the exploration noise of a whole
+    # rollout — the T draws its act steps would issue — is drawn AHEAD of the rollout's graph on a side stream (iterations 3-5);
+    # the same calls in the same order: everything below stays bit-identical to the host-driven loop.  A categorical policy's act
+    # step is not the fused explore pass: its draws stay inside the step.
+    assert captured.environment.generator_free
+    # ... and AdversarialMotionPrior draws a step's expert transitions inside the step (`step_draws_random`): drawing the noise
+    # ahead would change the order of the generator's consumers
+    assert graphed.noise_draws == (T * 3 if kind == "continuous" else 0)
     # ... and a replay issues no C call at all: the push entry point was only called in iterations 0-3
     assert appends() - pushes_before == T * 4
     # when no post_step hook touches the transition on the device (the continuous preset), the captured step's epilogue and
