@@ -1058,3 +1058,45 @@ def test_trainer_flushes_a_pending_log_before_last_info_answers():
     trainer.agent.iteration = 0
     trainer.run_training_loop()
     assert logger.entries == [("checkpoint", 0), (1, 1.0, 64), (2, 2.0, 96), ("checkpoint", 2), (3, 3.0, 128), ("checkpoint", 3)]
+
+
+# ------------------------------------------------------------------------------------------------ third part of round 6
+def test_packed_mean_var_is_the_finalize_row_itself_or_a_cat():
+    """What a cross-rank merge gathers is ``mean | var`` as one row: the two halves of one allocation are handed over as they are
+    (no launch); anything else is concatenated."""
+    from cusrl_amd import ops
+
+    row = torch.arange(6, dtype=torch.float32)
+    mean, var = row[:3], row[3:]
+    packed = ops.packed_mean_var(mean, var)
+    assert packed.data_ptr() == row.data_ptr() and torch.equal(packed, row)
+    for other_mean, other_var in ((mean.clone(), var), (mean, var.clone()), (row[1:4], row[3:]), (row[::2], row[1::2])):
+        packed = ops.packed_mean_var(other_mean, other_var)
+        assert torch.equal(packed, torch.cat((other_mean, other_var))) and packed.data_ptr() != row.data_ptr()
+
+
+def test_ahead_of_time_noise_draws_are_opt_in_contracts():
+    """The exploration noise of a rollout may only be drawn ahead of it when nothing else consumes torch's generator inside the
+    rollout: an env says so (``generator_free`` — off by default, and off for the synthetic env wherever its fused step does not
+    run), a hook that draws inside an env step says the opposite (``step_draws_random``: AdversarialMotionPrior)."""
+    from cusrl_amd.hook.auxiliary import AdversarialMotionPrior, RandomNetworkDistillation
+    from cusrl_amd.template.environment import Environment
+    from cusrl_amd.template.hook import Hook
+
+    assert Environment.generator_free is False and Hook.step_draws_random is False
+    assert AdversarialMotionPrior.step_draws_random is True and RandomNetworkDistillation.step_draws_random is False
+    env = cusrl.testing.SyntheticEnvironment(8, 4, 2, device="cpu")
+    assert not env.fused and not env.generator_free  # (no GPU: torch-generator form)
+    actor = cusrl.Actor.Factory(cusrl.Mlp.Factory((16, 16)), cusrl.NormalDist.Factory())(4, 2)
+    assert actor.pending_noise is None and actor.noise_shape is None
+
+
+def test_side_stream_module_names_its_switches():
+    """``utils/streams.py`` needs a GPU to do anything; what a CPU process can hold is that it imports and documents its switches."""
+    from cusrl_amd.utils import streams
+
+    assert callable(streams.side_stream) and callable(streams.runs_beside)
+    integration = (ROOT / "INTEGRATION.md").read_text()
+    for switch in ("CUSRL_SIDE_STREAM_PROBE", "CUSRL_SIDE_STREAM_PRIORITY", "CUSRL_NORMED_MAIN_FIRST", "CUSRL_STEP_MAIN_FIRST",
+                   "CUSRL_PREDRAW_NOISE", "CUSRL_TWO_WINDOW_STEP"):
+        assert switch in integration, switch
