@@ -20,7 +20,7 @@ import torch
 
 __all__ = ["runs_beside", "side_stream"]
 
-_SPIN_CYCLES = 400_000  # torch.cuda._sleep: ~100-200 us on this part — long against an event's submission, short against a start-up
+_SPIN_CYCLES = 2_000_000  # torch.cuda._sleep: ~0.8 ms on this part — long against an event's submission AND against a host thread that is descheduled for a moment, short against a start-up
 _CANDIDATES = 12
 
 
