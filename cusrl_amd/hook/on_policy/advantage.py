@@ -21,33 +21,41 @@ from cusrl_amd.utils import distributed
 __all__ = ["AdvantageNormalization", "AdvantageReduction"]
 
 
+_CHANNEL_REDUCTIONS = {"sum": torch.sum, "mean": torch.mean}
+
+
 class AdvantageReduction(Hook):
-    """Collapse a multi-channel advantage to ``[..., 1]`` by (weighted) sum or mean inside ``objective``."""
+    """Collapse a multi-channel advantage ``[..., C]`` to ``[..., 1]`` inside ``objective``: a (weighted) sum or mean over the
+    channels (surface and arithmetic of cusrl/hook/on_policy/advantage.py:13-71: product with the weights first, then the
+    reduction; ``weight`` is a mutable attribute).  The weights live in ONE place — :meth:`_set_weight` keeps the tuple the
+    schedule sees and the device tensor the objective multiplies with in step, for ``init`` and for ``update_attribute`` alike."""
 
     def __init__(self, reduction: Literal["sum", "mean"] = "sum", weight: Sequence[float] | None = None):
-        if reduction not in ("sum", "mean"):
+        if reduction not in _CHANNEL_REDUCTIONS:
             raise ValueError(f"Unsupported reduction '{reduction}'")
         super().__init__(training_only=True)
         self.reduction = reduction
-        self.weight: tuple[float, ...] | None = None if weight is None else tuple(weight)
-        self.register_mutable("weight")
+        self.weight: tuple[float, ...] | None = None
         self._weight_tensor: Tensor | None = None
+        self._set_weight(weight, on_device=False)
+        self.register_mutable("weight")
+
+    def _set_weight(self, weight: Sequence[float] | None, on_device: bool = True):
+        self.weight = None if weight is None else tuple(weight)
+        self._weight_tensor = self.agent.to_tensor(self.weight) if on_device and self.weight is not None else None
 
     def init(self):
-        self._weight_tensor = None if self.weight is None else self.agent.to_tensor(self.weight)
+        self._set_weight(self.weight)
 
     def objective(self, metadata, batch):
         advantage: Tensor = batch["advantage"]
-        if self._weight_tensor is not None:
-            advantage = advantage * self._weight_tensor
-        reduce = advantage.sum if self.reduction == "sum" else advantage.mean
-        batch["advantage"] = reduce(-1, keepdim=True)
+        weighted = advantage if self._weight_tensor is None else advantage * self._weight_tensor
+        batch["advantage"] = _CHANNEL_REDUCTIONS[self.reduction](weighted, -1, keepdim=True)
 
     def update_attribute(self, name: str, value: Any):
         super().update_attribute(name, value)
         if name == "weight":
-            self.weight = None if value is None else tuple(value)
-            self._weight_tensor = None if value is None else self.agent.to_tensor(self.weight)
+            self._set_weight(value)
 
 
 class AdvantageNormalization(Hook):
