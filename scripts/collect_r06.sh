@@ -1,6 +1,8 @@
 #!/bin/bash
 # Everything profiles/r06/ is made of besides the probe / experiment files of the round, in GPU sessions of one MI355X each.
-# Usage (through gpurun): bash scripts/collect_r06.sh <part>     part = tests | bench | profile | configs
+# Usage (through gpurun): bash scripts/collect_r06.sh <part>     part = tests | bench | profile | configs | third
+# (third = the third part of the round: final-tree lines + one-rank pairs + rocprofv3 stats, the one-rank floors / switches /
+#  pre_update timelines, the side-stream priority, step-order and noise-draw A/Bs — each script writes under gpurun_out/)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r06final
@@ -59,6 +61,14 @@ profile)
   bash scripts/gpu_r06_timeline.sh r06final/timeline "update 1 tail" > "$O/timeline.log" 2>&1
   python scripts/kernel_bench.py --envs 4096 1048576 --json "$O/kernel_bench_graph_timed.json" 2>/dev/null | grep -v amdgpu > "$O/kernel_bench_graph_timed.txt"
   tail -5 "$O/kernel_bench_graph_timed.txt"
+  ;;
+third)
+  bash scripts/gpu_r06_third_part_lines.sh
+  bash scripts/gpu_one_rank_floor.sh
+  bash scripts/gpu_one_rank_sequence.sh
+  bash scripts/gpu_side_stream_ab.sh
+  bash scripts/gpu_step_order_ab.sh
+  bash scripts/gpu_predraw_ab.sh
   ;;
 configs)
   for c in "config1 --compile" "config2 --compile" "config3 --compile" "config4" "config5 --compile"; do
