@@ -149,7 +149,8 @@ int64_t cusrl_gae_num_partials(int64_t T, int64_t N, int64_t D);
  * Column statistics of x [rows, D] as per-block {sum, sumsq} partials (double[num_partials][D][2]). */
 int cusrl_col_stats(const float *x, int64_t rows, int64_t D, double *stat_partials, void *stream);
 int64_t cusrl_col_stats_num_partials(int64_t rows, int64_t D);
-/* mean[d], var[d] (unbiased, correction = 1, like torch.var_mean) from partials, fixed summation order. */
+/* mean[d], var[d] (unbiased, correction = 1, like torch.var_mean) from partials, fixed summation order.  mean and var may be the
+ * halves of ONE float[2 D] row (var = mean + D): what a cross-rank merge all-gathers (cusrl_normalize_from_gathered). */
 int cusrl_stats_finalize(const double *stat_partials, int64_t num_partials, int64_t D, int64_t count,
                          float *mean, float *var, void *stream);
 /* x = (x - mean) / sqrt(var + eps) in place, true division (advantage.py:114-115). */
